@@ -1,0 +1,122 @@
+"""ctypes binding of libapertis_hip.so (the C ABI declared in include/apertis_hip.h).
+
+The library is loaded lazily (safe after fork(); DataLoader workers never touch HIP) and there
+is NO fallback: if the .so is missing or a call returns an error code, ApertisHipError is
+raised.  Nothing in this package routes compute through PyTorch eager ops or the CPU oracle.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapertis_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+
+
+class ApertisHipError(RuntimeError):
+    pass
+
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i64, _i32, _f32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint64
+
+# name -> (restype, argtypes).  Order and meaning mirror include/apertis_hip.h exactly.
+SIGNATURES = {
+    "apertis_abi_version": (ctypes.c_int, []),
+    "apertis_arch": (ctypes.c_char_p, []),
+    "apertis_strerror": (ctypes.c_char_p, [_i32]),
+    "apertis_scan_chunk_len": (_i64, [_i64, _i64, _i64]),
+    "apertis_scan_num_chunks": (_i64, [_i64, _i64, _i64]),
+    "apertis_selective_scan_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
+                                          _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apertis_selective_scan_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
+                                          _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apertis_ssm_gate_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_ssm_gate_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64,
+                                    _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_ssm_gate_bwd_blocks": (_i64, [_i64, _i64]),
+    "apertis_dwconv_silu_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_dwconv_silu_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64,
+                                       _i64, _i32, _vp]),
+    "apertis_dwconv_bwd_blocks": (_i64, [_i64, _i64, _i64]),
+    "apertis_moe_gate_topk_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "apertis_moe_gate_topk_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "apertis_moe_plan_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "apertis_moe_plan": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "apertis_moe_gather_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_moe_gather_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                         _i32, _i32, _vp]),
+    "apertis_moe_gather_ln_bwd_blocks": (_i64, [_i64, _i64]),
+    "apertis_moe_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apertis_moe_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
+                                       _i32, _i32, _vp]),
+    "apertis_grouped_gemm_nt": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
+                                       _i32, _i32, _vp]),
+    "apertis_grouped_gemm_nn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_act_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _u64, _i32, _vp]),
+}
+
+
+class _Lib:
+    """CDLL wrapper that binds each entry point on first use with its declared signature."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        if name not in SIGNATURES:
+            raise AttributeError(name)
+        try:
+            fn = getattr(self._cdll, name)
+        except AttributeError:
+            raise ApertisHipError(f"{LIB_PATH} does not export {name}: rebuild with "
+                                  "`python -m apertis_llm_amd.build --force`") from None
+        fn.restype, fn.argtypes = SIGNATURES[name]
+        setattr(self, name, fn)
+        return fn
+
+
+def load():
+    """Return the loaded library. Raises ApertisHipError if the .so is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ApertisHipError(
+                f"{LIB_PATH} not found: build it with `python -m apertis_llm_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU or eager fallback.")
+        _lib = _Lib(ctypes.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().apertis_strerror(int(rc)).decode()
+        raise ApertisHipError(f"{what} failed: {msg} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    import torch
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise ApertisHipError(f"unsupported dtype {t.dtype}: kernels take float32 or bfloat16")

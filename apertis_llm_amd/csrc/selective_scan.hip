@@ -1,0 +1,646 @@
+// Selective-SSM scan for gfx950 (MI355X): chunked associative scan, forward and backward.
+//
+// Reference semantics: SelectiveLinearAttention._ssm_pytorch_scan_recurrent
+// (/root/reference/src/model/core.py:337-353).  The recurrence is element-wise on B*Dn
+// independent channels:   s_t = a_t*s_{t-1} + Bt_t,   y_t = C_t*s_t,   a_t = exp(delta_t*A).
+// Pairs (a, b) compose associatively as (a2*a1, a2*b1 + b2); nothing ever divides by a
+// cumulative product (the reference's parallel form core.py:331 does and overflows).
+//
+// Structure (HBM-bound; algorithmic bytes per token = 3*Dn*e + 4*h fwd, 5*Dn*e + 8*h bwd):
+//   work-group = (batch b, chunk of LT tokens, tile of 64 channels), 256 threads = 4 waves;
+//   lane = channel (64 consecutive channels = one contiguous row segment of the token-major
+//   [B,L,Dn] tensors), wave = a segment of LT/4 consecutive tokens.
+//   1. tiles of Bt / C / dy are staged HBM -> LDS with the widest loads the slice alignment
+//      allows (16 B per lane when possible), so HBM sees whole row segments;
+//   2. each thread scans its own column of the LDS tile sequentially in fp32 registers;
+//   3. segments are stitched through a 4x64 LDS table, chunks through a [B,nchunks,Dn]
+//      fp32 workspace and a tiny prefix kernel (three launches per direction).
+//   The backward recomputes the states inside the chunk from the saved chunk carry-in and
+//   runs the adjoint recurrence right-to-left with mu_t = a_t*lambda_t as the carried value.
+#include "common.h"
+
+namespace {
+
+constexpr int TC = 64;     // channels per tile (= wave width)
+constexpr int NSEG = 4;    // token segments per tile (= waves per work-group)
+constexpr int NTHREADS = TC * NSEG;
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// sum over an aligned group of `n` lanes (n power of two <= 64); every lane gets the sum
+__device__ __forceinline__ float group_sum(float v, int n) {
+  if (n == 16) {  // one DPP row: rotate-and-add, no LDS traffic
+    v += dpp_mov<0x128>(v);  // row_ror:8
+    v += dpp_mov<0x124>(v);  // row_ror:4
+    v += dpp_mov<0x122>(v);  // row_ror:2
+    v += dpp_mov<0x121>(v);  // row_ror:1
+    return v;
+  }
+  for (int off = n >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__device__ __forceinline__ float softplus_f(float x) {
+  // torch.nn.functional.softplus(beta=1, threshold=20)
+  return x > 20.f ? x : log1pf(expf(x));
+}
+
+template <int VB> struct vec_bytes;
+template <> struct vec_bytes<16> { typedef uint4 type; };
+template <> struct vec_bytes<8> { typedef uint2 type; };
+template <> struct vec_bytes<4> { typedef uint32_t type; };
+template <> struct vec_bytes<2> { typedef uint16_t type; };
+
+template <int VB> __device__ __forceinline__ typename vec_bytes<VB>::type zero_vec() {
+  typename vec_bytes<VB>::type z;
+  __builtin_memset(&z, 0, VB);
+  return z;
+}
+
+// HBM -> LDS: LT rows of ROWB bytes each (LDS pitch = ROWB), source rows `rsb` bytes apart.
+// Rows >= rows_valid and bytes >= bytes_valid are zero-filled.
+template <int VB, int ROWB, int LT>
+__device__ __forceinline__ void stage_in(char *lds, const char *g, int64_t rsb, int rows_valid,
+                                         int bytes_valid, int tid) {
+  typedef typename vec_bytes<VB>::type V;
+  constexpr int CPR = ROWB / VB;
+  constexpr int TOTAL = LT * CPR;
+  constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+  V regs[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    int idx = tid + it * NTHREADS;
+    int row = idx / CPR, cb = (idx % CPR) * VB;
+    bool ok = idx < TOTAL && row < rows_valid && cb < bytes_valid;
+    regs[it] = ok ? *reinterpret_cast<const V *>(g + (int64_t)row * rsb + cb) : zero_vec<VB>();
+  }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    int idx = tid + it * NTHREADS;
+    if (idx < TOTAL) *reinterpret_cast<V *>(lds + idx * VB) = regs[it];
+  }
+}
+
+// LDS -> HBM, mirror of stage_in.
+template <int VB, int ROWB, int LT>
+__device__ __forceinline__ void stage_out(const char *lds, char *g, int64_t rsb, int rows_valid,
+                                          int bytes_valid, int tid) {
+  typedef typename vec_bytes<VB>::type V;
+  constexpr int CPR = ROWB / VB;
+  constexpr int TOTAL = LT * CPR;
+  constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    int idx = tid + it * NTHREADS;
+    int row = idx / CPR, cb = (idx % CPR) * VB;
+    if (idx < TOTAL && row < rows_valid && cb < bytes_valid)
+      *reinterpret_cast<V *>(g + (int64_t)row * rsb + cb) =
+          *reinterpret_cast<const V *>(lds + idx * VB);
+  }
+}
+
+// delta tile: dl[t][hh] for the HT = 64/N heads covered by the channel tile
+template <int LT>
+__device__ __forceinline__ void stage_delta(float *dl, const float *dlt, int64_t tok0, int rows_valid,
+                                            int head0, int h, int HT, int softplus, int tid) {
+  for (int idx = tid; idx < LT * HT; idx += NTHREADS) {
+    int t = idx / HT, hh = idx - t * HT;
+    float v = 0.f;
+    if (t < rows_valid && head0 + hh < h) {
+      v = dlt[(tok0 + t) * h + head0 + hh];
+      if (softplus) v = softplus_f(v);
+    }
+    dl[idx] = v;
+  }
+}
+
+struct ScanDims {
+  int64_t B, L, h, N, Dn;
+  int log2N, HT, nchunks, softplus;
+};
+
+// ---------------------------------------------------------------------------------------
+// pass 1 (forward): per-chunk aggregate (P = prod a, S = state from zero) -> agg[b][j][c]
+template <typename TIN, int VB, int LT>
+__global__ void __launch_bounds__(NTHREADS)
+scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
+               const TIN *__restrict__ Bt, int64_t bt_rs, float2 *__restrict__ agg, ScanDims d) {
+  constexpr int ROWB = TC * sizeof(TIN);
+  constexpr int TS = LT / NSEG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TIN *bt = reinterpret_cast<TIN *>(smem);
+  float *dl = reinterpret_cast<float *>(smem + LT * ROWB);
+  float2 *segs = reinterpret_cast<float2 *>(smem + LT * ROWB + LT * d.HT * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
+  const int c0 = ct * TC, c = c0 + lane;
+  const int64_t t0 = (int64_t)chunk * LT;
+  const int rows_valid = (int)min((int64_t)LT, d.L - t0);
+  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
+  const int64_t tok0 = (int64_t)b * d.L + t0;
+
+  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt),
+                         reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
+                         bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
+  const float A2 = c < d.Dn ? -expf(A_log[c]) * LOG2E_F : 0.f;
+  __syncthreads();
+
+  float P = 1.f, S = 0.f;
+  const int hh = lane >> d.log2N;
+#pragma unroll
+  for (int i = 0; i < TS; ++i) {
+    int t = seg * TS + i;
+    float a = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
+    S = fmaf(a, S, to_f32(bt[t * TC + lane]));
+    P *= a;
+  }
+  segs[seg * TC + lane] = make_float2(P, S);
+  __syncthreads();
+  if (seg == 0 && c < d.Dn) {
+#pragma unroll
+    for (int s = 1; s < NSEG; ++s) {
+      float2 q = segs[s * TC + lane];
+      S = fmaf(q.x, S, q.y);
+      P *= q.x;
+    }
+    agg[((int64_t)b * d.nchunks + chunk) * d.Dn + c] = make_float2(P, S);
+  }
+}
+
+// pass 2: exclusive prefix over chunks. dir=+1 forward (carry0 = h0), dir=-1 reverse (carry0 = 0)
+__global__ void scan_chunk_prefix(const float2 *__restrict__ agg, const float *__restrict__ init,
+                                  float *__restrict__ carry_in, float *__restrict__ last,
+                                  int64_t B, int64_t Dn, int nchunks, int reverse) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Dn) return;
+  int64_t b = i / Dn, c = i - b * Dn;
+  float carry = init ? init[i] : 0.f;
+  const int64_t base = b * nchunks * Dn + c;
+  constexpr int U = 8;
+  for (int j0 = 0; j0 < nchunks; j0 += U) {
+    float2 q[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = j0 + u;
+      int jj = reverse ? nchunks - 1 - j : j;
+      q[u] = j < nchunks ? agg[base + (int64_t)jj * Dn] : make_float2(1.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int j = j0 + u;
+      if (j < nchunks) {
+        int jj = reverse ? nchunks - 1 - j : j;
+        carry_in[base + (int64_t)jj * Dn] = carry;
+        carry = fmaf(q[u].x, carry, q[u].y);
+      }
+    }
+  }
+  if (last) last[i] = carry;
+}
+
+// pass 3 (forward): replay each chunk from its carry-in, write y
+template <typename TIN, typename TY, int VB, int LT>
+__global__ void __launch_bounds__(NTHREADS)
+scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
+                const TIN *__restrict__ Bt, int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs,
+                const float *__restrict__ h_in, TY *__restrict__ y, int64_t y_rs, ScanDims d) {
+  constexpr int ROWB = TC * sizeof(TIN);
+  constexpr int TS = LT / NSEG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TIN *bt = reinterpret_cast<TIN *>(smem);
+  TIN *cc = reinterpret_cast<TIN *>(smem + LT * ROWB);
+  float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB);
+  float2 *segs = reinterpret_cast<float2 *>(smem + 2 * LT * ROWB + LT * d.HT * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
+  const int c0 = ct * TC, c = c0 + lane;
+  const int64_t t0 = (int64_t)chunk * LT;
+  const int rows_valid = (int)min((int64_t)LT, d.L - t0);
+  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
+  const int64_t tok0 = (int64_t)b * d.L + t0;
+
+  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt),
+                         reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
+                         bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc),
+                         reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
+                         c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
+  const bool chan_ok = c < d.Dn;
+  const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
+  float hcar = chan_ok ? h_in[((int64_t)b * d.nchunks + chunk) * d.Dn + c] : 0.f;
+  __syncthreads();
+
+  float a[TS];
+  float P = 1.f, S = 0.f;
+  const int hh = lane >> d.log2N;
+#pragma unroll
+  for (int i = 0; i < TS; ++i) {
+    int t = seg * TS + i;
+    a[i] = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
+    S = fmaf(a[i], S, to_f32(bt[t * TC + lane]));
+    P *= a[i];
+  }
+  segs[seg * TC + lane] = make_float2(P, S);
+  __syncthreads();
+  for (int s = 0; s < seg; ++s) {
+    float2 q = segs[s * TC + lane];
+    hcar = fmaf(q.x, hcar, q.y);
+  }
+  float hst = hcar;
+  if constexpr (sizeof(TY) == 4) {
+    // one dword per lane, 256 B per wave-instruction: full-rate plain stores
+    TY *yp = y + (tok0 + seg * TS) * y_rs + c;
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+      int t = seg * TS + i;
+      hst = fmaf(a[i], hst, to_f32(bt[t * TC + lane]));
+      float yv = to_f32(cc[t * TC + lane]) * hst;
+      if (chan_ok && t < rows_valid) yp[(int64_t)i * y_rs] = from_f32<TY>(yv);
+    }
+  } else {
+    // 2-byte outputs: write in place into the C tile (each thread owns its column), then
+    // store whole row segments
+    static_assert(sizeof(TY) == sizeof(TIN), "bf16 y requires bf16 Bt/C");
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+      int t = seg * TS + i;
+      hst = fmaf(a[i], hst, to_f32(bt[t * TC + lane]));
+      float yv = to_f32(cc[t * TC + lane]) * hst;
+      reinterpret_cast<TY *>(cc)[t * TC + lane] = from_f32<TY>(yv);
+    }
+    __syncthreads();
+    // y rows are contiguous [.., Dn]; alignment of the y slice may be lower than Bt's: use 2 B
+    // granularity unless y_rs and c0 allow wider (decided by the host through VB of y == VB)
+    stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(cc),
+                            reinterpret_cast<char *>(y + tok0 * y_rs + c0), y_rs * sizeof(TY),
+                            rows_valid, ch_valid * (int)sizeof(TY), tid);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// backward pass 1: reverse chunk aggregates (P = prod a, M = mu at chunk start from zero)
+//   u_t = dy_t*C_t,  mu_t = a_t*(u_t + mu_{t+1})
+template <typename TIN, typename TY, int VB, int VBY, int LT>
+__global__ void __launch_bounds__(NTHREADS)
+scan_bwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
+               const TIN *__restrict__ C, int64_t c_rs, const TY *__restrict__ dy, int64_t dy_rs,
+               float2 *__restrict__ agg, ScanDims d) {
+  constexpr int ROWB = TC * sizeof(TIN);
+  constexpr int ROWY = TC * sizeof(TY);
+  constexpr int TS = LT / NSEG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TIN *cc = reinterpret_cast<TIN *>(smem);
+  TY *gy = reinterpret_cast<TY *>(smem + LT * ROWB);
+  float *dl = reinterpret_cast<float *>(smem + LT * ROWB + LT * ROWY);
+  float2 *segs = reinterpret_cast<float2 *>(smem + LT * ROWB + LT * ROWY + LT * d.HT * 4);
+
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
+  const int c0 = ct * TC, c = c0 + lane;
+  const int64_t t0 = (int64_t)chunk * LT;
+  const int rows_valid = (int)min((int64_t)LT, d.L - t0);
+  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
+  const int64_t tok0 = (int64_t)b * d.L + t0;
+
+  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc),
+                         reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
+                         c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_in<VBY, ROWY, LT>(reinterpret_cast<char *>(gy),
+                          reinterpret_cast<const char *>(dy + tok0 * dy_rs + c0),
+                          dy_rs * sizeof(TY), rows_valid, ch_valid * (int)sizeof(TY), tid);
+  stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
+  const float A2 = c < d.Dn ? -expf(A_log[c]) * LOG2E_F : 0.f;
+  __syncthreads();
+
+  float P = 1.f, M = 0.f;
+  const int hh = lane >> d.log2N;
+#pragma unroll
+  for (int i = TS - 1; i >= 0; --i) {
+    int t = seg * TS + i;
+    float a = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
+    float u = to_f32(gy[t * TC + lane]) * to_f32(cc[t * TC + lane]);
+    M = a * (u + M);
+    P *= a;
+  }
+  segs[seg * TC + lane] = make_float2(P, M);
+  __syncthreads();
+  if (seg == 0 && c < d.Dn) {
+    // compose right-to-left: start from the last segment
+    float2 q = segs[(NSEG - 1) * TC + lane];
+    float Pt = q.x, Mt = q.y;
+#pragma unroll
+    for (int s = NSEG - 2; s >= 0; --s) {
+      float2 r = segs[s * TC + lane];
+      Mt = fmaf(r.x, Mt, r.y);
+      Pt *= r.x;
+    }
+    agg[((int64_t)b * d.nchunks + chunk) * d.Dn + c] = make_float2(Pt, Mt);
+  }
+}
+
+// backward pass 3: recompute states in the chunk, run the adjoint right-to-left
+template <typename TIN, typename TY, int VB, int VBY, int LT>
+__global__ void __launch_bounds__(NTHREADS)
+scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
+                const TIN *__restrict__ Bt, int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs,
+                const TY *__restrict__ dy, int64_t dy_rs, const float *__restrict__ h_in,
+                const float *__restrict__ mu_in, TIN *__restrict__ dBt, int64_t dbt_rs,
+                TIN *__restrict__ dC, int64_t dc_rs, float *__restrict__ d_dlt,
+                float *__restrict__ dA_part, ScanDims d) {
+  constexpr int ROWB = TC * sizeof(TIN);
+  constexpr int ROWY = TC * sizeof(TY);
+  constexpr int TS = LT / NSEG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TIN *bt = reinterpret_cast<TIN *>(smem);
+  TIN *cc = reinterpret_cast<TIN *>(smem + LT * ROWB);
+  TY *gy = reinterpret_cast<TY *>(smem + 2 * LT * ROWB);
+  float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB + LT * ROWY);
+  float *ddl = dl + LT * d.HT;
+  float *segs = ddl + LT * d.HT;  // [NSEG][TC][3]
+
+  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
+  const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
+  const int c0 = ct * TC, c = c0 + lane;
+  const int64_t t0 = (int64_t)chunk * LT;
+  const int rows_valid = (int)min((int64_t)LT, d.L - t0);
+  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
+  const int64_t tok0 = (int64_t)b * d.L + t0;
+  const int head0 = c0 >> d.log2N;
+
+  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt),
+                         reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
+                         bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc),
+                         reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
+                         c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_in<VBY, ROWY, LT>(reinterpret_cast<char *>(gy),
+                          reinterpret_cast<const char *>(dy + tok0 * dy_rs + c0),
+                          dy_rs * sizeof(TY), rows_valid, ch_valid * (int)sizeof(TY), tid);
+  stage_delta<LT>(dl, dlt, tok0, rows_valid, head0, (int)d.h, d.HT, d.softplus, tid);
+  const bool chan_ok = c < d.Dn;
+  const float Ac = chan_ok ? -expf(A_log[c]) : 0.f;
+  const float A2 = Ac * LOG2E_F;
+  const int64_t cidx = ((int64_t)b * d.nchunks + chunk) * d.Dn + c;
+  float hcar = chan_ok ? h_in[cidx] : 0.f;
+  float mcar = chan_ok ? mu_in[cidx] : 0.f;
+  __syncthreads();
+
+  float a[TS], hs[TS];
+  float P = 1.f, S = 0.f, M = 0.f;
+  const int hh = lane >> d.log2N;
+#pragma unroll
+  for (int i = 0; i < TS; ++i) {
+    int t = seg * TS + i;
+    a[i] = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
+    S = fmaf(a[i], S, to_f32(bt[t * TC + lane]));
+    P *= a[i];
+  }
+#pragma unroll
+  for (int i = TS - 1; i >= 0; --i) {
+    int t = seg * TS + i;
+    float u = to_f32(gy[t * TC + lane]) * to_f32(cc[t * TC + lane]);
+    M = a[i] * (u + M);
+  }
+  segs[(seg * TC + lane) * 3 + 0] = P;
+  segs[(seg * TC + lane) * 3 + 1] = S;
+  segs[(seg * TC + lane) * 3 + 2] = M;
+  __syncthreads();
+  for (int s = 0; s < seg; ++s)
+    hcar = fmaf(segs[(s * TC + lane) * 3 + 0], hcar, segs[(s * TC + lane) * 3 + 1]);
+  for (int s = NSEG - 1; s > seg; --s)
+    mcar = fmaf(segs[(s * TC + lane) * 3 + 0], mcar, segs[(s * TC + lane) * 3 + 2]);
+
+  // forward recompute of the states of this segment
+  float hst = hcar;
+#pragma unroll
+  for (int i = 0; i < TS; ++i) {
+    int t = seg * TS + i;
+    hst = fmaf(a[i], hst, to_f32(bt[t * TC + lane]));
+    hs[i] = hst;
+  }
+  // adjoint, right to left.  lambda_t = u_t + mu_{t+1};  mu_t = a_t*lambda_t
+  float mu = mcar, dA_acc = 0.f;
+#pragma unroll
+  for (int i = TS - 1; i >= 0; --i) {
+    int t = seg * TS + i;
+    float g = to_f32(gy[t * TC + lane]);
+    float lam = fmaf(g, to_f32(cc[t * TC + lane]), mu);
+    float hprev = i > 0 ? hs[i - 1] : hcar;
+    float q = lam * hprev * a[i] * Ac;  // dL/d(delta*A) * A  = da_t * a_t * A
+    float dlv = dl[t * d.HT + hh];
+    dA_acc = fmaf(q, dlv, dA_acc);       // dA_log[c] += da_t*a_t*delta_t*A
+    float qs = group_sum(q, (int)d.N);   // d delta[t, head] = sum_n da_t*a_t*A
+    if ((lane & ((int)d.N - 1)) == 0) ddl[t * d.HT + hh] = qs;
+    cc[t * TC + lane] = from_f32<TIN>(g * hs[i]);  // dC_t (in place: own column only)
+    bt[t * TC + lane] = from_f32<TIN>(lam);        // dBt_t
+    mu = a[i] * lam;
+  }
+  __syncthreads();  // dBt/dC/ddl tiles complete; segs free for reuse
+  segs[seg * TC + lane] = dA_acc;
+  stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(bt),
+                          reinterpret_cast<char *>(dBt + tok0 * dbt_rs + c0), dbt_rs * sizeof(TIN),
+                          rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(cc),
+                          reinterpret_cast<char *>(dC + tok0 * dc_rs + c0), dc_rs * sizeof(TIN),
+                          rows_valid, ch_valid * (int)sizeof(TIN), tid);
+  for (int idx = tid; idx < LT * d.HT; idx += NTHREADS) {
+    int t = idx / d.HT, hx = idx - t * d.HT;
+    if (t < rows_valid && head0 + hx < d.h) {
+      float v = ddl[idx];
+      if (d.softplus) v *= 1.f - expf(-dl[idx]);  // sigmoid(x) = 1 - exp(-softplus(x))
+      d_dlt[(tok0 + t) * d.h + head0 + hx] = v;
+    }
+  }
+  __syncthreads();
+  if (seg == 0 && chan_ok) {
+    float s = segs[lane] + segs[TC + lane] + segs[2 * TC + lane] + segs[3 * TC + lane];
+    dA_part[cidx] = s;
+  }
+}
+
+// column sums of a [rows, cols] fp32 matrix (deterministic order): out[c] = sum_r in[r][c]
+__global__ void __launch_bounds__(NTHREADS)
+colsum_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
+  __shared__ float part[NSEG][TC];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * TC + lane;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = seg; r < rows; r += NSEG) s += in[r * cols + c];
+  part[seg][lane] = s;
+  __syncthreads();
+  if (seg == 0 && c < cols) out[c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+}
+
+int ilog2_exact(int64_t n) {
+  int l = 0;
+  while ((1LL << l) < n) ++l;
+  return (1LL << l) == n ? l : -1;
+}
+
+constexpr int LT_DEFAULT = 64;
+
+int make_dims(ScanDims &d, int64_t B, int64_t L, int64_t h, int64_t N, int softplus) {
+  if (B <= 0 || L <= 0 || h <= 0 || N <= 0) return APERTIS_ERR_ARG;
+  int l2 = ilog2_exact(N);
+  if (l2 < 0 || N > TC) return APERTIS_ERR_UNSUPPORTED;  // d_state: power of two <= 64
+  d.B = B; d.L = L; d.h = h; d.N = N; d.Dn = h * N;
+  d.log2N = l2; d.HT = (int)(TC / N);
+  d.nchunks = (int)ceil_div64(L, LT_DEFAULT);
+  d.softplus = softplus;
+  if (B > 65535 || ceil_div64(d.Dn, TC) > 65535) return APERTIS_ERR_UNSUPPORTED;
+  return APERTIS_OK;
+}
+
+template <typename T> int slice_align(const void *p, int64_t rs, int64_t Dn) {
+  // bytes: pointer, row stride, the 64-channel tile step and the row length must all be
+  // multiples of the access width (so no access straddles the end of a row slice)
+  return common_align({(uint64_t)(uintptr_t)p, (uint64_t)rs * sizeof(T), (uint64_t)TC * sizeof(T),
+                       (uint64_t)Dn * sizeof(T)});
+}
+
+}  // namespace
+
+extern "C" int64_t apertis_scan_chunk_len(int64_t, int64_t, int64_t) { return LT_DEFAULT; }
+extern "C" int64_t apertis_scan_num_chunks(int64_t, int64_t L, int64_t) {
+  return ceil_div64(L, LT_DEFAULT);
+}
+
+namespace {
+
+template <typename TIN, typename TY, int VB>
+int launch_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
+               int64_t c_rs, const float *h0, void *y, int64_t y_rs, float *h_last, float *agg,
+               float *h_in, const ScanDims &d, hipStream_t st) {
+  constexpr int LT = LT_DEFAULT;
+  dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
+  size_t dlb = (size_t)LT * d.HT * 4;
+  size_t lds1 = LT * TC * sizeof(TIN) + dlb + NSEG * TC * sizeof(float2);
+  size_t lds3 = 2 * LT * TC * sizeof(TIN) + dlb + NSEG * TC * sizeof(float2);
+  hipLaunchKernelGGL((scan_fwd_state<TIN, VB, LT>), grid, block, lds1, st, dlt, A_log,
+                     (const TIN *)Bt, bt_rs, (float2 *)agg, d);
+  int64_t n = d.B * d.Dn;
+  hipLaunchKernelGGL(scan_chunk_prefix, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
+                     (const float2 *)agg, h0, h_in, h_last, d.B, d.Dn, d.nchunks, 0);
+  hipLaunchKernelGGL((scan_fwd_replay<TIN, TY, VB, LT>), grid, block, lds3, st, dlt, A_log,
+                     (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, h_in, (TY *)y, y_rs, d);
+  return apertis_check_launch();
+}
+
+template <typename TIN, typename TY, int VB, int VBY>
+int launch_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
+               int64_t c_rs, const void *dy, int64_t dy_rs, const float *h_in, void *dBt,
+               int64_t dbt_rs, void *dC, int64_t dc_rs, float *d_dlt, float *dA_log, float *agg,
+               float *mu_in, float *dA_part, const ScanDims &d, hipStream_t st) {
+  constexpr int LT = LT_DEFAULT;
+  dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
+  size_t dlb = (size_t)LT * d.HT * 4;
+  size_t lds1 = LT * TC * (sizeof(TIN) + sizeof(TY)) + dlb + NSEG * TC * sizeof(float2);
+  size_t lds3 = LT * TC * (2 * sizeof(TIN) + sizeof(TY)) + 2 * dlb + NSEG * TC * 3 * sizeof(float);
+  hipLaunchKernelGGL((scan_bwd_state<TIN, TY, VB, VBY, LT>), grid, block, lds1, st, dlt, A_log,
+                     (const TIN *)C, c_rs, (const TY *)dy, dy_rs, (float2 *)agg, d);
+  int64_t n = d.B * d.Dn;
+  hipLaunchKernelGGL(scan_chunk_prefix, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
+                     (const float2 *)agg, (const float *)nullptr, mu_in, (float *)nullptr, d.B,
+                     d.Dn, d.nchunks, 1);
+  hipLaunchKernelGGL((scan_bwd_replay<TIN, TY, VB, VBY, LT>), grid, block, lds3, st, dlt, A_log,
+                     (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const TY *)dy, dy_rs, h_in,
+                     mu_in, (TIN *)dBt, dbt_rs, (TIN *)dC, dc_rs, d_dlt, dA_part, d);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(d.Dn, TC)), dim3(NTHREADS), 0, st,
+                     dA_part, dA_log, d.B * d.nchunks, d.Dn);
+  return apertis_check_launch();
+}
+
+}  // namespace
+
+extern "C" int apertis_selective_scan_fwd(const float *dlt, const float *A_log, const void *Bt,
+                                          int64_t bt_rs, const void *C, int64_t c_rs,
+                                          const float *h0, void *y, int64_t y_rs, float *h_last,
+                                          float *agg, float *h_in, int64_t B, int64_t L, int64_t h,
+                                          int64_t N, int dtype_bc, int dtype_y, int delta_softplus,
+                                          void *stream) {
+  if (!dlt || !A_log || !Bt || !C || !y || !agg || !h_in) return APERTIS_ERR_ARG;
+  ScanDims d;
+  int rc = make_dims(d, B, L, h, N, delta_softplus);
+  if (rc) return rc;
+  if (bt_rs < d.Dn || c_rs < d.Dn || y_rs < d.Dn) return APERTIS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define FWD(TIN, TY, VB) \
+  return launch_fwd<TIN, TY, VB>(dlt, A_log, Bt, bt_rs, C, c_rs, h0, y, y_rs, h_last, agg, h_in, d, st)
+  if (dtype_bc == APERTIS_F32 && dtype_y == APERTIS_F32) {
+    int al = std::min(slice_align<float>(Bt, bt_rs, d.Dn), slice_align<float>(C, c_rs, d.Dn));
+    if (al >= 16) FWD(float, float, 16);
+    if (al >= 8) FWD(float, float, 8);
+    FWD(float, float, 4);
+  } else if (dtype_bc == APERTIS_BF16 && dtype_y == APERTIS_F32) {
+    int al = std::min(slice_align<bf16_t>(Bt, bt_rs, d.Dn), slice_align<bf16_t>(C, c_rs, d.Dn));
+    if (al >= 16) FWD(bf16_t, float, 16);
+    if (al >= 8) FWD(bf16_t, float, 8);
+    if (al >= 4) FWD(bf16_t, float, 4);
+    FWD(bf16_t, float, 2);
+  } else if (dtype_bc == APERTIS_BF16 && dtype_y == APERTIS_BF16) {
+    int al = std::min({slice_align<bf16_t>(Bt, bt_rs, d.Dn), slice_align<bf16_t>(C, c_rs, d.Dn),
+                       slice_align<bf16_t>(y, y_rs, d.Dn)});
+    if (al >= 16) FWD(bf16_t, bf16_t, 16);
+    if (al >= 8) FWD(bf16_t, bf16_t, 8);
+    if (al >= 4) FWD(bf16_t, bf16_t, 4);
+    FWD(bf16_t, bf16_t, 2);
+  }
+#undef FWD
+  return APERTIS_ERR_UNSUPPORTED;
+}
+
+extern "C" int apertis_selective_scan_bwd(const float *dlt, const float *A_log, const void *Bt,
+                                          int64_t bt_rs, const void *C, int64_t c_rs,
+                                          const void *dy, int64_t dy_rs, const float *h_in,
+                                          void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs,
+                                          float *d_dlt, float *dA_log, float *agg, float *mu_in,
+                                          float *dA_part, int64_t B, int64_t L, int64_t h,
+                                          int64_t N, int dtype_bc, int dtype_y, int delta_softplus,
+                                          void *stream) {
+  if (!dlt || !A_log || !Bt || !C || !dy || !h_in || !dBt || !dC || !d_dlt || !dA_log || !agg ||
+      !mu_in || !dA_part)
+    return APERTIS_ERR_ARG;
+  ScanDims d;
+  int rc = make_dims(d, B, L, h, N, delta_softplus);
+  if (rc) return rc;
+  if (bt_rs < d.Dn || c_rs < d.Dn || dy_rs < d.Dn || dbt_rs < d.Dn || dc_rs < d.Dn)
+    return APERTIS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define BWD(TIN, TY, VB, VBY)                                                                   \
+  return launch_bwd<TIN, TY, VB, VBY>(dlt, A_log, Bt, bt_rs, C, c_rs, dy, dy_rs, h_in, dBt,     \
+                                      dbt_rs, dC, dc_rs, d_dlt, dA_log, agg, mu_in, dA_part, d, st)
+  if (dtype_bc == APERTIS_F32 && dtype_y == APERTIS_F32) {
+    int al = std::min({slice_align<float>(Bt, bt_rs, d.Dn), slice_align<float>(C, c_rs, d.Dn),
+                       slice_align<float>(dBt, dbt_rs, d.Dn), slice_align<float>(dC, dc_rs, d.Dn),
+                       slice_align<float>(dy, dy_rs, d.Dn)});
+    if (al >= 16) BWD(float, float, 16, 16);
+    if (al >= 8) BWD(float, float, 8, 8);
+    BWD(float, float, 4, 4);
+  } else if (dtype_bc == APERTIS_BF16) {
+    int al = std::min({slice_align<bf16_t>(Bt, bt_rs, d.Dn), slice_align<bf16_t>(C, c_rs, d.Dn),
+                       slice_align<bf16_t>(dBt, dbt_rs, d.Dn), slice_align<bf16_t>(dC, dc_rs, d.Dn)});
+    if (dtype_y == APERTIS_F32) {
+      int aly = slice_align<float>(dy, dy_rs, d.Dn);
+      if (al >= 16 && aly >= 16) BWD(bf16_t, float, 16, 16);
+      if (al >= 8 && aly >= 16) BWD(bf16_t, float, 8, 16);
+      if (al >= 8 && aly >= 8) BWD(bf16_t, float, 8, 8);
+      if (al >= 4) BWD(bf16_t, float, 4, 4);
+      BWD(bf16_t, float, 2, 4);
+    } else if (dtype_y == APERTIS_BF16) {
+      int aly = slice_align<bf16_t>(dy, dy_rs, d.Dn);
+      int a2 = std::min(al, aly);
+      if (a2 >= 16) BWD(bf16_t, bf16_t, 16, 16);
+      if (a2 >= 8) BWD(bf16_t, bf16_t, 8, 8);
+      if (a2 >= 4) BWD(bf16_t, bf16_t, 4, 4);
+      BWD(bf16_t, bf16_t, 2, 2);
+    }
+  }
+#undef BWD
+  return APERTIS_ERR_UNSUPPORTED;
+}

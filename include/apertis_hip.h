@@ -1,0 +1,221 @@
+/*
+ * apertis_hip.h — C ABI of libapertis_hip.so, the MI355X (gfx950) kernel library behind the
+ * Apertis hot path (selective-SSM scan, MoE router/permute/grouped-GEMM, patch-embed GEMM).
+ *
+ * The reference (CuzImSlymi/Apertis-LLM) is pure Python and has no FFI of its own; each entry
+ * point below replaces a chain of torch ops inside one reference function, cited per function
+ * as /root/reference/<file>:<lines>.  INTEGRATION.md shows the ctypes stubs a reference
+ * maintainer would add.
+ *
+ * Conventions (every function):
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); kernels never allocate;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no sync;
+ *   - returns 0 (APERTIS_OK) or a negative error code; never throws across the ABI;
+ *   - re-entrant, no process-global state, safe to dlopen lazily after fork().
+ */
+#ifndef APERTIS_HIP_H
+#define APERTIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APERTIS_OK 0
+#define APERTIS_ERR_ARG (-1)         /* null pointer / negative size / bad enum            */
+#define APERTIS_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for       */
+#define APERTIS_ERR_LAUNCH (-3)      /* hipGetLastError() after a launch was not success   */
+
+#define APERTIS_F32 0
+#define APERTIS_BF16 1
+
+#define APERTIS_ACT_NONE 0
+#define APERTIS_ACT_GELU 1 /* erf GELU, torch.nn.GELU() default */
+#define APERTIS_ACT_RELU 2
+#define APERTIS_ACT_SILU 3
+
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes. */
+int apertis_abi_version(void);
+/* Name of the code-object architecture this library was compiled for ("gfx950"). */
+const char *apertis_arch(void);
+/* Human-readable text for an error code returned by any function below. */
+const char *apertis_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Selective-SSM scan  (replaces SelectiveLinearAttention._ssm_pytorch_scan_recurrent,
+ * src/model/core.py:337-353, the semantic ground truth; and _ssm_scan_parallel :324-335)
+ *
+ *   A[c]    = -exp(A_log[c])                      c = head*N + n   (h*N = Dn channels)
+ *   delta   = softplus(dlt) if delta_softplus else dlt      (core.py:383)
+ *   a[b,t,c]= exp(delta[b,t,head(c)] * A[c])
+ *   s[b,t,c]= a[b,t,c]*s[b,t-1,c] + Bt[b,t,c]     s[b,-1,c] = h0[b,c] or 0
+ *   y[b,t,c]= C[b,t,c]*s[b,t,c]
+ *
+ * Layout: token-major.  dlt is [B,L,h] fp32 (row stride h).  Bt, C are [B,L,Dn] views with an
+ * explicit row stride in ELEMENTS (they are column slices of the x_param_proj output,
+ * core.py:377-385) and batch stride L*row_stride.  y is [B,L,Dn] with row stride y_rs.
+ * dtype_bc / dtype_y select fp32 or bf16 storage; state and arithmetic are always fp32.
+ *
+ * Chunked scan: L is cut into chunks of apertis_scan_chunk_len() tokens.
+ *   agg   : workspace  [B, nchunks, Dn, 2] fp32   (chunk aggregates, scratch)
+ *   h_in  : output     [B, nchunks, Dn]    fp32   (state entering each chunk; saved for bwd)
+ *   h_last: optional   [B, Dn] fp32 final state (core.py:351 new_ssm_state), may be NULL
+ * ------------------------------------------------------------------------------------------ */
+int64_t apertis_scan_chunk_len(int64_t B, int64_t L, int64_t Dn);
+int64_t apertis_scan_num_chunks(int64_t B, int64_t L, int64_t Dn);
+
+int apertis_selective_scan_fwd(const float *dlt, const float *A_log,
+                               const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                               const float *h0, void *y, int64_t y_rs, float *h_last,
+                               float *agg, float *h_in,
+                               int64_t B, int64_t L, int64_t h, int64_t N,
+                               int dtype_bc, int dtype_y, int delta_softplus, void *stream);
+
+/* Backward of the scan (no reference code: autograd through core.py:347-349).
+ *   dy            : [B,L,Dn] (row stride dy_rs, dtype_y)
+ *   dBt, dC       : [B,L,Dn] views (row strides dbt_rs/dc_rs, dtype_bc)
+ *   d_dlt         : [B,L,h] fp32; gradient w.r.t. dlt (through softplus if delta_softplus)
+ *   dA_log        : [h*N] fp32 (overwritten)
+ *   h_in          : saved by the forward
+ *   agg           : workspace [B,nchunks,Dn,2] fp32
+ *   mu_in         : workspace [B,nchunks,Dn]   fp32
+ *   dA_part       : workspace [B*nchunks, Dn]  fp32
+ */
+int apertis_selective_scan_bwd(const float *dlt, const float *A_log,
+                               const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                               const void *dy, int64_t dy_rs, const float *h_in,
+                               void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs,
+                               float *d_dlt, float *dA_log,
+                               float *agg, float *mu_in, float *dA_part,
+                               int64_t B, int64_t L, int64_t h, int64_t N,
+                               int dtype_bc, int dtype_y, int delta_softplus, void *stream);
+
+/* Post-scan gate (core.py:395-396):  out = (y + D[c]*xc) * silu(z),  all [T,Dn] row-major
+ * with row strides; dtype_io for xc/z/out, dtype_y for y.  Backward returns dy, dxc, dz, dD. */
+int apertis_ssm_gate_fwd(const void *y, int64_t y_rs, const void *xc, int64_t xc_rs,
+                         const void *z, int64_t z_rs, const float *D, void *out, int64_t out_rs,
+                         int64_t T, int64_t Dn, int dtype_y, int dtype_io, void *stream);
+int apertis_ssm_gate_bwd(const void *dout, int64_t dout_rs, const void *y, int64_t y_rs,
+                         const void *xc, int64_t xc_rs, const void *z, int64_t z_rs,
+                         const float *D, void *dy, int64_t dy_rs, void *dxc, int64_t dxc_rs,
+                         void *dz, int64_t dz_rs, float *dD_part /* [nblk,Dn] */,
+                         int64_t nblk, int64_t T, int64_t Dn, int dtype_y, int dtype_io,
+                         void *stream);
+int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn);
+
+/* Depthwise causal conv1d (k taps, left pad k-1, keep first L) + SiLU on token-major data
+ * (replaces core.py:368-375: transpose -> nn.Conv1d(groups=Dn, padding=k-1)[:, :, :L] ->
+ * transpose -> F.silu).  x,out: [B,L,Dn] with row strides; w: [Dn,k] fp32; bias: [Dn] fp32. */
+int apertis_dwconv_silu_fwd(const void *x, int64_t x_rs, const float *w, const float *bias,
+                            void *out, int64_t out_rs, int64_t B, int64_t L, int64_t Dn,
+                            int64_t k, int dtype_io, void *stream);
+int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float *w, const float *bias,
+                            const void *dout, int64_t dout_rs, void *dx, int64_t dx_rs,
+                            float *dw_part /* [nblk,Dn,k] */, float *db_part /* [nblk,Dn] */,
+                            int64_t nblk, int64_t B, int64_t L, int64_t Dn, int64_t k,
+                            int dtype_io, void *stream);
+int64_t apertis_dwconv_bwd_blocks(int64_t B, int64_t L, int64_t Dn);
+
+/* ------------------------------------------------------------------------------------------
+ * MoE router gating  (replaces AdaptiveExpertSystem.forward core.py:491-492,529)
+ *   g = softmax(logits)              logits [S,E] fp32 (already noised if training)
+ *   (p, idx) = topk(g, K) descending, ties -> lowest expert index first
+ *   w = p / (sum(p) + 1e-6)
+ * Outputs: gates [S,E] fp32, idx [S,K] int32, w [S,K] fp32.
+ * Backward: given dw [S,K] and dgates [S,E] (from the aux losses) returns dlogits [S,E].
+ * ------------------------------------------------------------------------------------------ */
+int apertis_moe_gate_topk_fwd(const float *logits, float *gates, int32_t *idx, float *w,
+                              int64_t S, int64_t E, int64_t K, void *stream);
+int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx, const float *dw,
+                              const float *dgates, float *dlogits,
+                              int64_t S, int64_t E, int64_t K, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MoE dispatch plan  (replaces the K x E Python loop core.py:547-591: nonzero / capacity /
+ * overflow top-n by gate weight).  Canonical row order: expert-major, then k, then token
+ * (equivalent to the reference's k-major loop because capacity is per expert).
+ *   capacity <= 0 means "no limit" (eval, core.py:508).
+ *   active   : optional [E] uint8 mask of experts not dropped (core.py:514-521), NULL = all.
+ * Outputs:
+ *   expert_offsets [E+1] int32 : row range of each expert in the permuted order
+ *   row_token [S*K] int32, row_k [S*K] int32 : (token, k) of each kept row (first total rows)
+ *   slot_of [S,K] int32 : permuted row of assignment (s,k) or -1 if dropped
+ * Workspace ws: apertis_moe_plan_workspace_bytes(S,E,K) bytes, int32-aligned.
+ * ------------------------------------------------------------------------------------------ */
+int64_t apertis_moe_plan_workspace_bytes(int64_t S, int64_t E, int64_t K);
+int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_t *active,
+                     int64_t capacity, int32_t *expert_offsets, int32_t *row_token,
+                     int32_t *row_k, int32_t *slot_of, void *ws,
+                     int64_t S, int64_t E, int64_t K, void *stream);
+
+/* Gather + per-expert LayerNorm (core.py:593 gather, :436 expert LayerNorm):
+ *   xg[r,:] = LN_e(x[row_token[r],:]) * gamma[e] + beta[e],   e = expert owning row r.
+ * x [S,H] dtype_x; gamma,beta [E,H] fp32; xg [cap_rows,H] dtype_out; mean,rstd [cap_rows] fp32.
+ * Rows >= expert_offsets[E] are left untouched.  max_rows bounds the launch (no host sync). */
+int apertis_moe_gather_ln_fwd(const void *x, const int32_t *row_token,
+                              const int32_t *expert_offsets, const float *gamma,
+                              const float *beta, float eps, void *xg, float *mean, float *rstd,
+                              int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_out,
+                              void *stream);
+/* Backward: dxg [rows,H] -> per-row dx contribution dxr [rows,H] (LN backward), plus partial
+ * sums for dgamma/dbeta [nblk,E,H].  Rows are later scattered by apertis_moe_combine_*. */
+int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
+                              const int32_t *expert_offsets, const float *gamma,
+                              const float *mean, const float *rstd, const void *dxg,
+                              void *dxr, float *dgamma_part, float *dbeta_part, int64_t nblk,
+                              int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_g,
+                              void *stream);
+int64_t apertis_moe_gather_ln_bwd_blocks(int64_t max_rows, int64_t H);
+
+/* Combine (core.py:594,605 weights * expert_output, index_add_):
+ *   out[s,:] = sum_{k asc, slot_of[s,k]>=0} wk[s,k] * yr[slot_of[s,k],:]   (zeros if none)
+ * with_weights=0 uses weight 1 (used to scatter the LN-backward rows).  */
+int apertis_moe_combine_fwd(const void *yr, const int32_t *slot_of, const float *wk,
+                            void *out, int64_t S, int64_t H, int64_t K, int with_weights,
+                            int dtype_yr, int dtype_out, void *stream);
+/* Backward of combine: dyr[r,:] = wk[s,k]*dout[s,:]; dwk[s,k] = <dout[s,:], yr[r,:]> */
+int apertis_moe_combine_bwd(const void *dout, const void *yr, const int32_t *row_token,
+                            const int32_t *row_k, const int32_t *expert_offsets,
+                            const float *wk, void *dyr, float *dwk, int64_t max_rows,
+                            int64_t S, int64_t H, int64_t K, int64_t E, int dtype_dout,
+                            int dtype_yr, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped GEMM on CDNA4 MFMA  (replaces the per-expert nn.Linear calls core.py:437,440,596;
+ * with E=1 also the patch-embed Conv2d-as-GEMM multimodal/module.py:35-40,102 and
+ * vision_projection core.py:1035,1209).
+ *
+ * Rows of A/C are grouped by expert: group e owns rows [offsets[e], offsets[e+1]).
+ *   NT  (forward)   : C[r,n]  = act( sum_k A[r,k] * W[e,n,k] + bias[e,n] )   W [E,N,K]
+ *   NN  (dgrad)     : C[r,n]  = sum_k A[r,k] * W[e,k,n]                      W [E,K,N]
+ *   TN  (wgrad)     : dW[e,m,n] = sum_{r in e} A[r,m] * Bm[r,n]   (+ dbias[e,m] = sum_r A[r,m])
+ * dtype: APERTIS_BF16 -> bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16;
+ *        APERTIS_F32  -> fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+ * max_rows bounds the grid (offsets live on the device; no host sync).
+ * pre_act (optional, NT only): also stores the pre-activation (needed by the backward).
+ * dropout (NT only): if drop_p>0 the activation output is multiplied by a keep mask /(1-p)
+ *   from a counter-based hash of (seed, row, col) so the backward can regenerate it
+ *   (reference: nn.Dropout inside each expert, core.py:439).
+ * ------------------------------------------------------------------------------------------ */
+int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
+                            const int32_t *offsets, void *C, void *pre_act,
+                            int64_t max_rows, int64_t N, int64_t K, int64_t E,
+                            int act, float drop_p, uint64_t seed,
+                            int dtype, int dtype_out, void *stream);
+int apertis_grouped_gemm_nn(const void *A, const void *W, const int32_t *offsets, void *C,
+                            int64_t max_rows, int64_t N, int64_t K, int64_t E,
+                            int dtype, int dtype_out, void *stream);
+int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
+                            float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
+                            int64_t E, int dtype, void *stream);
+/* Elementwise backward of act+dropout: dpre = dh * mask/(1-p) * act'(pre). In place allowed. */
+int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void *dpre,
+                            const int32_t *offsets, int64_t max_rows, int64_t N, int64_t E,
+                            int act, float drop_p, uint64_t seed, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APERTIS_HIP_H */

@@ -1,0 +1,173 @@
+"""Parity of the HIP selective scan (through the C ABI) with the CPU oracle and with the golden
+vectors captured from the reference (tests/golden/scan_*.npz, made by tools/gen_golden.py).
+
+Tolerances: the reference target is fp32 results within 1e-4 rtol (BASELINE.json north_star);
+fp32 checks below use rtol 1e-4 with a small atol scaled to the tensor magnitude.
+"""
+import math
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _close(got, ref, name, rtol=RTOL, atol_scale=2e-6):
+    ref = ref.to(torch.float64)
+    got = got.detach().cpu().to(torch.float64)
+    atol = atol_scale * float(ref.abs().max()) + 1e-30
+    bad = (got - ref).abs() > atol + rtol * ref.abs()
+    assert not bad.any(), f"{name}: {int(bad.sum())} / {bad.numel()} outside rtol {rtol}; max abs diff " \
+                          f"{float((got - ref).abs().max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+
+
+def _run(dev, delta, A_log, Bt, C, dy, h0=None, **kw):
+    from apertis_llm_amd import ops
+    d = delta.float().to(dev).requires_grad_(True)
+    a = A_log.float().to(dev).requires_grad_(True)
+    b = Bt.to(dev).requires_grad_(True)
+    c = C.to(dev).requires_grad_(True)
+    res = ops.selective_scan(d, a, b, c, None if h0 is None else h0.float().to(dev), return_last=True, **kw)
+    y, hl = res
+    y.backward(dy.to(dev).to(y.dtype))
+    return y, hl, d.grad, a.grad, b.grad, c.grad
+
+
+@pytest.mark.parametrize("name", ["L1", "L7", "L64", "L257", "L2048", "bigdelta"])
+def test_scan_golden_fp32(dev, name):
+    g = load_golden("scan_" + name)
+    y, hl, dd, da, db, dc = _run(dev, g["delta"], g["A_log"], g["Bt"], g["C"], g["dy"], g.get("h0"))
+    _close(y, g["y"], "y")
+    if "h_last" in g:
+        _close(hl, g["h_last"], "h_last")
+    _close(dd, g["d_delta"], "d_delta", atol_scale=1e-5)
+    _close(da, g["dA_log"], "dA_log", atol_scale=1e-5)
+    _close(db, g["dBt"], "dBt")
+    _close(dc, g["dC"], "dC")
+    if name == "bigdelta":
+        assert int(g["parallel_nonfinite"]) > 0  # the reference's cumsum form blows up here; we must not
+        assert torch.isfinite(y).all()
+
+
+def test_scan_golden_f64_reference(dev):
+    """fp32 kernel against the reference run in float64: bounds the kernel's own rounding."""
+    g = load_golden("scan_L257_f64")
+    y, hl, dd, da, db, dc = _run(dev, g["delta"], g["A_log"], g["Bt"].float(), g["C"].float(), g["dy"].float())
+    _close(y, g["y"], "y", rtol=2e-5)
+    _close(db, g["dBt"], "dBt", rtol=2e-5)
+    _close(dd, g["d_delta"], "d_delta", rtol=2e-5, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("B,L,h,N", [(2, 130, 11, 16), (1, 4096, 4, 16), (3, 64, 14, 16), (2, 100, 5, 8), (1, 77, 2, 64)])
+@pytest.mark.parametrize("softplus", [False, True])
+def test_scan_vs_oracle_strided_views(dev, B, L, h, N, softplus):
+    """Bt/C taken as the strided column slices of one projection output (core.py:377-385),
+    ragged L, channel tiles with tails (Dn=176), in-kernel softplus."""
+    from oracle import ref_cpu
+    torch.manual_seed(L * h)
+    R = math.ceil(h * N / 4)
+    Dn = h * N
+    p = torch.randn(B, L, R + 2 * Dn)
+    logits = torch.randn(B, L, h) - 4.0
+    A_log = torch.empty(h, N).uniform_(math.log(0.5), math.log(0.99))
+    dy = torch.randn(B, L, Dn)
+    h0 = torch.randn(B, Dn)
+    delta = torch.nn.functional.softplus(logits)
+    Bt, C = p[..., R:R + Dn], p[..., R + Dn:]
+    yo, hlo = ref_cpu.scan_recurrent(delta, A_log, Bt, C, h0)
+    ddo, dao, dbo, dco = ref_cpu.scan_backward(delta, A_log, Bt, C, dy, h0)
+    if softplus:
+        ddo = ddo * torch.sigmoid(logits)
+
+    from apertis_llm_amd import ops
+    pd = p.to(dev).requires_grad_(True)
+    dl = (logits if softplus else delta).to(dev).requires_grad_(True)
+    al = A_log.to(dev).requires_grad_(True)
+    y, hl = ops.selective_scan(dl, al, pd[..., R:R + Dn], pd[..., R + Dn:], h0.to(dev), delta_softplus=softplus,
+                               return_last=True)
+    y.backward(dy.to(dev))
+    _close(y, yo, "y")
+    _close(hl, hlo, "h_last")
+    _close(dl.grad, ddo, "d_delta", atol_scale=2e-5)
+    _close(al.grad, dao, "dA_log", atol_scale=2e-5)
+    _close(pd.grad[..., R:R + Dn], dbo, "dBt")
+    _close(pd.grad[..., R + Dn:], dco, "dC")
+    assert float(pd.grad[..., :R].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("y_dtype", [torch.float32, torch.bfloat16])
+def test_scan_bf16_io(dev, y_dtype):
+    """bf16 Bt/C (what bf16 autocast hands the op): compare with the oracle fed the SAME
+    bf16-rounded inputs; the state stays fp32 so only output rounding differs."""
+    from oracle import ref_cpu
+    torch.manual_seed(3)
+    B, L, h, N = 2, 300, 11, 16
+    Dn = h * N
+    R = 44
+    p = torch.randn(B, L, R + 2 * Dn).bfloat16()
+    delta = torch.nn.functional.softplus(torch.randn(B, L, h) - 4.0)
+    A_log = torch.empty(h, N).uniform_(math.log(0.5), math.log(0.99))
+    dy = torch.randn(B, L, Dn).to(y_dtype)
+    Bt, C = p[..., R:R + Dn], p[..., R + Dn:]
+    yo, _ = ref_cpu.scan_recurrent(delta, A_log, Bt.float(), C.float())
+    ddo, dao, dbo, dco = ref_cpu.scan_backward(delta, A_log, Bt.float(), C.float(), dy.float())
+    from apertis_llm_amd import ops
+    pd = p.to(dev).requires_grad_(True)
+    dl = delta.to(dev).requires_grad_(True)
+    al = A_log.to(dev).requires_grad_(True)
+    y = ops.selective_scan(dl, al, pd[..., R:R + Dn], pd[..., R + Dn:], y_dtype=y_dtype)
+    assert y.dtype == y_dtype
+    y.backward(dy.to(dev))
+    out_tol = 1e-4 if y_dtype == torch.float32 else 8e-3   # bf16 has 8 significant bits
+    _close(y, yo, "y", rtol=out_tol, atol_scale=out_tol)
+    _close(dl.grad, ddo, "d_delta", atol_scale=2e-5)
+    _close(al.grad, dao, "dA_log", atol_scale=2e-5)
+    _close(pd.grad[..., R:R + Dn], dbo, "dBt", rtol=8e-3, atol_scale=8e-3)   # stored as bf16
+    _close(pd.grad[..., R + Dn:], dco, "dC", rtol=8e-3, atol_scale=8e-3)
+
+
+def test_scan_full_size_properties(dev):
+    """BASELINE config sizes (seq 4096, 11 heads x 16): size-independent properties.
+    (1) splitting the sequence and chaining the carried state reproduces the one-shot scan;
+    (2) linearity in Bt;  (3) dBt of a scan with C=1, dy=1 equals the reverse cumulative
+    product sum, checked through the adjoint identity <dy, y(Bt)> == <dBt, Bt>."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(0)
+    B, L, h, N = 4, 4096, 11, 16
+    Dn = h * N
+    delta = torch.nn.functional.softplus(torch.randn(B, L, h, device=dev) - 5.5)
+    A_log = torch.empty(h, N, device=dev).uniform_(math.log(0.5), math.log(0.99))
+    Bt = torch.randn(B, L, Dn, device=dev)
+    Bt2 = torch.randn(B, L, Dn, device=dev)
+    C = torch.randn(B, L, Dn, device=dev)
+    y, hl = ops.selective_scan(delta, A_log, Bt, C, return_last=True)
+    ya, ha = ops.selective_scan(delta[:, :1500], A_log, Bt[:, :1500], C[:, :1500], return_last=True)
+    yb, hb = ops.selective_scan(delta[:, 1500:].contiguous(), A_log, Bt[:, 1500:], C[:, 1500:], h0=ha, return_last=True)
+    _close(torch.cat([ya, yb], 1), y.cpu(), "split/chain", rtol=2e-5, atol_scale=2e-6)
+    _close(hb, hl.cpu(), "final state", rtol=2e-5)
+    y2 = ops.selective_scan(delta, A_log, Bt2, C)
+    y12 = ops.selective_scan(delta, A_log, Bt + Bt2, C)
+    _close(y12, (y + y2).cpu(), "linearity", rtol=1e-4, atol_scale=1e-5)
+    Btg = Bt.clone().requires_grad_(True)
+    dy = torch.randn(B, L, Dn, device=dev)
+    yg = ops.selective_scan(delta, A_log, Btg, C)
+    yg.backward(dy)
+    lhs = float((dy.double() * yg.double()).sum())
+    rhs = float((Btg.grad.double() * Bt.double()).sum())
+    assert abs(lhs - rhs) <= 1e-4 * abs(lhs) + 1e-3, (lhs, rhs)
+
+
+def test_scan_rejects_bad_input(dev):
+    from apertis_llm_amd import ops
+    from apertis_llm_amd._lib import ApertisHipError
+    d = torch.rand(1, 8, 2, device=dev)
+    A = torch.zeros(2, 12, device=dev)   # d_state not a power of two
+    x = torch.randn(1, 8, 24, device=dev)
+    with pytest.raises(ApertisHipError):
+        ops.selective_scan(d, A, x, x)
+    with pytest.raises(ApertisHipError):
+        ops.selective_scan(d.cpu(), A.cpu(), x.cpu(), x.cpu())

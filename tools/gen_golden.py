@@ -1,0 +1,279 @@
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (imported from /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box; the .npz data
+fixtures do).  Import recipe per SURVEY.md §8(c): stub torchvision / wandb in sys.modules, then
+`from src.model.core import ...`.  Every fixture is inputs + the reference's outputs; nothing
+of the reference's source is stored.
+
+    python tools/gen_golden.py            # writes tests/golden/, prints oracle-vs-reference diffs
+"""
+import importlib.machinery
+import json
+import math
+import os
+import sys
+import types
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def _stub(name, classes=()):
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    for c in classes:
+        setattr(m, c, type(c, (), {"__init__": lambda self, *a, **k: None}))
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    tv = _stub("torchvision")
+    tv.transforms = _stub("torchvision.transforms", ["Compose", "Resize", "ToTensor", "Normalize"])
+    _stub("wandb")
+    sys.path.insert(0, "/root/reference")
+    import src.model.core as core
+    return core
+
+
+def npz(name, **arrs):
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KB)")
+
+
+def sd_arrays(sd, prefix="sd::"):
+    return {prefix + k: v for k, v in sd.items()}
+
+
+def gen_scan(core):
+    """S2: (delta, A_log, Bt, C[, h0]) -> y, h_L and dy -> d_delta, dA_log, dBt, dC."""
+    from oracle import ref_cpu
+    cases = [  # name, B, L, h, N, delta_mean, with_h0, dtype
+        ("L1", 2, 1, 2, 16, -5.5, False, torch.float32),
+        ("L7", 2, 7, 3, 16, -5.5, True, torch.float32),
+        ("L64", 1, 64, 2, 16, -5.5, False, torch.float32),
+        ("L257", 2, 257, 2, 16, -3.0, True, torch.float32),
+        ("L2048", 1, 2048, 1, 4, -5.5, False, torch.float32),
+        ("L257_f64", 1, 257, 1, 16, -4.0, False, torch.float64),
+        ("bigdelta", 1, 512, 1, 16, -1.0, False, torch.float32),  # sum(delta*|A|) >> 87: the parallel form NaNs
+    ]
+    for name, B, L, h, N, dmean, with_h0, dt in cases:
+        g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % (2 ** 31))
+        cfg = core.ApertisConfig(hidden_size=16 * h, num_attention_heads=h, ssm_d_state=N,
+                                 attention_type="selective_ssm")
+        mod = core.SelectiveLinearAttention(cfg).to(dt)
+        delta = torch.nn.functional.softplus(torch.randn(B, L, h, generator=g, dtype=dt) + dmean)
+        if name == "bigdelta":
+            delta = delta + 0.3
+        A_log = (torch.rand(h, N, generator=g, dtype=dt) * (math.log(0.99) - math.log(0.5)) + math.log(0.5))
+        Bt = torch.randn(B, L, h * N, generator=g, dtype=dt)
+        C = torch.randn(B, L, h * N, generator=g, dtype=dt)
+        dy = torch.randn(B, L, h * N, generator=g, dtype=dt)
+        h0 = torch.randn(B, h * N, generator=g, dtype=dt) if with_h0 else None
+        leaves = [t.clone().requires_grad_(True) for t in (delta, A_log, Bt, C)]
+        d_, a_, b_, c_ = leaves
+        # reference layouts: delta (B,h,L,1); Bt/C/u (B,h,L,N)  (core.py:383-386)
+        to_bhln = lambda t: t.view(B, L, h, N).transpose(1, 2)
+        mod.use_cache = with_h0
+        res = mod._ssm_pytorch_scan_recurrent(to_bhln(b_), d_.transpose(1, 2).unsqueeze(-1), a_, to_bhln(b_),
+                                              to_bhln(c_), None if h0 is None else h0.view(B, h, N))
+        y_ref, hl_ref = res if with_h0 else (res, None)
+        y_tm = y_ref.transpose(1, 2).contiguous().view(B, L, h * N)        # core.py:394
+        y_tm.backward(dy)
+        # oracle cross-check
+        yo, hlo = ref_cpu.scan_recurrent(delta, A_log, Bt, C, h0)
+        go = ref_cpu.scan_backward(delta, A_log, Bt, C, dy, h0)
+        errs = [float((yo - y_tm).abs().max())] + [float((o - l.grad).abs().max() / (l.grad.abs().max() + 1e-30))
+                                                   for o, l in zip(go, leaves)]
+        print(f"  scan_{name}: oracle-vs-reference y abs {errs[0]:.2e}; grad rel (d_delta,dA_log,dBt,dC) "
+              + " ".join(f"{e:.1e}" for e in errs[1:]))
+        par = mod._ssm_scan_parallel(to_bhln(Bt), delta.transpose(1, 2).unsqueeze(-1), A_log, to_bhln(Bt), to_bhln(C))
+        arrs = dict(delta=delta, A_log=A_log, Bt=Bt, C=C, dy=dy, y=y_tm, d_delta=d_.grad, dA_log=a_.grad,
+                    dBt=b_.grad, dC=c_.grad, parallel_nonfinite=int((~torch.isfinite(par)).sum()))
+        if with_h0:
+            arrs.update(h0=h0, h_last=hl_ref.reshape(B, h * N))
+        npz("scan_" + name, **arrs)
+
+
+def gen_ssm_layer(core):
+    from oracle import ref_cpu
+    torch.manual_seed(11)
+    cfg = core.ApertisConfig(hidden_size=48, num_attention_heads=3, ssm_d_state=16, attention_type="selective_ssm")
+    mod = core.SelectiveLinearAttention(cfg).eval()
+    with torch.no_grad():  # move the SSM parameters off their init so the test is not trivial
+        mod.A_log.add_(0.1 * torch.randn_like(mod.A_log))
+        mod.D.add_(0.1 * torch.randn_like(mod.D))
+    x = torch.randn(2, 37, 48)
+    with torch.no_grad():
+        out, y_ssm, cache = mod(x, output_attentions=True, use_cache=True)
+    sd = {k: v.detach() for k, v in mod.state_dict().items()}
+    oo, parts = ref_cpu.ssm_layer(sd, "", x, 3, 16, cfg.ssm_dt_rank, return_parts=True)
+    print(f"  ssm_layer: oracle-vs-reference out {float((oo - out).abs().max()):.2e}  "
+          f"y {float((parts['y'] - y_ssm).abs().max()):.2e}")
+    npz("ssm_layer", x=x, out=out, y_ssm=y_ssm, conv_state=cache[0], ssm_state=cache[1].reshape(2, -1),
+        dt_rank=cfg.ssm_dt_rank, **sd_arrays(sd))
+
+
+def _capture_dispatch(mod, x):
+    """Run AdaptiveExpertSystem and record, per expert call, which tokens it received."""
+    flat = x.reshape(-1, x.shape[-1])
+    calls = []
+
+    def mk(j):
+        def hook(_m, inp):
+            rows = inp[0]
+            eq = (rows.unsqueeze(1) == flat.unsqueeze(0)).all(-1)     # rows are unique random vectors
+            calls.append((j, eq.float().argmax(1).tolist()))
+        return hook
+    hs = [mod.experts[j].register_forward_pre_hook(mk(j)) for j in range(len(mod.experts))]
+    out = mod(x)
+    for h_ in hs:
+        h_.remove()
+    return out, calls
+
+
+def gen_moe(core):
+    from oracle import ref_cpu
+    for name, training, S_shape, E, K, H, I in [("eval", False, (2, 40), 8, 2, 32, 64),
+                                                 ("train_overflow", True, (2, 64), 4, 2, 32, 64),
+                                                 ("eval_k3", False, (1, 48), 8, 3, 32, 64)]:
+        torch.manual_seed(zlib.crc32(name.encode()) % 1000)
+        cfg = core.ApertisConfig(hidden_size=H, intermediate_size=I, num_attention_heads=2, use_expert_system=True,
+                                 num_experts=E, experts_per_token=K, hidden_dropout_prob=0.0,
+                                 use_noisy_top_k_routing=False, use_expert_dropout=False)
+        mod = core.AdaptiveExpertSystem(cfg, activation_function_override="gelu")
+        with torch.no_grad():
+            for p in mod.parameters():      # default init is tiny/zero: randomise so routing is non-trivial
+                p.copy_(torch.randn_like(p) * (0.5 if p.dim() > 1 else 0.2))
+            for j in range(E):
+                mod.experts[j][0].weight.add_(1.0)
+            mod.router_norm.weight.add_(1.0)
+            if training:                    # skew the router so that capacity overflows deterministically
+                mod.router.bias[0] += 2.0
+        mod.train(training)
+        x = torch.randn(*S_shape, H)
+        with torch.no_grad():
+            (out, lb, rz), calls = _capture_dispatch(mod, x)
+        sd = {k: v.detach() for k, v in mod.state_dict().items()}
+        o_out, o_lb, o_rz, aux = ref_cpu.moe_layer(sd, "", x, E, K, "gelu", cfg.layer_norm_eps, training=training)
+        # reference kept sets per (k, e): calls come k-major, experts ascending
+        kept = {}
+        k_cur, last_e = 0, -1
+        for j, toks in calls:
+            if j <= last_e:
+                k_cur += 1
+            last_e = j
+            kept[(k_cur, j)] = sorted(toks)
+        ref_rows = []
+        for e in range(E):
+            for k in range(K):
+                ref_rows += [(t, k, e) for t in kept.get((k, e), [])]
+        offs, row_token, row_k = aux["offsets"], aux["row_token"], aux["row_k"]
+        ora_rows = [(int(row_token[r]), int(row_k[r]), e) for e in range(E) for r in range(offs[e], offs[e + 1])]
+        gates = aux["gates"]
+        srt = torch.sort(gates, dim=-1, descending=True).values
+        min_gap = float((srt[:, :K] - srt[:, 1:K + 1]).min())
+        print(f"  moe_{name}: out diff {float((o_out - out).abs().max()):.2e} lb {float(abs(o_lb - lb)):.1e} "
+              f"rz {float(abs(o_rz - rz)):.1e} rows equal {ora_rows == ref_rows} kept {len(ref_rows)}/{x.shape[0] * x.shape[1] * K} "
+              f"min top-k prob gap {min_gap:.2e}")
+        assert ora_rows == ref_rows
+        npz("moe_" + name, x=x, out=out, lb=lb, rz=rz, logits=aux["logits"], gates=gates, idx=aux["idx"], w=aux["w"],
+            kept_rows=np.asarray(ref_rows, dtype=np.int32), expert_offsets=offs, min_gap=min_gap,
+            E=E, K=K, training=int(training), capacity=(ref_cpu.expert_capacity(x.shape[0] * x.shape[1], E, 1.25) if training else -1),
+            eps=cfg.layer_norm_eps, **sd_arrays(sd))
+
+
+def gen_vision(core):
+    from oracle import ref_cpu
+    torch.manual_seed(5)
+    cfg = core.ApertisConfig(hidden_size=48, num_attention_heads=3, multimodal=True, image_size=32, vision_embed_dim=32,
+                             vision_patch_size=8, vision_layers=2, vision_heads=2)
+    from src.multimodal.module import UnifiedMultimodalEncoder
+    enc = UnifiedMultimodalEncoder(cfg).eval()
+    proj = torch.nn.Linear(32, 48)
+    px = torch.randn(2, 3, 32, 32)
+    with torch.no_grad():
+        pe = enc.patch_embed(px).flatten(2).transpose(1, 2)
+        feats = enc(px)
+        pr = proj(feats)
+    sd = {k: v.detach() for k, v in enc.state_dict().items()}
+    o_pe = ref_cpu.patch_embed(sd, "", px, 8)[:, 1:] - sd["vision_pos_embed"][:, 1:]
+    o_feats = ref_cpu.vision_encoder(sd, "", px, 8, 2, 2)
+    print(f"  vision: patch-embed diff {float((o_pe - pe).abs().max()):.2e} encoder diff {float((o_feats - feats).abs().max()):.2e}")
+    npz("vision", pixel_values=px, patch_embeds=pe, features=feats, projected=pr, proj_weight=proj.weight, proj_bias=proj.bias,
+        **sd_arrays(sd))
+
+
+def gen_models(core):
+    from oracle import ref_cpu
+    specs = {
+        "model_ssm_dense": dict(use_expert_system=False, multimodal=False),
+        "model_ssm_moe": dict(use_expert_system=True, num_experts=4, experts_per_token=2, multimodal=False),
+        "model_ssm_moe_mm": dict(use_expert_system=True, num_experts=4, experts_per_token=2, multimodal=True, image_size=32,
+                                 vision_embed_dim=24, vision_patch_size=8, vision_layers=1, vision_heads=2),
+    }
+    for name, extra in specs.items():
+        torch.manual_seed(zlib.crc32(name.encode()) % 1000)
+        cfg = core.ApertisConfig(vocab_size=96, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                 intermediate_size=64, attention_type="selective_ssm", **extra)
+        model = core.ApertisForCausalLM(cfg).eval()
+        with torch.no_grad():  # widen the init so logits are not ~0
+            for n_, p in model.named_parameters():
+                if p.dim() > 1 and "token_embeddings" not in n_:
+                    p.mul_(8.0)
+        ids = torch.randint(4, 96, (2, 12))
+        labels = ids.clone()
+        labels[0, :3] = -100
+        px = torch.randn(2, 3, 32, 32) if extra.get("multimodal") else None
+        with torch.no_grad():
+            out = model(input_ids=ids, pixel_values=px, labels=labels, use_cache=False)
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        o_loss, o_logits = ref_cpu.model_forward(sd, dict(cfg.to_dict()), ids, px, labels)
+        rel = float(((o_logits - out[1]).abs() / (out[1].abs() + 1e-3)).max())
+        print(f"  {name}: loss ref {float(out[0]):.6f} oracle {float(o_loss):.6f}; logits max rel diff {rel:.2e}")
+        arrs = dict(input_ids=ids, labels=labels, loss=out[0], logits=out[1], config_json=json.dumps(cfg.to_dict()),
+                    **sd_arrays(sd))
+        if px is not None:
+            arrs["pixel_values"] = px
+        npz(name, **arrs)
+
+
+def gen_dims(core):
+    table = {}
+    for target, moe in [("125M", False), ("350M", True), ("1.5B", True), ("10M", False), ("7B", False), ("3B", True)]:
+        d = core.calculate_model_dimensions(target, 32000, use_expert_system=moe)
+        cfg = core.ApertisConfig(vocab_size=32000, hidden_size=d["hidden_size"], num_hidden_layers=d["num_hidden_layers"],
+                                 num_attention_heads=d["num_attention_heads"], intermediate_size=d["intermediate_size"],
+                                 use_expert_system=moe)
+        table[f"{target}|{int(moe)}"] = dict(dims={k: v for k, v in d.items()}, estimate=core.estimate_model_parameters(cfg))
+    parse = {s: core.parse_param_count(s) for s in ["10M", "1.5B", "350m", "70B", "125000000", "2.5k"]}
+    defaults = core.ApertisConfig().to_dict()
+    ssm_cfg = core.ApertisConfig(attention_type="selective_ssm", hidden_size=704, num_attention_heads=11,
+                                 use_expert_system=True).to_dict()
+    with open(os.path.join(OUT, "config_and_dims.json"), "w") as f:
+        json.dump(dict(dims=table, parse=parse, config_defaults=defaults, config_ssm_moe=ssm_cfg), f, indent=1, sort_keys=True)
+    print("  wrote config_and_dims.json")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    core = import_reference()
+    print("reference imported from /root/reference")
+    gen_scan(core)
+    gen_ssm_layer(core)
+    gen_moe(core)
+    gen_vision(core)
+    gen_models(core)
+    gen_dims(core)
