@@ -37,10 +37,10 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_ssm_gate_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "apertis_ssm_gate_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64,
-                                    _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
+                                    _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "apertis_ssm_gate_bwd_blocks": (_i64, [_i64, _i64]),
     "apertis_dwconv_silu_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "apertis_dwconv_silu_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64,
+    "apertis_dwconv_silu_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                        _i64, _i32, _vp]),
     "apertis_dwconv_bwd_blocks": (_i64, [_i64, _i64, _i64]),
     "apertis_moe_gate_topk_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
@@ -48,15 +48,14 @@ SIGNATURES = {
     "apertis_moe_plan_workspace_bytes": (_i64, [_i64, _i64, _i64]),
     "apertis_moe_plan": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "apertis_moe_gather_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
-    "apertis_moe_gather_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+    "apertis_moe_gather_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _i32, _i32, _vp]),
-    "apertis_moe_gather_ln_bwd_blocks": (_i64, [_i64, _i64]),
     "apertis_moe_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_moe_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _i32, _i32, _vp]),
     "apertis_grouped_gemm_nt": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
                                        _i32, _i32, _vp]),
-    "apertis_grouped_gemm_nn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_cast_transpose": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_act_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _u64, _i32, _vp]),
 }

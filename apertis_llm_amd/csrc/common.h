@@ -24,7 +24,7 @@ static inline int apertis_check_launch() {
   return e == hipSuccess ? APERTIS_OK : APERTIS_ERR_LAUNCH;
 }
 
-static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // largest power-of-two byte width (<=16) that divides every value in the list
 static inline int common_align(std::initializer_list<uint64_t> vals) {

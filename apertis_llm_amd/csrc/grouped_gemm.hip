@@ -1,0 +1,505 @@
+// Grouped GEMM on CDNA4 matrix cores (gfx950) for the MoE expert MLPs, and with one group the
+// patch-embed / vision-projection GEMMs.
+//
+// Reference: the per-expert nn.Linear calls of AdaptiveExpertSystem
+// (/root/reference/src/model/core.py:434-442,596) - 16 small addmm launches per layer there,
+// one launch per GEMM here.  Rows are expert-sorted (apertis_moe_plan); group e owns rows
+// [offsets[e], offsets[e+1]).  Tiles never straddle a group; the grid is sized from an upper
+// bound on rows and every work-group finds its (group, m-tile) from the device-side offsets,
+// so no host sync is needed.
+//
+// Tile: 128 (rows) x 128 (cols) x 128 B of K per step (64 bf16 / 32 fp32), 256 threads =
+// 2x2 waves, each wave 64x64 = 4x4 MFMA tiles of 16x16.
+//   bf16: v_mfma_f32_16x16x32_bf16  (8 k per lane per instruction, fp32 accumulate)
+//   fp32: v_mfma_f32_16x16x4_f32    (exact fp32 FMA chain; the parity path)
+// The WEIGHT tile feeds the MFMA "A" operand and the ACTIVATION tile the "B" operand, so the
+// accumulator holds 4 consecutive output columns per lane (D row = n, D col = m): the epilogue
+// writes 8/16-byte pieces of output rows into an LDS staging tile and the tile leaves as whole
+// 16-byte-per-lane row segments.
+// LDS image of both operand tiles: [row][8 x 16-byte chunk], chunk index XOR (row & 7), which
+// makes the ds_read_b128 fragment reads conflict-free (rows are 128 B, two per bank row).
+// Global -> LDS goes through registers (one tile in flight, written to the other buffer after
+// the MFMAs of the current one: one barrier per K step).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 128;            // bytes of K per tile row
+constexpr int TILE_BYTES = BM * ROWB;  // 16 KiB per operand tile
+constexpr int NT = 256;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
+
+template <typename T> struct frag_t;
+template <> struct frag_t<bf16_t> { typedef bf16x8 type; };
+template <> struct frag_t<float> { typedef f32x4 type; };
+
+__device__ __forceinline__ void mma(f32x4 &acc, const bf16x8 &a, const bf16x8 &b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+// fp32: a 16-byte chunk holds 4 k-values of this lane's row; MFMA step j consumes element j
+// (both operands use the same k assignment, so the dot product is complete and exact fp32)
+__device__ __forceinline__ void mma(f32x4 &acc, const f32x4 &a, const f32x4 &b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+  switch (act) {
+    case APERTIS_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case APERTIS_ACT_RELU: return x > 0.f ? x : 0.f;
+    case APERTIS_ACT_SILU: return x / (1.f + expf(-x));
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case APERTIS_ACT_GELU:
+      return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    case APERTIS_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case APERTIS_ACT_SILU: { float s = 1.f / (1.f + expf(-x)); return s * (1.f + x * (1.f - s)); }
+    default: return 1.f;
+  }
+}
+
+// counter-based keep mask: 16 random bits per element from a 32-bit avalanche of
+// (element pair index, seed); the backward regenerates it from the same (seed,row,col)
+__device__ __forceinline__ bool drop_keep(uint64_t seed, int64_t row, int64_t col, int64_t ncols, uint32_t thresh16) {
+  uint64_t lin = (uint64_t)row * (uint64_t)ncols + (uint64_t)col;
+  uint32_t h = (uint32_t)(lin >> 1) ^ (uint32_t)seed;
+  h += (uint32_t)(lin >> 33) * 0x9E3779B9u + (uint32_t)(seed >> 32);
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  uint32_t r16 = (lin & 1) ? (h >> 16) : (h & 0xffffu);
+  return r16 >= thresh16;
+}
+
+struct TileCoord { int e, m0, rows_left; int64_t row0; bool valid; };
+
+// m-tile index -> (group, first row in group, rows left); mt counts tiles over all groups
+__device__ __forceinline__ TileCoord find_tile(const int32_t *offsets, int E, int mt) {
+  TileCoord t; t.valid = false;
+  int acc = 0;
+  for (int e = 0; e < E; ++e) {
+    int r0 = offsets[e], r1 = offsets[e + 1];
+    int nt = (r1 - r0 + BM - 1) / BM;
+    if (mt < acc + nt) {
+      t.e = e; t.m0 = (mt - acc) * BM; t.row0 = (int64_t)r0 + t.m0; t.rows_left = r1 - r0 - t.m0; t.valid = true;
+      return t;
+    }
+    acc += nt;
+  }
+  return t;
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
+// contiguous run of tiles so neighbouring tiles (same activation rows, next weight columns)
+// meet in one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <typename T>
+__device__ __forceinline__ void load_tile_regs(uint4 (&regs)[4], const T *base, int64_t ld, int rows_valid,
+                                               int k0, int K, int tid) {
+  constexpr int KPC = 16 / sizeof(T);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + i * NT;
+    int row = q >> 3, c = q & 7;
+    int k = k0 + c * KPC;
+    if (row < rows_valid && k < K)
+      regs[i] = *reinterpret_cast<const uint4 *>(base + (int64_t)row * ld + k);
+    else
+      regs[i] = make_uint4(0, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ void store_tile_lds(char *lds, const uint4 (&regs)[4], int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + i * NT;
+    int row = q >> 3, c = q & 7;
+    *reinterpret_cast<uint4 *>(lds + row * ROWB + ((c ^ (row & 7)) << 4)) = regs[i];
+  }
+}
+
+template <typename T, typename TO>
+__global__ void __launch_bounds__(NT)
+grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float *__restrict__ bias,
+                  const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
+                  int N, int K, int E, int n_tiles, int act, float drop_p, uint64_t seed) {
+  typedef typename frag_t<T>::type frag;
+  constexpr int KPC = 16 / sizeof(T);
+  constexpr int BK = ROWB / sizeof(T);
+  constexpr int CPITCH = BN * sizeof(TO) + 16;  // padded C staging pitch
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
+  const TileCoord tc = find_tile(offsets, E, mt);
+  if (!tc.valid) return;
+  const int n0 = ntile * BN;
+  const int rows_valid = min(BM, tc.rows_left);
+  const int cols_valid = min(BN, N - n0);
+  const T *xbase = X + tc.row0 * K;
+  const T *wbase = W + ((int64_t)tc.e * N + n0) * K;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (K + BK - 1) / BK;
+  uint4 xr[4], wr[4];
+  load_tile_regs<T>(xr, xbase, K, rows_valid, 0, K, tid);
+  load_tile_regs<T>(wr, wbase, K, cols_valid, 0, K, tid);
+  store_tile_lds(smem, xr, tid);
+  store_tile_lds(smem + TILE_BYTES, wr, tid);
+  __syncthreads();
+
+  const int frow = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    char *xs = smem + (kt & 1) * 2 * TILE_BYTES;
+    char *ws = xs + TILE_BYTES;
+    if (kt + 1 < nk) {
+      load_tile_regs<T>(xr, xbase, K, rows_valid, (kt + 1) * BK, K, tid);
+      load_tile_regs<T>(wr, wbase, K, cols_valid, (kt + 1) * BK, K, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      frag wf[4], xf[4];
+      const int chunk = kk * 4 + fg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int wrow = wn * 64 + i * 16 + frow;
+        wf[i] = *reinterpret_cast<const frag *>(ws + wrow * ROWB + ((chunk ^ (wrow & 7)) << 4));
+        int xrow = wm * 64 + i * 16 + frow;
+        xf[i] = *reinterpret_cast<const frag *>(xs + xrow * ROWB + ((chunk ^ (xrow & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
+    }
+    if (kt + 1 < nk) {
+      char *xn = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+      store_tile_lds(xn, xr, tid);
+      store_tile_lds(xn + TILE_BYTES, wr, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j] = D tile (n-subtile i, m-subtile j); lane: m = frow, n = fg*4 + reg
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+  float bv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
+      bv[i][r] = (bias && n < N) ? bias[(int64_t)tc.e * N + n] : 0.f;
+    }
+  constexpr int CPR = BN * sizeof(TO) / 16;  // 16-byte chunks per output row
+  auto flush_tile = [&](TO *dst) {
+    __syncthreads();
+    for (int q = tid; q < BM * CPR; q += NT) {
+      int row = q / CPR, c = q % CPR;
+      int ncol = c * (16 / (int)sizeof(TO));
+      if (row < rows_valid && ncol < cols_valid)
+        *reinterpret_cast<uint4 *>(dst + (tc.row0 + row) * N + n0 + ncol) =
+            *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
+    }
+    __syncthreads();
+  };
+  if (pre_act) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int m = wm * 64 + j * 16 + frow, n = wn * 64 + i * 16 + fg * 4;
+        TO *p = reinterpret_cast<TO *>(smem + m * CPITCH) + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = from_f32<TO>(acc[i][j][r] + bv[i][r]);
+      }
+    flush_tile(pre_act);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int m = wm * 64 + j * 16 + frow, n = wn * 64 + i * 16 + fg * 4;
+      TO *p = reinterpret_cast<TO *>(smem + m * CPITCH) + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[i][r];
+        v = to_f32(from_f32<TO>(v));  // the activation sees the pre-activation as stored (bf16-rounded under bf16)
+        v = act_fwd(v, act);
+        if (drop_p > 0.f)
+          v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+        p[r] = from_f32<TO>(v);
+      }
+    }
+  flush_tile(C);
+}
+
+// dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
+template <typename T>
+__global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict__ pre, T *__restrict__ dpre,
+                                  const int32_t *__restrict__ offsets, int64_t max_rows, int N, int E, int act,
+                                  float drop_p, uint64_t seed) {
+  const int64_t total_rows = min((int64_t)offsets[E], max_rows);
+  const int64_t nvec = total_rows * N / 4;
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lin = v * 4;
+    const int64_t row = lin / N;
+    const int col = (int)(lin - row * N);
+    float d[4], p[4], o[4];
+    if constexpr (sizeof(T) == 4) {
+      float4 a = *reinterpret_cast<const float4 *>(dh + lin), b = *reinterpret_cast<const float4 *>(pre + lin);
+      d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; p[0] = b.x; p[1] = b.y; p[2] = b.z; p[3] = b.w;
+    } else {
+      typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+      bf4 a = *reinterpret_cast<const bf4 *>(dh + lin), b = *reinterpret_cast<const bf4 *>(pre + lin);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { d[j] = (float)a[j]; p[j] = (float)b[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g = d[j] * act_grad(p[j], act);
+      if (drop_p > 0.f) g = drop_keep(seed, row, col + j, N, thresh16) ? g * keep_scale : 0.f;
+      o[j] = g;
+    }
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4 *>(dpre + lin) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+      bf4 r = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+      *reinterpret_cast<bf4 *>(dpre + lin) = r;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// TN (weight gradient):  dW[e][m][n] = sum_{r in group e} A[r][m] * Bm[r][n]
+// K dimension = the group's rows.  Both operands are K-strided in memory, so tiles are staged
+// as [k][row] images (k = token row, 64 bf16 / 32 fp32 per step) and fragments are gathered
+// transposed: bf16 with ds_read_b64_tr_b16, fp32 with scalar LDS reads.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(NT)
+grouped_gemm_tn_k(const T *__restrict__ A, const T *__restrict__ Bm, const int32_t *__restrict__ offsets,
+                  float *__restrict__ dW, float *__restrict__ dbias, int M, int N, int m_tiles, int n_tiles) {
+  // LDS images: As[k][BM] and Bs[k][BN], k = 32 rows per step, element rows of 128*sizeof(T) bytes
+  constexpr int BKR = 32;                       // token rows per step
+  constexpr int PITCH = BM * sizeof(T) + 16;    // bytes per k-row (+16 pad against bank conflicts)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *As = smem, *Bs = smem + BKR * PITCH;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = tile / (m_tiles * n_tiles);
+  const int rem = tile - e * m_tiles * n_tiles;
+  const int mt = rem / n_tiles, ntile = rem - mt * n_tiles;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int r_begin = offsets[e], r_end = offsets[e + 1];
+  const int mvalid = min(BM, M - m0), nvalid = min(BN, N - n0);
+
+  f32x4 acc[4][4];  // acc[i][j]: D rows = m-subtile i (from A), D cols = n-subtile j (from Bm)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;  // column sum of A for dbias (threads 0..BM-1 of the ntile==0 blocks)
+
+  constexpr int EPC = 16 / sizeof(T);            // elements per 16-byte chunk
+  constexpr int CPRW = BM / EPC;                 // chunks per k-row
+  constexpr int LOADS = BKR * CPRW / NT;         // 16-byte loads per thread per operand
+  const int frow = lane & 15, fg = lane >> 4;
+
+  for (int r0 = r_begin; r0 < r_end; r0 += BKR) {
+    uint4 ar[LOADS], br[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int q = tid + i * NT;
+      int kr = q / CPRW, c = q % CPRW;
+      int col = c * EPC;
+      bool rok = r0 + kr < r_end;
+      ar[i] = (rok && col < mvalid) ? *reinterpret_cast<const uint4 *>(A + (int64_t)(r0 + kr) * M + m0 + col)
+                                    : make_uint4(0, 0, 0, 0);
+      br[i] = (rok && col < nvalid) ? *reinterpret_cast<const uint4 *>(Bm + (int64_t)(r0 + kr) * N + n0 + col)
+                                    : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();  // previous step's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) {
+      int q = tid + i * NT;
+      int kr = q / CPRW, c = q % CPRW;
+      *reinterpret_cast<uint4 *>(As + kr * PITCH + c * 16) = ar[i];
+      *reinterpret_cast<uint4 *>(Bs + kr * PITCH + c * 16) = br[i];
+    }
+    __syncthreads();
+    if (dbias && ntile == 0 && tid < BM) {
+#pragma unroll 8
+      for (int kr = 0; kr < BKR; ++kr) bsum += to_f32(*reinterpret_cast<const T *>(As + kr * PITCH + tid * sizeof(T)));
+    }
+    if constexpr (sizeof(T) == 2) {
+      // one MFMA 16x16x32 consumes all 32 k-rows: lane (frow, fg) needs k = 8*fg .. 8*fg+7 for
+      // its row/col; two transposed reads of 4 k-rows x 16 columns each
+      typedef __attribute__((ext_vector_type(4))) short s16x4;
+      bf16x8 af[4], bf[4];
+      const int lr = lane & 15;           // lane within its 16-lane group
+      const int trow = lr >> 2, tcol4 = (lr & 3) * 4;  // address this lane supplies: row q, cols 4p..4p+3
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        union { bf16x8 v; s16x4 h[2]; } ua, ub;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          int krow = 8 * fg + 4 * hh + trow;
+          const char *pa = As + krow * PITCH + (wm * 64 + i * 16 + tcol4) * 2;
+          const char *pb = Bs + krow * PITCH + (wn * 64 + i * 16 + tcol4) * 2;
+          ua.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pa);
+          ub.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)pb);
+        }
+        af[i] = ua.v; bf[i] = ub.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma(acc[i][j], af[i], bf[j]);
+    } else {
+      // fp32: MFMA 16x16x4 step s: lane supplies A[m=frow][k=4s+fg], B[k=4s+fg][n=frow]
+#pragma unroll
+      for (int s = 0; s < BKR / 4; ++s) {
+        const int krow = 4 * s + fg;
+        float af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          af[i] = *reinterpret_cast<const float *>(As + krow * PITCH + (wm * 64 + i * 16 + frow) * 4);
+          bf[i] = *reinterpret_cast<const float *>(Bs + krow * PITCH + (wn * 64 + i * 16 + frow) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  // D layout: col = lane&15 -> n, row = fg*4+reg -> m
+  float *out = dW + (int64_t)e * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int m = m0 + wm * 64 + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + frow;
+        if (m < M && n < N) out[(int64_t)m * N + n] = acc[i][j][r];
+      }
+  if (dbias && ntile == 0 && tid < mvalid) dbias[(int64_t)e * M + m0 + tid] = bsum;
+}
+
+template <typename T> bool aligned16(const void *p, int64_t ld) {
+  return (((uintptr_t)p) & 15) == 0 && ((ld * sizeof(T)) & 15) == 0;
+}
+
+template <typename T, typename TO>
+int launch_nt(const void *A, const void *W, const float *bias, const int32_t *offsets, void *C, void *pre_act,
+              int64_t max_rows, int64_t N, int64_t K, int64_t E, int act, float drop_p, uint64_t seed,
+              hipStream_t st) {
+  if (!aligned16<T>(A, K) || !aligned16<T>(W, K) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)))
+    return APERTIS_ERR_UNSUPPORTED;
+  const int n_tiles = (int)ceil_div64(N, BN);
+  const int64_t m_tiles = ceil_div64(max_rows, BM) + E;  // each group adds at most one partial tile
+  const int64_t grid = m_tiles * n_tiles;
+  if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+  size_t lds = std::max<size_t>(4 * TILE_BYTES, (size_t)BM * (BN * sizeof(TO) + 16));
+  auto kern = grouped_gemm_nt_k<T, TO>;
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
+                     (TO *)pre_act, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+  return apertis_check_launch();
+}
+
+}  // namespace
+
+extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias, const int32_t *offsets,
+                                       void *C, void *pre_act, int64_t max_rows, int64_t N, int64_t K, int64_t E,
+                                       int act, float drop_p, uint64_t seed, int dtype, int dtype_out, void *stream) {
+  if (!A || !W || !offsets || !C || max_rows < 0 || N <= 0 || K <= 0 || E <= 0) return APERTIS_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
+  if (max_rows == 0) return APERTIS_OK;
+  if (max_rows > 0x7fffffffLL || N > 0x3fffffff || K > 0x3fffffff) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == APERTIS_BF16 && dtype_out == APERTIS_BF16) {
+    if (K % 8 || N % 8) return APERTIS_ERR_UNSUPPORTED;
+    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, max_rows, N, K, E, act, drop_p, seed, st);
+  }
+  if (dtype == APERTIS_BF16 && dtype_out == APERTIS_F32) {
+    if (K % 8 || N % 4) return APERTIS_ERR_UNSUPPORTED;
+    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, max_rows, N, K, E, act, drop_p, seed, st);
+  }
+  if (dtype == APERTIS_F32 && dtype_out == APERTIS_F32) {
+    if (K % 4 || N % 4) return APERTIS_ERR_UNSUPPORTED;
+    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, max_rows, N, K, E, act, drop_p, seed, st);
+  }
+  return APERTIS_ERR_UNSUPPORTED;
+}
+
+extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets, float *dW,
+                                       float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, int dtype,
+                                       void *stream) {
+  if (!A || !Bm || !offsets || !dW || max_rows < 0 || M <= 0 || N <= 0 || E <= 0) return APERTIS_ERR_ARG;
+  if (M > 0x3fffffff || N > 0x3fffffff || max_rows > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int m_tiles = (int)ceil_div64(M, BM), n_tiles = (int)ceil_div64(N, BN);
+  const int64_t grid = (int64_t)E * m_tiles * n_tiles;
+  if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+  if (dtype == APERTIS_BF16) {
+    if (M % 8 || N % 8 || !aligned16<bf16_t>(A, M) || !aligned16<bf16_t>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
+    size_t lds = 2 * 32 * (BM * 2 + 16);
+    hipLaunchKernelGGL(grouped_gemm_tn_k<bf16_t>, dim3((unsigned)grid), dim3(NT), lds, st, (const bf16_t *)A,
+                       (const bf16_t *)Bm, offsets, dW, dbias, (int)M, (int)N, m_tiles, n_tiles);
+  } else if (dtype == APERTIS_F32) {
+    if (M % 4 || N % 4 || !aligned16<float>(A, M) || !aligned16<float>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
+    size_t lds = 2 * 32 * (BM * 4 + 16);
+    hipLaunchKernelGGL(grouped_gemm_tn_k<float>, dim3((unsigned)grid), dim3(NT), lds, st, (const float *)A,
+                       (const float *)Bm, offsets, dW, dbias, (int)M, (int)N, m_tiles, n_tiles);
+  } else {
+    return APERTIS_ERR_ARG;
+  }
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void *dpre, const int32_t *offsets,
+                                       int64_t max_rows, int64_t N, int64_t E, int act, float drop_p, uint64_t seed,
+                                       int dtype, void *stream) {
+  if (!dh || !pre_act || !dpre || !offsets || max_rows < 0 || N <= 0 || E <= 0) return APERTIS_ERR_ARG;
+  if (N % 4) return APERTIS_ERR_UNSUPPORTED;
+  if (max_rows == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t nvec = max_rows * N / 4;
+  int64_t nb = ceil_div64(nvec, 256);
+  dim3 grid((unsigned)(nb < 8192 ? nb : 8192)), block(256);
+  if (dtype == APERTIS_BF16)
+    hipLaunchKernelGGL(act_dropout_bwd_k<bf16_t>, grid, block, 0, st, (const bf16_t *)dh, (const bf16_t *)pre_act,
+                       (bf16_t *)dpre, offsets, max_rows, (int)N, (int)E, act, drop_p, seed);
+  else if (dtype == APERTIS_F32)
+    hipLaunchKernelGGL(act_dropout_bwd_k<float>, grid, block, 0, st, (const float *)dh, (const float *)pre_act,
+                       (float *)dpre, offsets, max_rows, (int)N, (int)E, act, drop_p, seed);
+  else
+    return APERTIS_ERR_ARG;
+  return apertis_check_launch();
+}

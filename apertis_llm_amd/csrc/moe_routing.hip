@@ -1,0 +1,679 @@
+// MoE routing for gfx950: gate softmax/top-k, the dispatch plan (histogram + capacity +
+// radix-select + stable ranks), gather + per-expert LayerNorm, and the weighted combine.
+//
+// Reference: AdaptiveExpertSystem.forward, /root/reference/src/model/core.py:470-607.
+// The reference walks a K x E Python loop with host syncs (nonzero / .any() / topk); here the
+// whole plan is built on the device with no host round-trip.  Canonical row order is
+// expert-major, then k, then ascending token - equivalent to the reference's k-major loop
+// because capacity is consumed per expert.
+//
+// All of these are HBM/latency-bound integer and row-streaming kernels: one wave per row with
+// 8/16-byte vector accesses, integer atomics only (deterministic), float atomics only for the
+// LayerNorm affine gradients.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXE = 64;  // experts
+constexpr int MAXK = 8;   // experts per token
+
+// ------------------------------------------------------------------------------------------
+// gate: softmax -> top-K (ties: lowest expert index) -> renormalised weights
+// ------------------------------------------------------------------------------------------
+template <int EC>  // EC > 0: compile-time expert count; EC == 0: runtime E <= MAXE
+__global__ void gate_topk_fwd_k(const float *__restrict__ logits, float *__restrict__ gates,
+                                int32_t *__restrict__ idx, float *__restrict__ w, int64_t S, int E_rt,
+                                int K) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  constexpr int CAP = EC > 0 ? EC : MAXE;
+  const int E = EC > 0 ? EC : E_rt;
+  float v[CAP];
+  const float *row = logits + s * E;
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) { v[i] = row[i]; m = fmaxf(m, v[i]); }
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) { v[i] = expf(v[i] - m); sum += v[i]; }
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) { v[i] = v[i] / sum; gates[s * E + i] = v[i]; }
+  uint64_t chosen = 0;
+  float p[MAXK];
+  float psum = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    if (k < K) {
+      float best = -1.f;
+      int bi = 0;
+#pragma unroll
+      for (int i = 0; i < CAP; ++i)
+        if (i < E && !((chosen >> i) & 1) && v[i] > best) { best = v[i]; bi = i; }
+      chosen |= 1ull << bi;
+      idx[s * K + k] = bi;
+      p[k] = best;
+      psum += best;
+    }
+  }
+  const float den = psum + 1e-6f;  // core.py:529
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k)
+    if (k < K) w[s * K + k] = p[k] / den;
+}
+
+// dlogits from dw (through renorm + top-k gather) and dgates (aux losses), softmax backward
+template <int EC>
+__global__ void gate_topk_bwd_k(const float *__restrict__ gates, const int32_t *__restrict__ idx,
+                                const float *__restrict__ dw, const float *__restrict__ dgates,
+                                float *__restrict__ dlogits, int64_t S, int E_rt, int K) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  constexpr int CAP = EC > 0 ? EC : MAXE;
+  const int E = EC > 0 ? EC : E_rt;
+  float g[CAP], dg[CAP];
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) { g[i] = gates[s * E + i]; dg[i] = dgates ? dgates[s * E + i] : 0.f; }
+  if (dw) {
+    float psum = 0.f, dot = 0.f;
+    for (int k = 0; k < K; ++k) {
+      int e = idx[s * K + k];
+      float pe = 0.f;
+#pragma unroll
+      for (int i = 0; i < CAP; ++i)
+        if (i == e) pe = g[i];
+      psum += pe;
+      dot += dw[s * K + k] * pe;
+    }
+    const float den = psum + 1e-6f;
+    const float corr = dot / (den * den);
+    for (int k = 0; k < K; ++k) {
+      int e = idx[s * K + k];
+      float dp = dw[s * K + k] / den - corr;
+#pragma unroll
+      for (int i = 0; i < CAP; ++i)
+        if (i == e) dg[i] += dp;
+    }
+  }
+  float inner = 0.f;
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) inner += dg[i] * g[i];
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) dlogits[s * E + i] = g[i] * (dg[i] - inner);
+}
+
+// ------------------------------------------------------------------------------------------
+// dispatch plan
+// ------------------------------------------------------------------------------------------
+struct PlanWs {
+  int32_t *total, *keep, *mode, *quota, *seg_start;
+  uint32_t *thr;
+  int32_t *cnt_g, *cnt_t;  // [P][NCH]
+  int P, NCH;
+};
+
+PlanWs carve_ws(void *ws, int64_t S, int64_t E, int64_t K) {
+  PlanWs w;
+  w.P = (int)(E * K);
+  w.NCH = (int)ceil_div64(S, 64);
+  int32_t *p = (int32_t *)ws;
+  w.total = p; p += w.P;
+  w.keep = p; p += w.P;
+  w.mode = p; p += w.P;
+  w.quota = p; p += w.P;
+  w.seg_start = p; p += w.P;
+  w.thr = (uint32_t *)p; p += w.P;
+  w.cnt_g = p; p += (int64_t)w.P * w.NCH;
+  w.cnt_t = p;
+  return w;
+}
+
+__global__ void plan_hist_k(const int32_t *__restrict__ idx, int32_t *__restrict__ total, int64_t SK,
+                            int E, int K) {
+  __shared__ int32_t h[MAXE * MAXK];
+  const int P = E * K;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) h[i] = 0;
+  __syncthreads();
+  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < SK; a += (int64_t)gridDim.x * blockDim.x) {
+    int e = idx[a];
+    int k = (int)(a % K);
+    if (e >= 0 && e < E) atomicAdd(&h[e * K + k], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P; i += blockDim.x)
+    if (h[i]) atomicAdd(&total[i], h[i]);
+}
+
+// per expert: consume capacity k-major (core.py:547-576); then lay the segments out expert-major
+__global__ void plan_capacity_k(PlanWs w, const uint8_t *__restrict__ active, int64_t capacity,
+                                int32_t *__restrict__ offsets, int E, int K) {
+  const int e = threadIdx.x;
+  if (e < E) {
+    int64_t load = 0;
+    const bool on = active ? active[e] != 0 : true;
+    for (int k = 0; k < K; ++k) {
+      const int p = e * K + k;
+      const int tot = w.total[p];
+      int64_t keep = tot;
+      if (!on) keep = 0;
+      else if (capacity > 0) {
+        int64_t rem = capacity - load;
+        keep = rem <= 0 ? 0 : (tot < rem ? tot : rem);
+      }
+      w.keep[p] = (int)keep;
+      w.mode[p] = keep == 0 ? 0 : (keep == tot ? 1 : 2);
+      w.quota[p] = 0;
+      w.thr[p] = 0;
+      load += keep;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int ee = 0; ee < E; ++ee) {
+      offsets[ee] = run;
+      for (int k = 0; k < K; ++k) {
+        w.seg_start[ee * K + k] = run;
+        run += w.keep[ee * K + k];
+      }
+    }
+    offsets[E] = run;
+  }
+}
+
+// overflowing (e,k) slot: find the keep-th largest gate weight T (radix select on the float
+// bits; weights are >= 0 so unsigned order == float order) and how many ties at T to keep
+__global__ void __launch_bounds__(1024)
+plan_select_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk, int64_t S, int K) {
+  const int p = blockIdx.x;
+  if (w.mode[p] != 2) return;
+  const int e = p / K, k = p - e * K;
+  __shared__ int32_t hist[256];
+  __shared__ uint32_t s_prefix, s_mask;
+  __shared__ int32_t s_need;
+  if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_need = w.keep[p]; }
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const uint32_t prefix = s_prefix, mask = s_mask;
+    for (int64_t s = threadIdx.x; s < S; s += blockDim.x) {
+      if (idx[s * K + k] == e) {
+        uint32_t bits = __float_as_uint(wk[s * K + k]);
+        if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & 255], 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int need = s_need, cum = 0;
+      for (int b = 255; b >= 0; --b) {
+        if (cum + hist[b] >= need) {
+          s_need = need - cum;
+          s_prefix = prefix | ((uint32_t)b << shift);
+          s_mask = mask | (255u << shift);
+          break;
+        }
+        cum += hist[b];
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { w.thr[p] = s_prefix; w.quota[p] = s_need; }
+}
+
+__device__ __forceinline__ void plan_flags(const PlanWs &w, const int32_t *idx, const float *wk, int64_t s,
+                                           int64_t S, int k, int E, int K, int &e, bool &fg, bool &ft) {
+  e = -1; fg = false; ft = false;
+  if (s < S) {
+    e = idx[s * K + k];
+    if (e >= 0 && e < E) {
+      const int p = e * K + k;
+      const int m = w.mode[p];
+      if (m == 1) fg = true;
+      else if (m == 2) {
+        uint32_t bits = __float_as_uint(wk[s * K + k]);
+        uint32_t t = w.thr[p];
+        fg = bits > t;
+        ft = bits == t;
+      }
+    } else e = -1;
+  }
+}
+
+// per 64-token chunk and (e,k): number of kept-for-sure rows and of threshold ties
+__global__ void plan_count_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk,
+                             int64_t S, int E, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (chunk >= w.NCH) return;
+  const int64_t s = chunk * 64 + lane;
+  for (int k = 0; k < K; ++k) {
+    int e; bool fg, ft;
+    plan_flags(w, idx, wk, s, S, k, E, K, e, fg, ft);
+    for (int ee = 0; ee < E; ++ee) {
+      unsigned long long bg = __ballot(e == ee && fg);
+      unsigned long long bt = __ballot(e == ee && ft);
+      if (lane == 0) {
+        w.cnt_g[(int64_t)(ee * K + k) * w.NCH + chunk] = __popcll(bg);
+        w.cnt_t[(int64_t)(ee * K + k) * w.NCH + chunk] = __popcll(bt);
+      }
+    }
+  }
+}
+
+// in-place exclusive scan of 2P arrays of NCH ints (blockIdx.x picks the array)
+__global__ void __launch_bounds__(256) plan_scan_k(PlanWs w) {
+  int32_t *arr = (blockIdx.x < (unsigned)w.P ? w.cnt_g + (int64_t)blockIdx.x * w.NCH
+                                              : w.cnt_t + (int64_t)(blockIdx.x - w.P) * w.NCH);
+  __shared__ int32_t part[256];
+  const int per = (w.NCH + 255) / 256;
+  const int b0 = threadIdx.x * per, b1 = min(b0 + per, w.NCH);
+  int sum = 0;
+  for (int i = b0; i < b1; ++i) sum += arr[i];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { int t = part[i]; part[i] = run; run += t; }
+  }
+  __syncthreads();
+  int run = part[threadIdx.x];
+  for (int i = b0; i < b1; ++i) { int t = arr[i]; arr[i] = run; run += t; }
+}
+
+__global__ void plan_assign_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk,
+                              int32_t *__restrict__ row_token, int32_t *__restrict__ row_k,
+                              int32_t *__restrict__ slot_of, int64_t S, int E, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (chunk >= w.NCH) return;
+  const int64_t s = chunk * 64 + lane;
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int k = 0; k < K; ++k) {
+    int e; bool fg, ft;
+    plan_flags(w, idx, wk, s, S, k, E, K, e, fg, ft);
+    int pre_g = 0, pre_t = 0;
+    for (int ee = 0; ee < E; ++ee) {
+      unsigned long long bg = __ballot(e == ee && fg);
+      unsigned long long bt = __ballot(e == ee && ft);
+      if (e == ee) { pre_g = __popcll(bg & lt); pre_t = __popcll(bt & lt); }
+    }
+    if (s < S) {
+      int slot = -1;
+      if (e >= 0 && (fg || ft)) {
+        const int p = e * K + k;
+        const int gb = w.cnt_g[(int64_t)p * w.NCH + chunk] + pre_g;
+        const int tb = w.cnt_t[(int64_t)p * w.NCH + chunk] + pre_t;
+        const int q = w.quota[p];
+        if (fg || tb < q) {
+          slot = w.seg_start[p] + gb + (tb < q ? tb : q);
+          row_token[slot] = (int32_t)s;
+          row_k[slot] = k;
+        }
+      }
+      slot_of[s * K + k] = slot;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// row helpers: a wave owns one row of H elements, lane handles 4-element chunks lane+64*i
+// ------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float4 load4(const T *p);
+template <> __device__ __forceinline__ float4 load4<float>(const float *p) {
+  return *reinterpret_cast<const float4 *>(p);
+}
+template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t *p) {
+  uint2 u = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) {
+  *reinterpret_cast<float4 *>(p) = v;
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v) {
+  typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+  bf4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+  *reinterpret_cast<bf4 *>(p) = o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__device__ __forceinline__ int expert_of_row(const int32_t *offsets, int E, int r) {
+  int e = 0;
+  while (e + 1 < E && offsets[e + 1] <= r) ++e;
+  return e;
+}
+
+// xg[r,:] = LayerNorm(x[row_token[r],:]) * gamma[e] + beta[e]   (IT chunks of 4 per lane)
+template <typename TX, typename TO, int IT>
+__global__ void __launch_bounds__(256)
+gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
+                const int32_t *__restrict__ offsets, const float *__restrict__ gamma,
+                const float *__restrict__ beta, float eps, TO *__restrict__ xg,
+                float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t max_rows, int H, int E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= max_rows || r >= offsets[E]) return;
+  const int e = expert_of_row(offsets, E, (int)r);
+  const TX *src = x + (int64_t)row_token[r] * H;
+  float4 v[IT];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int c = (lane + 64 * i) * 4;
+    v[i] = c < H ? load4<TX>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+  const float *ga = gamma + (int64_t)e * H, *be = beta + (int64_t)e * H;
+  TO *dst = xg + r * H;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      float4 g4 = load4<float>(ga + c), b4 = load4<float>(be + c);
+      float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                             (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+      store4<TO>(dst + c, o);
+    }
+  }
+  if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+}
+
+// LayerNorm backward per row; dgamma/dbeta accumulated per wave over RPW consecutive rows and
+// flushed with float atomics when the expert changes (rows are expert-sorted)
+template <typename TX, typename TG, int IT>
+__global__ void __launch_bounds__(256)
+gather_ln_bwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
+                const int32_t *__restrict__ offsets, const float *__restrict__ gamma,
+                const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
+                const TG *__restrict__ dxg, TG *__restrict__ dxr, float *__restrict__ dgamma,
+                float *__restrict__ dbeta, int64_t max_rows, int H, int E, int RPW) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = min((int64_t)offsets[E], max_rows);
+  int64_t r0 = wave * RPW, r1 = min(r0 + RPW, total);
+  if (r0 >= total) return;
+  float4 ag[IT], ab[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
+  int e = expert_of_row(offsets, E, (int)r0);
+  auto flush = [&](int ee) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float *dg = dgamma + (int64_t)ee * H + c, *db = dbeta + (int64_t)ee * H + c;
+        atomicAdd(dg + 0, ag[i].x); atomicAdd(dg + 1, ag[i].y); atomicAdd(dg + 2, ag[i].z); atomicAdd(dg + 3, ag[i].w);
+        atomicAdd(db + 0, ab[i].x); atomicAdd(db + 1, ab[i].y); atomicAdd(db + 2, ab[i].z); atomicAdd(db + 3, ab[i].w);
+      }
+      ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+    }
+  };
+  for (int64_t r = r0; r < r1; ++r) {
+    while (e + 1 < E && offsets[e + 1] <= r) { flush(e); ++e; }
+    const TX *src = x + (int64_t)row_token[r] * H;
+    const TG *dsrc = dxg + r * H;
+    const float mean = mean_i[r], rstd = rstd_i[r];
+    const float *ga = gamma + (int64_t)e * H;
+    float4 xh[IT], gd[IT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float4 xv = load4<TX>(src + c), dv = load4<TG>(dsrc + c), g4 = load4<float>(ga + c);
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        gd[i] = make_float4(dv.x * g4.x, dv.y * g4.y, dv.z * g4.z, dv.w * g4.w);
+        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+      } else { xh[i] = make_float4(0, 0, 0, 0); gd[i] = make_float4(0, 0, 0, 0); }
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+    TG *dst = dxr + r * H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H)
+        store4<TG>(dst + c, make_float4(rstd * (gd[i].x - m1 - xh[i].x * m2), rstd * (gd[i].y - m1 - xh[i].y * m2),
+                                        rstd * (gd[i].z - m1 - xh[i].z * m2), rstd * (gd[i].w - m1 - xh[i].w * m2)));
+    }
+  }
+  flush(e);
+}
+
+// out[s,:] = sum_k (w[s,k] or 1) * yr[slot_of[s,k],:], k ascending (== index_add_ order, core.py:605)
+template <typename TY, typename TO, int IT>
+__global__ void __launch_bounds__(256)
+combine_fwd_k(const TY *__restrict__ yr, const int32_t *__restrict__ slot_of, const float *__restrict__ wk,
+              TO *__restrict__ out, int64_t S, int H, int K, int with_w) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  float4 acc[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) acc[i] = make_float4(0, 0, 0, 0);
+  for (int k = 0; k < K; ++k) {
+    const int slot = slot_of[s * K + k];
+    if (slot < 0) continue;
+    const float wv = with_w ? wk[s * K + k] : 1.f;
+    const TY *src = yr + (int64_t)slot * H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float4 v = load4<TY>(src + c);
+        // separate multiply then add, like `expert_output * weights` followed by index_add_
+        acc[i].x += v.x * wv; acc[i].y += v.y * wv; acc[i].z += v.z * wv; acc[i].w += v.w * wv;
+      }
+    }
+  }
+  TO *dst = out + s * H;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int c = (lane + 64 * i) * 4;
+    if (c < H) store4<TO>(dst + c, acc[i]);
+  }
+}
+
+// dyr[r,:] = w[s,k]*dout[s,:];  dwk[s,k] = <dout[s,:], yr[r,:]>
+template <typename TD, typename TY, int IT>
+__global__ void __launch_bounds__(256)
+combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int32_t *__restrict__ row_token,
+              const int32_t *__restrict__ row_k, const int32_t *__restrict__ offsets,
+              const float *__restrict__ wk, TY *__restrict__ dyr, float *__restrict__ dwk, int64_t max_rows,
+              int H, int K, int E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= max_rows || r >= offsets[E]) return;
+  const int64_t s = row_token[r];
+  const int k = row_k[r];
+  const float wv = wk[s * K + k];
+  const TD *dsrc = dout + s * H;
+  const TY *ysrc = yr + r * H;
+  TY *dst = dyr + r * H;
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      float4 d = load4<TD>(dsrc + c), y = load4<TY>(ysrc + c);
+      dot += (d.x * y.x + d.y * y.y) + (d.z * y.z + d.w * y.w);
+      store4<TY>(dst + c, make_float4(d.x * wv, d.y * wv, d.z * wv, d.w * wv));
+    }
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) dwk[s * K + k] = dot;
+}
+
+int check_H(int64_t H) { return (H > 0 && H % 4 == 0 && H <= 256 * 16) ? APERTIS_OK : APERTIS_ERR_UNSUPPORTED; }
+
+}  // namespace
+
+// dispatch a kernel template on IT = ceil(H/256) in {1,2,3,4,6,8,12,16}
+#define DISPATCH_IT(H, ...)                                    \
+  do {                                                         \
+    int it_ = (int)ceil_div64((H), 256);                       \
+    if (it_ <= 1) { constexpr int IT = 1; __VA_ARGS__; }              \
+    else if (it_ <= 2) { constexpr int IT = 2; __VA_ARGS__; }         \
+    else if (it_ <= 3) { constexpr int IT = 3; __VA_ARGS__; }         \
+    else if (it_ <= 4) { constexpr int IT = 4; __VA_ARGS__; }         \
+    else if (it_ <= 6) { constexpr int IT = 6; __VA_ARGS__; }         \
+    else if (it_ <= 8) { constexpr int IT = 8; __VA_ARGS__; }         \
+    else if (it_ <= 12) { constexpr int IT = 12; __VA_ARGS__; }       \
+    else { constexpr int IT = 16; __VA_ARGS__; }                      \
+  } while (0)
+
+#define DISPATCH_2T(da, db, ...)                                                           \
+  do {                                                                                     \
+    if ((da) == APERTIS_F32 && (db) == APERTIS_F32) { typedef float TA; typedef float TB; __VA_ARGS__; }        \
+    else if ((da) == APERTIS_F32 && (db) == APERTIS_BF16) { typedef float TA; typedef bf16_t TB; __VA_ARGS__; } \
+    else if ((da) == APERTIS_BF16 && (db) == APERTIS_F32) { typedef bf16_t TA; typedef float TB; __VA_ARGS__; } \
+    else if ((da) == APERTIS_BF16 && (db) == APERTIS_BF16) { typedef bf16_t TA; typedef bf16_t TB; __VA_ARGS__; } \
+    else return APERTIS_ERR_ARG;                                                           \
+  } while (0)
+
+extern "C" int apertis_moe_gate_topk_fwd(const float *logits, float *gates, int32_t *idx, float *w,
+                                         int64_t S, int64_t E, int64_t K, void *stream) {
+  if (!logits || !gates || !idx || !w || S < 0) return APERTIS_ERR_ARG;
+  if (E < 1 || E > MAXE || K < 1 || K > MAXK || K > E) return APERTIS_ERR_UNSUPPORTED;
+  if (S == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(S, 256)), block(256);
+#define GO(EC) hipLaunchKernelGGL(gate_topk_fwd_k<EC>, grid, block, 0, st, logits, gates, idx, w, S, (int)E, (int)K)
+  if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
+#undef GO
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx, const float *dw,
+                                         const float *dgates, float *dlogits, int64_t S, int64_t E,
+                                         int64_t K, void *stream) {
+  if (!gates || !idx || !dlogits || S < 0) return APERTIS_ERR_ARG;
+  if (E < 1 || E > MAXE || K < 1 || K > MAXK || K > E) return APERTIS_ERR_UNSUPPORTED;
+  if (S == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(S, 256)), block(256);
+#define GO(EC) hipLaunchKernelGGL(gate_topk_bwd_k<EC>, grid, block, 0, st, gates, idx, dw, dgates, dlogits, S, (int)E, (int)K)
+  if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
+#undef GO
+  return apertis_check_launch();
+}
+
+extern "C" int64_t apertis_moe_plan_workspace_bytes(int64_t S, int64_t E, int64_t K) {
+  int64_t P = E * K, NCH = ceil_div64(S > 0 ? S : 1, 64);
+  return (6 * P + 2 * P * NCH) * 4 + 64;
+}
+
+extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_t *active,
+                                int64_t capacity, int32_t *expert_offsets, int32_t *row_token,
+                                int32_t *row_k, int32_t *slot_of, void *ws, int64_t S, int64_t E,
+                                int64_t K, void *stream) {
+  if (!idx || !w || !expert_offsets || !row_token || !row_k || !slot_of || !ws || S < 0) return APERTIS_ERR_ARG;
+  if (E < 1 || E > MAXE || K < 1 || K > MAXK) return APERTIS_ERR_UNSUPPORTED;
+  if (S * K > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  PlanWs pw = carve_ws(ws, S > 0 ? S : 1, E, K);
+  hipMemsetAsync(pw.total, 0, sizeof(int32_t) * pw.P, st);
+  if (S > 0) {
+    int64_t nb = ceil_div64(S * K, 256);
+    hipLaunchKernelGGL(plan_hist_k, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, idx, pw.total, S * K,
+                       (int)E, (int)K);
+  }
+  hipLaunchKernelGGL(plan_capacity_k, dim3(1), dim3(64), 0, st, pw, active, capacity, expert_offsets, (int)E, (int)K);
+  if (S > 0) {
+    if (capacity > 0)
+      hipLaunchKernelGGL(plan_select_k, dim3(pw.P), dim3(1024), 0, st, pw, idx, w, S, (int)K);
+    dim3 cgrid((unsigned)ceil_div64(pw.NCH, 4)), cblock(256);
+    hipLaunchKernelGGL(plan_count_k, cgrid, cblock, 0, st, pw, idx, w, S, (int)E, (int)K);
+    hipLaunchKernelGGL(plan_scan_k, dim3(2 * pw.P), dim3(256), 0, st, pw);
+    hipLaunchKernelGGL(plan_assign_k, cgrid, cblock, 0, st, pw, idx, w, row_token, row_k, slot_of, S, (int)E, (int)K);
+  }
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_gather_ln_fwd(const void *x, const int32_t *row_token,
+                                         const int32_t *expert_offsets, const float *gamma,
+                                         const float *beta, float eps, void *xg, float *mean,
+                                         float *rstd, int64_t max_rows, int64_t H, int64_t E,
+                                         int dtype_x, int dtype_out, void *stream) {
+  if (!x || !row_token || !expert_offsets || !gamma || !beta || !xg || !mean || !rstd || max_rows < 0)
+    return APERTIS_ERR_ARG;
+  if (check_H(H) || E < 1 || E > MAXE) return APERTIS_ERR_UNSUPPORTED;
+  if (max_rows == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(max_rows, 4)), block(256);
+  DISPATCH_2T(dtype_x, dtype_out, DISPATCH_IT(H, hipLaunchKernelGGL((gather_ln_fwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TA *)x, row_token, expert_offsets, gamma, beta, eps, (TB *)xg, mean, rstd, max_rows, (int)H, (int)E)));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
+                                         const int32_t *expert_offsets, const float *gamma,
+                                         const float *mean, const float *rstd, const void *dxg,
+                                         void *dxr, float *dgamma, float *dbeta, int64_t max_rows,
+                                         int64_t H, int64_t E, int dtype_x, int dtype_g, void *stream) {
+  if (!x || !row_token || !expert_offsets || !gamma || !mean || !rstd || !dxg || !dxr || !dgamma || !dbeta ||
+      max_rows < 0)
+    return APERTIS_ERR_ARG;
+  if (check_H(H) || E < 1 || E > MAXE) return APERTIS_ERR_UNSUPPORTED;
+  if (max_rows == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int RPW = 16;
+  dim3 grid((unsigned)ceil_div64(ceil_div64(max_rows, RPW), 4)), block(256);
+  DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((gather_ln_bwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TA *)x, row_token, expert_offsets, gamma, mean, rstd, (const TB *)dxg, (TB *)dxr, dgamma, dbeta,
+      max_rows, (int)H, (int)E, RPW)));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_combine_fwd(const void *yr, const int32_t *slot_of, const float *wk, void *out,
+                                       int64_t S, int64_t H, int64_t K, int with_weights, int dtype_yr,
+                                       int dtype_out, void *stream) {
+  if (!yr || !slot_of || !out || (with_weights && !wk) || S < 0) return APERTIS_ERR_ARG;
+  if (check_H(H) || K < 1 || K > MAXK) return APERTIS_ERR_UNSUPPORTED;
+  if (S == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(S, 4)), block(256);
+  DISPATCH_2T(dtype_yr, dtype_out, DISPATCH_IT(H, hipLaunchKernelGGL((combine_fwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TA *)yr, slot_of, wk, (TB *)out, S, (int)H, (int)K, with_weights)));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_combine_bwd(const void *dout, const void *yr, const int32_t *row_token,
+                                       const int32_t *row_k, const int32_t *expert_offsets, const float *wk,
+                                       void *dyr, float *dwk, int64_t max_rows, int64_t S, int64_t H,
+                                       int64_t K, int64_t E, int dtype_dout, int dtype_yr, void *stream) {
+  if (!dout || !yr || !row_token || !row_k || !expert_offsets || !wk || !dyr || !dwk || max_rows < 0)
+    return APERTIS_ERR_ARG;
+  if (check_H(H) || K < 1 || K > MAXK || E < 1 || E > MAXE) return APERTIS_ERR_UNSUPPORTED;
+  if (max_rows == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(max_rows, 4)), block(256);
+  DISPATCH_2T(dtype_dout, dtype_yr, DISPATCH_IT(H, hipLaunchKernelGGL((combine_bwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TA *)dout, (const TB *)yr, row_token, row_k, expert_offsets, wk, (TB *)dyr, dwk, max_rows, (int)H,
+      (int)K, (int)E)));
+  return apertis_check_launch();
+}

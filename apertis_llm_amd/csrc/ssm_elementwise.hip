@@ -1,0 +1,429 @@
+// Memory-bound companions of the scan on token-major [T, Dn] data (gfx950):
+//   - depthwise causal conv1d + SiLU   (reference core.py:368-375)
+//   - post-scan skip + gate            (reference core.py:395-396)
+//   - fp32 -> {fp32,bf16} cast with an optional transposed copy (compute copies of the expert
+//     weights: [E,R,C] and [E,C,R], so forward and dgrad both read K-contiguous operands)
+// Geometry shared by the first two: a thread owns ONE 4-channel chunk (16 B fp32 / 8 B bf16) and
+// walks tokens, so per-channel reductions (dD, dw, dbias) stay in registers; a block covers
+// RP = 256/CPR rows at a time (CPR = Dn/4 chunks per row) and leaves [nblk, ...] partials that a
+// deterministic column-sum kernel folds.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float4 ld4(const T *p);
+template <> __device__ __forceinline__ float4 ld4<float>(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+template <> __device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t *p) {
+  uint2 u = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void st4(T *p, float4 v);
+template <> __device__ __forceinline__ void st4<float>(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, float4 v) {
+  typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+  bf4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+  *reinterpret_cast<bf4 *>(p) = o;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+
+struct Geo { int CPR, RP; };
+__host__ __device__ inline Geo make_geo(int64_t Dn) {
+  Geo g; g.CPR = (int)(Dn / 4); g.RP = g.CPR >= 256 ? 1 : 256 / g.CPR; return g;
+}
+
+// ---------------------------------------------------------------- gate
+template <typename TY, typename TIO>
+__global__ void __launch_bounds__(256)
+ssm_gate_fwd_k(const TY *__restrict__ y, int64_t y_rs, const TIO *__restrict__ xc, int64_t xc_rs,
+               const TIO *__restrict__ z, int64_t z_rs, const float *__restrict__ D, TIO *__restrict__ out,
+               int64_t out_rs, int64_t T, int Dn) {
+  const Geo g = make_geo(Dn);
+  const int rr = threadIdx.x / g.CPR;
+  if (rr >= g.RP) return;
+  for (int c = threadIdx.x - rr * g.CPR; c < g.CPR; c += 256) {
+    const float4 d4 = ld4<float>(D + c * 4);
+    for (int64_t t = (int64_t)blockIdx.x * g.RP + rr; t < T; t += (int64_t)gridDim.x * g.RP) {
+      float4 yv = ld4<TY>(y + t * y_rs + c * 4), xv = ld4<TIO>(xc + t * xc_rs + c * 4), zv = ld4<TIO>(z + t * z_rs + c * 4);
+      float4 o = make_float4((yv.x + d4.x * xv.x) * siluf_(zv.x), (yv.y + d4.y * xv.y) * siluf_(zv.y),
+                             (yv.z + d4.z * xv.z) * siluf_(zv.z), (yv.w + d4.w * xv.w) * siluf_(zv.w));
+      st4<TIO>(out + t * out_rs + c * 4, o);
+    }
+  }
+}
+
+template <typename TY, typename TIO>
+__global__ void __launch_bounds__(256)
+ssm_gate_bwd_k(const TIO *__restrict__ dout, int64_t dout_rs, const TY *__restrict__ y, int64_t y_rs,
+               const TIO *__restrict__ xc, int64_t xc_rs, const TIO *__restrict__ z, int64_t z_rs,
+               const float *__restrict__ D, TY *__restrict__ dy, int64_t dy_rs, TIO *__restrict__ dxc, int64_t dxc_rs,
+               TIO *__restrict__ dz, int64_t dz_rs, float *__restrict__ dD_part, int64_t T, int Dn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *red = reinterpret_cast<float4 *>(smem);  // [RP][CPR]
+  const Geo g = make_geo(Dn);
+  const int rr = threadIdx.x / g.CPR;
+  const bool on = rr < g.RP;
+  for (int c0 = 0; c0 < g.CPR; c0 += 256) {
+    const int c = c0 + (on ? threadIdx.x - rr * g.CPR : 0);
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (on && c < g.CPR) {
+      const float4 d4 = ld4<float>(D + c * 4);
+      for (int64_t t = (int64_t)blockIdx.x * g.RP + rr; t < T; t += (int64_t)gridDim.x * g.RP) {
+        float4 go = ld4<TIO>(dout + t * dout_rs + c * 4), yv = ld4<TY>(y + t * y_rs + c * 4);
+        float4 xv = ld4<TIO>(xc + t * xc_rs + c * 4), zv = ld4<TIO>(z + t * z_rs + c * 4);
+        float gy[4], gx[4], gz[4];
+        const float go_[4] = {go.x, go.y, go.z, go.w}, y_[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float x_[4] = {xv.x, xv.y, xv.z, xv.w}, z_[4] = {zv.x, zv.y, zv.z, zv.w}, d_[4] = {d4.x, d4.y, d4.z, d4.w};
+        float a_[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float sz = siluf_(z_[j]);
+          gy[j] = go_[j] * sz;
+          gx[j] = gy[j] * d_[j];
+          gz[j] = go_[j] * (y_[j] + d_[j] * x_[j]) * silu_grad(z_[j]);
+          a_[j] += gy[j] * x_[j];
+        }
+        acc = make_float4(a_[0], a_[1], a_[2], a_[3]);
+        st4<TY>(dy + t * dy_rs + c * 4, make_float4(gy[0], gy[1], gy[2], gy[3]));
+        st4<TIO>(dxc + t * dxc_rs + c * 4, make_float4(gx[0], gx[1], gx[2], gx[3]));
+        st4<TIO>(dz + t * dz_rs + c * 4, make_float4(gz[0], gz[1], gz[2], gz[3]));
+      }
+    }
+    __syncthreads();
+    if (on && c < g.CPR) red[rr * min(g.CPR, 256) + (c - c0)] = acc;
+    __syncthreads();
+    if (on && rr == 0 && c < g.CPR) {
+      float4 s = red[c - c0];
+      for (int r = 1; r < g.RP; ++r) {
+        float4 v = red[r * min(g.CPR, 256) + (c - c0)];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4 *>(dD_part + (int64_t)blockIdx.x * Dn + c * 4) = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- depthwise causal conv + SiLU
+constexpr int CONV_TT = 32;  // tokens per thread run
+
+template <typename T, int KW>
+__global__ void __launch_bounds__(256)
+dwconv_silu_fwd_k(const T *__restrict__ x, int64_t x_rs, const float *__restrict__ w, const float *__restrict__ bias,
+                  T *__restrict__ out, int64_t out_rs, int64_t B, int64_t L, int Dn) {
+  const Geo g = make_geo(Dn);
+  const int rr = threadIdx.x / g.CPR;
+  if (rr >= g.RP) return;
+  const int64_t runs_per_seq = ceil_div64(L, CONV_TT);
+  for (int c = threadIdx.x - rr * g.CPR; c < g.CPR; c += 256) {
+    float wv[4][KW], bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bv[j] = bias[c * 4 + j];
+#pragma unroll
+      for (int q = 0; q < KW; ++q) wv[j][q] = w[(c * 4 + j) * KW + q];
+    }
+    for (int64_t run = (int64_t)blockIdx.x * g.RP + rr; run < B * runs_per_seq; run += (int64_t)gridDim.x * g.RP) {
+      const int64_t b = run / runs_per_seq, t0 = (run - b * runs_per_seq) * CONV_TT;
+      const T *xb = x + b * L * x_rs + c * 4;
+      T *ob = out + b * L * out_rs + c * 4;
+      float win[KW][4];  // win[q] = x[t-(KW-1)+q]
+#pragma unroll
+      for (int q = 0; q < KW - 1; ++q) {
+        int64_t tt = t0 - (KW - 1) + q;
+        float4 v = tt >= 0 ? ld4<T>(xb + tt * x_rs) : make_float4(0, 0, 0, 0);
+        win[q + 1][0] = v.x; win[q + 1][1] = v.y; win[q + 1][2] = v.z; win[q + 1][3] = v.w;
+      }
+      const int64_t t1 = min(t0 + CONV_TT, L);
+      for (int64_t t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int q = 0; q < KW - 1; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) win[q][j] = win[q + 1][j];
+        float4 v = ld4<T>(xb + t * x_rs);
+        win[KW - 1][0] = v.x; win[KW - 1][1] = v.y; win[KW - 1][2] = v.z; win[KW - 1][3] = v.w;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float s = bv[j];
+#pragma unroll
+          for (int q = 0; q < KW; ++q) s += wv[j][q] * win[q][j];
+          s = to_f32(from_f32<T>(s));  // conv output is stored in the activation dtype before SiLU
+          o[j] = siluf_(s);
+        }
+        st4<T>(ob + t * out_rs, make_float4(o[0], o[1], o[2], o[3]));
+      }
+    }
+  }
+}
+
+// backward: dpre[t] = dout[t]*silu'(pre[t]); dx[t] = sum_q w[q]*dpre[t+(KW-1)-q]; dw,db partials
+template <typename T, int KW>
+__global__ void __launch_bounds__(256)
+dwconv_silu_bwd_k(const T *__restrict__ x, int64_t x_rs, const float *__restrict__ w, const float *__restrict__ bias,
+                  const T *__restrict__ dout, int64_t dout_rs, T *__restrict__ dx, int64_t dx_rs,
+                  float *__restrict__ dw_part, float *__restrict__ db_part, int64_t B, int64_t L, int Dn) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *red = reinterpret_cast<float *>(smem);  // [RP][CPR][4*(KW+1)]
+  constexpr int NA = 4 * (KW + 1);
+  const Geo g = make_geo(Dn);
+  const int rr = threadIdx.x / g.CPR;
+  const bool on = rr < g.RP;
+  const int64_t runs_per_seq = ceil_div64(L, CONV_TT);
+  for (int c0 = 0; c0 < g.CPR; c0 += 256) {
+    const int c = c0 + (on ? threadIdx.x - rr * g.CPR : 0);
+    float accw[4][KW], accb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { accb[j] = 0.f;
+#pragma unroll
+      for (int q = 0; q < KW; ++q) accw[j][q] = 0.f; }
+    if (on && c < g.CPR) {
+      float wv[4][KW], bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bv[j] = bias[c * 4 + j];
+#pragma unroll
+        for (int q = 0; q < KW; ++q) wv[j][q] = w[(c * 4 + j) * KW + q];
+      }
+      for (int64_t run = (int64_t)blockIdx.x * g.RP + rr; run < B * runs_per_seq; run += (int64_t)gridDim.x * g.RP) {
+        const int64_t b = run / runs_per_seq, t0 = (run - b * runs_per_seq) * CONV_TT;
+        const T *xb = x + b * L * x_rs + c * 4;
+        const T *gb = dout + b * L * dout_rs + c * 4;
+        T *dxb = dx + b * L * dx_rs + c * 4;
+        const int64_t t1 = min(t0 + CONV_TT, L);
+        // sliding x window win[q] = x[t-(KW-1)+q] and dpre history dp[q] = dpre[t-(KW-1)+q];
+        // walk t over [t0, t1+KW-1): dpre[t] for t>=t1 belongs to the next run but feeds our dx
+        float win[KW][4], dp[KW][4];
+#pragma unroll
+        for (int q = 0; q < KW; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { win[q][j] = 0.f; dp[q][j] = 0.f; }
+#pragma unroll
+        for (int q = 0; q < KW - 1; ++q) {
+          int64_t tt = t0 - (KW - 1) + q;
+          if (tt >= 0) { float4 v = ld4<T>(xb + tt * x_rs); win[q + 1][0] = v.x; win[q + 1][1] = v.y; win[q + 1][2] = v.z; win[q + 1][3] = v.w; }
+        }
+        for (int64_t t = t0; t < t1 + (KW - 1); ++t) {
+#pragma unroll
+          for (int q = 0; q < KW - 1; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { win[q][j] = win[q + 1][j]; dp[q][j] = dp[q + 1][j]; }
+          if (t < L) {
+            float4 v = ld4<T>(xb + t * x_rs), gv = ld4<T>(gb + t * dout_rs);
+            win[KW - 1][0] = v.x; win[KW - 1][1] = v.y; win[KW - 1][2] = v.z; win[KW - 1][3] = v.w;
+            const float g_[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float s = bv[j];
+#pragma unroll
+              for (int q = 0; q < KW; ++q) s += wv[j][q] * win[q][j];
+              s = to_f32(from_f32<T>(s));
+              float d = g_[j] * silu_grad(s);
+              dp[KW - 1][j] = d;
+              if (t < t1) {  // own tokens only: parameter gradients are not double counted
+                accb[j] += d;
+#pragma unroll
+                for (int q = 0; q < KW; ++q) accw[j][q] += d * win[q][j];
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { win[KW - 1][j] = 0.f; dp[KW - 1][j] = 0.f; }
+          }
+          // dx[t'] with t' = t-(KW-1): sum_q w[q]*dpre[t'+(KW-1)-q] = sum_q w[q]*dp[KW-1-q]
+          const int64_t tp = t - (KW - 1);
+          if (tp >= t0 && tp < t1) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              float s = 0.f;
+#pragma unroll
+              for (int q = 0; q < KW; ++q) s += wv[j][q] * dp[KW - 1 - q][j];
+              o[j] = s;
+            }
+            st4<T>(dxb + tp * dx_rs, make_float4(o[0], o[1], o[2], o[3]));
+          }
+        }
+      }
+    }
+    const int cw = min(g.CPR, 256);
+    __syncthreads();
+    if (on && c < g.CPR) {
+      float *r = red + ((int64_t)rr * cw + (c - c0)) * NA;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j * (KW + 1) + KW] = accb[j];
+#pragma unroll
+        for (int q = 0; q < KW; ++q) r[j * (KW + 1) + q] = accw[j][q];
+      }
+    }
+    __syncthreads();
+    if (on && rr == 0 && c < g.CPR) {
+      for (int j = 0; j < 4; ++j) {
+        for (int q = 0; q <= KW; ++q) {
+          float s = 0.f;
+          for (int r = 0; r < g.RP; ++r) s += red[((int64_t)r * cw + (c - c0)) * NA + j * (KW + 1) + q];
+          if (q < KW) dw_part[((int64_t)blockIdx.x * Dn + c * 4 + j) * KW + q] = s;
+          else db_part[(int64_t)blockIdx.x * Dn + c * 4 + j] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// out[c] = sum_r in[r][c], fixed order
+__global__ void __launch_bounds__(256)
+colsum_rows_k(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = seg; r < rows; r += 4) s += in[r * cols + c];
+  part[seg][lane] = s;
+  __syncthreads();
+  if (seg == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// ---------------------------------------------------------------- cast (+ transposed copy)
+template <typename TO>
+__global__ void __launch_bounds__(256)
+cast_transpose_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__restrict__ dstT, int R, int C) {
+  __shared__ float tile[64][65];
+  const int64_t e = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const float *s = src + e * (int64_t)R * C;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    float v = (r < R && c < C) ? s[(int64_t)r * C + c] : 0.f;
+    tile[i][tx] = v;
+    if (dst && r < R && c < C) dst[e * (int64_t)R * C + (int64_t)r * C + c] = from_f32<TO>(v);
+  }
+  __syncthreads();
+  if (dstT)
+    for (int i = ty; i < 64; i += 4) {
+      int c = c0 + i, r = r0 + tx;
+      if (r < R && c < C) dstT[e * (int64_t)R * C + (int64_t)c * R + r] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
+int gate_blocks(int64_t T, int64_t Dn) {
+  Geo g = make_geo(Dn);
+  int64_t nb = ceil_div64(T, (int64_t)g.RP * 8);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(nb, 2048));
+}
+int conv_blocks(int64_t B, int64_t L, int64_t Dn) {
+  Geo g = make_geo(Dn);
+  int64_t runs = B * ceil_div64(L, CONV_TT);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(ceil_div64(runs, g.RP), 4096));
+}
+bool rows_ok(int64_t Dn) { return Dn > 0 && Dn % 4 == 0 && Dn <= 4 * 4096; }
+
+}  // namespace
+
+extern "C" int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn) { return gate_blocks(T, Dn); }
+extern "C" int64_t apertis_dwconv_bwd_blocks(int64_t B, int64_t L, int64_t Dn) { return conv_blocks(B, L, Dn); }
+
+#define GATE_TYPES(dy_, dio_, ...)                                                                    \
+  do {                                                                                                \
+    if ((dy_) == APERTIS_F32 && (dio_) == APERTIS_F32) { typedef float TY; typedef float TIO; __VA_ARGS__; }        \
+    else if ((dy_) == APERTIS_F32 && (dio_) == APERTIS_BF16) { typedef float TY; typedef bf16_t TIO; __VA_ARGS__; } \
+    else if ((dy_) == APERTIS_BF16 && (dio_) == APERTIS_BF16) { typedef bf16_t TY; typedef bf16_t TIO; __VA_ARGS__; } \
+    else return APERTIS_ERR_UNSUPPORTED;                                                              \
+  } while (0)
+
+extern "C" int apertis_ssm_gate_fwd(const void *y, int64_t y_rs, const void *xc, int64_t xc_rs, const void *z,
+                                    int64_t z_rs, const float *D, void *out, int64_t out_rs, int64_t T, int64_t Dn,
+                                    int dtype_y, int dtype_io, void *stream) {
+  if (!y || !xc || !z || !D || !out || T < 0) return APERTIS_ERR_ARG;
+  if (!rows_ok(Dn) || (y_rs | xc_rs | z_rs | out_rs) % 4) return APERTIS_ERR_UNSUPPORTED;
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(gate_blocks(T, Dn)), block(256);
+  GATE_TYPES(dtype_y, dtype_io, hipLaunchKernelGGL((ssm_gate_fwd_k<TY, TIO>), grid, block, 0, st, (const TY *)y, y_rs,
+                                                   (const TIO *)xc, xc_rs, (const TIO *)z, z_rs, D, (TIO *)out, out_rs, T,
+                                                   (int)Dn));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_ssm_gate_bwd(const void *dout, int64_t dout_rs, const void *y, int64_t y_rs, const void *xc,
+                                    int64_t xc_rs, const void *z, int64_t z_rs, const float *D, void *dy, int64_t dy_rs,
+                                    void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *dD_part, float *dD,
+                                    int64_t T, int64_t Dn, int dtype_y, int dtype_io, void *stream) {
+  if (!dout || !y || !xc || !z || !D || !dy || !dxc || !dz || !dD_part || !dD || T < 0) return APERTIS_ERR_ARG;
+  if (!rows_ok(Dn) || (dout_rs | y_rs | xc_rs | z_rs | dy_rs | dxc_rs | dz_rs) % 4) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = gate_blocks(T, Dn);
+  Geo g = make_geo(Dn);
+  size_t lds = (size_t)g.RP * std::min(g.CPR, 256) * sizeof(float4);
+  dim3 grid(nblk), block(256);
+  GATE_TYPES(dtype_y, dtype_io, hipLaunchKernelGGL((ssm_gate_bwd_k<TY, TIO>), grid, block, lds, st, (const TIO *)dout,
+                                                   dout_rs, (const TY *)y, y_rs, (const TIO *)xc, xc_rs, (const TIO *)z,
+                                                   z_rs, D, (TY *)dy, dy_rs, (TIO *)dxc, dxc_rs, (TIO *)dz, dz_rs, dD_part,
+                                                   T, (int)Dn));
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(256), 0, st, dD_part, dD, (int64_t)nblk, Dn);
+  return apertis_check_launch();
+}
+
+#define CONV_DISPATCH(k_, dt_, ...)                                                             \
+  do {                                                                                          \
+    if ((dt_) == APERTIS_F32) { typedef float T;                                                \
+      if ((k_) == 2) { constexpr int KW = 2; __VA_ARGS__; } else if ((k_) == 3) { constexpr int KW = 3; __VA_ARGS__; } \
+      else if ((k_) == 4) { constexpr int KW = 4; __VA_ARGS__; } else return APERTIS_ERR_UNSUPPORTED; }  \
+    else if ((dt_) == APERTIS_BF16) { typedef bf16_t T;                                         \
+      if ((k_) == 2) { constexpr int KW = 2; __VA_ARGS__; } else if ((k_) == 3) { constexpr int KW = 3; __VA_ARGS__; } \
+      else if ((k_) == 4) { constexpr int KW = 4; __VA_ARGS__; } else return APERTIS_ERR_UNSUPPORTED; }  \
+    else return APERTIS_ERR_ARG;                                                                \
+  } while (0)
+
+extern "C" int apertis_dwconv_silu_fwd(const void *x, int64_t x_rs, const float *w, const float *bias, void *out,
+                                       int64_t out_rs, int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
+                                       void *stream) {
+  if (!x || !w || !bias || !out || B < 0 || L < 0) return APERTIS_ERR_ARG;
+  if (!rows_ok(Dn) || (x_rs | out_rs) % 4) return APERTIS_ERR_UNSUPPORTED;
+  if (B == 0 || L == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(conv_blocks(B, L, Dn)), block(256);
+  CONV_DISPATCH(k, dtype_io, hipLaunchKernelGGL((dwconv_silu_fwd_k<T, KW>), grid, block, 0, st, (const T *)x, x_rs, w, bias,
+                                                (T *)out, out_rs, B, L, (int)Dn));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float *w, const float *bias, const void *dout,
+                                       int64_t dout_rs, void *dx, int64_t dx_rs, float *dw_part, float *db_part,
+                                       float *dw, float *db, int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
+                                       void *stream) {
+  if (!x || !w || !bias || !dout || !dx || !dw_part || !db_part || !dw || !db || B < 0 || L < 0) return APERTIS_ERR_ARG;
+  if (!rows_ok(Dn) || (x_rs | dout_rs | dx_rs) % 4 || k < 2 || k > 4) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = conv_blocks(B, L, Dn);
+  Geo g = make_geo(Dn);
+  size_t lds = (size_t)g.RP * std::min(g.CPR, 256) * 4 * (k + 1) * sizeof(float);
+  dim3 grid(nblk), block(256);
+  CONV_DISPATCH(k, dtype_io, hipLaunchKernelGGL((dwconv_silu_bwd_k<T, KW>), grid, block, lds, st, (const T *)x, x_rs, w,
+                                                bias, (const T *)dout, dout_rs, (T *)dx, dx_rs, dw_part, db_part, B, L,
+                                                (int)Dn));
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn * k, 64)), dim3(256), 0, st, dw_part, dw, (int64_t)nblk,
+                     Dn * k);
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(256), 0, st, db_part, db, (int64_t)nblk, Dn);
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R, int64_t C,
+                                      int dtype_out, void *stream) {
+  if (!src || (!dst && !dstT) || E <= 0 || R <= 0 || C <= 0) return APERTIS_ERR_ARG;
+  if (R > 0x3fffffff || C > 0x3fffffff || E > 65535 || ceil_div64(R, 64) > 65535) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(C, 64), (unsigned)ceil_div64(R, 64), (unsigned)E), block(256);
+  if (dtype_out == APERTIS_BF16)
+    hipLaunchKernelGGL(cast_transpose_k<bf16_t>, grid, block, 0, st, src, (bf16_t *)dst, (bf16_t *)dstT, (int)R, (int)C);
+  else if (dtype_out == APERTIS_F32)
+    hipLaunchKernelGGL(cast_transpose_k<float>, grid, block, 0, st, src, (float *)dst, (float *)dstT, (int)R, (int)C);
+  else
+    return APERTIS_ERR_ARG;
+  return apertis_check_launch();
+}

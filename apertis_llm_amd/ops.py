@@ -16,15 +16,15 @@ def _require_gpu(*ts):
                                   "there is no CPU fallback" % t.device)
 
 
-def _row_stride(t, width):
-    """Row stride (elements) of a [..., rows, width] view whose rows are `width` contiguous
-    elements apart by a constant stride and whose leading dims are packed on top of it."""
-    if t.stride(-1) != 1:
-        raise ApertisHipError("innermost dimension must be contiguous")
-    rs = t.stride(-2)
-    if t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * rs:
-        raise ApertisHipError("batch stride must equal L * row_stride")
-    return rs
+def _rows(t, width):
+    """(tensor, row_stride): a [B,L,width] view usable by the kernels as is (unit inner stride,
+    constant row stride, batch stride = L*row_stride), else a packed copy."""
+    ok = t.stride(-1) == 1 and t.stride(-2) >= width
+    if ok and t.dim() == 3 and t.shape[0] > 1 and t.stride(0) != t.shape[1] * t.stride(1):
+        ok = False
+    if not ok:
+        t = t.contiguous()
+    return t, t.stride(-2)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -47,7 +47,7 @@ class _SelectiveScan(torch.autograd.Function):
         A_log = A_log.float().contiguous()
         if h0 is not None:
             h0 = h0.float().reshape(B, Dn).contiguous()
-        bt_rs, c_rs = _row_stride(Bt, Dn), _row_stride(C, Dn)
+        (Bt, bt_rs), (C, c_rs) = _rows(Bt, Dn), _rows(C, Dn)
         nch = lib.apertis_scan_num_chunks(B, L, Dn)
         dev = dlt.device
         y = torch.empty(B, L, Dn, device=dev, dtype=y_dtype)
@@ -81,8 +81,8 @@ class _SelectiveScan(torch.autograd.Function):
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         mu_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         dA_part = torch.empty(B * nch, Dn, device=dev, dtype=torch.float32)
-        check(lib.apertis_selective_scan_bwd(ptr(dlt), ptr(A_log), ptr(Bt), _row_stride(Bt, Dn), ptr(C),
-                                             _row_stride(C, Dn), ptr(dy), Dn, ptr(h_in), ptr(dBt), Dn, ptr(dC), Dn,
+        check(lib.apertis_selective_scan_bwd(ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C),
+                                             C.stride(-2), ptr(dy), Dn, ptr(h_in), ptr(dBt), Dn, ptr(dC), Dn,
                                              ptr(d_dlt), ptr(dA_log), ptr(agg), ptr(mu_in), ptr(dA_part),
                                              B, L, h, N, dtype_code(Bt), dtype_code(dy), int(sp), stream_ptr()),
               "apertis_selective_scan_bwd")
@@ -96,3 +96,342 @@ def selective_scan(dlt, A_log, Bt, C, h0=None, delta_softplus=False, y_dtype=tor
     Bt/C [B,L,h*N] fp32 or bf16 (strided column slices are taken as they are), h0 [B,h*N] or
     None.  Returns y [B,L,h*N] (and the final state [B,h*N] when return_last)."""
     return _SelectiveScan.apply(dlt, A_log, Bt, C, h0, delta_softplus, y_dtype, return_last)
+
+
+# ----------------------------------------------------------------------------------------------
+# SSM companions: depthwise causal conv + SiLU, post-scan gate
+# ----------------------------------------------------------------------------------------------
+class _DwConvSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _require_gpu(x, w, b)
+        lib = _lib.load()
+        B, L, Dn = x.shape
+        x, x_rs = _rows(x, Dn)
+        w2 = w.detach().float().reshape(Dn, -1).contiguous()
+        b2 = b.detach().float().contiguous()
+        k = w2.shape[1]
+        out = torch.empty(B, L, Dn, device=x.device, dtype=x.dtype)
+        check(lib.apertis_dwconv_silu_fwd(ptr(x), x_rs, ptr(w2), ptr(b2), ptr(out), Dn, B, L, Dn, k, dtype_code(x),
+                                          stream_ptr()), "apertis_dwconv_silu_fwd")
+        ctx.save_for_backward(x, w2, b2)
+        ctx.wshape = w.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, w2, b2 = ctx.saved_tensors
+        B, L, Dn = x.shape
+        k = w2.shape[1]
+        dout = dout.contiguous()
+        nblk = lib.apertis_dwconv_bwd_blocks(B, L, Dn)
+        dev = x.device
+        dx = torch.empty(B, L, Dn, device=dev, dtype=x.dtype)
+        dw_part = torch.empty(nblk, Dn, k, device=dev, dtype=torch.float32)
+        db_part = torch.empty(nblk, Dn, device=dev, dtype=torch.float32)
+        dw = torch.empty(Dn, k, device=dev, dtype=torch.float32)
+        db = torch.empty(Dn, device=dev, dtype=torch.float32)
+        check(lib.apertis_dwconv_silu_bwd(ptr(x), x.stride(-2), ptr(w2), ptr(b2), ptr(dout), Dn, ptr(dx), Dn,
+                                          ptr(dw_part), ptr(db_part), ptr(dw), ptr(db), B, L, Dn, k, dtype_code(x),
+                                          stream_ptr()), "apertis_dwconv_silu_bwd")
+        return dx, dw.reshape(ctx.wshape), db
+
+
+def dwconv_silu(x, weight, bias):
+    """silu(causal depthwise conv1d(x)) on token-major x [B,L,Dn] (reference core.py:368-375).
+    weight [Dn,1,k] (nn.Conv1d layout), bias [Dn]."""
+    return _DwConvSilu.apply(x, weight, bias)
+
+
+class _SsmGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, xc, z, D):
+        _require_gpu(y, xc, z, D)
+        lib = _lib.load()
+        B, L, Dn = y.shape
+        y, y_rs = _rows(y, Dn)
+        xc, xc_rs = _rows(xc, Dn)
+        z, z_rs = _rows(z, Dn)
+        if xc.dtype != z.dtype:
+            raise ApertisHipError("xc and z must share a dtype")
+        Df = D.detach().float().contiguous()
+        out = torch.empty(B, L, Dn, device=y.device, dtype=xc.dtype)
+        check(lib.apertis_ssm_gate_fwd(ptr(y), y_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(out), Dn, B * L, Dn,
+                                       dtype_code(y), dtype_code(xc), stream_ptr()), "apertis_ssm_gate_fwd")
+        ctx.save_for_backward(y, xc, z, Df)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        y, xc, z, Df = ctx.saved_tensors
+        B, L, Dn = y.shape
+        dout = dout.contiguous()
+        dev = y.device
+        nblk = lib.apertis_ssm_gate_bwd_blocks(B * L, Dn)
+        dy = torch.empty(B, L, Dn, device=dev, dtype=y.dtype)
+        dxc = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
+        dz = torch.empty(B, L, Dn, device=dev, dtype=z.dtype)
+        part = torch.empty(nblk, Dn, device=dev, dtype=torch.float32)
+        dD = torch.empty(Dn, device=dev, dtype=torch.float32)
+        check(lib.apertis_ssm_gate_bwd(ptr(dout), Dn, ptr(y), y.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
+                                       ptr(Df), ptr(dy), Dn, ptr(dxc), Dn, ptr(dz), Dn, ptr(part), ptr(dD), B * L, Dn,
+                                       dtype_code(y), dtype_code(xc), stream_ptr()), "apertis_ssm_gate_bwd")
+        return dy, dxc, dz, dD
+
+
+def ssm_gate(y, xc, z, D):
+    """(y + D*xc) * silu(z)  (reference core.py:395-396); y fp32 or bf16, xc/z/out share a dtype."""
+    return _SsmGate.apply(y, xc, z, D)
+
+
+# ----------------------------------------------------------------------------------------------
+# MoE: gate, plan, gather+LayerNorm, grouped linear, combine
+# ----------------------------------------------------------------------------------------------
+class _GateTopK(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, K):
+        _require_gpu(logits)
+        lib = _lib.load()
+        logits = logits.float().contiguous()
+        S, E = logits.shape
+        dev = logits.device
+        gates = torch.empty(S, E, device=dev, dtype=torch.float32)
+        idx = torch.empty(S, K, device=dev, dtype=torch.int32)
+        w = torch.empty(S, K, device=dev, dtype=torch.float32)
+        check(lib.apertis_moe_gate_topk_fwd(ptr(logits), ptr(gates), ptr(idx), ptr(w), S, E, K, stream_ptr()),
+              "apertis_moe_gate_topk_fwd")
+        ctx.save_for_backward(gates, idx)
+        ctx.K = K
+        ctx.mark_non_differentiable(idx)
+        return gates, idx, w
+
+    @staticmethod
+    def backward(ctx, dgates, _didx, dw):
+        lib = _lib.load()
+        gates, idx = ctx.saved_tensors
+        S, E = gates.shape
+        dgates = None if dgates is None else dgates.float().contiguous()
+        dw = None if dw is None else dw.float().contiguous()
+        dlogits = torch.empty_like(gates)
+        check(lib.apertis_moe_gate_topk_bwd(ptr(gates), ptr(idx), ptr(dw), ptr(dgates), ptr(dlogits), S, E, ctx.K,
+                                            stream_ptr()), "apertis_moe_gate_topk_bwd")
+        return dlogits, None
+
+
+def moe_gate_topk(logits, K):
+    """softmax -> top-K -> renormalised weights (reference core.py:491-492,529).
+    Returns gates [S,E] fp32, idx [S,K] int32 (descending probability, ties lowest index),
+    w [S,K] fp32."""
+    return _GateTopK.apply(logits, K)
+
+
+class MoePlan:
+    """Device-side dispatch plan (reference core.py:547-591), canonical expert-major order."""
+    __slots__ = ("offsets", "row_token", "row_k", "slot_of", "S", "E", "K", "max_rows")
+
+
+def moe_plan(idx, w, E, capacity=None, active=None):
+    """idx [S,K] int32, w [S,K] fp32.  capacity None/<=0 = unlimited (eval).  active: optional
+    [E] bool mask of experts that are not dropped.  No host sync: row counts stay on the device;
+    max_rows is the static bound min(S*K, E*capacity) used to size buffers and grids."""
+    _require_gpu(idx, w)
+    lib = _lib.load()
+    S, K = idx.shape
+    dev = idx.device
+    idx = idx.to(torch.int32).contiguous()
+    w = w.detach().float().contiguous()
+    cap = int(capacity) if capacity is not None and capacity > 0 else 0
+    p = MoePlan()
+    p.S, p.E, p.K = S, E, K
+    p.max_rows = min(S * K, E * cap) if cap > 0 else S * K
+    p.offsets = torch.empty(E + 1, device=dev, dtype=torch.int32)
+    p.row_token = torch.empty(max(S * K, 1), device=dev, dtype=torch.int32)
+    p.row_k = torch.empty(max(S * K, 1), device=dev, dtype=torch.int32)
+    p.slot_of = torch.empty(S, K, device=dev, dtype=torch.int32)
+    ws = torch.empty(lib.apertis_moe_plan_workspace_bytes(S, E, K) // 4 + 1, device=dev, dtype=torch.int32)
+    act = None if active is None else active.to(torch.uint8).contiguous()
+    check(lib.apertis_moe_plan(ptr(idx), ptr(w), ptr(act), cap, ptr(p.offsets), ptr(p.row_token), ptr(p.row_k),
+                               ptr(p.slot_of), ptr(ws), S, E, K, stream_ptr()), "apertis_moe_plan")
+    return p
+
+
+class _GatherLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, plan, eps, out_dtype):
+        _require_gpu(x, gamma, beta)
+        lib = _lib.load()
+        x = x.contiguous()
+        S, H = x.shape
+        g = gamma.detach().float().contiguous()
+        b = beta.detach().float().contiguous()
+        dev = x.device
+        R = max(plan.max_rows, 1)
+        xg = torch.empty(R, H, device=dev, dtype=out_dtype)
+        mean = torch.empty(R, device=dev, dtype=torch.float32)
+        rstd = torch.empty(R, device=dev, dtype=torch.float32)
+        check(lib.apertis_moe_gather_ln_fwd(ptr(x), ptr(plan.row_token), ptr(plan.offsets), ptr(g), ptr(b), float(eps),
+                                            ptr(xg), ptr(mean), ptr(rstd), plan.max_rows, H, plan.E, dtype_code(x),
+                                            dtype_code(xg), stream_ptr()), "apertis_moe_gather_ln_fwd")
+        ctx.save_for_backward(x, g, mean, rstd)
+        ctx.plan = plan
+        return xg
+
+    @staticmethod
+    def backward(ctx, dxg):
+        lib = _lib.load()
+        x, g, mean, rstd = ctx.saved_tensors
+        plan = ctx.plan
+        S, H = x.shape
+        dev = x.device
+        dxg = dxg.contiguous()
+        dxr = torch.empty_like(dxg)
+        dgamma = torch.zeros(plan.E, H, device=dev, dtype=torch.float32)
+        dbeta = torch.zeros(plan.E, H, device=dev, dtype=torch.float32)
+        check(lib.apertis_moe_gather_ln_bwd(ptr(x), ptr(plan.row_token), ptr(plan.offsets), ptr(g), ptr(mean), ptr(rstd),
+                                            ptr(dxg), ptr(dxr), ptr(dgamma), ptr(dbeta), plan.max_rows, H, plan.E,
+                                            dtype_code(x), dtype_code(dxg), stream_ptr()), "apertis_moe_gather_ln_bwd")
+        dx = torch.empty(S, H, device=dev, dtype=x.dtype)
+        check(lib.apertis_moe_combine_fwd(ptr(dxr), ptr(plan.slot_of), None, ptr(dx), S, H, plan.K, 0, dtype_code(dxr),
+                                          dtype_code(dx), stream_ptr()), "apertis_moe_combine_fwd(scatter)")
+        return dx, dgamma, dbeta, None, None, None
+
+
+def moe_gather_ln(x, gamma, beta, plan, eps, out_dtype=None):
+    """xg[r] = LayerNorm_e(x[token(r)]) for every kept row r, expert-sorted (reference core.py:593
+    gather + :436 per-expert LayerNorm).  x [S,H]; gamma/beta [E,H]."""
+    return _GatherLN.apply(x, gamma, beta, plan, eps, out_dtype or x.dtype)
+
+
+class _Combine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, yr, w, plan, out_dtype):
+        _require_gpu(yr, w)
+        lib = _lib.load()
+        yr = yr.contiguous()
+        wf = w.float().contiguous()
+        H = yr.shape[1]
+        out = torch.empty(plan.S, H, device=yr.device, dtype=out_dtype)
+        check(lib.apertis_moe_combine_fwd(ptr(yr), ptr(plan.slot_of), ptr(wf), ptr(out), plan.S, H, plan.K, 1,
+                                          dtype_code(yr), dtype_code(out), stream_ptr()), "apertis_moe_combine_fwd")
+        ctx.save_for_backward(yr, wf)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        yr, wf = ctx.saved_tensors
+        plan = ctx.plan
+        H = yr.shape[1]
+        dout = dout.contiguous()
+        dyr = torch.empty_like(yr)
+        dw = torch.zeros(plan.S, plan.K, device=yr.device, dtype=torch.float32)
+        check(lib.apertis_moe_combine_bwd(ptr(dout), ptr(yr), ptr(plan.row_token), ptr(plan.row_k), ptr(plan.offsets),
+                                          ptr(wf), ptr(dyr), ptr(dw), plan.max_rows, plan.S, H, plan.K, plan.E,
+                                          dtype_code(dout), dtype_code(yr), stream_ptr()), "apertis_moe_combine_bwd")
+        return dyr, dw, None, None
+
+
+def moe_combine(yr, w, plan, out_dtype=None):
+    """out[s] = sum_k w[s,k] * yr[slot(s,k)] over kept assignments, k ascending (reference
+    core.py:594,605); dropped tokens give exact zeros."""
+    return _Combine.apply(yr, w, plan, out_dtype or yr.dtype)
+
+
+def cast_transpose(w, dtype, want_plain=True, want_transposed=True):
+    """Compute copies of an fp32 master weight [E,R,C]: ([E,R,C], [E,C,R]) in `dtype`."""
+    _require_gpu(w)
+    lib = _lib.load()
+    w = w.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    w = w.contiguous()
+    E, R, C = w.shape
+    plain = torch.empty(E, R, C, device=w.device, dtype=dtype) if want_plain else None
+    tr = torch.empty(E, C, R, device=w.device, dtype=dtype) if want_transposed else None
+    code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
+    check(lib.apertis_cast_transpose(ptr(w), ptr(plain), ptr(tr), E, R, C, code, stream_ptr()), "apertis_cast_transpose")
+    return plain, tr
+
+
+_ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "relu": _lib.ACT_RELU,
+         "silu": _lib.ACT_SILU, "swish": _lib.ACT_SILU}
+
+
+class _GroupedLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype):
+        _require_gpu(x, weight, bias, offsets)
+        lib = _lib.load()
+        E, N, K = weight.shape
+        if x.dtype != compute_dtype:
+            x = x.to(compute_dtype)
+        x = x.contiguous()
+        if x.shape[1] != K:
+            raise ApertisHipError(f"grouped_linear: x {tuple(x.shape)} vs weight {tuple(weight.shape)}")
+        need_grad = any(ctx.needs_input_grad[:3])
+        if compute_dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous():
+            wc = weight.detach()
+            wt = cast_transpose(weight, compute_dtype, want_plain=False)[1] if need_grad else None
+        else:
+            wc, wt = cast_transpose(weight, compute_dtype, want_transposed=need_grad)
+        bf = None if bias is None else bias.detach().float().contiguous()
+        code = dtype_code(x)
+        act_code = _ACTS[act]
+        out = torch.empty(x.shape[0], N, device=x.device, dtype=compute_dtype)
+        pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
+        check(lib.apertis_grouped_gemm_nt(ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), max_rows, N, K, E,
+                                          act_code, float(drop_p), int(seed), code, code, stream_ptr()),
+              "apertis_grouped_gemm_nt")
+        ctx.save_for_backward(x, wt, pre, offsets)
+        ctx.cfg = (E, N, K, max_rows, act_code, float(drop_p), int(seed), bias is not None, weight.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, wt, pre, offsets = ctx.saved_tensors
+        E, N, K, max_rows, act_code, drop_p, seed, has_bias, wdtype = ctx.cfg
+        code = dtype_code(x)
+        dout = dout.to(x.dtype).contiguous()
+        if act_code != _lib.ACT_NONE:
+            dpre = torch.empty_like(dout)
+            check(lib.apertis_act_dropout_bwd(ptr(dout), ptr(pre), ptr(dpre), ptr(offsets), max_rows, N, E, act_code,
+                                              drop_p, seed, code, stream_ptr()), "apertis_act_dropout_bwd")
+        else:
+            dpre = dout
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib.apertis_grouped_gemm_nt(ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, max_rows, K, N, E,
+                                              _lib.ACT_NONE, 0.0, 0, code, code, stream_ptr()),
+                  "apertis_grouped_gemm_nt(dgrad)")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
+            db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
+            check(lib.apertis_grouped_gemm_tn(ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, code,
+                                              stream_ptr()), "apertis_grouped_gemm_tn")
+            dw = dw.to(wdtype)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def grouped_linear(x, weight, bias, offsets, max_rows, act=None, drop_p=0.0, seed=0, compute_dtype=None):
+    """Per-group  act(x @ W[e].T + b[e])  with optional fused inverted dropout, on MFMA.
+    x [R,K] rows sorted by group, weight [E,N,K] (nn.Linear layout, fp32 master), bias [E,N],
+    offsets [E+1] int32 device tensor.  Rows >= offsets[E] are neither read nor written.
+    (reference: expert Linear/activation/Dropout/Linear, core.py:437-440)"""
+    return _GroupedLinear.apply(x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype or x.dtype)
+
+
+def linear_mfma(x, weight, bias=None, act=None, compute_dtype=None):
+    """Dense act(x @ W.T + b) through the same MFMA tile (one group).  Used for the patch-embed
+    GEMM and vision_projection (reference multimodal/module.py:102, core.py:1209)."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    M = x2.shape[0]
+    offsets = torch.tensor([0, M], device=x.device, dtype=torch.int32)
+    out = grouped_linear(x2, weight.unsqueeze(0), None if bias is None else bias.unsqueeze(0), offsets, M, act, 0.0, 0,
+                         compute_dtype or x.dtype)
+    return out.reshape(*lead, weight.shape[0])

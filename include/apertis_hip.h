@@ -100,9 +100,10 @@ int apertis_ssm_gate_fwd(const void *y, int64_t y_rs, const void *xc, int64_t xc
 int apertis_ssm_gate_bwd(const void *dout, int64_t dout_rs, const void *y, int64_t y_rs,
                          const void *xc, int64_t xc_rs, const void *z, int64_t z_rs,
                          const float *D, void *dy, int64_t dy_rs, void *dxc, int64_t dxc_rs,
-                         void *dz, int64_t dz_rs, float *dD_part /* [nblk,Dn] */,
-                         int64_t nblk, int64_t T, int64_t Dn, int dtype_y, int dtype_io,
-                         void *stream);
+                         void *dz, int64_t dz_rs,
+                         float *dD_part /* workspace [apertis_ssm_gate_bwd_blocks, Dn] */,
+                         float *dD /* [Dn] out */, int64_t T, int64_t Dn, int dtype_y,
+                         int dtype_io, void *stream);
 int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn);
 
 /* Depthwise causal conv1d (k taps, left pad k-1, keep first L) + SiLU on token-major data
@@ -113,9 +114,11 @@ int apertis_dwconv_silu_fwd(const void *x, int64_t x_rs, const float *w, const f
                             int64_t k, int dtype_io, void *stream);
 int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float *w, const float *bias,
                             const void *dout, int64_t dout_rs, void *dx, int64_t dx_rs,
-                            float *dw_part /* [nblk,Dn,k] */, float *db_part /* [nblk,Dn] */,
-                            int64_t nblk, int64_t B, int64_t L, int64_t Dn, int64_t k,
-                            int dtype_io, void *stream);
+                            float *dw_part /* workspace [nblk,Dn,k] */,
+                            float *db_part /* workspace [nblk,Dn] */,
+                            float *dw /* [Dn,k] out */, float *db /* [Dn] out */,
+                            int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
+                            void *stream); /* nblk = apertis_dwconv_bwd_blocks(B,L,Dn) */
 int64_t apertis_dwconv_bwd_blocks(int64_t B, int64_t L, int64_t Dn);
 
 /* ------------------------------------------------------------------------------------------
@@ -159,15 +162,15 @@ int apertis_moe_gather_ln_fwd(const void *x, const int32_t *row_token,
                               const float *beta, float eps, void *xg, float *mean, float *rstd,
                               int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_out,
                               void *stream);
-/* Backward: dxg [rows,H] -> per-row dx contribution dxr [rows,H] (LN backward), plus partial
- * sums for dgamma/dbeta [nblk,E,H].  Rows are later scattered by apertis_moe_combine_*. */
+/* Backward: dxg [rows,H] -> per-row dx contribution dxr [rows,H] (LayerNorm backward); the
+ * affine gradients are ACCUMULATED into dgamma/dbeta [E,H] fp32 (caller zero-fills) with float
+ * atomics.  The rows are later scattered to tokens by apertis_moe_combine_fwd(with_weights=0). */
 int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
                               const int32_t *expert_offsets, const float *gamma,
                               const float *mean, const float *rstd, const void *dxg,
-                              void *dxr, float *dgamma_part, float *dbeta_part, int64_t nblk,
+                              void *dxr, float *dgamma, float *dbeta,
                               int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_g,
                               void *stream);
-int64_t apertis_moe_gather_ln_bwd_blocks(int64_t max_rows, int64_t H);
 
 /* Combine (core.py:594,605 weights * expert_output, index_add_):
  *   out[s,:] = sum_{k asc, slot_of[s,k]>=0} wk[s,k] * yr[slot_of[s,k],:]   (zeros if none)
@@ -188,11 +191,14 @@ int apertis_moe_combine_bwd(const void *dout, const void *yr, const int32_t *row
  * vision_projection core.py:1035,1209).
  *
  * Rows of A/C are grouped by expert: group e owns rows [offsets[e], offsets[e+1]).
- *   NT  (forward)   : C[r,n]  = act( sum_k A[r,k] * W[e,n,k] + bias[e,n] )   W [E,N,K]
- *   NN  (dgrad)     : C[r,n]  = sum_k A[r,k] * W[e,k,n]                      W [E,K,N]
- *   TN  (wgrad)     : dW[e,m,n] = sum_{r in e} A[r,m] * Bm[r,n]   (+ dbias[e,m] = sum_r A[r,m])
- * dtype: APERTIS_BF16 -> bf16 operands, fp32 accumulate on v_mfma_f32_32x32x16_bf16;
- *        APERTIS_F32  -> fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+ *   NT  (forward, and dgrad against the transposed weight copy):
+ *         C[r,n]  = act( sum_k A[r,k] * W[e,n,k] + bias[e,n] )              W [E,N,K]
+ *   TN  (wgrad)   dW[e,m,n] = sum_{r in e} A[r,m] * Bm[r,n],  dbias[e,m] = sum_r A[r,m]
+ *   (the data gradient dX = dY * W is an NT product against W^T [E,K,N]; the compute copies
+ *    W and W^T are produced together by apertis_cast_transpose, so every operand is
+ *    K-contiguous and no NN kernel exists)
+ * dtype: APERTIS_BF16 -> bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16;
+ *        APERTIS_F32  -> fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
  * max_rows bounds the grid (offsets live on the device; no host sync).
  * pre_act (optional, NT only): also stores the pre-activation (needed by the backward).
  * dropout (NT only): if drop_p>0 the activation output is multiplied by a keep mask /(1-p)
@@ -204,12 +210,13 @@ int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
                             int64_t max_rows, int64_t N, int64_t K, int64_t E,
                             int act, float drop_p, uint64_t seed,
                             int dtype, int dtype_out, void *stream);
-int apertis_grouped_gemm_nn(const void *A, const void *W, const int32_t *offsets, void *C,
-                            int64_t max_rows, int64_t N, int64_t K, int64_t E,
-                            int dtype, int dtype_out, void *stream);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
                             int64_t E, int dtype, void *stream);
+/* Compute copies of fp32 master weights src [E,R,C]: dst [E,R,C] and/or dstT [E,C,R] in
+ * dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call. */
+int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R,
+                           int64_t C, int dtype_out, void *stream);
 /* Elementwise backward of act+dropout: dpre = dh * mask/(1-p) * act'(pre). In place allowed. */
 int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void *dpre,
                             const int32_t *offsets, int64_t max_rows, int64_t N, int64_t E,

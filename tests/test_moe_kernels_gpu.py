@@ -1,0 +1,254 @@
+"""Kernel-level parity of the MoE path (through the C ABI) with the CPU oracle / golden vectors.
+Integer outputs (top-k indices, dispatch plan, permutation) are compared bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, name, rtol=1e-4, atol_scale=2e-6):
+    ref = ref.detach().cpu().to(torch.float64)
+    got = got.detach().cpu().to(torch.float64)
+    atol = atol_scale * float(ref.abs().max()) + 1e-30
+    bad = (got - ref).abs() > atol + rtol * ref.abs()
+    assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.numel()} outside rtol {rtol}; max abs diff " \
+                          f"{float((got - ref).abs().max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+
+
+# ------------------------------------------------------------------ gate
+@pytest.mark.parametrize("name", ["moe_eval", "moe_train_overflow", "moe_eval_k3"])
+def test_gate_topk_golden(dev, name):
+    from apertis_llm_amd import ops
+    g = load_golden(name)
+    K = int(g["K"])
+    gates, idx, w = ops.moe_gate_topk(g["logits"].to(dev), K)
+    assert torch.equal(idx.cpu().long(), g["idx"].long()), "top-k indices must be bit-exact"
+    _close(gates, g["gates"], "gates", rtol=1e-5)
+    _close(w, g["w"], "w", rtol=1e-5)
+
+
+@pytest.mark.parametrize("S,E,K", [(1000, 8, 2), (77, 4, 1), (513, 16, 3), (300, 5, 2), (64, 64, 8)])
+def test_gate_topk_backward(dev, S, E, K):
+    from apertis_llm_amd import ops
+    from oracle import ref_cpu
+    torch.manual_seed(S + E)
+    logits = torch.randn(S, E) * 2
+    lo = logits.clone().requires_grad_(True)
+    gates_o = F.softmax(lo, -1)
+    p, idx_o = ref_cpu.topk_lowest_index_first(gates_o, K)
+    w_o = p / (p.sum(-1, keepdim=True) + 1e-6)
+    dw, dg = torch.randn(S, K), torch.randn(S, E)
+    (w_o * dw).sum().add((gates_o * dg).sum()).backward()
+    ld = logits.to(dev).requires_grad_(True)
+    gates, idx, w = ops.moe_gate_topk(ld, K)
+    assert torch.equal(idx.cpu().long(), idx_o)
+    ((w * dw.to(dev)).sum() + (gates * dg.to(dev)).sum()).backward()
+    _close(ld.grad, lo.grad, "dlogits", atol_scale=1e-5)
+
+
+def test_gate_ties_lowest_index_first(dev):
+    from apertis_llm_amd import ops
+    logits = torch.zeros(5, 8)
+    logits[1, 3] = logits[1, 6] = 1.0
+    _, idx, _ = ops.moe_gate_topk(logits.to(dev), 2)
+    assert idx.cpu().tolist() == [[0, 1], [3, 6], [0, 1], [0, 1], [0, 1]]
+
+
+# ------------------------------------------------------------------ plan
+def _plan_case(dev, S, E, K, cap, seed, skew=0.0, ties=False, active=None):
+    from apertis_llm_amd import ops
+    from oracle import ref_cpu
+    rng = np.random.default_rng(seed)
+    logits = rng.standard_normal((S, E)).astype(np.float32)
+    logits[:, 0] += skew
+    if ties:
+        logits = np.round(logits)       # many equal rows -> equal weights
+    gates, idx, w = ops.moe_gate_topk(torch.from_numpy(logits).to(dev), K)
+    act_t = None if active is None else torch.tensor(active, device=dev)
+    plan = ops.moe_plan(idx, w, E, cap, act_t)
+    offs, rt, rk, slot = ref_cpu.dispatch_plan(idx.cpu().numpy(), w.cpu().numpy(), E, cap, active)
+    total = int(offs[-1])
+    assert plan.offsets.cpu().tolist() == offs.tolist()
+    assert plan.row_token.cpu().numpy()[:total].tolist() == rt.tolist()
+    assert plan.row_k.cpu().numpy()[:total].tolist() == rk.tolist()
+    assert plan.slot_of.cpu().numpy().tolist() == slot.tolist()
+    return total
+
+
+@pytest.mark.parametrize("S,E,K", [(4096, 8, 2), (1000, 8, 2), (63, 4, 2), (64, 4, 1), (65, 16, 3), (5000, 64, 8), (1, 2, 2)])
+def test_plan_eval_no_capacity(dev, S, E, K):
+    assert _plan_case(dev, S, E, K, None, seed=S) == S * K
+
+
+@pytest.mark.parametrize("S,E,K,skew", [(4096, 8, 2, 0.0), (4096, 8, 2, 2.0), (1000, 4, 2, 1.0), (777, 8, 3, 3.0), (8192, 8, 2, 0.5)])
+def test_plan_train_capacity_overflow(dev, S, E, K, skew):
+    from oracle import ref_cpu
+    cap = ref_cpu.expert_capacity(S, E, 1.25)
+    total = _plan_case(dev, S, E, K, cap, seed=S + 1, skew=skew)
+    assert total <= E * cap
+
+
+def test_plan_ties_and_dropped_experts(dev):
+    _plan_case(dev, 2000, 8, 2, 100, seed=5, skew=1.0, ties=True)
+    _plan_case(dev, 900, 8, 2, 150, seed=6, active=[1, 0, 1, 1, 0, 1, 1, 1])
+    _plan_case(dev, 900, 8, 2, None, seed=7, active=[0, 1, 1, 1, 1, 1, 1, 1])
+
+
+def test_plan_golden_kept_rows(dev):
+    """kept (token,k,expert) rows captured from the reference's own dispatch loop."""
+    from apertis_llm_amd import ops
+    for name in ["moe_eval", "moe_train_overflow", "moe_eval_k3"]:
+        g = load_golden(name)
+        E, K, cap = int(g["E"]), int(g["K"]), int(g["capacity"])
+        plan = ops.moe_plan(g["idx"].int().to(dev), g["w"].to(dev), E, cap if cap > 0 else None)
+        offs = plan.offsets.cpu().tolist()
+        assert offs == g["expert_offsets"].tolist()
+        rt, rk = plan.row_token.cpu().tolist(), plan.row_k.cpu().tolist()
+        rows = [(rt[r], rk[r], e) for e in range(E) for r in range(offs[e], offs[e + 1])]
+        assert rows == [tuple(r) for r in g["kept_rows"].tolist()], name
+
+
+# ------------------------------------------------------------------ gather+LN, combine
+@pytest.mark.parametrize("H,dt", [(32, torch.float32), (704, torch.float32), (256, torch.bfloat16), (1028, torch.float32)])
+def test_gather_ln_and_combine(dev, H, dt):
+    from apertis_llm_amd import ops
+    torch.manual_seed(H)
+    S, E, K = 333, 8, 2
+    x = torch.randn(S, H) * 2 + 0.5
+    gamma, beta = torch.randn(E, H), torch.randn(E, H)
+    logits = torch.randn(S, E)
+    gates, idx, w = ops.moe_gate_topk(logits.to(dev), K)
+    plan = ops.moe_plan(idx, w, E, 70)
+    offs = plan.offsets.cpu().tolist()
+    total = offs[-1]
+    rt = plan.row_token.cpu()[:total].long()
+    rk = plan.row_k.cpu()[:total].long()
+    eo = torch.repeat_interleave(torch.arange(E), torch.tensor([offs[e + 1] - offs[e] for e in range(E)]))
+    xd = x.to(dev).to(dt).requires_grad_(True)
+    gd, bd = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+    wd = w.detach().clone().requires_grad_(True)
+    xg = ops.moe_gather_ln(xd, gd, bd, plan, 1e-12)
+    out = ops.moe_combine(xg, wd, plan)
+    dout = torch.randn(S, H)
+    out.backward(dout.to(dev).to(dt))
+    # oracle in fp32/fp64 on the same (possibly bf16-rounded) input
+    xr = x.to(dt).double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    wr = w.detach().cpu().double().requires_grad_(True)
+    xn = F.layer_norm(xr[rt], (H,), None, None, 1e-12) * gr[eo] + br[eo]
+    if dt == torch.bfloat16:
+        xn_q = xn + (xn.detach().to(torch.bfloat16).double() - xn.detach())   # straight-through rounding
+    else:
+        xn_q = xn
+    o = torch.zeros(S, H, dtype=torch.float64).index_add(0, rt, xn_q * wr[rt, rk].unsqueeze(1))
+    o.backward(dout.to(dt).double())
+    tol = dict(rtol=1e-4, atol_scale=5e-6) if dt == torch.float32 else dict(rtol=2e-2, atol_scale=2e-2)
+    _close(xg[:total], xn, "xg", **tol)
+    _close(out, o, "combine", **tol)
+    _close(xd.grad, xr.grad, "dx", **(tol if dt == torch.float32 else dict(rtol=5e-2, atol_scale=3e-2)))
+    _close(gd.grad, gr.grad, "dgamma", rtol=1e-3 if dt == torch.float32 else 3e-2, atol_scale=1e-4 if dt == torch.float32 else 2e-2)
+    _close(bd.grad, br.grad, "dbeta", rtol=1e-3 if dt == torch.float32 else 3e-2, atol_scale=1e-4 if dt == torch.float32 else 2e-2)
+    _close(wd.grad, wr.grad, "dw", rtol=1e-3 if dt == torch.float32 else 3e-2, atol_scale=1e-4 if dt == torch.float32 else 2e-2)
+
+
+# ------------------------------------------------------------------ grouped GEMM
+def _grouped_ref(x, W, b, sizes, act):
+    outs, r = [], 0
+    for e, m in enumerate(sizes):
+        u = x[r:r + m] @ W[e].T + (b[e] if b is not None else 0)
+        outs.append(u)
+        r += m
+    u = torch.cat(outs) if outs else x.new_zeros(0, W.shape[1])
+    return {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, None: (lambda t: t)}[act](u)
+
+
+@pytest.mark.parametrize("sizes,N,K,act", [
+    ([5, 0, 300, 129, 128, 1, 77, 64], 64, 32, "gelu"),
+    ([200, 333], 136, 100, None),
+    ([1000], 704, 260, "silu"),
+    ([17, 17, 17, 17], 8, 4, "relu"),
+])
+def test_grouped_linear_fp32_exact_path(dev, sizes, N, K, act):
+    """fp32 operands on v_mfma_f32_16x16x4_f32: an exact fp32 FMA chain -> reference tolerance
+    1e-4 rtol (measured ~1e-6)."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(N + K)
+    E, R = len(sizes), sum(sizes)
+    pad = 7                                   # rows beyond offsets[E] must stay untouched
+    x = torch.randn(R + pad, K)
+    W, b = torch.randn(E, N, K) / K ** 0.5, torch.randn(E, N)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+    dout = torch.randn(R + pad, N)
+    xd = x.to(dev).requires_grad_(True)
+    Wd, bd = W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = ops.grouped_linear(xd, Wd, bd, offsets.to(dev), R + pad, act=act)
+    (out[:R] * dout[:R].to(dev)).sum().backward()
+    xr, Wr, br = x[:R].double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = _grouped_ref(xr, Wr, br, sizes, act)
+    (ref * dout[:R].double()).sum().backward()
+    _close(out[:R], ref, "out", rtol=1e-4, atol_scale=1e-5)
+    _close(xd.grad[:R], xr.grad, "dx", rtol=1e-4, atol_scale=1e-5)
+    _close(Wd.grad, Wr.grad, "dW", rtol=1e-4, atol_scale=1e-5)
+    _close(bd.grad, br.grad, "db", rtol=1e-4, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("sizes,N,K", [([700, 100, 0, 513], 256, 128), ([640] * 8, 1024, 256), ([300, 5], 704, 2816)])
+def test_grouped_linear_bf16_mfma(dev, sizes, N, K):
+    """bf16 operands / fp32 accumulate: compare with fp64 math on the SAME bf16-rounded operands;
+    only the output rounding (bf16, 2^-8) and fp32 accumulation order differ."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(N)
+    E, R = len(sizes), sum(sizes)
+    x = torch.randn(R, K).bfloat16()
+    W, b = (torch.randn(E, N, K) / K ** 0.5), torch.randn(E, N)
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32)
+    dout = torch.randn(R, N).bfloat16()
+    xd = x.to(dev).requires_grad_(True)
+    Wd, bd = W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = ops.grouped_linear(xd, Wd, bd, offsets.to(dev), R, act="gelu", compute_dtype=torch.bfloat16)
+    assert out.dtype == torch.bfloat16
+    out.backward(dout.to(dev))
+    Wq = W.bfloat16().double()
+    xr, Wr, br = x.double().requires_grad_(True), Wq.requires_grad_(True), b.double().requires_grad_(True)
+    ref = _grouped_ref(xr, Wr, br, sizes, "gelu")
+    ref.backward(dout.double())
+    _close(out, ref, "out", rtol=1e-2, atol_scale=6e-3)
+    _close(xd.grad, xr.grad, "dx", rtol=2e-2, atol_scale=1e-2)
+    _close(Wd.grad, Wr.grad, "dW", rtol=2e-2, atol_scale=1e-2)
+    _close(bd.grad, br.grad, "db", rtol=2e-2, atol_scale=1e-2)
+
+
+def test_grouped_linear_dropout_mask_consistency(dev):
+    from apertis_llm_amd import ops
+    torch.manual_seed(0)
+    R, N, K, p = 1024, 512, 64, 0.1
+    x = torch.randn(R, K, device=dev, requires_grad=True)
+    W = torch.randn(1, N, K, device=dev) / 8
+    offsets = torch.tensor([0, R], dtype=torch.int32, device=dev)
+    full = ops.grouped_linear(x, W, None, offsets, R, act="relu")
+    y1 = ops.grouped_linear(x, W, None, offsets, R, act="relu", drop_p=p, seed=1234)
+    y1b = ops.grouped_linear(x, W, None, offsets, R, act="relu", drop_p=p, seed=1234)
+    y2 = ops.grouped_linear(x, W, None, offsets, R, act="relu", drop_p=p, seed=99)
+    assert torch.equal(y1, y1b) and not torch.equal(y1, y2)
+    pos = full > 0
+    kept = (y1 != 0) & pos
+    frac = float(kept.sum()) / float(pos.sum())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    _close(y1[kept], full[kept] / (1 - p), "kept values scaled")
+    # backward uses the same mask: d/dx of sum(y1) equals that of sum(full*mask/(1-p))
+    mask = kept.float() / (1 - p)
+    g1, = torch.autograd.grad(y1.sum(), x, retain_graph=True)
+    g2, = torch.autograd.grad((full * mask).sum(), x)
+    _close(g1, g2, "dropout backward", rtol=1e-4, atol_scale=1e-5)
+
+
+def test_linear_mfma_dense(dev):
+    from apertis_llm_amd import ops
+    torch.manual_seed(1)
+    x, W, b = torch.randn(3, 50, 72), torch.randn(40, 72) / 8, torch.randn(40)
+    out = ops.linear_mfma(x.to(dev), W.to(dev), b.to(dev))
+    _close(out, F.linear(x.double(), W.double(), b.double()), "dense", rtol=1e-4, atol_scale=1e-5)
