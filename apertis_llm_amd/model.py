@@ -1,0 +1,958 @@
+"""Host-side mirror of the reference's model API for the hot path (Python, as the reference is).
+
+Same importable names, constructor keywords, config fields, state-dict keys and forward
+contracts as /root/reference/src/model/core.py, so a checkpoint or a `config.json` written by
+either side loads in the other and `apertis train` / `apertis chat` callers need no change.
+What differs is underneath: the selective scan, the depthwise conv, the gate, the whole MoE
+dispatch and the expert GEMMs run as HIP kernels through libapertis_hip.so (apertis_llm_amd.ops);
+stock torch (rocBLAS / hipBLASLt) keeps the plain dense projections, LayerNorm, embeddings and
+the loss.  There is no eager fallback for the kernel paths: off-GPU they raise ApertisHipError.
+"""
+import inspect
+import json
+import logging
+import math
+import os
+from pathlib import Path
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .multimodal import UnifiedMultimodalEncoder
+
+logger = logging.getLogger(__name__)
+
+
+# ----------------------------------------------------------------------------------------------
+# ApertisConfig  (reference core.py:67-256)
+# ----------------------------------------------------------------------------------------------
+class ApertisConfig:
+    """Flat config object; `to_dict()` is the full attribute dict and round-trips through
+    `config.json` exactly like the reference's (core.py:212-256)."""
+
+    def __init__(self, vocab_size: int = 32000, hidden_size: int = 768, num_hidden_layers: int = 12,
+                 num_attention_heads: int = 12, intermediate_size: int = 3072, hidden_act: str = "gelu",
+                 hidden_dropout_prob: float = 0.1, attention_probs_dropout_prob: float = 0.1,
+                 max_position_embeddings: int = 2048, type_vocab_size: int = 2, initializer_range: float = 0.02,
+                 layer_norm_eps: float = 1e-12, pad_token_id: int = 0, bos_token_id: int = 1, eos_token_id: int = 2,
+                 unk_token_id: int = 3, position_embedding_type: str = "rotary", use_cache: bool = True,
+                 classifier_dropout: float = None, model_type: str = "apertis", tie_word_embeddings: bool = True,
+                 rope_theta: float = 10000.0, sliding_window: Optional[int] = None,
+                 attention_type: str = "standard_mha", ssm_d_inner: Optional[int] = None, ssm_d_state: int = 16,
+                 ssm_dt_rank: Union[int, str] = "auto", ssm_conv_kernel: int = 4, use_flash_attention: bool = False,
+                 use_expert_system: bool = False, num_experts: int = 8, experts_per_token: int = 2,
+                 multimodal: bool = False, image_size: int = 224, vision_embed_dim: int = 768,
+                 vision_patch_size: int = 16, vision_layers: int = 12, vision_heads: int = 12,
+                 output_attentions: bool = False, output_hidden_states: bool = False,
+                 load_balancing_loss_coef: float = 0.01, expert_capacity_factor: float = 1.25,
+                 noisy_routing_alpha: float = 0.1, expert_dropout_prob: float = 0.1,
+                 router_z_loss_coef: float = 0.001, expert_output_gating: bool = False,
+                 use_noisy_top_k_routing: bool = True, use_expert_capacity_limit: bool = True,
+                 use_expert_dropout: bool = True, use_router_z_loss: bool = True,
+                 use_load_balancing_loss: bool = True, use_rmsnorm: bool = False, use_swiglu: bool = False,
+                 **kwargs):
+        given = dict(locals())
+        # attribute order follows the reference so a dumped config.json lists keys identically
+        for name in ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads", "hidden_act",
+                     "intermediate_size", "hidden_dropout_prob", "attention_probs_dropout_prob",
+                     "max_position_embeddings", "type_vocab_size", "initializer_range", "layer_norm_eps",
+                     "pad_token_id", "bos_token_id", "eos_token_id", "unk_token_id", "position_embedding_type",
+                     "use_cache", "classifier_dropout", "model_type", "tie_word_embeddings", "rope_theta",
+                     "sliding_window", "attention_type", "ssm_d_state"):
+            setattr(self, name, given[name])
+        derived = num_attention_heads * ssm_d_state
+        if attention_type == "selective_ssm":                         # core.py:153-157
+            if ssm_d_inner is not None and ssm_d_inner != derived:
+                logger.warning("ssm_d_inner=%s overridden by num_attention_heads*ssm_d_state=%s", ssm_d_inner, derived)
+            self.ssm_d_inner = derived
+        else:
+            self.ssm_d_inner = 2 * hidden_size if ssm_d_inner is None else ssm_d_inner
+        self.ssm_dt_rank = math.ceil(hidden_size / 16) if ssm_dt_rank == "auto" else int(ssm_dt_rank)
+        for name in ("ssm_conv_kernel", "use_flash_attention", "use_expert_system", "num_experts",
+                     "experts_per_token", "multimodal", "image_size", "vision_embed_dim", "vision_patch_size",
+                     "vision_layers", "vision_heads", "output_attentions", "output_hidden_states",
+                     "load_balancing_loss_coef", "expert_capacity_factor", "noisy_routing_alpha",
+                     "expert_dropout_prob", "router_z_loss_coef", "expert_output_gating", "use_noisy_top_k_routing",
+                     "use_expert_capacity_limit", "use_expert_dropout", "use_router_z_loss",
+                     "use_load_balancing_loss", "use_rmsnorm", "use_swiglu"):
+            setattr(self, name, given[name])
+        if not use_expert_system:                                     # core.py:200-204
+            self.num_experts = 0
+            self.experts_per_token = 0
+        else:
+            self.experts_per_token = min(num_experts, experts_per_token) if num_experts > 0 else 0
+        for key, value in kwargs.items():
+            if not hasattr(self, key):
+                logger.warning("Ignoring unknown config parameter: %s=%s", key, value)
+
+    @classmethod
+    def from_dict(cls, config_dict: Dict[str, Any]):
+        params = inspect.signature(cls.__init__).parameters
+        keep = {k: v for k, v in config_dict.items() if (k in params and k != "self") or k == "kwargs"}
+        if keep.get("ssm_dt_rank") == "auto":
+            keep["ssm_dt_rank"] = math.ceil(keep.get("hidden_size", 768) / 16)
+        return cls(**keep)
+
+    def to_dict(self) -> Dict[str, Any]:
+        return self.__dict__
+
+    @classmethod
+    def from_pretrained(cls, model_name_or_path: str):
+        if os.path.isfile(model_name_or_path) and model_name_or_path.endswith(".json"):
+            path = model_name_or_path
+        else:
+            path = os.path.join(model_name_or_path, "config.json")
+            if not os.path.exists(path) and os.path.isdir(model_name_or_path):
+                parent = os.path.join(Path(model_name_or_path).parent, "config.json")
+                if os.path.exists(parent):
+                    path = parent
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Config file not found. Looked for: '{path}' based on input '{model_name_or_path}'")
+        with open(path, "r", encoding="utf-8") as f:
+            return cls.from_dict(json.load(f))
+
+    def save_pretrained(self, save_directory: str):
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "config.json"), "w", encoding="utf-8") as f:
+            json.dump(self.to_dict(), f, indent=2)
+
+
+def _activation_module(name: str) -> nn.Module:
+    if name == "relu":
+        return nn.ReLU()
+    if name in ("silu", "swish"):
+        return nn.SiLU()
+    if name != "gelu":
+        logger.warning("Unsupported activation %s; using GELU", name)
+    return nn.GELU()
+
+
+def _activation_name(name: str) -> str:
+    return name if name in ("gelu", "relu", "silu", "swish") else "gelu"
+
+
+def _compute_dtype(t: torch.Tensor) -> torch.dtype:
+    """bf16 under torch.autocast (the reference trains under fp16 autocast, pipeline.py:533; the
+    MI355X build maps that to bf16 and drops the GradScaler), else the tensor's own dtype."""
+    if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype("cuda")
+        return torch.bfloat16 if dt in (torch.bfloat16, torch.float16) else dt
+    return t.dtype if t.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+class RMSNorm(nn.Module):
+    """x / (||x||_2 / sqrt(D) + eps) * scale  (reference core.py:30-59)."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6):
+        super().__init__()
+        self.hidden_size, self.eps = hidden_size, eps
+        self.scale = nn.Parameter(torch.ones(hidden_size))
+
+    def forward(self, x):
+        rms = x.norm(p=2, dim=-1, keepdim=True) * (self.hidden_size ** -0.5)
+        return self.scale * (x / (rms + self.eps))
+
+
+class RotaryEmbedding(nn.Module):
+    """Interleaved-pair rotary embedding over the full projection width (reference core.py:258-293)."""
+
+    def __init__(self, dim: int, max_position_embeddings: int = 2048, base: float = 10000):
+        super().__init__()
+        if dim % 2:
+            raise ValueError(f"RoPE dimension must be even, got {dim}")
+        self.dim, self.max_position_embeddings, self.base = dim, max_position_embeddings, base
+        inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+        ang = torch.outer(torch.arange(max_position_embeddings, dtype=torch.float32), inv)
+        self.register_buffer("inv_freq", inv, persistent=False)
+        self.register_buffer("cos_cached", ang.cos(), persistent=False)
+        self.register_buffer("sin_cached", ang.sin(), persistent=False)
+
+    def forward(self, x, position_ids=None):
+        B, L, _ = x.shape
+        if position_ids is None:
+            position_ids = torch.arange(L, device=x.device).unsqueeze(0)
+        cos, sin = self.cos_cached[position_ids], self.sin_cached[position_ids]
+        pairs = x.float().reshape(B, L, -1, 2)
+        a, b = pairs[..., 0], pairs[..., 1]
+        return torch.stack((a * cos - b * sin, a * sin + b * cos), dim=-1).reshape(B, L, self.dim).type_as(x)
+
+
+# ----------------------------------------------------------------------------------------------
+# SelectiveLinearAttention  (reference core.py:295-401) on HIP kernels
+# ----------------------------------------------------------------------------------------------
+class SelectiveLinearAttention(nn.Module):
+    """in_proj_x/z -> depthwise causal conv + SiLU -> x_param_proj -> (dt feats, Bt, C) ->
+    softplus(dt_proj_head) -> selective scan -> +D*x -> *SiLU(z) -> out_proj.
+
+    One code path for training, prefill and cached decode: the chunked HIP scan reproduces the
+    sequential recurrence (core.py:337-353), which is what the reference's trainer actually
+    executes (use_cache defaults to True).  The overflow-prone cumsum form (core.py:324-335) is
+    not emulated."""
+
+    def __init__(self, config: ApertisConfig):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.d_state = config.ssm_d_state
+        self.d_inner = self.num_heads * self.d_state
+        self.dt_rank = config.ssm_dt_rank
+        self.conv_kernel_size = config.ssm_conv_kernel
+        self.in_proj_x = nn.Linear(self.hidden_size, self.d_inner, bias=False)
+        self.in_proj_z = nn.Linear(self.hidden_size, self.d_inner, bias=False)
+        # kept as nn.Conv1d so parameter names/shapes/initialisation match the checkpoint format
+        self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, self.conv_kernel_size, groups=self.d_inner,
+                                padding=self.conv_kernel_size - 1)
+        self.x_param_proj = nn.Linear(self.d_inner, self.dt_rank + 2 * self.d_inner, bias=False)
+        self.dt_proj_head = nn.Linear(self.dt_rank, self.num_heads, bias=True)
+        nn.init.uniform_(self.dt_proj_head.bias, a=math.log(1e-3), b=math.log(1e-2))
+        self.A_log = nn.Parameter(torch.empty(self.num_heads, self.d_state).uniform_(math.log(0.5), math.log(0.99)))
+        self.D = nn.Parameter(torch.ones(self.d_inner))
+        self.out_proj = nn.Linear(self.d_inner, self.hidden_size, bias=False)
+        self.use_cache = False
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                output_attentions: bool = False, use_cache: bool = False):
+        self.use_cache = use_cache
+        B, L, _ = hidden_states.shape
+        Dn, R, kw = self.d_inner, self.dt_rank, self.conv_kernel_size
+        conv_prev = ssm_prev = None
+        if past_key_value is not None:
+            conv_prev, ssm_prev = past_key_value
+        xp = self.in_proj_x(hidden_states)                                   # [B,L,Dn]   core.py:366
+        z = self.in_proj_z(hidden_states)                                    #            core.py:367
+        conv_in = xp
+        if conv_prev is not None and use_cache and conv_prev.shape[1] == Dn and conv_prev.shape[2] == kw - 1:
+            # the reference prepends the cached window and keeps the FIRST L conv outputs
+            # (core.py:369-373); reproduced as is so cached decode matches `apertis chat`
+            conv_in = torch.cat([conv_prev.transpose(1, 2).to(xp.dtype), xp], dim=1)
+        conv_state = conv_in[:, -(kw - 1):].transpose(1, 2).detach() if use_cache else None
+        xc = ops.dwconv_silu(conv_in, self.conv1d.weight, self.conv1d.bias)[:, :L]      # core.py:373-375
+        p = self.x_param_proj(xc)                                            # [B,L,R+2Dn] core.py:376
+        dt_logits = self.dt_proj_head(p[..., :R]).float()                    # [B,L,h]    core.py:382
+        h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None
+        # Bt/C are column slices of p taken in place (core.py:384-385); softplus (core.py:383)
+        # is applied inside the scan kernel
+        res = ops.selective_scan(dt_logits, self.A_log, p[..., R:R + Dn], p[..., R + Dn:], h0=h0,
+                                 delta_softplus=True, y_dtype=torch.float32, return_last=use_cache)
+        y, h_last = res if use_cache else (res, None)
+        gated = ops.ssm_gate(y, xc, z, self.D)                               # core.py:395-396
+        out = self.out_proj(gated)                                           # core.py:397
+        cache = (conv_state, h_last.reshape(B, self.num_heads, self.d_state)) if use_cache else None
+        return out, (y if output_attentions else None), cache
+
+
+# ----------------------------------------------------------------------------------------------
+# AdaptiveExpertSystem  (reference core.py:403-607) on HIP kernels
+# ----------------------------------------------------------------------------------------------
+class AdaptiveExpertSystem(nn.Module):
+    """Top-K routed mixture of `LayerNorm -> Linear -> act -> Dropout -> Linear` experts.
+
+    Parameters are held stacked ([E, ...]) for the grouped GEMMs; `state_dict()` /
+    `load_state_dict()` expose the reference's per-expert names `experts.{e}.{0,1,4}.*`."""
+
+    _STACKED = (("0.weight", "expert_ln_weight"), ("0.bias", "expert_ln_bias"), ("1.weight", "expert_w1"),
+                ("1.bias", "expert_b1"), ("4.weight", "expert_w2"), ("4.bias", "expert_b2"))
+
+    def __init__(self, config: ApertisConfig, activation_function_override: Optional[str] = None):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.intermediate_size = config.intermediate_size
+        self.num_experts = config.num_experts
+        self.experts_per_token = config.experts_per_token
+        self.load_balancing_loss_coef = config.load_balancing_loss_coef if self.num_experts > 0 else 0.0
+        self.expert_capacity_factor = config.expert_capacity_factor
+        self.router_z_loss_coef = config.router_z_loss_coef if self.num_experts > 0 else 0.0
+        self.noisy_routing_alpha = config.noisy_routing_alpha if self.num_experts > 0 else 0.0
+        self.expert_dropout_prob = config.expert_dropout_prob if self.num_experts > 0 else 0.0
+        on = self.num_experts > 0
+        self.use_noisy_top_k_routing = config.use_noisy_top_k_routing and on
+        self.use_expert_capacity_limit = config.use_expert_capacity_limit and on
+        self.use_expert_dropout = config.use_expert_dropout and on
+        self.use_router_z_loss = config.use_router_z_loss and on
+        self.use_load_balancing_loss = config.use_load_balancing_loss and on
+        self.router = self.experts = self.w_noise = None
+        if not on:
+            return
+        E, H, I = self.num_experts, self.hidden_size, self.intermediate_size
+        self.activation = _activation_name(activation_function_override or config.hidden_act)
+        self.hidden_dropout_prob = config.hidden_dropout_prob
+        self.router_norm = nn.LayerNorm(H, eps=config.layer_norm_eps)
+        self.router = nn.Linear(H, E)
+        self.experts = True  # marker: experts exist (the reference holds an nn.ModuleList here)
+        k1, k2 = 1.0 / math.sqrt(H), 1.0 / math.sqrt(I)     # nn.Linear default init bounds
+        self.expert_ln_weight = nn.Parameter(torch.ones(E, H))
+        self.expert_ln_bias = nn.Parameter(torch.zeros(E, H))
+        self.expert_w1 = nn.Parameter(torch.empty(E, I, H).uniform_(-k1, k1))
+        self.expert_b1 = nn.Parameter(torch.empty(E, I).uniform_(-k1, k1))
+        self.expert_w2 = nn.Parameter(torch.empty(E, H, I).uniform_(-k2, k2))
+        self.expert_b2 = nn.Parameter(torch.empty(E, H).uniform_(-k2, k2))
+        if config.use_noisy_top_k_routing:
+            self.w_noise = nn.Parameter(torch.zeros(E))
+        self._register_state_dict_hook(self._split_experts)
+        self._register_load_state_dict_pre_hook(self._stack_experts)
+
+    # -- checkpoint format: experts.{e}.{0,1,4}.{weight,bias} -----------------------------------
+    @staticmethod
+    def _split_experts(module, state_dict, prefix, local_metadata):
+        for suffix, name in module._STACKED:
+            stacked = state_dict.pop(prefix + name)
+            for e in range(module.num_experts):
+                state_dict[f"{prefix}experts.{e}.{suffix}"] = stacked[e]
+        return state_dict
+
+    def _stack_experts(self, state_dict, prefix, *args):
+        for suffix, name in self._STACKED:
+            keys = [f"{prefix}experts.{e}.{suffix}" for e in range(self.num_experts)]
+            if all(k in state_dict for k in keys):
+                state_dict[prefix + name] = torch.stack([state_dict.pop(k) for k in keys])
+
+    def init_expert_weights(self, std: float):
+        """ApertisModel._init_weights applied to the stacked experts (core.py:1045-1054)."""
+        with torch.no_grad():
+            self.expert_w1.normal_(0.0, std)
+            self.expert_w2.normal_(0.0, std)
+            self.expert_b1.zero_()
+            self.expert_b2.zero_()
+            self.expert_ln_weight.fill_(1.0)
+            self.expert_ln_bias.zero_()
+
+    def forward(self, hidden_states):
+        zero = hidden_states.new_zeros(())
+        if self.num_experts <= 0 or self.router is None:
+            return hidden_states, zero, zero
+        B, L, H = hidden_states.shape
+        S, E, K = B * L, self.num_experts, self.experts_per_token
+        xf = hidden_states.reshape(S, H)
+        logits = self.router(self.router_norm(xf)).float()                                # core.py:481-482
+        if self.use_noisy_top_k_routing and self.training:                                # core.py:485-488
+            logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
+        gates, idx, w = ops.moe_gate_topk(logits, K)                                      # core.py:491-492,529
+        lb_loss, rz_loss = zero, zero
+        if self.use_load_balancing_loss and self.training and self.load_balancing_loss_coef > 0:   # :499-505
+            frac = torch.zeros(E, device=xf.device).index_add_(0, idx.reshape(-1).long(),
+                                                               torch.ones(S * K, device=xf.device)) / S
+            lb_loss = self.load_balancing_loss_coef * E * torch.sum(frac * gates.mean(dim=0))
+        capacity = None
+        if self.use_expert_capacity_limit and self.training:                              # core.py:508-511
+            capacity = max(1, math.floor((S / E) * self.expert_capacity_factor)) if S > 0 else 0
+        active = None
+        if self.use_expert_dropout and self.training and self.expert_dropout_prob > 0:    # core.py:514-521
+            n_drop = min(math.floor(E * self.expert_dropout_prob), E - 1)
+            if n_drop > 0:
+                active = torch.ones(E, dtype=torch.bool)
+                active[torch.randperm(E)[:n_drop]] = False
+                active = active.to(xf.device)
+        if self.use_router_z_loss and self.training and self.router_z_loss_coef > 0:      # core.py:524-526
+            rz_loss = self.router_z_loss_coef * torch.mean(torch.logsumexp(logits, dim=-1) ** 2)
+
+        cd = _compute_dtype(xf)
+        plan = ops.moe_plan(idx, w, E, capacity, active)                                  # core.py:547-591
+        xg = ops.moe_gather_ln(xf, self.expert_ln_weight, self.expert_ln_bias, plan, self.config.layer_norm_eps,
+                               out_dtype=cd)                                              # core.py:593 + :436
+        p_drop = self.hidden_dropout_prob if self.training else 0.0
+        seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p_drop > 0 else 0
+        h = ops.grouped_linear(xg, self.expert_w1, self.expert_b1, plan.offsets, plan.max_rows, act=self.activation,
+                               drop_p=p_drop, seed=seed, compute_dtype=cd)                # core.py:437-439
+        yr = ops.grouped_linear(h, self.expert_w2, self.expert_b2, plan.offsets, plan.max_rows,
+                                compute_dtype=cd)                                         # core.py:440
+        out = ops.moe_combine(yr, w, plan, out_dtype=xf.dtype)                            # core.py:594,605
+        return out.reshape(B, L, H), lb_loss.to(hidden_states.dtype), rz_loss.to(hidden_states.dtype)
+
+
+class StateTrackingRecurrentCell(nn.Module):
+    """Present in the reference (core.py:609-637) but never instantiated by any model path; kept
+    as an importable name only."""
+
+    def __init__(self, hidden_size: int):
+        super().__init__()
+        raise NotImplementedError("StateTrackingRecurrentCell is dead code in the reference and is not part of "
+                                  "the MI355X hot path")
+
+
+# ----------------------------------------------------------------------------------------------
+# Attention / feed-forward / layer glue  (reference core.py:639-1018)
+# ----------------------------------------------------------------------------------------------
+class ApertisAttention(nn.Module):
+    def __init__(self, config: ApertisConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = self.hidden_size // self.num_attention_heads
+        if config.attention_type in ("selective_ssm", "selective_linear"):
+            self.attention_mechanism_impl = SelectiveLinearAttention(config)
+            self._ssm = True
+        else:
+            if config.attention_type != "standard_mha":
+                logger.error("Unsupported attention_type '%s'; using 'standard_mha'", config.attention_type)
+                config.attention_type = "standard_mha"
+            bias = config.attention_probs_dropout_prob == 0.0            # reference quirk, core.py:652
+            self.q_proj = nn.Linear(self.hidden_size, self.hidden_size, bias=bias)
+            self.k_proj = nn.Linear(self.hidden_size, self.hidden_size, bias=bias)
+            self.v_proj = nn.Linear(self.hidden_size, self.hidden_size, bias=bias)
+            self.out_proj = nn.Linear(self.hidden_size, self.hidden_size, bias=bias)
+            self.attention_mechanism_impl = None
+            self._ssm = False
+        norm = RMSNorm if config.use_rmsnorm else nn.LayerNorm
+        self.pre_norm = norm(config.hidden_size, eps=config.layer_norm_eps)
+        self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.attention_dropout = nn.Dropout(config.attention_probs_dropout_prob)
+        self.rope = None
+        if config.position_embedding_type == "rotary" and not self._ssm:
+            self.rope = RotaryEmbedding(config.hidden_size, config.max_position_embeddings, config.rope_theta)
+
+    def _heads(self, t):
+        B, L, _ = t.shape
+        return t.view(B, L, self.num_attention_heads, self.attention_head_size).transpose(1, 2)
+
+    def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False):
+        x = self.pre_norm(hidden_s)
+        if self._ssm:
+            out, proxy, cache = self.attention_mechanism_impl(x, attention_mask=att_mask, position_ids=pos_ids,
+                                                              past_key_value=past_kv, output_attentions=output_att,
+                                                              use_cache=use_c)
+        else:
+            # standard_mha is outside the accelerated path: stock torch.
+            q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+            if self.rope is not None:
+                q, k = self.rope(q, pos_ids), self.rope(k, pos_ids)
+            if use_c and past_kv is not None:
+                k, v = torch.cat([past_kv[0], k], dim=1), torch.cat([past_kv[1], v], dim=1)
+            cache = (k, v) if use_c else None
+            qh, kh, vh = self._heads(q), self._heads(k), self._heads(v)
+            Lq, Lk = qh.shape[2], kh.shape[2]
+            if att_mask is None and Lq > 1:
+                i = torch.arange(Lq, device=x.device).unsqueeze(1) + (Lk - Lq)
+                att_mask = torch.zeros(Lq, Lk, device=x.device, dtype=qh.dtype).masked_fill_(
+                    i < torch.arange(Lk, device=x.device).unsqueeze(0), torch.finfo(qh.dtype).min)
+            if output_att:
+                scores = qh @ kh.transpose(-1, -2) / math.sqrt(self.attention_head_size)
+                probs = F.softmax(scores + att_mask if att_mask is not None else scores, dim=-1)
+                proxy = probs
+                ctxv = self.attention_dropout(probs) @ vh
+            else:
+                proxy = None
+                ctxv = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=att_mask,
+                                                      dropout_p=self.attention_dropout.p if self.training else 0.0)
+            out = self.out_proj(ctxv.transpose(1, 2).reshape(x.shape[0], Lq, self.hidden_size))
+        return self.output_dropout(out) + hidden_s, proxy, cache
+
+
+class SwiGLUFFN(nn.Module):
+    """w_down(silu(w_gate x) * w_up x), width 2/3*I rounded up to 256 (reference core.py:925-993)."""
+
+    def __init__(self, config: ApertisConfig, intermediate_size: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.intermediate_size = intermediate_size if intermediate_size is not None else config.intermediate_size
+        self.ffn_dim = max(256, -(-int(self.intermediate_size * 2 / 3) // 256) * 256)
+        self.w_gate = nn.Linear(self.hidden_size, self.ffn_dim, bias=False)
+        self.w_up = nn.Linear(self.hidden_size, self.ffn_dim, bias=False)
+        self.w_down = nn.Linear(self.ffn_dim, self.hidden_size, bias=False)
+        self.dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, x):
+        return self.dropout(self.w_down(F.silu(self.w_gate(x)) * self.w_up(x)))
+
+
+class ApertisFeedForward(nn.Module):
+    def __init__(self, config: ApertisConfig):
+        super().__init__()
+        self.config = config
+        norm = RMSNorm if config.use_rmsnorm else nn.LayerNorm
+        self.pre_norm = norm(config.hidden_size, eps=config.layer_norm_eps)
+        self.is_expert_system = False
+        if config.use_swiglu:                                            # SwiGLU wins over MoE, core.py:849-859
+            self.ffn = SwiGLUFFN(config)
+        elif config.use_expert_system and config.num_experts > 0:
+            self.ffn = AdaptiveExpertSystem(config, activation_function_override=config.hidden_act)
+            self.is_expert_system = True
+        else:
+            self.ffn = nn.Sequential(nn.Linear(config.hidden_size, config.intermediate_size),
+                                     _activation_module(config.hidden_act), nn.Dropout(config.hidden_dropout_prob),
+                                     nn.Linear(config.intermediate_size, config.hidden_size))
+        self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def forward(self, hidden_s):
+        x = self.pre_norm(hidden_s)
+        lb = rz = hidden_s.new_zeros(())
+        if self.is_expert_system:
+            out, lb, rz = self.ffn(x)
+        else:
+            out = self.ffn(x)
+        return self.output_dropout(out) + hidden_s, lb, rz
+
+
+class ApertisLayer(nn.Module):
+    def __init__(self, config: ApertisConfig):
+        super().__init__()
+        self.config = config
+        self.attention = ApertisAttention(config)
+        self.feed_forward = ApertisFeedForward(config)
+
+    def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False):
+        x, att_w, cache = self.attention(hidden_s, att_mask, pos_ids, past_kv, output_att, use_c)
+        x, lb, rz = self.feed_forward(x)
+        return x, att_w, cache, lb, rz
+
+
+# ----------------------------------------------------------------------------------------------
+# ApertisModel / ApertisForCausalLM  (reference core.py:1020-1648)
+# ----------------------------------------------------------------------------------------------
+class ApertisModel(nn.Module):
+    def __init__(self, config: ApertisConfig):
+        super().__init__()
+        self.config = config
+        self.padding_idx = config.pad_token_id
+        self.vocab_size = config.vocab_size
+        self.token_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        self.abs_pos_embeddings = None
+        if config.position_embedding_type == "absolute":
+            self.abs_pos_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.multimodal_encoder = None
+        self.vision_projection = nn.Identity()
+        if config.multimodal:
+            self.multimodal_encoder = UnifiedMultimodalEncoder(config)
+            if config.vision_embed_dim != config.hidden_size:
+                self.vision_projection = nn.Linear(config.vision_embed_dim, config.hidden_size)
+        self.layers = nn.ModuleList([ApertisLayer(config) for _ in range(config.num_hidden_layers)])
+        norm = RMSNorm if config.use_rmsnorm else nn.LayerNorm
+        self.final_post_norm = norm(config.hidden_size, eps=config.layer_norm_eps)
+        self.embed_dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.apply(self._init_weights)
+        self.gradient_checkpointing = False
+
+    def _init_weights(self, module):
+        """normal(0, initializer_range) for Linear/Embedding, zero biases, unit norms; dt bias
+        re-drawn in [ln 1e-3, ln 1e-2] (reference core.py:1045-1062)."""
+        std = self.config.initializer_range
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(0.0, std)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(0.0, std)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+        elif isinstance(module, nn.LayerNorm):
+            if module.bias is not None:
+                module.bias.data.zero_()
+            if module.weight is not None:
+                module.weight.data.fill_(1.0)
+        elif isinstance(module, RMSNorm):
+            module.scale.data.fill_(1.0)
+        elif isinstance(module, AdaptiveExpertSystem) and module.router is not None:
+            module.init_expert_weights(std)
+        if isinstance(module, SelectiveLinearAttention):
+            nn.init.uniform_(module.dt_proj_head.bias, a=math.log(1e-3), b=math.log(1e-2))
+
+    def gradient_checkpointing_enable(self):
+        self.gradient_checkpointing = True
+
+    def get_input_embeddings(self):
+        return self.token_embeddings
+
+    def set_input_embeddings(self, embs):
+        self.token_embeddings = embs
+
+    def resize_token_embeddings(self, new_num_tokens: int) -> nn.Embedding:
+        old = self.token_embeddings
+        new = nn.Embedding(new_num_tokens, self.config.hidden_size, self.padding_idx, device=old.weight.device,
+                           dtype=old.weight.dtype)
+        self._init_weights(new)
+        n = min(old.num_embeddings, new_num_tokens)
+        new.weight.data[:n] = old.weight.data[:n]
+        self.token_embeddings = new
+        self.config.vocab_size = self.vocab_size = new_num_tokens
+        if self.padding_idx is not None and self.padding_idx >= new_num_tokens:
+            self.padding_idx = 0
+            self.token_embeddings.padding_idx = 0
+        return self.token_embeddings
+
+    def _prepare_decoder_attention_mask(self, attention_mask, input_shape, inputs_embeds, past_len):
+        """Additive causal+padding mask for the stock-attention fallback, or None when nothing is
+        padded (reference core.py:1088-1139).  Ignored by the selective-SSM path."""
+        if attention_mask is None or bool(torch.all(attention_mask.bool())):
+            return None
+        B, Lq = input_shape
+        allow = None
+        if Lq > 1:
+            Lk = past_len + Lq
+            causal = torch.ones(Lk, Lk, dtype=torch.bool, device=inputs_embeds.device).tril()[past_len:]
+            allow = causal[None, None] & attention_mask[:, None, None, :].bool()
+        elif past_len > 0:
+            allow = attention_mask[:, None, None, :].bool()
+        if allow is None:
+            return None
+        return (1.0 - allow.to(inputs_embeds.dtype)) * torch.finfo(inputs_embeds.dtype).min
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, pixel_values=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None):
+        cfg = self.config
+        use_c = cfg.use_cache if use_cache is None else use_cache
+        out_att = cfg.output_attentions if output_attentions is None else output_attentions
+        out_hs = cfg.output_hidden_states if output_hidden_states is None else output_hidden_states
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("Specify one of input_ids or inputs_embeds.")
+        if inputs_embeds is None:
+            if input_ids is None:
+                raise ValueError("input_ids required if inputs_embeds is None.")
+            inputs_embeds = self.token_embeddings(input_ids)
+        B, Lq = inputs_embeds.shape[:2]
+        ssm = cfg.attention_type != "standard_mha"
+        past_len = 0
+        if past_key_values is not None and past_key_values[0] is not None and not ssm:
+            past_len = past_key_values[0][0].shape[1]
+        pos = position_ids
+        if pos is None:
+            pos = torch.arange(past_len, past_len + Lq, device=inputs_embeds.device).unsqueeze(0).expand(B, -1)
+        if cfg.position_embedding_type == "absolute" and self.abs_pos_embeddings is not None:
+            inputs_embeds = inputs_embeds + self.abs_pos_embeddings(pos)
+        x, pos_layers = inputs_embeds, pos
+        if cfg.multimodal and pixel_values is not None and past_len == 0:              # core.py:1207-1227
+            img = self.vision_projection_forward(self.multimodal_encoder(pixel_values))
+            n_img = img.shape[1]
+            x = torch.cat([img.to(inputs_embeds.dtype), inputs_embeds], dim=1)
+            img_pos = torch.arange(n_img, device=x.device).unsqueeze(0).expand(B, -1)
+            pos_layers = torch.cat([img_pos, pos + n_img], dim=1)
+            if attention_mask is not None and attention_mask.shape[1] == Lq:
+                attention_mask = torch.cat([attention_mask.new_ones(B, n_img), attention_mask], dim=1)
+            elif attention_mask is None:
+                attention_mask = torch.ones(B, n_img + Lq, dtype=torch.long, device=x.device)
+        elif cfg.multimodal and pixel_values is not None:
+            logger.warning("pixel_values provided with past_key_values: image ignored for this step")
+        x = self.embed_dropout(x)
+        mask = None if ssm else self._prepare_decoder_attention_mask(attention_mask, (B, x.shape[1]), x, past_len)
+
+        all_hs, all_att, all_cache = [], [], []
+        lb_tot, rz_tot = x.new_zeros(()), x.new_zeros(())
+        for i, layer in enumerate(self.layers):
+            if out_hs:
+                all_hs.append(x)
+            past = past_key_values[i] if past_key_values and i < len(past_key_values) else None
+            if self.gradient_checkpointing and self.training and not use_c:             # core.py:1258
+                x, att_w, cache, lb, rz = torch.utils.checkpoint.checkpoint(layer, x, mask, pos_layers, past, out_att,
+                                                                            use_c, use_reentrant=False)
+            else:
+                x, att_w, cache, lb, rz = layer(x, mask, pos_layers, past, out_att, use_c)
+            if out_att:
+                all_att.append(att_w)
+            if use_c:
+                all_cache.append(cache)
+            if cfg.use_expert_system:
+                lb_tot, rz_tot = lb_tot + lb, rz_tot + rz
+        x = self.final_post_norm(x)
+        if out_hs:
+            all_hs.append(x)
+        return (x, tuple(all_hs) if out_hs and all_hs else None, tuple(all_att) if out_att and all_att else None,
+                tuple(all_cache) if use_c and all_cache else None,
+                lb_tot if cfg.use_expert_system else None, rz_tot if cfg.use_expert_system else None)
+
+    def vision_projection_forward(self, feats):
+        """Linear(vision_embed_dim -> hidden) on the MFMA GEMM tile (core.py:1035,1209)."""
+        if isinstance(self.vision_projection, nn.Identity):
+            return feats
+        return ops.linear_mfma(feats, self.vision_projection.weight, self.vision_projection.bias,
+                               compute_dtype=_compute_dtype(feats))
+
+
+class ApertisForCausalLM(nn.Module):
+    def __init__(self, config: ApertisConfig):
+        super().__init__()
+        self.config = config
+        self.model = ApertisModel(config)
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        if config.tie_word_embeddings:
+            self.lm_head.weight = self.model.token_embeddings.weight
+        else:
+            self.lm_head.weight.data.normal_(0.0, config.initializer_range)
+
+    def load_state_dict(self, state_dict, strict=True):
+        return super().load_state_dict(state_dict, strict=strict)
+
+    def save_pretrained(self, save_directory):
+        os.makedirs(save_directory, exist_ok=True)
+        torch.save(self.state_dict(), os.path.join(save_directory, "pytorch_model.bin"))
+        self.config.save_pretrained(save_directory)
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, new_lm_head):
+        self.lm_head = new_lm_head
+
+    def get_input_embeddings(self):
+        return self.model.token_embeddings
+
+    def gradient_checkpointing_enable(self):
+        self.model.gradient_checkpointing_enable()
+
+    def resize_token_embeddings(self, new_num_tokens: int) -> nn.Linear:
+        self.model.resize_token_embeddings(new_num_tokens)
+        if self.config.tie_word_embeddings and self.lm_head.weight.shape[0] == new_num_tokens:
+            pass
+        if self.config.tie_word_embeddings:
+            self.lm_head.weight = self.model.token_embeddings.weight
+            self.lm_head.out_features = new_num_tokens
+        else:
+            old = self.lm_head
+            self.lm_head = nn.Linear(self.config.hidden_size, new_num_tokens, bias=False, device=old.weight.device,
+                                     dtype=old.weight.dtype)
+            self.lm_head.weight.data.normal_(0.0, self.config.initializer_range)
+            n = min(old.out_features, new_num_tokens)
+            self.lm_head.weight.data[:n] = old.weight.data[:n]
+        self.config.vocab_size = self.lm_head.out_features
+        return self.lm_head
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, pixel_values=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None):
+        """Returns the reference's 7-tuple (loss, logits, hidden_states, attentions,
+        past_key_values, lb_loss, rz_loss)  (core.py:1361-1472)."""
+        outs = self.model(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                          past_key_values=past_key_values, inputs_embeds=inputs_embeds, pixel_values=pixel_values,
+                          use_cache=use_cache, output_attentions=output_attentions,
+                          output_hidden_states=output_hidden_states)
+        hs = outs[0]
+        if self.config.multimodal and pixel_values is not None and past_key_values is None and input_ids is not None:
+            start = hs.shape[1] - input_ids.shape[1]                     # text positions are last, core.py:1399-1406
+            if start >= 0:
+                hs = hs[:, start:]
+        logits = self.lm_head(hs)
+        loss = None
+        if labels is not None:
+            sl, tl = logits[..., :-1, :], labels[..., 1:]
+            n = min(sl.shape[1], tl.shape[1])
+            if n == 0:
+                loss = torch.zeros((), device=logits.device, requires_grad=self.training)
+            else:
+                loss = F.cross_entropy(sl[:, :n].reshape(-1, sl.shape[-1]).float(), tl[:, :n].reshape(-1),
+                                       ignore_index=-100)
+            if outs[4] is not None:
+                loss = loss + outs[4]
+            if outs[5] is not None:
+                loss = loss + outs[5]
+        return (loss, logits) + outs[1:]
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None,
+                                      position_ids_override=None, **kwargs):
+        B, L = input_ids.shape
+        if past_key_values is not None:
+            ids = input_ids[:, -1:]
+            pos = torch.full((B, 1), attention_mask.shape[1] - 1, dtype=torch.long, device=input_ids.device)
+        else:
+            ids = input_ids
+            pos = torch.arange(L, device=input_ids.device).unsqueeze(0).expand(B, -1)
+        if position_ids_override is not None:
+            pos = position_ids_override
+        inputs = {"input_ids": ids, "past_key_values": past_key_values, "attention_mask": attention_mask,
+                  "position_ids": pos, "use_cache": kwargs.get("use_cache", True)}
+        if past_key_values is None and "pixel_values" in kwargs:
+            inputs["pixel_values"] = kwargs["pixel_values"]
+        return inputs
+
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, position_ids=None, pixel_values=None,
+                 max_new_tokens: Optional[int] = 20, min_new_tokens: Optional[int] = 0, do_sample: Optional[bool] = False,
+                 temperature: Optional[float] = 1.0, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
+                 repetition_penalty: Optional[float] = 1.0, eos_token_id=None, pad_token_id=None,
+                 use_cache: bool = True, **kwargs):
+        """Greedy / top-k / top-p / repetition-penalty decoding loop (reference core.py:1520-1644)."""
+        if input_ids is None:
+            raise ValueError("input_ids must be provided.")
+        B, prompt_len = input_ids.shape
+        temp = max(temperature, 1e-6) if do_sample else 1.0
+        eos = self.config.eos_token_id if eos_token_id is None else eos_token_id
+        eos = [] if eos is None else (eos if isinstance(eos, list) else [eos])
+        pad = pad_token_id if pad_token_id is not None else self.config.pad_token_id
+        pad = 0 if pad is None else pad
+        mask = torch.ones_like(input_ids) if attention_mask is None else attention_mask
+        pos = position_ids
+        if pos is None:
+            pos = torch.arange(prompt_len, device=input_ids.device).unsqueeze(0).expand(B, -1)
+        px = pixel_values
+        if self.config.multimodal and px is not None:
+            n_img = (self.config.image_size // self.config.vision_patch_size) ** 2 + 1
+            mask = torch.cat([mask.new_ones(B, n_img), mask], dim=1)
+            pos = torch.cat([torch.arange(n_img, device=input_ids.device).unsqueeze(0).expand(B, -1), pos + n_img], dim=1)
+        tokens, past = input_ids, None
+        alive = torch.ones(B, dtype=torch.long, device=input_ids.device)
+        for _ in range(max_new_tokens):
+            inp = self.prepare_inputs_for_generation(tokens if past is None else tokens[:, -1:], past_key_values=past,
+                                                     attention_mask=mask,
+                                                     position_ids_override=pos if past is None else None,
+                                                     pixel_values=px, use_cache=use_cache)
+            px = None
+            out = self(input_ids=inp["input_ids"], attention_mask=inp["attention_mask"],
+                       position_ids=inp["position_ids"], past_key_values=inp["past_key_values"],
+                       pixel_values=inp.get("pixel_values"), use_cache=inp["use_cache"])
+            nxt_logits = out[1][:, -1, :].float()
+            past = out[4] if use_cache else None
+            if repetition_penalty != 1.0:
+                for b in range(B):
+                    if alive[b]:
+                        seen = tokens[b][tokens[b] < nxt_logits.shape[-1]]
+                        for t_ in seen.tolist():                    # divides once per occurrence, like the reference
+                            nxt_logits[b, t_] /= repetition_penalty
+            if do_sample:
+                if temp != 1.0:
+                    nxt_logits = nxt_logits / temp
+                if top_k > 0:
+                    kth = torch.topk(nxt_logits, top_k).values[:, -1:]
+                    nxt_logits = nxt_logits.masked_fill(nxt_logits < kth, float("-inf"))
+                if top_p < 1.0:
+                    srt, order = torch.sort(nxt_logits, descending=True)
+                    drop = torch.cumsum(F.softmax(srt, dim=-1), dim=-1) > top_p
+                    drop[..., 1:] = drop[..., :-1].clone()
+                    drop[..., 0] = False
+                    nxt_logits = nxt_logits.masked_fill(torch.zeros_like(drop).scatter_(-1, order, drop), float("-inf"))
+                nxt = torch.multinomial(F.softmax(nxt_logits, dim=-1), 1).squeeze(1)
+            else:
+                nxt = torch.argmax(nxt_logits, dim=-1)
+            nxt = nxt * alive + pad * (1 - alive)
+            tokens = torch.cat([tokens, nxt.unsqueeze(-1)], dim=-1)
+            mask = torch.cat([mask, alive.unsqueeze(-1).to(mask.dtype)], dim=1)
+            for e_ in eos:
+                if e_ is not None:
+                    alive = alive.masked_fill((nxt == e_) & (alive == 1), 0)
+            if alive.max() == 0 and tokens.shape[1] - prompt_len >= min_new_tokens:
+                break
+        return tokens
+
+
+# ----------------------------------------------------------------------------------------------
+# Model sizing  (reference core.py:1709-2105)
+# ----------------------------------------------------------------------------------------------
+def parse_param_count(param_str: Union[str, int]) -> int:
+    """'10M' / '1.5B' / '350k' / int -> integer parameter count (core.py:1709-1739)."""
+    if isinstance(param_str, int):
+        return param_str
+    s = str(param_str).strip().upper()
+    if not s:
+        raise ValueError("Parameter string cannot be empty.")
+    mult = {"K": 1_000, "M": 1_000_000, "B": 1_000_000_000}.get(s[-1], 1)
+    if mult != 1:
+        s = s[:-1]
+    try:
+        return int(float(s) * mult)
+    except ValueError:
+        raise ValueError(f"Invalid numeric value in parameter string: '{param_str}'")
+
+
+def _calculate_params_for_dims(vocab_size, hidden_size, num_layers, intermediate_size, tie_word_embeddings=True,
+                               use_expert_system=False, num_experts=0) -> int:
+    """The reference's MHA-shaped estimator (4h^2 attention), used for sizing even for SSM models
+    (core.py:1741-1769)."""
+    h, I = hidden_size, intermediate_size
+    p = vocab_size * h * (1 if tie_word_embeddings else 2)
+    p += num_layers * 4 * h * h
+    if use_expert_system and num_experts > 0:
+        p += num_layers * (num_experts * 2 * h * I + h * num_experts)
+    else:
+        p += num_layers * 2 * h * I
+    return p + (2 * num_layers + 1) * 2 * h
+
+
+def calculate_model_dimensions(target_params_str, vocab_size, use_expert_system=False, num_experts_target=8,
+                               min_hidden_size=256, max_hidden_size=8192, min_layers=2, max_layers=128,
+                               head_dim_preference=64, intermediate_multiple_of=256, intermediate_ratio=4.0,
+                               tie_word_embeddings=True) -> Dict[str, Any]:
+    """Grid search (layers in steps of 2, hidden a multiple of the head dim with a growing step,
+    I = 4h rounded up to 256) for the closest estimated parameter count; reproduces the
+    reference's choices exactly (core.py:1771-1893; golden table in tests/golden)."""
+    target = parse_param_count(target_params_str)
+    hd = head_dim_preference
+    best, best_diff = None, float("inf")
+
+    def dims_for(h):
+        heads = max(1, h // hd)
+        I = max(intermediate_multiple_of, -(-int(h * intermediate_ratio) // intermediate_multiple_of) * intermediate_multiple_of)
+        return heads, I
+
+    for layers in range(min_layers, max_layers + 1, 2):
+        cur = min_hidden_size
+        while cur <= max_hidden_size:
+            h = cur if cur % hd == 0 else (cur // hd + 1) * hd
+            h = h or hd
+            if h > max_hidden_size:
+                break
+            heads, I = dims_for(h)
+            params = _calculate_params_for_dims(vocab_size, h, layers, I, tie_word_embeddings, use_expert_system,
+                                                num_experts_target if use_expert_system else 0)
+            diff = abs(params - target)
+            if diff < best_diff:
+                best_diff = diff
+                best = {"hidden_size": h, "num_hidden_layers": layers, "num_attention_heads": heads,
+                        "intermediate_size": I, "calculated_params": params, "target_params": target,
+                        "param_diff": diff}
+            if params > target and diff > best_diff:
+                break
+            cur += max(hd, h // 16)
+            if cur > max_hidden_size and best is None:
+                cur = max_hidden_size
+    if best is None:
+        h = min_hidden_size
+        heads, I = dims_for(h)
+        params = _calculate_params_for_dims(vocab_size, h, min_layers, I, tie_word_embeddings, use_expert_system,
+                                            num_experts_target if use_expert_system else 0)
+        return {"hidden_size": h, "num_hidden_layers": min_layers, "num_attention_heads": heads,
+                "intermediate_size": I, "calculated_params": params, "target_params": target,
+                "param_diff": abs(params - target), "備考": "Fallback configuration"}
+    return best
+
+
+def estimate_model_parameters(config: ApertisConfig) -> int:
+    """Parameter estimate from a config (core.py:1895-1965): embeddings (+ untied head), 4h^2
+    attention, dense or E-expert FFN (+ router), 2L+1 norms, absolute positions, vision projection."""
+    h, I, L = config.hidden_size, config.intermediate_size, config.num_hidden_layers
+    total = config.vocab_size * h * (1 if config.tie_word_embeddings else 2)
+    ffn = 2 * h * I
+    if config.use_expert_system and config.num_experts > 0:
+        ffn = config.num_experts * 2 * h * I + h * config.num_experts
+    total += L * (4 * h * h + ffn) + (2 * L + 1) * 2 * h
+    if config.position_embedding_type == "absolute":
+        total += config.max_position_embeddings * h
+    if config.multimodal and config.vision_embed_dim != h:
+        total += config.vision_embed_dim * h
+    return total
+
+
+def create_apertis_model(target_param_count: Union[str, int] = "125M", vocab_size_override: Optional[int] = None,
+                         multimodal: bool = False, use_flash_attention: bool = False, use_expert_system: bool = False,
+                         num_experts_target_override: Optional[int] = None,
+                         experts_per_token_target_override: Optional[int] = None,
+                         attention_type_override: Optional[str] = None, ssm_d_inner: Optional[int] = None,
+                         ssm_d_state: int = 16, ssm_dt_rank: Union[int, str] = "auto", ssm_conv_kernel: int = 4,
+                         config_overrides: Optional[Dict[str, Any]] = None) -> ApertisForCausalLM:
+    """Size a model for a parameter budget and build it (reference core.py:1969-2105)."""
+    vocab = vocab_size_override if vocab_size_override is not None else ApertisConfig(**(config_overrides or {})).vocab_size
+    dims = calculate_model_dimensions(target_param_count, vocab, use_expert_system=use_expert_system,
+                                      num_experts_target=8 if num_experts_target_override is None else num_experts_target_override)
+    cfg = {k: dims[k] for k in ("hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size")}
+    cfg["vocab_size"] = vocab
+    cfg["attention_type"] = attention_type_override or "standard_mha"
+    cfg.update(multimodal=multimodal, use_flash_attention=use_flash_attention, use_expert_system=use_expert_system,
+               ssm_d_inner=ssm_d_inner, ssm_d_state=ssm_d_state, ssm_dt_rank=ssm_dt_rank, ssm_conv_kernel=ssm_conv_kernel)
+    if use_expert_system:
+        cfg["num_experts"] = 8 if num_experts_target_override is None else num_experts_target_override
+        cfg["experts_per_token"] = 2 if experts_per_token_target_override is None else experts_per_token_target_override
+    if config_overrides:
+        cfg.update(config_overrides)
+    h, heads = cfg["hidden_size"], cfg["num_attention_heads"]
+    if h % heads != 0:
+        head_dim = h // heads if heads > 0 else 64
+        if head_dim > 0 and h % head_dim == 0:
+            cfg["num_attention_heads"] = h // head_dim
+        else:
+            cfg["num_attention_heads"] = next((i for i in range(min(heads, h), 0, -1) if h % i == 0), 1)
+    config = ApertisConfig(**cfg)
+    logger.info("Model configured with H=%d L=%d A=%d I=%d V=%d (~%.2fM params by the reference estimator)",
+                config.hidden_size, config.num_hidden_layers, config.num_attention_heads, config.intermediate_size,
+                config.vocab_size, estimate_model_parameters(config) / 1e6)
+    return ApertisForCausalLM(config)

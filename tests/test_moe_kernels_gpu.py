@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _close(got, ref, name, rtol=1e-4, atol_scale=2e-6):
-    ref = ref.detach().cpu().to(torch.float64)
+    ref = torch.as_tensor(ref).detach().cpu().to(torch.float64)
     got = got.detach().cpu().to(torch.float64)
     atol = atol_scale * float(ref.abs().max()) + 1e-30
     bad = (got - ref).abs() > atol + rtol * ref.abs()

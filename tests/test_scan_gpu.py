@@ -17,7 +17,7 @@ RTOL = 1e-4
 
 
 def _close(got, ref, name, rtol=RTOL, atol_scale=2e-6):
-    ref = ref.to(torch.float64)
+    ref = torch.as_tensor(ref).to(torch.float64)
     got = got.detach().cpu().to(torch.float64)
     atol = atol_scale * float(ref.abs().max()) + 1e-30
     bad = (got - ref).abs() > atol + rtol * ref.abs()
