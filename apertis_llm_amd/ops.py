@@ -9,6 +9,49 @@ from . import _lib
 from ._lib import ApertisHipError, check, dtype_code, ptr, stream_ptr
 
 
+_TIMER = None
+
+
+def set_kernel_timer(timer):
+    """Install (or clear with None) a KernelTimer: the named C-ABI calls are bracketed with HIP
+    events on the launch stream so bench.py can report per-launch durations."""
+    global _TIMER
+    _TIMER = timer
+
+
+class KernelTimer:
+    """Collects (name, start_event, end_event, work) for selected entry points.  `work` is the
+    algorithmic bytes or flops of the call, or a callable evaluated after the run (for counts
+    that live on the device)."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, work in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += float(work() if callable(work) else work)
+        return out
+
+
+def _launch(name, fn, args, work=0.0):
+    t = _TIMER
+    if t is None or name not in t.names:
+        check(fn(*args), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    rc = fn(*args)
+    e.record()
+    check(rc, name)
+    t.records.append((name, s, e, work))
+
+
 def _require_gpu(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -54,10 +97,10 @@ class _SelectiveScan(torch.autograd.Function):
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
-        check(lib.apertis_selective_scan_fwd(ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn,
-                                             ptr(h_last), ptr(agg), ptr(h_in), B, L, h, N, dtype_code(Bt),
-                                             dtype_code(y), int(delta_softplus), stream_ptr()),
-              "apertis_selective_scan_fwd")
+        work = B * L * (Dn * (2 * Bt.element_size() + y.element_size()) + 4 * h) + 4 * h * N   # algorithmic bytes
+        _launch("apertis_selective_scan_fwd", lib.apertis_selective_scan_fwd,
+                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(agg),
+                 ptr(h_in), B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr()), work)
         ctx.save_for_backward(dlt, A_log, Bt, C, h_in)
         ctx.cfg = (B, L, h, N, bool(delta_softplus))
         ctx.mark_non_differentiable(*([h_last] if return_last else []))
@@ -81,11 +124,11 @@ class _SelectiveScan(torch.autograd.Function):
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         mu_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         dA_part = torch.empty(B * nch, Dn, device=dev, dtype=torch.float32)
-        check(lib.apertis_selective_scan_bwd(ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C),
-                                             C.stride(-2), ptr(dy), Dn, ptr(h_in), ptr(dBt), Dn, ptr(dC), Dn,
-                                             ptr(d_dlt), ptr(dA_log), ptr(agg), ptr(mu_in), ptr(dA_part),
-                                             B, L, h, N, dtype_code(Bt), dtype_code(dy), int(sp), stream_ptr()),
-              "apertis_selective_scan_bwd")
+        work = B * L * (Dn * (4 * Bt.element_size() + dy.element_size()) + 8 * h) + 8 * h * N  # algorithmic bytes
+        _launch("apertis_selective_scan_bwd", lib.apertis_selective_scan_bwd,
+                (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(dy), Dn, ptr(h_in), ptr(dBt), Dn,
+                 ptr(dC), Dn, ptr(d_dlt), ptr(dA_log), ptr(agg), ptr(mu_in), ptr(dA_part), B, L, h, N, dtype_code(Bt),
+                 dtype_code(dy), int(sp), stream_ptr()), work)
         return d_dlt, dA_log, dBt, dC, None, None, None, None
 
 
@@ -356,6 +399,18 @@ def cast_transpose(w, dtype, want_plain=True, want_transposed=True):
     return plain, tr
 
 
+class _RowsWork:
+    """flops of a grouped GEMM = (rows actually routed, read from the device after the run) x
+    flops per row."""
+    __slots__ = ("offsets", "E", "per_row")
+
+    def __init__(self, offsets, E, per_row):
+        self.offsets, self.E, self.per_row = offsets, E, per_row
+
+    def __call__(self):
+        return float(self.offsets[self.E].item()) * self.per_row
+
+
 _ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "relu": _lib.ACT_RELU,
          "silu": _lib.ACT_SILU, "swish": _lib.ACT_SILU}
 
@@ -382,9 +437,9 @@ class _GroupedLinear(torch.autograd.Function):
         act_code = _ACTS[act]
         out = torch.empty(x.shape[0], N, device=x.device, dtype=compute_dtype)
         pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
-        check(lib.apertis_grouped_gemm_nt(ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), max_rows, N, K, E,
-                                          act_code, float(drop_p), int(seed), code, code, stream_ptr()),
-              "apertis_grouped_gemm_nt")
+        _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), max_rows, N, K, E, act_code, float(drop_p),
+                 int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         ctx.save_for_backward(x, wt, pre, offsets)
         ctx.cfg = (E, N, K, max_rows, act_code, float(drop_p), int(seed), bias is not None, weight.dtype)
         return out
@@ -405,14 +460,15 @@ class _GroupedLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            check(lib.apertis_grouped_gemm_nt(ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, max_rows, K, N, E,
-                                              _lib.ACT_NONE, 0.0, 0, code, code, stream_ptr()),
-                  "apertis_grouped_gemm_nt(dgrad)")
+            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                    (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, max_rows, K, N, E, _lib.ACT_NONE, 0.0, 0, code,
+                     code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
             db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
-            check(lib.apertis_grouped_gemm_tn(ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, code,
-                                              stream_ptr()), "apertis_grouped_gemm_tn")
+            _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
+                    (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, code, stream_ptr()),
+                    _RowsWork(offsets, E, 2.0 * N * K))
             dw = dw.to(wdtype)
         return dx, dw, db, None, None, None, None, None, None
 

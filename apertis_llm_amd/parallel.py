@@ -1,0 +1,161 @@
+"""Data parallelism for the Apertis hot path: one process per GPU, gradients averaged with
+bucketed all-reduce (RCCL over xGMI on MI355X; `backend="nccl"` is RCCL on ROCm) on a side HIP
+stream, overlapped with the rest of backward.
+
+Replaces torch DistributedDataParallel as the reference uses it (src/training/pipeline.py:463:
+DDP(find_unused_parameters=False), gradient MEAN over ranks, default 25 MB buckets).  Choices
+made for point-to-point xGMI (7 links x ~153 GB/s per GPU, ring collectives are per-link bound):
+  - large buckets (default 128 MiB) so each all-reduce is bandwidth- not latency-bound;
+  - gradients live INSIDE the flat bucket buffers (param.grad is a view), so a bucket is ready the
+    moment its last gradient is accumulated and nothing is copied before the collective;
+  - buckets are filled in reverse parameter order = the order backward produces gradients;
+  - the collective is issued on a dedicated stream behind an event recorded on the compute
+    stream; `finish()` makes the compute stream wait before clipping / the optimizer;
+  - optional bf16 wire format (halves bytes on the links) with fp32 accumulation buffers.
+MoE capacity and auxiliary losses are rank-local, exactly as under DDP: N-rank DP equals the mean
+of independently computed per-shard gradients.
+"""
+import contextlib
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "offsets", "pending", "work", "wire")
+
+    def __init__(self, flat, params, offsets):
+        self.flat, self.params, self.offsets = flat, params, offsets
+        self.pending = len(params)
+        self.work = None
+        self.wire = None
+
+
+class BucketedDataParallel(nn.Module):
+    def __init__(self, module: nn.Module, bucket_bytes: int = 128 << 20, process_group=None,
+                 reduce_dtype: Optional[torch.dtype] = None, broadcast_parameters: bool = True):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reduce_dtype = reduce_dtype
+        self._sync = True
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.device = params[0].device
+        self._cuda = self.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self._cuda else None
+        if broadcast_parameters and self.world_size > 1:
+            # DDP semantics: every replica starts from rank 0's parameters and buffers
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                                   group=process_group)
+        self.buckets: List[_Bucket] = []
+        self._slot = {}
+        self._build_buckets(list(reversed(params)), bucket_bytes)
+
+    # ------------------------------------------------------------------------------------------
+    def _build_buckets(self, params, bucket_bytes):
+        cur, cur_bytes = [], 0
+        groups = []
+        for p in params:
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != cur[0].dtype):
+                groups.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            groups.append(cur)
+        for g in groups:
+            total = sum(-(-p.numel() // 64) * 64 for p in g)          # 256-byte aligned slices (fp32)
+            flat = torch.zeros(total, device=self.device, dtype=g[0].dtype)
+            offsets, off = [], 0
+            for p in g:
+                offsets.append(off)
+                p.grad = flat[off:off + p.numel()].view_as(p)
+                off += -(-p.numel() // 64) * 64
+            b = _Bucket(flat, g, offsets)
+            bi = len(self.buckets)
+            self.buckets.append(b)
+            for i, p in enumerate(g):
+                self._slot[id(p)] = i
+                p.register_post_accumulate_grad_hook(self._make_hook(bi))
+
+    def _make_hook(self, bi):
+        def hook(p):
+            b = self.buckets[bi]
+            i = self._slot[id(p)]
+            view = b.flat[b.offsets[i]:b.offsets[i] + p.numel()].view_as(p)
+            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
+                # autograd replaced the gradient tensor: fold it back into the bucket
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view
+            b.pending -= 1
+            if b.pending == 0 and self._sync and self.world_size > 1:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b: _Bucket):
+        inv = 1.0 / self.world_size
+        if self._cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                if self.reduce_dtype is not None and self.reduce_dtype != b.flat.dtype:
+                    b.wire = b.flat.to(self.reduce_dtype)
+                    dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, group=self.group)
+                    b.flat.copy_(b.wire).mul_(inv)
+                    b.wire.record_stream(self.comm_stream)
+                else:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+                    b.flat.mul_(inv)
+        else:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def finish(self):
+        """Call after backward(), before clipping / optimizer.step(): waits for the reductions."""
+        if self.world_size > 1 and self._sync:
+            for b in self.buckets:
+                if b.pending != 0 and b.pending != len(b.params):
+                    raise RuntimeError("a gradient bucket is partially filled: some parameter received no gradient "
+                                       "(find_unused_parameters=False semantics, reference pipeline.py:463)")
+                if b.pending == len(b.params):   # nothing arrived (e.g. frozen sub-module): still reduce zeros
+                    self._launch(b)
+            if self._cuda:
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            else:
+                for b in self.buckets:
+                    if b.work is not None:
+                        b.work.wait()
+                        b.flat.mul_(1.0 / self.world_size)
+                        b.work = None
+        for b in self.buckets:
+            b.pending = len(b.params)
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the flat buffers (gradients stay views into them)."""
+        for b in self.buckets:
+            b.flat.zero_()
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Skip the all-reduce for this backward (gradient-accumulation micro-steps)."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+            for b in self.buckets:
+                b.pending = len(b.params)
+
+    def gradient_bytes(self) -> int:
+        return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)

@@ -1,0 +1,102 @@
+"""CPU baseline leg of bench.py — ORACLE CODE, test/measurement infrastructure only.
+
+Times the CPU restatement (oracle/ref_cpu.py, verified against the reference in the build
+container) on the GPU box's host cores for a BOUNDED sample of the benchmark workload and
+extrapolates to the whole model.  It is a reported baseline ("port"), never the target.
+"""
+import math
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+from . import ref_cpu
+
+
+def _random_layer_state(H, h, N, I, E, R, moe, gen):
+    Dn = h * N
+    r = lambda *s: torch.randn(*s, generator=gen) * 0.02
+    sd = {}
+    p = "model.layers.0.attention."
+    sd[p + "pre_norm.weight"], sd[p + "pre_norm.bias"] = torch.ones(H), torch.zeros(H)
+    q = p + "attention_mechanism_impl."
+    sd[q + "in_proj_x.weight"], sd[q + "in_proj_z.weight"] = r(Dn, H), r(Dn, H)
+    sd[q + "conv1d.weight"], sd[q + "conv1d.bias"] = torch.randn(Dn, 1, 4, generator=gen) * 0.5, torch.zeros(Dn)
+    sd[q + "x_param_proj.weight"] = r(R + 2 * Dn, Dn)
+    sd[q + "dt_proj_head.weight"] = r(h, R)
+    sd[q + "dt_proj_head.bias"] = torch.empty(h).uniform_(math.log(1e-3), math.log(1e-2), generator=gen)
+    sd[q + "A_log"] = torch.empty(h, N).uniform_(math.log(0.5), math.log(0.99), generator=gen)
+    sd[q + "D"] = torch.ones(Dn)
+    sd[q + "out_proj.weight"] = r(H, Dn)
+    f = "model.layers.0.feed_forward."
+    sd[f + "pre_norm.weight"], sd[f + "pre_norm.bias"] = torch.ones(H), torch.zeros(H)
+    if moe:
+        g = f + "ffn."
+        sd[g + "router_norm.weight"], sd[g + "router_norm.bias"] = torch.ones(H), torch.zeros(H)
+        sd[g + "router.weight"], sd[g + "router.bias"] = r(E, H), torch.zeros(E)
+        for e in range(E):
+            sd[f"{g}experts.{e}.0.weight"], sd[f"{g}experts.{e}.0.bias"] = torch.ones(H), torch.zeros(H)
+            sd[f"{g}experts.{e}.1.weight"], sd[f"{g}experts.{e}.1.bias"] = r(I, H), torch.zeros(I)
+            sd[f"{g}experts.{e}.4.weight"], sd[f"{g}experts.{e}.4.bias"] = r(H, I), torch.zeros(H)
+    else:
+        sd[f + "ffn.0.weight"], sd[f + "ffn.0.bias"] = r(I, H), torch.zeros(I)
+        sd[f + "ffn.3.weight"], sd[f + "ffn.3.bias"] = r(H, I), torch.zeros(H)
+    return sd
+
+
+def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, budget_s=25.0, threads=None):
+    """fwd+bwd of ONE layer of the given shape at B=1, seq L, plus the lm_head+CE, through the
+    oracle with torch autograd; extrapolated to n_layers_total layers.  Returns a dict."""
+    # the recurrence is a Python loop of tiny ops: more threads than ~32 only adds pool overhead
+    threads = threads or min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(0)
+    R = math.ceil(H / 16)
+    sd = _random_layer_state(H, h, N, I, E, R, moe, gen)
+    for v in sd.values():
+        v.requires_grad_(True)
+    emb = (torch.randn(vocab, H, generator=gen) * 0.02).requires_grad_(True)
+    ids = torch.randint(4, vocab, (1, L), generator=gen)
+    cfg = dict(hidden_size=H, layer_norm_eps=1e-12, num_hidden_layers=1, num_attention_heads=h, ssm_d_state=N,
+               ssm_dt_rank=R, use_expert_system=moe, num_experts=E, experts_per_token=K, hidden_act="gelu")
+
+    def one_layer():
+        x = F.embedding(ids, emb)
+        lp = "model.layers.0."
+        hh = F.layer_norm(x, (H,), sd[lp + "attention.pre_norm.weight"], sd[lp + "attention.pre_norm.bias"], 1e-12)
+        x = x + ref_cpu.ssm_layer(sd, lp + "attention.attention_mechanism_impl.", hh, h, N, R)
+        hh = F.layer_norm(x, (H,), sd[lp + "feed_forward.pre_norm.weight"], sd[lp + "feed_forward.pre_norm.bias"], 1e-12)
+        if moe:
+            f, _, _, _ = ref_cpu.moe_layer(sd, lp + "feed_forward.ffn.", hh, E, K, "gelu", 1e-12, training=False)
+        else:
+            f = F.linear(F.gelu(F.linear(hh, sd[lp + "feed_forward.ffn.0.weight"], sd[lp + "feed_forward.ffn.0.bias"])),
+                         sd[lp + "feed_forward.ffn.3.weight"], sd[lp + "feed_forward.ffn.3.bias"])
+        return x + f
+
+    t0 = time.perf_counter()
+    y = one_layer()
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    y.sum().backward()
+    t_bwd = time.perf_counter() - t0
+    # head: final LN + tied lm_head + CE, fwd+bwd
+    xh = y.detach().requires_grad_(True)
+    t0 = time.perf_counter()
+    logits = F.linear(F.layer_norm(xh, (H,)), emb)
+    loss = F.cross_entropy(logits[:, :-1].reshape(-1, vocab), ids[:, 1:].reshape(-1))
+    loss.backward()
+    t_head = time.perf_counter() - t0
+    step_s = n_layers_total * (t_fwd + t_bwd) + t_head
+    return {"value": L / step_s, "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (torch-CPU restatement, sequential-recurrence scan as the reference trainer executes it) "
+                      f"fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, fp32; layer fwd {t_fwd:.2f}s "
+                      f"bwd {t_bwd:.2f}s head {t_head:.2f}s; step time extrapolated as {n_layers_total}x layer + head"}
+
+
+if __name__ == "__main__":   # child process of bench.py: prints one JSON object
+    import json
+    import sys
+    a = [int(v) for v in sys.argv[1:]]
+    H, h, N, I, E, K, moe, L, vocab, layers = a
+    print(json.dumps(time_layer(H, h, N, I, E, K, bool(moe), L, vocab, layers)))
