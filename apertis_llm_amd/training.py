@@ -37,7 +37,10 @@ class TrainStep:
         self.dp = BucketedDataParallel(model, bucket_bytes=bucket_bytes, reduce_dtype=reduce_dtype) if self.world > 1 else None
         self.model = model
         self.optimizer = build_optimizer(model, lr, weight_decay)
-        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(self.optimizer, max_lr=lr, total_steps=max(total_steps, 2),
+        total_steps = max(int(total_steps), 2)
+        if abs(0.1 * total_steps - 1.0) < 1e-9:      # OneCycleLR divides by (pct_start*total - 1): avoid the 0/0 case
+            total_steps += 1
+        self.scheduler = torch.optim.lr_scheduler.OneCycleLR(self.optimizer, max_lr=lr, total_steps=total_steps,
                                                              pct_start=0.1, anneal_strategy="cos", div_factor=25.0,
                                                              final_div_factor=10000.0)
         self.max_grad_norm = max_grad_norm
