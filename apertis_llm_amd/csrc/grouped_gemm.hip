@@ -21,6 +21,7 @@
 // Global -> LDS goes through registers (one tile in flight, written to the other buffer after
 // the MFMAs of the current one: one barrier per K step).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -48,20 +49,43 @@ __device__ __forceinline__ void mma(f32x4 &acc, const f32x4 &a, const f32x4 &b) 
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
 }
 
-__device__ __forceinline__ float act_fwd(float x, int act) {
+// erf: exact (ocml erff) on the fp32 parity path; on the bf16 path Abramowitz-Stegun 7.1.26
+// (max abs error 1.5e-7, far below bf16's 2^-8) with hardware exp2/rcp - the ocml erff costs more
+// VALU time than the whole K loop of a K=704 tile.
+template <bool FAST> __device__ __forceinline__ float erf_t(float x) {
+  if constexpr (!FAST) {
+    return erff(x);
+  } else {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * LOG2E_F);
+    const float r = 1.f - p * t * e;
+    return copysignf(r, x);
+  }
+}
+template <bool FAST> __device__ __forceinline__ float exp_t(float x) {
+  if constexpr (FAST) return __builtin_amdgcn_exp2f(x * LOG2E_F);
+  else return expf(x);
+}
+
+template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
-    case APERTIS_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case APERTIS_ACT_GELU: return 0.5f * x * (1.f + erf_t<FAST>(x * 0.70710678118654752f));
     case APERTIS_ACT_RELU: return x > 0.f ? x : 0.f;
-    case APERTIS_ACT_SILU: return x / (1.f + expf(-x));
+    case APERTIS_ACT_SILU: return x / (1.f + exp_t<FAST>(-x));
     default: return x;
   }
 }
-__device__ __forceinline__ float act_grad(float x, int act) {
+template <bool FAST> __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
-      return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+      return 0.5f * (1.f + erf_t<FAST>(x * 0.70710678118654752f)) + x * 0.3989422804014327f * exp_t<FAST>(-0.5f * x * x);
     case APERTIS_ACT_RELU: return x > 0.f ? 1.f : 0.f;
-    case APERTIS_ACT_SILU: { float s = 1.f / (1.f + expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case APERTIS_ACT_SILU: { float s = 1.f / (1.f + exp_t<FAST>(-x)); return s * (1.f + x * (1.f - s)); }
     default: return 1.f;
   }
 }
@@ -79,12 +103,16 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, int64_t row, int64_t co
 
 struct TileCoord { int e, m0, rows_left; int64_t row0; bool valid; };
 
-// m-tile index -> (group, first row in group, rows left); mt counts tiles over all groups
-__device__ __forceinline__ TileCoord find_tile(const int32_t *offsets, int E, int mt) {
+// m-tile index -> (group, first row in group, rows left); mt counts tiles over all groups.
+// The E+1 offsets are fetched by E+1 lanes in one go and scanned from LDS (a serial chain of
+// dependent global loads here costs about a microsecond per tile).
+__device__ __forceinline__ TileCoord find_tile(const int32_t *offsets, int E, int mt, int32_t *s_off, int tid) {
+  for (int i = tid; i <= E; i += NT) s_off[i] = offsets[i];
+  __syncthreads();
   TileCoord t; t.valid = false;
   int acc = 0;
   for (int e = 0; e < E; ++e) {
-    int r0 = offsets[e], r1 = offsets[e + 1];
+    int r0 = s_off[e], r1 = s_off[e + 1];
     int nt = (r1 - r0 + BM - 1) / BM;
     if (mt < acc + nt) {
       t.e = e; t.m0 = (mt - acc) * BM; t.row0 = (int64_t)r0 + t.m0; t.rows_left = r1 - r0 - t.m0; t.valid = true;
@@ -128,7 +156,23 @@ __device__ __forceinline__ void store_tile_lds(char *lds, const uint4 (&regs)[4]
   }
 }
 
-template <typename T, typename TO>
+// one 1-KiB LDS-DMA piece: 8 tile rows x 128 B.  The LDS image is lane-linear (wave-uniform base +
+// lane*16), so the XOR swizzle is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and
+// again on the fragment read.  Rows past the group's end are clamped to its last row (their
+// outputs are never stored).
+template <typename T>
+__device__ __forceinline__ void glds_piece(char *lds_piece, const T *base, int64_t ld, int row0, int rows_valid,
+                                           int k0, int lane) {
+  constexpr int KPC = 16 / sizeof(T);
+  int r = row0 + (lane >> 3);
+  int c = (lane & 7) ^ (r & 7);
+  r = min(r, rows_valid - 1);
+  const T *src = base + (int64_t)r * ld + k0 + c * KPC;
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                   (__attribute__((address_space(3))) void *)lds_piece, 16, 0, 0);
+}
+
+template <typename T, typename TO, bool GLDS>
 __global__ void __launch_bounds__(NT)
 grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float *__restrict__ bias,
                   const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
@@ -143,8 +187,9 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
-  const TileCoord tc = find_tile(offsets, E, mt);
+  const TileCoord tc = find_tile(offsets, E, mt, reinterpret_cast<int32_t *>(smem), tid);
   if (!tc.valid) return;
+  __syncthreads();  // offsets scratch is about to be overwritten by the first tiles
   const int n0 = ntile * BN;
   const int rows_valid = min(BM, tc.rows_left);
   const int cols_valid = min(BN, N - n0);
@@ -158,21 +203,8 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = (K + BK - 1) / BK;
-  uint4 xr[4], wr[4];
-  load_tile_regs<T>(xr, xbase, K, rows_valid, 0, K, tid);
-  load_tile_regs<T>(wr, wbase, K, cols_valid, 0, K, tid);
-  store_tile_lds(smem, xr, tid);
-  store_tile_lds(smem + TILE_BYTES, wr, tid);
-  __syncthreads();
-
   const int frow = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    char *xs = smem + (kt & 1) * 2 * TILE_BYTES;
-    char *ws = xs + TILE_BYTES;
-    if (kt + 1 < nk) {
-      load_tile_regs<T>(xr, xbase, K, rows_valid, (kt + 1) * BK, K, tid);
-      load_tile_regs<T>(wr, wbase, K, cols_valid, (kt + 1) * BK, K, tid);
-    }
+  auto compute_tile = [&](const char *xs, const char *ws) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       frag wf[4], xf[4];
@@ -189,12 +221,45 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
     }
-    if (kt + 1 < nk) {
-      char *xn = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
-      store_tile_lds(xn, xr, tid);
-      store_tile_lds(xn + TILE_BYTES, wr, tid);
+  };
+  if constexpr (GLDS) {
+    // direct-to-LDS loads, ONE 32 KiB operand buffer, two barriers per K step; latency is hidden
+    // by the other resident work-groups (4 per CU at 35 KiB LDS / <=128 VGPRs).  Needs K % BK == 0.
+    char *xs = smem, *ws = smem + TILE_BYTES;
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int piece = wave * 4 + j;   // 16 pieces of 8 rows per operand tile
+        glds_piece<T>(xs + piece * 1024, xbase, K, piece * 8, rows_valid, kt * BK, lane);
+        glds_piece<T>(ws + piece * 1024, wbase, K, piece * 8, cols_valid, kt * BK, lane);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute_tile(xs, ws);
+      __syncthreads();
     }
+  } else {
+    uint4 xr[4], wr[4];
+    load_tile_regs<T>(xr, xbase, K, rows_valid, 0, K, tid);
+    load_tile_regs<T>(wr, wbase, K, cols_valid, 0, K, tid);
+    store_tile_lds(smem, xr, tid);
+    store_tile_lds(smem + TILE_BYTES, wr, tid);
     __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      char *xs = smem + (kt & 1) * 2 * TILE_BYTES;
+      char *ws = xs + TILE_BYTES;
+      if (kt + 1 < nk) {
+        load_tile_regs<T>(xr, xbase, K, rows_valid, (kt + 1) * BK, K, tid);
+        load_tile_regs<T>(wr, wbase, K, cols_valid, (kt + 1) * BK, K, tid);
+      }
+      compute_tile(xs, ws);
+      if (kt + 1 < nk) {
+        char *xn = smem + ((kt + 1) & 1) * 2 * TILE_BYTES;
+        store_tile_lds(xn, xr, tid);
+        store_tile_lds(xn + TILE_BYTES, wr, tid);
+      }
+      __syncthreads();
+    }
   }
 
   // epilogue: acc[i][j] = D tile (n-subtile i, m-subtile j); lane: m = frow, n = fg*4 + reg
@@ -242,7 +307,160 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[i][r];
         v = to_f32(from_f32<TO>(v));  // the activation sees the pre-activation as stored (bf16-rounded under bf16)
-        v = act_fwd(v, act);
+        v = act_fwd<sizeof(T) == 2>(v, act);
+        if (drop_p > 0.f)
+          v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+        p[r] = from_f32<TO>(v);
+      }
+    }
+  flush_tile(C);
+}
+
+// ------------------------------------------------------------------------------------------
+// Big-tile NT kernel: 256 x 256 x 64 (bf16), 512 threads = 2(M) x 4(N) waves, each wave 128 x 64
+// = 8 x 4 MFMA tiles of 16x16.  A 128^2 tile needs ~64 flop per L2 byte, i.e. ~39 TB/s from L2 at
+// the MFMA peak - more than the chip's L2 can deliver; 256^2 halves that.  Operands arrive by
+// LDS-DMA (global_load_lds, 16 B/lane) into a double-buffered 2 x 64 KiB ring, one barrier per K
+// step (the next tile's DMA is in flight during the MFMAs of the current one).  Same swizzle,
+// operand roles and epilogue as the 128^2 kernel.  One work-group per CU (128 KiB LDS).
+// ------------------------------------------------------------------------------------------
+constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
+constexpr int TILE2_BYTES = BM2 * ROWB;  // 32 KiB per operand tile
+
+__device__ __forceinline__ TileCoord find_tile256(const int32_t *offsets, int E, int mt, int32_t *s_off, int tid) {
+  for (int i = tid; i <= E; i += NT2) s_off[i] = offsets[i];
+  __syncthreads();
+  TileCoord t; t.valid = false;
+  int acc = 0;
+  for (int e = 0; e < E; ++e) {
+    int r0 = s_off[e], r1 = s_off[e + 1];
+    int nt = (r1 - r0 + BM2 - 1) / BM2;
+    if (mt < acc + nt) {
+      t.e = e; t.m0 = (mt - acc) * BM2; t.row0 = (int64_t)r0 + t.m0; t.rows_left = r1 - r0 - t.m0; t.valid = true;
+      return t;
+    }
+    acc += nt;
+  }
+  return t;
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(NT2)
+grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act, int N, int K,
+                     int E, int n_tiles, int act, float drop_p, uint64_t seed) {
+  typedef bf16_t T;
+  typedef bf16x8 frag;
+  constexpr int BK = 64;
+  constexpr int CPITCH = BN2 * sizeof(TO) + 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: rows [wm*128,+128), cols [wn*64,+64)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
+  const TileCoord tc = find_tile256(offsets, E, mt, reinterpret_cast<int32_t *>(smem), tid);
+  if (!tc.valid) return;
+  __syncthreads();
+  const int n0 = ntile * BN2;
+  const int rows_valid = min(BM2, tc.rows_left);
+  const int cols_valid = min(BN2, N - n0);
+  const T *xbase = X + tc.row0 * K;
+  const T *wbase = W + ((int64_t)tc.e * N + n0) * K;
+
+  f32x4 acc[4][8];  // [n-subtile][m-subtile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = K / BK;
+  const int frow = lane & 15, fg = lane >> 4;
+  auto stage = [&](int buf, int kt) {
+    char *xs = smem + buf * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave * 4 + j;  // 32 pieces of 8 rows per operand tile
+      glds_piece<T>(xs + piece * 1024, xbase, K, piece * 8, rows_valid, kt * BK, lane);
+      glds_piece<T>(ws + piece * 1024, wbase, K, piece * 8, cols_valid, kt * BK, lane);
+    }
+  };
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // tile kt has landed for every wave; buffer (kt+1)&1 is free again
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char *xs = smem + (kt & 1) * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      frag wf[4], xf[8];
+      const int chunk = kk * 4 + fg;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int wrow = wn * 64 + i * 16 + frow;
+        wf[i] = *reinterpret_cast<const frag *>(ws + wrow * ROWB + ((chunk ^ (wrow & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int xrow = wm * 128 + j * 16 + frow;
+        xf[j] = *reinterpret_cast<const frag *>(xs + xrow * ROWB + ((chunk ^ (xrow & 7)) << 4));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mma(acc[i][j], wf[i], xf[j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+
+  // epilogue (same contract as the 128^2 kernel)
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+  float bv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
+      bv[i][r] = (bias && n < N) ? bias[(int64_t)tc.e * N + n] : 0.f;
+    }
+  constexpr int CPR = BN2 * sizeof(TO) / 16;
+  auto flush_tile = [&](TO *dst) {
+    __syncthreads();
+    for (int q = tid; q < BM2 * CPR; q += NT2) {
+      int row = q / CPR, c = q % CPR;
+      int ncol = c * (16 / (int)sizeof(TO));
+      if (row < rows_valid && ncol < cols_valid)
+        *reinterpret_cast<uint4 *>(dst + (tc.row0 + row) * N + n0 + ncol) =
+            *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
+    }
+    __syncthreads();
+  };
+  __syncthreads();  // every wave is done reading the operand ring before it becomes the C tile
+  if (pre_act) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int m = wm * 128 + j * 16 + frow, n = wn * 64 + i * 16 + fg * 4;
+        TO *p = reinterpret_cast<TO *>(smem + m * CPITCH) + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = from_f32<TO>(acc[i][j][r] + bv[i][r]);
+      }
+    flush_tile(pre_act);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int m = wm * 128 + j * 16 + frow, n = wn * 64 + i * 16 + fg * 4;
+      TO *p = reinterpret_cast<TO *>(smem + m * CPITCH) + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[i][r];
+        v = to_f32(from_f32<TO>(v));
+        v = act_fwd<true>(v, act);
         if (drop_p > 0.f)
           v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
         p[r] = from_f32<TO>(v);
@@ -276,7 +494,7 @@ __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict_
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float g = d[j] * act_grad(p[j], act);
+      float g = d[j] * act_grad<sizeof(T) == 2>(p[j], act);
       if (drop_p > 0.f) g = drop_keep(seed, row, col + j, N, thresh16) ? g * keep_scale : 0.f;
       o[j] = g;
     }
@@ -425,11 +643,33 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
   const int64_t m_tiles = ceil_div64(max_rows, BM) + E;  // each group adds at most one partial tile
   const int64_t grid = m_tiles * n_tiles;
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
-  size_t lds = std::max<size_t>(4 * TILE_BYTES, (size_t)BM * (BN * sizeof(TO) + 16));
-  auto kern = grouped_gemm_nt_k<T, TO>;
-  if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                     (TO *)pre_act, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+  constexpr int BK = ROWB / sizeof(T);
+  if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    if (K % 64 == 0 && N >= 512 && max_rows >= 4096 && !getenv("APERTIS_GEMM_TILE128")) {
+      const int nt2 = (int)ceil_div64(N, BN2);
+      const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;
+      size_t lds2 = std::max<size_t>(4 * TILE2_BYTES, (size_t)BM2 * (BN2 * sizeof(TO) + 16));
+      auto k2 = grouped_gemm_nt256_k<TO>;
+      hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+      hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(NT2), lds2, st, (const bf16_t *)A, (const bf16_t *)W, bias,
+                         offsets, (TO *)C, (TO *)pre_act, (int)N, (int)K, (int)E, nt2, act, drop_p, seed);
+      return apertis_check_launch();
+    }
+  }
+  const size_t cstage = (size_t)BM * (BN * sizeof(TO) + 16);
+  if (K % BK == 0 && sizeof(T) == 2 && getenv("APERTIS_GEMM_GLDS128")) {
+    size_t lds = std::max<size_t>(2 * TILE_BYTES, cstage);
+    auto kern = grouped_gemm_nt_k<T, TO, true>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
+                       (TO *)pre_act, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+  } else {
+    size_t lds = std::max<size_t>(4 * TILE_BYTES, cstage);
+    auto kern = grouped_gemm_nt_k<T, TO, false>;
+    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
+                       (TO *)pre_act, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+  }
   return apertis_check_launch();
 }
 
@@ -441,7 +681,7 @@ extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float
   if (!A || !W || !offsets || !C || max_rows < 0 || N <= 0 || K <= 0 || E <= 0) return APERTIS_ERR_ARG;
   if (drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
   if (max_rows == 0) return APERTIS_OK;
-  if (max_rows > 0x7fffffffLL || N > 0x3fffffff || K > 0x3fffffff) return APERTIS_ERR_UNSUPPORTED;
+  if (max_rows > 0x7fffffffLL || N > 0x3fffffff || K > 0x3fffffff || E > 4096) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_BF16) {
     if (K % 8 || N % 8) return APERTIS_ERR_UNSUPPORTED;

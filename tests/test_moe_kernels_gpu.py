@@ -196,7 +196,8 @@ def test_grouped_linear_fp32_exact_path(dev, sizes, N, K, act):
     _close(bd.grad, br.grad, "db", rtol=1e-4, atol_scale=1e-5)
 
 
-@pytest.mark.parametrize("sizes,N,K", [([700, 100, 0, 513], 256, 128), ([640] * 8, 1024, 256), ([300, 5], 704, 2816)])
+@pytest.mark.parametrize("sizes,N,K", [([700, 100, 0, 513], 256, 128), ([640] * 8, 1024, 256), ([300, 5], 704, 2816),
+                                        ([3000, 0, 1500, 257, 1, 600], 704, 128), ([4100, 90], 512, 704)])
 def test_grouped_linear_bf16_mfma(dev, sizes, N, K):
     """bf16 operands / fp32 accumulate: compare with fp64 math on the SAME bf16-rounded operands;
     only the output rounding (bf16, 2^-8) and fp32 accumulation order differ."""

@@ -1,0 +1,84 @@
+"""Kernel micro-benchmarks at BASELINE shapes (runs on the GPU box).
+    python tools/microbench.py scan|gemm|all
+Reports algorithmic GB/s or TFLOP/s per C-ABI call (HIP events, median of reps)."""
+import math
+import sys
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from apertis_llm_amd import ops
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def scan():
+    for (B, L, h, N, dt) in [(8, 4096, 11, 16, torch.bfloat16), (16, 4096, 11, 16, torch.bfloat16),
+                             (32, 4096, 11, 16, torch.bfloat16), (32, 4096, 11, 16, torch.float32),
+                             (8, 4096, 4, 16, torch.bfloat16), (32, 2048, 14, 16, torch.bfloat16),
+                             (64, 4096, 11, 16, torch.bfloat16)]:
+        Dn, R = h * N, math.ceil(h * 64 / 16)
+        p = torch.randn(B, L, R + 2 * Dn, device=dev).to(dt)
+        dl = torch.randn(B, L, h, device=dev) - 4
+        A = torch.empty(h, N, device=dev).uniform_(math.log(.5), math.log(.99))
+        dy = torch.randn(B, L, Dn, device=dev)
+        pg, dlg, Ag = p.clone().requires_grad_(True), dl.clone().requires_grad_(True), A.clone().requires_grad_(True)
+        f = lambda: ops.selective_scan(dl, A, p[..., R:R + Dn], p[..., R + Dn:], delta_softplus=True)
+        t_f = timeit(f)
+        y = ops.selective_scan(dlg, Ag, pg[..., R:R + Dn], pg[..., R + Dn:], delta_softplus=True)
+        def b():
+            torch.autograd.grad(y, (dlg, Ag, pg), dy, retain_graph=True)
+        t_b = timeit(b)
+        e = p.element_size()
+        T = B * L
+        fb = T * (Dn * (2 * e + 4) + 4 * h)
+        bb = T * (Dn * (4 * e + 4) + 8 * h)
+        print(f"scan B={B} L={L} Dn={Dn} {str(dt)[6:]}: fwd {t_f*1e3:7.1f} us {fb/t_f/1e6:7.0f} GB/s ({fb/t_f/8e9*100:4.1f}%)  "
+              f"bwd(+autograd overhead) {t_b*1e3:7.1f} us {bb/t_b/1e6:7.0f} GB/s ({bb/t_b/8e9*100:4.1f}%)  [{fb/1e6:.0f}/{bb/1e6:.0f} MB]")
+
+
+def gemm():
+    import numpy as np
+    for (rows, N, K, E) in [(40960, 2816, 704, 8), (40960, 704, 2816, 8), (81920, 2816, 704, 8), (81920, 704, 2816, 8),
+                            (10240, 1024, 256, 8), (65536, 4096, 4096, 8), (32768, 352, 704, 1), (32768, 704, 176, 1)]:
+        x = torch.randn(rows, K, device=dev).bfloat16()
+        W = torch.randn(E, N, K, device=dev) / K ** 0.5
+        offs = torch.tensor(np.linspace(0, rows, E + 1).astype(np.int32), device=dev)
+        wc, wt = ops.cast_transpose(W, torch.bfloat16)
+        out = torch.empty(rows, N, device=dev, dtype=torch.bfloat16)
+        pre = torch.empty_like(out)
+        from apertis_llm_amd import _lib
+        lib = _lib.load()
+        P, S = _lib.ptr, _lib.stream_ptr
+        def nt():
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, rows, N, K, E, 0, 0.0, 0, 1, 1, S())
+        def nt_epi():
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), rows, N, K, E, 1, 0.1, 7, 1, 1, S())
+        dw = torch.empty(E, N, K, device=dev)
+        def tn():
+            lib.apertis_grouped_gemm_tn(P(out), P(x), P(offs), P(dw), None, rows, N, K, E, 1, S())
+        fl = 2.0 * rows * N * K
+        t1, t2, t3 = timeit(nt), timeit(nt_epi), timeit(tn)
+        print(f"gemm rows={rows} N={N} K={K} E={E}: NT {t1*1e3:7.1f} us {fl/t1/1e9:6.0f} TF  NT+gelu+drop+pre {t2*1e3:7.1f} us "
+              f"{fl/t2/1e9:6.0f} TF  TN {t3*1e3:7.1f} us {fl/t3/1e9:6.0f} TF")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("scan", "all"):
+        scan()
+    if what in ("gemm", "all"):
+        gemm()
