@@ -50,6 +50,9 @@ SIGNATURES = {
     "apertis_moe_gather_ln_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
     "apertis_moe_gather_ln_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                          _i32, _i32, _vp]),
+    "apertis_layernorm_fwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_layernorm_bwd_blocks": (_i64, [_i64, _i64]),
     "apertis_moe_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_moe_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _i32, _i32, _vp]),
@@ -57,6 +60,7 @@ SIGNATURES = {
                                        _i32, _i32, _vp]),
     "apertis_cast_transpose": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_colsum_f32": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "apertis_act_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _u64, _i32, _vp]),
 }
 

@@ -629,6 +629,153 @@ grouped_gemm_tn_k(const T *__restrict__ A, const T *__restrict__ Bm, const int32
   if (dbias && ntile == 0 && tid < mvalid) dbias[(int64_t)e * M + m0 + tid] = bsum;
 }
 
+// ------------------------------------------------------------------------------------------
+// TN v2 (bf16): 128 x 128 output tile per (expert, m-tile, n-tile), K = the expert's rows in
+// steps of 64.  Operand images As[64 k][128 m], Bs[64 k][128 n] arrive by LDS-DMA into a
+// double-buffered ring (2 x 32 KiB), full K steps only; the last partial step is staged through
+// registers with zero fill.  k-rows are 256 B = one LDS bank row, so the transposed fragment
+// reads (ds_read_b64_tr_b16: 4 k-rows x 32 B per 16-lane group, two groups per half-wave) would
+// be 8-way conflicted; the 32-byte window index is XORed with f(k) = (k&3)|((k>>3)&1)<<2 on the
+// DMA source address and on the read, which spreads the 8 rows of a half-wave over the 8 windows.
+// Bm feeds the MFMA A operand, A the B operand: a lane's accumulator holds 4 consecutive n of one
+// m, so dW leaves through an LDS staging tile as 16-byte row pieces.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tn_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+
+__global__ void __launch_bounds__(NT)
+grouped_gemm_tn2_k(const bf16_t *__restrict__ A, const bf16_t *__restrict__ Bm, const int32_t *__restrict__ offsets,
+                   float *__restrict__ dW, float *__restrict__ dbias, int M, int N, int m_tiles, int n_tiles) {
+  typedef bf16_t T;
+  constexpr int BKR = 64;              // rows (K) per step
+  constexpr int KROWB = BM * 2;        // 256 B per k-row
+  constexpr int STAGE = 2 * BKR * KROWB;  // As + Bs = 32 KiB
+  constexpr int CP = BN * 4 + 16;      // fp32 C staging pitch
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = tile / (m_tiles * n_tiles);
+  const int rem = tile - e * m_tiles * n_tiles;
+  const int mt = rem / n_tiles, ntile = rem - mt * n_tiles;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int r_begin = offsets[e], r_end = offsets[e + 1];
+  const int mvalid = min(BM, M - m0), nvalid = min(BN, N - n0);
+  const int nfull = (r_end - r_begin) / BKR;
+  const int tail = (r_end - r_begin) - nfull * BKR;
+  const int nsteps = nfull + (tail ? 1 : 0);
+
+  f32x4 acc[4][4];  // [n-subtile j][m-subtile i]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  // LDS-DMA of one full K step: 16 pieces per operand (4 k-rows each), 4 per wave
+  auto stage = [&](int buf, int step) {
+    char *as = smem + buf * STAGE, *bs = as + BKR * KROWB;
+    const int64_t r0 = (int64_t)r_begin + (int64_t)step * BKR;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave * 4 + j;
+      const int krow = piece * 4 + (lane >> 4);
+      const int cpos = lane & 15;
+      const int csrc = (((cpos >> 1) ^ tn_swz(krow)) << 1) | (cpos & 1);
+      const int ca = min(csrc * 8, mvalid - 8), cb = min(csrc * 8, nvalid - 8);   // clamp column chunk (masked at store)
+      const T *pa = A + (r0 + krow) * M + m0 + ca;
+      const T *pb = Bm + (r0 + krow) * N + n0 + cb;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa,
+                                       (__attribute__((address_space(3))) void *)(as + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb,
+                                       (__attribute__((address_space(3))) void *)(bs + piece * 1024), 16, 0, 0);
+    }
+  };
+  // register-staged, zero-filled tail step (rows >= r_end contribute nothing)
+  auto stage_tail = [&](int buf, int step) {
+    char *as = smem + buf * STAGE, *bs = as + BKR * KROWB;
+    const int64_t r0 = (int64_t)r_begin + (int64_t)step * BKR;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int q = tid + it * NT;            // 1024 chunks of 16 B per operand
+      const int krow = q >> 4, cpos = q & 15;
+      const int csrc = (((cpos >> 1) ^ tn_swz(krow)) << 1) | (cpos & 1);
+      const bool rok = krow < tail;
+      uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+      if (rok && csrc * 8 < mvalid) va = *reinterpret_cast<const uint4 *>(A + (r0 + krow) * M + m0 + csrc * 8);
+      if (rok && csrc * 8 < nvalid) vb = *reinterpret_cast<const uint4 *>(Bm + (r0 + krow) * N + n0 + csrc * 8);
+      *reinterpret_cast<uint4 *>(as + q * 16) = va;
+      *reinterpret_cast<uint4 *>(bs + q * 16) = vb;
+    }
+  };
+
+  const int frow = lane & 15, fg = lane >> 4;
+  const int lr = lane & 15, trow = lr >> 2, tcol4 = (lr & 3) * 4;
+  if (nsteps > 0) {
+    if (nfull > 0) stage(0, 0); else stage_tail(0, 0);
+  }
+  for (int st = 0; st < nsteps; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nsteps) {
+      if (st + 1 < nfull) stage((st + 1) & 1, st + 1); else stage_tail((st + 1) & 1, st + 1);
+    }
+    const char *as = smem + (st & 1) * STAGE, *bs = as + BKR * KROWB;
+    if (dbias && ntile == 0 && tid < BM) {
+      const int c = tid >> 3, within = (tid & 7) * 2;
+#pragma unroll 8
+      for (int kr = 0; kr < BKR; ++kr) {
+        const int cp = (((c >> 1) ^ tn_swz(kr)) << 1) | (c & 1);
+        bsum += to_f32(*reinterpret_cast<const T *>(as + kr * KROWB + cp * 16 + within));
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {       // two 32-deep MFMA k-blocks per step
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        union { bf16x8 v; s16x4 h[2]; } ua, ub;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int krow = kb * 32 + 8 * fg + 4 * hh + trow;
+          const int sw = tn_swz(krow);
+          const int colA = wm * 64 + i * 16 + tcol4, colB = wn * 64 + i * 16 + tcol4;   // element columns
+          const int offA = ((((colA >> 4) ^ sw) << 5) | ((colA & 15) * 2));
+          const int offB = ((((colB >> 4) ^ sw) << 5) | ((colB & 15) * 2));
+          ua.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4 *)(as + krow * KROWB + offA));
+          ub.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4 *)(bs + krow * KROWB + offB));
+        }
+        af[i] = ua.v; bf[i] = ub.v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma(acc[j][i], bf[j], af[i]);
+    }
+  }
+  // epilogue: D row = n (fg*4+r within subtile j), D col = m (frow within subtile i)
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = wm * 64 + i * 16 + frow, n = wn * 64 + j * 16 + fg * 4;
+      *reinterpret_cast<f32x4 *>(smem + m * CP + n * 4) = acc[j][i];
+    }
+  __syncthreads();
+  float *out = dW + (int64_t)e * M * N;
+  for (int q = tid; q < BM * (BN / 4); q += NT) {
+    const int row = q >> 5, c = q & 31;
+    if (row < mvalid && c * 4 < nvalid)
+      *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + row) * N + n0 + c * 4) =
+          *reinterpret_cast<const uint4 *>(smem + row * CP + c * 16);
+  }
+  if (dbias && ntile == 0 && tid < mvalid) dbias[(int64_t)e * M + m0 + tid] = bsum;
+}
+
 template <typename T> bool aligned16(const void *p, int64_t ld) {
   return (((uintptr_t)p) & 15) == 0 && ((ld * sizeof(T)) & 15) == 0;
 }
@@ -709,6 +856,13 @@ extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int3
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   if (dtype == APERTIS_BF16) {
     if (M % 8 || N % 8 || !aligned16<bf16_t>(A, M) || !aligned16<bf16_t>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
+    if (!getenv("APERTIS_GEMM_TN_V1")) {
+      size_t lds = std::max<size_t>(2 * 2 * 64 * 256, (size_t)BM * (BN * 4 + 16));
+      hipFuncSetAttribute((const void *)grouped_gemm_tn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(grouped_gemm_tn2_k, dim3((unsigned)grid), dim3(NT), lds, st, (const bf16_t *)A,
+                         (const bf16_t *)Bm, offsets, dW, dbias, (int)M, (int)N, m_tiles, n_tiles);
+      return apertis_check_launch();
+    }
     size_t lds = 2 * 32 * (BM * 2 + 16);
     hipLaunchKernelGGL(grouped_gemm_tn_k<bf16_t>, dim3((unsigned)grid), dim3(NT), lds, st, (const bf16_t *)A,
                        (const bf16_t *)Bm, offsets, dW, dbias, (int)M, (int)N, m_tiles, n_tiles);

@@ -363,9 +363,9 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
                 float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t max_rows, int H, int E) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= max_rows || r >= offsets[E]) return;
-  const int e = expert_of_row(offsets, E, (int)r);
-  const TX *src = x + (int64_t)row_token[r] * H;
+  if (r >= max_rows || (offsets && r >= offsets[E])) return;
+  const int e = offsets ? expert_of_row(offsets, E, (int)r) : 0;
+  const TX *src = x + (row_token ? (int64_t)row_token[r] : r) * H;   // row_token == NULL: plain LayerNorm
   float4 v[IT];
   float sum = 0.f;
 #pragma unroll
@@ -408,21 +408,30 @@ gather_ln_bwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
                 const int32_t *__restrict__ offsets, const float *__restrict__ gamma,
                 const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
                 const TG *__restrict__ dxg, TG *__restrict__ dxr, float *__restrict__ dgamma,
-                float *__restrict__ dbeta, int64_t max_rows, int H, int E, int RPW) {
+                float *__restrict__ dbeta, float *__restrict__ part, int64_t max_rows, int H, int E, int RPW) {
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t total = min((int64_t)offsets[E], max_rows);
+  const int64_t total = offsets ? min((int64_t)offsets[E], max_rows) : max_rows;
   int64_t r0 = wave * RPW, r1 = min(r0 + RPW, total);
-  if (r0 >= total) return;
   float4 ag[IT], ab[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
-  int e = expert_of_row(offsets, E, (int)r0);
+  if (part) {
+    // single-group mode: this wave's sums go to part[wave][2][H] (zeros if it has no rows) and a
+    // fixed-order column sum folds them - deterministic, no atomic contention on 2H addresses
+    if (r0 >= total) r1 = r0;
+  } else if (r0 >= total) {
+    return;
+  }
+  int e = (offsets && r0 < total) ? expert_of_row(offsets, E, (int)r0) : 0;
   auto flush = [&](int ee) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       int c = (lane + 64 * i) * 4;
-      if (c < H) {
+      if (c < H && part) {
+        *reinterpret_cast<float4 *>(part + (wave * 2 + 0) * H + c) = ag[i];
+        *reinterpret_cast<float4 *>(part + (wave * 2 + 1) * H + c) = ab[i];
+      } else if (c < H) {
         float *dg = dgamma + (int64_t)ee * H + c, *db = dbeta + (int64_t)ee * H + c;
         atomicAdd(dg + 0, ag[i].x); atomicAdd(dg + 1, ag[i].y); atomicAdd(dg + 2, ag[i].z); atomicAdd(dg + 3, ag[i].w);
         atomicAdd(db + 0, ab[i].x); atomicAdd(db + 1, ab[i].y); atomicAdd(db + 2, ab[i].z); atomicAdd(db + 3, ab[i].w);
@@ -431,8 +440,8 @@ gather_ln_bwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
     }
   };
   for (int64_t r = r0; r < r1; ++r) {
-    while (e + 1 < E && offsets[e + 1] <= r) { flush(e); ++e; }
-    const TX *src = x + (int64_t)row_token[r] * H;
+    while (offsets && e + 1 < E && offsets[e + 1] <= r) { flush(e); ++e; }
+    const TX *src = x + (row_token ? (int64_t)row_token[r] : r) * H;
     const TG *dsrc = dxg + r * H;
     const float mean = mean_i[r], rstd = rstd_i[r];
     const float *ga = gamma + (int64_t)e * H;
@@ -526,6 +535,23 @@ combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int3
   }
   dot = wave_sum(dot);
   if (lane == 0) dwk[s * K + k] = dot;
+}
+
+// out[c] = sum_w part[w][c] over c in [0, 2H): first H -> dgamma, next H -> dbeta (fixed order)
+__global__ void __launch_bounds__(256)
+ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t nwaves, int H) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < 2 * H)
+    for (int64_t w = seg; w < nwaves; w += 4) s += part[w * 2 * H + c];
+  red[seg][lane] = s;
+  __syncthreads();
+  if (seg == 0 && c < 2 * H) {
+    float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (c < H) dgamma[c] = t; else dbeta[c - H] = t;
+  }
 }
 
 int check_H(int64_t H) { return (H > 0 && H % 4 == 0 && H <= 256 * 16) ? APERTIS_OK : APERTIS_ERR_UNSUPPORTED; }
@@ -641,11 +667,11 @@ extern "C" int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token
   if (check_H(H) || E < 1 || E > MAXE) return APERTIS_ERR_UNSUPPORTED;
   if (max_rows == 0) return APERTIS_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int RPW = 16;
+  const int RPW = 32;
   dim3 grid((unsigned)ceil_div64(ceil_div64(max_rows, RPW), 4)), block(256);
   DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((gather_ln_bwd_k<TA, TB, IT>), grid, block, 0, st,
       (const TA *)x, row_token, expert_offsets, gamma, mean, rstd, (const TB *)dxg, (TB *)dxr, dgamma, dbeta,
-      max_rows, (int)H, (int)E, RPW)));
+      (float *)nullptr, max_rows, (int)H, (int)E, RPW)));
   return apertis_check_launch();
 }
 
@@ -675,5 +701,48 @@ extern "C" int apertis_moe_combine_bwd(const void *dout, const void *yr, const i
   DISPATCH_2T(dtype_dout, dtype_yr, DISPATCH_IT(H, hipLaunchKernelGGL((combine_bwd_k<TA, TB, IT>), grid, block, 0, st,
       (const TA *)dout, (const TB *)yr, row_token, row_k, expert_offsets, wk, (TB *)dyr, dwk, max_rows, (int)H,
       (int)K, (int)E)));
+  return apertis_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------
+// Plain LayerNorm over the last dimension (the pre-norms of ApertisAttention / ApertisFeedForward
+// and final_post_norm, reference core.py:669,695,847,888,1040,1294) on the same row kernels:
+// fp32 residual stream in, compute-dtype (bf16 under autocast) activations out in one pass.
+// ------------------------------------------------------------------------------------------
+namespace { constexpr int LN_RPW = 32; }
+
+extern "C" int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H) {
+  (void)H;
+  return ceil_div64(ceil_div64(T > 0 ? T : 1, LN_RPW), 4) * 4;   // number of waves = partial rows
+}
+
+extern "C" int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps, void *y,
+                                     float *mean, float *rstd, int64_t T, int64_t H, int dtype_x, int dtype_y,
+                                     void *stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || T < 0) return APERTIS_ERR_ARG;
+  if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(T, 4)), block(256);
+  DISPATCH_2T(dtype_x, dtype_y, DISPATCH_IT(H, hipLaunchKernelGGL((gather_ln_fwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TA *)x, (const int32_t *)nullptr, (const int32_t *)nullptr, gamma, beta, eps, (TB *)y, mean, rstd, T, (int)H,
+      1)));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean, const float *rstd,
+                                     const void *dy, void *dx, float *part, float *dgamma, float *dbeta, int64_t T,
+                                     int64_t H, int dtype_x, int dtype_g, void *stream) {
+  if (!x || !gamma || !mean || !rstd || !dy || !dx || !part || !dgamma || !dbeta || T < 0) return APERTIS_ERR_ARG;
+  if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nwaves = apertis_layernorm_bwd_blocks(T, H);
+  dim3 grid((unsigned)(nwaves / 4)), block(256);
+  DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((gather_ln_bwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TA *)x, (const int32_t *)nullptr, (const int32_t *)nullptr, gamma, mean, rstd, (const TB *)dy, (TB *)dx,
+      (float *)nullptr, (float *)nullptr, part, T, (int)H, 1, LN_RPW)));
+  // part is [nwaves][2][H]: fold rows -> [2][H]
+  hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(256), 0, st, part, dgamma, dbeta, nwaves,
+                     (int)H);
   return apertis_check_launch();
 }

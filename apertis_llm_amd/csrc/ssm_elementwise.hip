@@ -427,3 +427,10 @@ extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, i
     return APERTIS_ERR_ARG;
   return apertis_check_launch();
 }
+
+extern "C" int apertis_colsum_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream) {
+  if (!in || !out || rows < 0 || cols <= 0) return APERTIS_ERR_ARG;
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(256), 0, (hipStream_t)stream, in, out, rows,
+                     cols);
+  return apertis_check_launch();
+}

@@ -143,6 +143,27 @@ def _compute_dtype(t: torch.Tensor) -> torch.dtype:
     return t.dtype if t.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 
+class HipLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / checkpoint keys) whose GPU forward+backward are the HIP row
+    kernels; under autocast it emits the compute dtype directly instead of fp32 + a cast kernel.
+    Off-GPU (only the stock-torch standard_mha fallback gets there) it is plain F.layer_norm."""
+
+    def forward(self, x):
+        H = x.shape[-1]
+        if x.is_cuda and H % 4 == 0 and H <= 4096 and x.dtype in (torch.float32, torch.bfloat16):
+            return ops.layer_norm(x, self.weight, self.bias, self.eps, out_dtype=_compute_dtype(x))
+        return super().forward(x)
+
+
+def _mfma_linear(x, weight, bias=None):
+    """x @ W.T (+b) on the MFMA GEMM tile when the shapes allow 16-byte rows, else stock F.linear
+    (both run on the GPU; this is a provider choice, not a fallback to the host)."""
+    K = weight.shape[1]
+    if x.is_cuda and K % 8 == 0 and weight.shape[0] % 8 == 0:
+        return ops.linear_mfma(x, weight, bias, compute_dtype=_compute_dtype(x))
+    return F.linear(x, weight, bias)
+
+
 class RMSNorm(nn.Module):
     """x / (||x||_2 / sqrt(D) + eps) * scale  (reference core.py:30-59)."""
 
@@ -221,8 +242,10 @@ class SelectiveLinearAttention(nn.Module):
         conv_prev = ssm_prev = None
         if past_key_value is not None:
             conv_prev, ssm_prev = past_key_value
-        xp = self.in_proj_x(hidden_states)                                   # [B,L,Dn]   core.py:366
-        z = self.in_proj_z(hidden_states)                                    #            core.py:367
+        # in_proj_x and in_proj_z share their input: one GEMM with the stacked weight, outputs are
+        # column views (core.py:366-367)
+        xz = _mfma_linear(hidden_states, torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
+        xp, z = xz[..., :Dn], xz[..., Dn:]
         conv_in = xp
         if conv_prev is not None and use_cache and conv_prev.shape[1] == Dn and conv_prev.shape[2] == kw - 1:
             # the reference prepends the cached window and keeps the FIRST L conv outputs
@@ -230,16 +253,22 @@ class SelectiveLinearAttention(nn.Module):
             conv_in = torch.cat([conv_prev.transpose(1, 2).to(xp.dtype), xp], dim=1)
         conv_state = conv_in[:, -(kw - 1):].transpose(1, 2).detach() if use_cache else None
         xc = ops.dwconv_silu(conv_in, self.conv1d.weight, self.conv1d.bias)[:, :L]      # core.py:373-375
-        p = self.x_param_proj(xc)                                            # [B,L,R+2Dn] core.py:376
+        # x_param_proj (core.py:376); output rows padded to a multiple of 8 columns so every row of
+        # p starts 16-byte aligned (the pad columns are zero weights and are never read)
+        wp = self.x_param_proj.weight
+        pad = (-wp.shape[0]) % 8
+        if pad:
+            wp = torch.cat([wp, wp.new_zeros(pad, wp.shape[1])], dim=0)
+        p = _mfma_linear(xc, wp)                                             # [B,L,R+2Dn(+pad)]
         dt_logits = self.dt_proj_head(p[..., :R]).float()                    # [B,L,h]    core.py:382
         h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None
         # Bt/C are column slices of p taken in place (core.py:384-385); softplus (core.py:383)
         # is applied inside the scan kernel
-        res = ops.selective_scan(dt_logits, self.A_log, p[..., R:R + Dn], p[..., R + Dn:], h0=h0,
+        res = ops.selective_scan(dt_logits, self.A_log, p[..., R:R + Dn], p[..., R + Dn:R + 2 * Dn], h0=h0,
                                  delta_softplus=True, y_dtype=torch.float32, return_last=use_cache)
         y, h_last = res if use_cache else (res, None)
         gated = ops.ssm_gate(y, xc, z, self.D)                               # core.py:395-396
-        out = self.out_proj(gated)                                           # core.py:397
+        out = _mfma_linear(gated, self.out_proj.weight)                     # core.py:397
         cache = (conv_state, h_last.reshape(B, self.num_heads, self.d_state)) if use_cache else None
         return out, (y if output_attentions else None), cache
 
@@ -397,7 +426,7 @@ class ApertisAttention(nn.Module):
             self.out_proj = nn.Linear(self.hidden_size, self.hidden_size, bias=bias)
             self.attention_mechanism_impl = None
             self._ssm = False
-        norm = RMSNorm if config.use_rmsnorm else nn.LayerNorm
+        norm = RMSNorm if config.use_rmsnorm else HipLayerNorm
         self.pre_norm = norm(config.hidden_size, eps=config.layer_norm_eps)
         self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
         self.attention_dropout = nn.Dropout(config.attention_probs_dropout_prob)
@@ -464,7 +493,7 @@ class ApertisFeedForward(nn.Module):
     def __init__(self, config: ApertisConfig):
         super().__init__()
         self.config = config
-        norm = RMSNorm if config.use_rmsnorm else nn.LayerNorm
+        norm = RMSNorm if config.use_rmsnorm else HipLayerNorm
         self.pre_norm = norm(config.hidden_size, eps=config.layer_norm_eps)
         self.is_expert_system = False
         if config.use_swiglu:                                            # SwiGLU wins over MoE, core.py:849-859
@@ -521,7 +550,7 @@ class ApertisModel(nn.Module):
             if config.vision_embed_dim != config.hidden_size:
                 self.vision_projection = nn.Linear(config.vision_embed_dim, config.hidden_size)
         self.layers = nn.ModuleList([ApertisLayer(config) for _ in range(config.num_hidden_layers)])
-        norm = RMSNorm if config.use_rmsnorm else nn.LayerNorm
+        norm = RMSNorm if config.use_rmsnorm else HipLayerNorm
         self.final_post_norm = norm(config.hidden_size, eps=config.layer_norm_eps)
         self.embed_dropout = nn.Dropout(config.hidden_dropout_prob)
         self.apply(self._init_weights)

@@ -42,13 +42,13 @@ class KernelTimer:
 def _launch(name, fn, args, work=0.0):
     t = _TIMER
     if t is None or name not in t.names:
-        check(fn(*args), name)
+        check(fn(*args), name.split("[")[0])
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     rc = fn(*args)
     e.record()
-    check(rc, name)
+    check(rc, name.split("[")[0])
     t.records.append((name, s, e, work))
 
 
@@ -399,6 +399,31 @@ def cast_transpose(w, dtype, want_plain=True, want_transposed=True):
     return plain, tr
 
 
+_SPLITK_ROWS = 1024
+_splitk_cache = {}
+
+
+def _splitk_offsets(rows, G, device):
+    key = (rows, G, str(device))
+    t = _splitk_cache.get(key)
+    if t is None:
+        t = torch.tensor([min(i * _SPLITK_ROWS, rows) for i in range(G + 1)], dtype=torch.int32, device=device)
+        _splitk_cache[key] = t
+    return t
+
+
+_dense_offsets_cache = {}
+
+
+def _dense_offsets(rows, device):
+    key = (rows, str(device))
+    t = _dense_offsets_cache.get(key)
+    if t is None:
+        t = torch.tensor([0, rows], dtype=torch.int32, device=device)
+        _dense_offsets_cache[key] = t
+    return t
+
+
 class _RowsWork:
     """flops of a grouped GEMM = (rows actually routed, read from the device after the run) x
     flops per row."""
@@ -437,7 +462,7 @@ class _GroupedLinear(torch.autograd.Function):
         act_code = _ACTS[act]
         out = torch.empty(x.shape[0], N, device=x.device, dtype=compute_dtype)
         pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
-        _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+        _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
                 (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), max_rows, N, K, E, act_code, float(drop_p),
                  int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         ctx.save_for_backward(x, wt, pre, offsets)
@@ -460,15 +485,33 @@ class _GroupedLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+            _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
                     (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, max_rows, K, N, E, _lib.ACT_NONE, 0.0, 0, code,
                      code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
-            db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
-            _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
-                    (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, code, stream_ptr()),
-                    _RowsWork(offsets, E, 2.0 * N * K))
+            if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
+                # dense layer: the K dimension of the weight gradient is ALL rows; cut it into
+                # pseudo-groups of _SPLITK_ROWS rows so the grid fills the chip, then fold the
+                # partials in a fixed order (deterministic split-K, no atomics)
+                G = -(-max_rows // _SPLITK_ROWS)
+                soffs = _splitk_offsets(max_rows, G, x.device)
+                part = torch.empty(G, N, K, device=x.device, dtype=torch.float32)
+                bpart = torch.empty(G, N, device=x.device, dtype=torch.float32) if has_bias else None
+                _launch("apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
+                        (ptr(dpre), ptr(x), ptr(soffs), ptr(part), ptr(bpart), max_rows, N, K, G, code, stream_ptr()),
+                        2.0 * max_rows * N * K)
+                dw = torch.empty(1, N, K, device=x.device, dtype=torch.float32)
+                check(lib.apertis_colsum_f32(ptr(part), ptr(dw), G, N * K, stream_ptr()), "apertis_colsum_f32")
+                db = None
+                if has_bias:
+                    db = torch.empty(1, N, device=x.device, dtype=torch.float32)
+                    check(lib.apertis_colsum_f32(ptr(bpart), ptr(db), G, N, stream_ptr()), "apertis_colsum_f32")
+            else:
+                dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
+                db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
+                _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
+                        (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, code, stream_ptr()),
+                        _RowsWork(offsets, E, 2.0 * N * K))
             dw = dw.to(wdtype)
         return dx, dw, db, None, None, None, None, None, None
 
@@ -481,13 +524,56 @@ def grouped_linear(x, weight, bias, offsets, max_rows, act=None, drop_p=0.0, see
     return _GroupedLinear.apply(x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype or x.dtype)
 
 
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        _require_gpu(x, weight, bias)
+        lib = _lib.load()
+        shape = x.shape
+        H = shape[-1]
+        x2 = x.reshape(-1, H).contiguous()
+        T = x2.shape[0]
+        g = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        y = torch.empty(T, H, device=x.device, dtype=out_dtype)
+        mean = torch.empty(T, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(T, device=x.device, dtype=torch.float32)
+        check(lib.apertis_layernorm_fwd(ptr(x2), ptr(g), ptr(b), float(eps), ptr(y), ptr(mean), ptr(rstd), T, H,
+                                        dtype_code(x2), dtype_code(y), stream_ptr()), "apertis_layernorm_fwd")
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.shape = shape
+        ctx.pdtypes = (weight.dtype, bias.dtype)
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x2, g, mean, rstd = ctx.saved_tensors
+        T, H = x2.shape
+        dy2 = dy.reshape(T, H).contiguous()
+        dx = torch.empty(T, H, device=x2.device, dtype=dy2.dtype)
+        nw = lib.apertis_layernorm_bwd_blocks(T, H)
+        part = torch.empty(nw, 2, H, device=x2.device, dtype=torch.float32)
+        dg = torch.empty(H, device=x2.device, dtype=torch.float32)
+        db = torch.empty(H, device=x2.device, dtype=torch.float32)
+        check(lib.apertis_layernorm_bwd(ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dy2), ptr(dx), ptr(part), ptr(dg), ptr(db),
+                                        T, H, dtype_code(x2), dtype_code(dy2), stream_ptr()), "apertis_layernorm_bwd")
+        return dx.reshape(ctx.shape).to(x2.dtype), dg.to(ctx.pdtypes[0]), db.to(ctx.pdtypes[1]), None, None
+
+
+def layer_norm(x, weight, bias, eps, out_dtype=None):
+    """LayerNorm over the last dimension; x fp32/bf16, statistics in fp32, output in out_dtype
+    (bf16 under autocast: the following GEMM reads it directly)."""
+    return _LayerNorm.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
 def linear_mfma(x, weight, bias=None, act=None, compute_dtype=None):
     """Dense act(x @ W.T + b) through the same MFMA tile (one group).  Used for the patch-embed
     GEMM and vision_projection (reference multimodal/module.py:102, core.py:1209)."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     M = x2.shape[0]
-    offsets = torch.tensor([0, M], device=x.device, dtype=torch.int32)
+    offsets = _dense_offsets(M, x.device)
     out = grouped_linear(x2, weight.unsqueeze(0), None if bias is None else bias.unsqueeze(0), offsets, M, act, 0.0, 0,
                          compute_dtype or x.dtype)
     return out.reshape(*lead, weight.shape[0])

@@ -172,6 +172,19 @@ int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
                               int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_g,
                               void *stream);
 
+/* Plain LayerNorm over the last dimension on the same row kernels (pre-norms and final norm,
+ * core.py:669,695,847,888,1040,1294): x [T,H] dtype_x -> y [T,H] dtype_y, mean/rstd [T] fp32.
+ * Backward: dx [T,H] (dtype_g = dtype of dy and dx), dgamma/dbeta [H] fp32 overwritten;
+ * part = workspace [apertis_layernorm_bwd_blocks(T,H), 2, H] fp32 (deterministic fold). */
+int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps,
+                          void *y, float *mean, float *rstd, int64_t T, int64_t H, int dtype_x,
+                          int dtype_y, void *stream);
+int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean,
+                          const float *rstd, const void *dy, void *dx, float *part,
+                          float *dgamma, float *dbeta, int64_t T, int64_t H, int dtype_x,
+                          int dtype_g, void *stream);
+int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H);
+
 /* Combine (core.py:594,605 weights * expert_output, index_add_):
  *   out[s,:] = sum_{k asc, slot_of[s,k]>=0} wk[s,k] * yr[slot_of[s,k],:]   (zeros if none)
  * with_weights=0 uses weight 1 (used to scatter the LN-backward rows).  */
@@ -217,6 +230,9 @@ int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offset
  * dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call. */
 int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R,
                            int64_t C, int dtype_out, void *stream);
+/* out[c] = sum_r in[r,c] over a row-major fp32 [rows, cols] matrix, fixed summation order
+ * (folds split-K partial weight gradients and per-block partial sums deterministically). */
+int apertis_colsum_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream);
 /* Elementwise backward of act+dropout: dpre = dh * mask/(1-p) * act'(pre). In place allowed. */
 int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void *dpre,
                             const int32_t *offsets, int64_t max_rows, int64_t N, int64_t E,

@@ -253,3 +253,52 @@ def test_linear_mfma_dense(dev):
     x, W, b = torch.randn(3, 50, 72), torch.randn(40, 72) / 8, torch.randn(40)
     out = ops.linear_mfma(x.to(dev), W.to(dev), b.to(dev))
     _close(out, F.linear(x.double(), W.double(), b.double()), "dense", rtol=1e-4, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("rows,N,K,dt", [(5000, 72, 40, torch.float32), (4608, 352, 704, torch.bfloat16)])
+def test_linear_mfma_splitk_wgrad(dev, rows, N, K, dt):
+    """Dense layer backward: the weight gradient is a deterministic split-K over row chunks."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(rows)
+    x, W, b = torch.randn(rows, K).to(dt), torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    dout = torch.randn(rows, N).to(dt)
+    xd, Wd, bd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    out = ops.linear_mfma(xd, Wd, bd, compute_dtype=dt)
+    out.backward(dout.to(dev))
+    g1 = Wd.grad.clone()
+    Wd.grad = None
+    xd.grad = None
+    bd.grad = None
+    ops.linear_mfma(xd, Wd, bd, compute_dtype=dt).backward(dout.to(dev))
+    assert torch.equal(g1, Wd.grad), "split-K fold must be bitwise reproducible"
+    Wq = W.to(dt).double()
+    xr, Wr, br = x.double().requires_grad_(True), Wq.requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.linear(xr, Wr, br)
+    ref.backward(dout.double())
+    tol = dict(rtol=1e-4, atol_scale=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol_scale=1e-2)
+    _close(out, ref, "out", **tol)
+    _close(xd.grad, xr.grad, "dx", **tol)
+    _close(Wd.grad, Wr.grad, "dW", **tol)
+    _close(bd.grad, br.grad, "db", **tol)
+
+
+@pytest.mark.parametrize("T,H,dt_in,dt_out", [(1000, 704, torch.float32, torch.float32), (333, 32, torch.float32, torch.float32),
+                                              (4100, 256, torch.float32, torch.bfloat16), (77, 1028, torch.float32, torch.float32)])
+def test_layer_norm_kernels(dev, T, H, dt_in, dt_out):
+    from apertis_llm_amd import ops
+    torch.manual_seed(T)
+    x = (torch.randn(T, H) * 3 + 1).to(dt_in)
+    w, b = torch.randn(H), torch.randn(H)
+    dy = torch.randn(T, H)
+    xd, wd, bd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.layer_norm(xd, wd, bd, 1e-12, out_dtype=dt_out)
+    assert y.dtype == dt_out
+    y.backward(dy.to(dev).to(dt_out))
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.layer_norm(xr, (H,), wr, br, 1e-12)
+    ref.backward(dy.to(dt_out).double())
+    tol = dict(rtol=1e-4, atol_scale=1e-5) if dt_out == torch.float32 else dict(rtol=1e-2, atol_scale=8e-3)
+    _close(y, ref, "y", **tol)
+    _close(xd.grad, xr.grad, "dx", **tol)
+    _close(wd.grad, wr.grad, "dgamma", rtol=1e-3, atol_scale=1e-4 if dt_out == torch.float32 else 1e-2)
+    _close(bd.grad, br.grad, "dbeta", rtol=1e-3, atol_scale=1e-4 if dt_out == torch.float32 else 1e-2)

@@ -1,0 +1,42 @@
+"""Launch each hot kernel a few times at BASELINE (1.5B, B=8/16, seq 4096) shapes - target of
+rocprofv3 --kernel-trace / --pmc runs (see profiles/README.md)."""
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from apertis_llm_amd import _lib, ops
+
+dev = torch.device("cuda:0")
+lib = _lib.load()
+P, S = _lib.ptr, _lib.stream_ptr
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+what = sys.argv[2] if len(sys.argv) > 2 else "all"
+
+if what in ("all", "scan"):
+    B, L, h, N = 16, 4096, 11, 16
+    Dn, R = h * N, 44
+    p = torch.randn(B, L, R + 2 * Dn, device=dev).bfloat16().requires_grad_(True)
+    dl = (torch.randn(B, L, h, device=dev) - 4).requires_grad_(True)
+    A = torch.empty(h, N, device=dev).uniform_(math.log(.5), math.log(.99)).requires_grad_(True)
+    dy = torch.randn(B, L, Dn, device=dev)
+    for _ in range(reps):
+        y = ops.selective_scan(dl, A, p[..., R:R + Dn], p[..., R + Dn:], delta_softplus=True)
+        y.backward(dy)
+if what in ("all", "gemm"):
+    rows, E = 40960, 8
+    offs = torch.tensor(np.linspace(0, rows, E + 1).astype(np.int32), device=dev)
+    for (N_, K_) in [(2816, 704), (704, 2816)]:
+        x = torch.randn(rows, K_, device=dev).bfloat16()
+        W = torch.randn(E, N_, K_, device=dev) / K_ ** 0.5
+        wc, wt = ops.cast_transpose(W, torch.bfloat16)
+        out = torch.empty(rows, N_, device=dev, dtype=torch.bfloat16)
+        pre = torch.empty_like(out)
+        dw = torch.empty(E, N_, K_, device=dev)
+        for _ in range(reps):
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, rows, N_, K_, E, 0, 0.0, 0, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), rows, N_, K_, E, 1, 0.1, 7, 1, 1, S())
+            lib.apertis_grouped_gemm_tn(P(out), P(x), P(offs), P(dw), None, rows, N_, K_, E, 1, S())
+torch.cuda.synchronize()
