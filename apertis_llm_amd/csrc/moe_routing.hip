@@ -537,19 +537,123 @@ combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int3
   if (lane == 0) dwk[s * K + k] = dot;
 }
 
-// out[c] = sum_w part[w][c] over c in [0, 2H): first H -> dgamma, next H -> dbeta (fixed order)
+// Plain LayerNorm backward.  Block = 4 waves x LN_RPW rows each, two rows in flight per wave
+// (the row loop is latency-bound otherwise); dx is written in x's dtype (the fp32 residual
+// stream); the affine gradients are reduced over the block's waves in LDS and leave as ONE
+// partial row per block, folded in a fixed order by ln_fold_k (deterministic, no atomics).
+constexpr int LN_RPW = 8;
+
+template <typename TX, typename TG, int IT>
 __global__ void __launch_bounds__(256)
-ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t nwaves, int H) {
-  __shared__ float red[4][64];
+layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean_i,
+                const float *__restrict__ rstd_i, const TG *__restrict__ dy, TX *__restrict__ dx,
+                float *__restrict__ part, int64_t T, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *red = reinterpret_cast<float4 *>(smem);  // [3 waves][2][H/4]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * LN_RPW, r1 = min(r0 + LN_RPW, T);
+  float4 ag[IT], ab[IT], g4[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+    int c = (lane + 64 * i) * 4;
+    g4[i] = c < H ? load4<float>(gamma + c) : make_float4(0, 0, 0, 0);
+  }
+  for (int64_t r = r0; r < r1; r += 2) {
+    const bool two = r + 1 < r1;
+    float4 xv[2][IT], dv[2][IT];
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t rr = (q == 0 || two) ? r + q : r;
+      mean[q] = mean_i[rr]; rstd[q] = rstd_i[rr];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        int c = (lane + 64 * i) * 4;
+        if (c < H) { xv[q][i] = load4<TX>(x + rr * H + c); dv[q][i] = load4<TG>(dy + rr * H + c); }
+        else { xv[q][i] = make_float4(0, 0, 0, 0); dv[q][i] = make_float4(0, 0, 0, 0); }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q == 1 && !two) break;
+      float s1 = 0.f, s2 = 0.f;
+      float4 xh[IT], gd[IT];
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        int c = (lane + 64 * i) * 4;
+        const float4 xq = xv[q][i], dq = dv[q][i];
+        xh[i] = make_float4((xq.x - mean[q]) * rstd[q], (xq.y - mean[q]) * rstd[q], (xq.z - mean[q]) * rstd[q],
+                            (xq.w - mean[q]) * rstd[q]);
+        gd[i] = make_float4(dq.x * g4[i].x, dq.y * g4[i].y, dq.z * g4[i].z, dq.w * g4[i].w);
+        if (c < H) {
+          ag[i].x += dq.x * xh[i].x; ag[i].y += dq.y * xh[i].y; ag[i].z += dq.z * xh[i].z; ag[i].w += dq.w * xh[i].w;
+          ab[i].x += dq.x; ab[i].y += dq.y; ab[i].z += dq.z; ab[i].w += dq.w;
+          s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+          s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+        }
+      }
+      const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+      TX *dst = dx + (r + q) * H;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        int c = (lane + 64 * i) * 4;
+        if (c < H)
+          store4<TX>(dst + c, make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2), rstd[q] * (gd[i].y - m1 - xh[i].y * m2),
+                                          rstd[q] * (gd[i].z - m1 - xh[i].z * m2), rstd[q] * (gd[i].w - m1 - xh[i].w * m2)));
+      }
+    }
+  }
+  // block reduction: waves 1..3 park their sums in LDS, wave 0 adds them in order and writes
+  const int Q = H / 4;
+  if (wv > 0) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int cq = lane + 64 * i;
+      if (cq < Q) { red[((wv - 1) * 2 + 0) * Q + cq] = ag[i]; red[((wv - 1) * 2 + 1) * Q + cq] = ab[i]; }
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int cq = lane + 64 * i;
+      if (cq < Q) {
+        float4 a = ag[i], b = ab[i];
+        for (int w = 0; w < 3; ++w) {
+          float4 u = red[(w * 2 + 0) * Q + cq], v = red[(w * 2 + 1) * Q + cq];
+          a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+          b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(part + ((int64_t)blockIdx.x * 2 + 0) * H + cq * 4) = a;
+        *reinterpret_cast<float4 *>(part + ((int64_t)blockIdx.x * 2 + 1) * H + cq * 4) = b;
+      }
+    }
+  }
+}
+
+// out[c] = sum_r part[r][c] over c in [0, 2H): first H -> dgamma, next H -> dbeta (fixed order)
+__global__ void __launch_bounds__(1024)
+ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t nrows, int H) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (c < 2 * H)
-    for (int64_t w = seg; w < nwaves; w += 4) s += part[w * 2 * H + c];
+  if (c < 2 * H) {
+    int64_t w = seg;
+    for (; w + 48 < nrows; w += 64) {   // four independent loads in flight
+      float a0 = part[w * 2 * H + c], a1 = part[(w + 16) * 2 * H + c], a2 = part[(w + 32) * 2 * H + c],
+            a3 = part[(w + 48) * 2 * H + c];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; w < nrows; w += 16) s += part[w * 2 * H + c];
+  }
   red[seg][lane] = s;
   __syncthreads();
   if (seg == 0 && c < 2 * H) {
-    float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
     if (c < H) dgamma[c] = t; else dbeta[c - H] = t;
   }
 }
@@ -709,11 +813,9 @@ extern "C" int apertis_moe_combine_bwd(const void *dout, const void *yr, const i
 // and final_post_norm, reference core.py:669,695,847,888,1040,1294) on the same row kernels:
 // fp32 residual stream in, compute-dtype (bf16 under autocast) activations out in one pass.
 // ------------------------------------------------------------------------------------------
-namespace { constexpr int LN_RPW = 32; }
-
 extern "C" int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H) {
   (void)H;
-  return ceil_div64(ceil_div64(T > 0 ? T : 1, LN_RPW), 4) * 4;   // number of waves = partial rows
+  return ceil_div64(T > 0 ? T : 1, 4 * LN_RPW);   // one partial row per block
 }
 
 extern "C" int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps, void *y,
@@ -736,13 +838,12 @@ extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const fl
   if (!x || !gamma || !mean || !rstd || !dy || !dx || !part || !dgamma || !dbeta || T < 0) return APERTIS_ERR_ARG;
   if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t nwaves = apertis_layernorm_bwd_blocks(T, H);
-  dim3 grid((unsigned)(nwaves / 4)), block(256);
-  DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((gather_ln_bwd_k<TA, TB, IT>), grid, block, 0, st,
-      (const TA *)x, (const int32_t *)nullptr, (const int32_t *)nullptr, gamma, mean, rstd, (const TB *)dy, (TB *)dx,
-      (float *)nullptr, (float *)nullptr, part, T, (int)H, 1, LN_RPW)));
-  // part is [nwaves][2][H]: fold rows -> [2][H]
-  hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(256), 0, st, part, dgamma, dbeta, nwaves,
+  const int64_t nblk = apertis_layernorm_bwd_blocks(T, H);
+  dim3 grid((unsigned)nblk), block(256);
+  const size_t lds = 3 * 2 * (size_t)H * sizeof(float);
+  DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((layernorm_bwd_k<TA, TB, IT>), grid, block, lds, st,
+      (const TA *)x, gamma, mean, rstd, (const TB *)dy, (TA *)dx, part, T, (int)H)));
+  hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(1024), 0, st, part, dgamma, dbeta, nblk,
                      (int)H);
   return apertis_check_launch();
 }

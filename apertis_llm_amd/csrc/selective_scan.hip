@@ -170,7 +170,10 @@ scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
   }
 }
 
-// pass 2: exclusive prefix over chunks. dir=+1 forward (carry0 = h0), dir=-1 reverse (carry0 = 0)
+// pass 2: exclusive prefix over chunks (reverse != 0: right-to-left).  One thread per (b, channel).
+// The whole column of up to U aggregates is fetched before the serial fma chain starts, so the
+// kernel costs one memory round trip instead of nchunks/8 of them.
+template <int U>
 __global__ void scan_chunk_prefix(const float2 *__restrict__ agg, const float *__restrict__ init,
                                   float *__restrict__ carry_in, float *__restrict__ last,
                                   int64_t B, int64_t Dn, int nchunks, int reverse) {
@@ -179,7 +182,6 @@ __global__ void scan_chunk_prefix(const float2 *__restrict__ agg, const float *_
   int64_t b = i / Dn, c = i - b * Dn;
   float carry = init ? init[i] : 0.f;
   const int64_t base = b * nchunks * Dn + c;
-  constexpr int U = 8;
   for (int j0 = 0; j0 < nchunks; j0 += U) {
     float2 q[U];
 #pragma unroll
@@ -525,8 +527,12 @@ int launch_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
   hipLaunchKernelGGL((scan_fwd_state<TIN, VB, LT>), grid, block, lds1, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (float2 *)agg, d);
   int64_t n = d.B * d.Dn;
-  hipLaunchKernelGGL(scan_chunk_prefix, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
-                     (const float2 *)agg, h0, h_in, h_last, d.B, d.Dn, d.nchunks, 0);
+  if (d.nchunks <= 64)
+    hipLaunchKernelGGL(scan_chunk_prefix<64>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
+                       (const float2 *)agg, h0, h_in, h_last, d.B, d.Dn, d.nchunks, 0);
+  else
+    hipLaunchKernelGGL(scan_chunk_prefix<16>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
+                       (const float2 *)agg, h0, h_in, h_last, d.B, d.Dn, d.nchunks, 0);
   hipLaunchKernelGGL((scan_fwd_replay<TIN, TY, VB, LT>), grid, block, lds3, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, h_in, (TY *)y, y_rs, d);
   return apertis_check_launch();
@@ -545,9 +551,12 @@ int launch_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
   hipLaunchKernelGGL((scan_bwd_state<TIN, TY, VB, VBY, LT>), grid, block, lds1, st, dlt, A_log,
                      (const TIN *)C, c_rs, (const TY *)dy, dy_rs, (float2 *)agg, d);
   int64_t n = d.B * d.Dn;
-  hipLaunchKernelGGL(scan_chunk_prefix, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
-                     (const float2 *)agg, (const float *)nullptr, mu_in, (float *)nullptr, d.B,
-                     d.Dn, d.nchunks, 1);
+  if (d.nchunks <= 64)
+    hipLaunchKernelGGL(scan_chunk_prefix<64>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
+                       (const float2 *)agg, (const float *)nullptr, mu_in, (float *)nullptr, d.B, d.Dn, d.nchunks, 1);
+  else
+    hipLaunchKernelGGL(scan_chunk_prefix<16>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
+                       (const float2 *)agg, (const float *)nullptr, mu_in, (float *)nullptr, d.B, d.Dn, d.nchunks, 1);
   hipLaunchKernelGGL((scan_bwd_replay<TIN, TY, VB, VBY, LT>), grid, block, lds3, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const TY *)dy, dy_rs, h_in,
                      mu_in, (TIN *)dBt, dbt_rs, (TIN *)dC, dc_rs, d_dlt, dA_part, d);

@@ -309,7 +309,7 @@ class AdaptiveExpertSystem(nn.Module):
         E, H, I = self.num_experts, self.hidden_size, self.intermediate_size
         self.activation = _activation_name(activation_function_override or config.hidden_act)
         self.hidden_dropout_prob = config.hidden_dropout_prob
-        self.router_norm = nn.LayerNorm(H, eps=config.layer_norm_eps)
+        self.router_norm = HipLayerNorm(H, eps=config.layer_norm_eps)
         self.router = nn.Linear(H, E)
         self.experts = True  # marker: experts exist (the reference holds an nn.ModuleList here)
         k1, k2 = 1.0 / math.sqrt(H), 1.0 / math.sqrt(I)     # nn.Linear default init bounds

@@ -551,14 +551,14 @@ class _LayerNorm(torch.autograd.Function):
         x2, g, mean, rstd = ctx.saved_tensors
         T, H = x2.shape
         dy2 = dy.reshape(T, H).contiguous()
-        dx = torch.empty(T, H, device=x2.device, dtype=dy2.dtype)
+        dx = torch.empty(T, H, device=x2.device, dtype=x2.dtype)
         nw = lib.apertis_layernorm_bwd_blocks(T, H)
         part = torch.empty(nw, 2, H, device=x2.device, dtype=torch.float32)
         dg = torch.empty(H, device=x2.device, dtype=torch.float32)
         db = torch.empty(H, device=x2.device, dtype=torch.float32)
         check(lib.apertis_layernorm_bwd(ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dy2), ptr(dx), ptr(part), ptr(dg), ptr(db),
                                         T, H, dtype_code(x2), dtype_code(dy2), stream_ptr()), "apertis_layernorm_bwd")
-        return dx.reshape(ctx.shape).to(x2.dtype), dg.to(ctx.pdtypes[0]), db.to(ctx.pdtypes[1]), None, None
+        return dx.reshape(ctx.shape), dg.to(ctx.pdtypes[0]), db.to(ctx.pdtypes[1]), None, None
 
 
 def layer_norm(x, weight, bias, eps, out_dtype=None):

@@ -174,7 +174,7 @@ int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
 
 /* Plain LayerNorm over the last dimension on the same row kernels (pre-norms and final norm,
  * core.py:669,695,847,888,1040,1294): x [T,H] dtype_x -> y [T,H] dtype_y, mean/rstd [T] fp32.
- * Backward: dx [T,H] (dtype_g = dtype of dy and dx), dgamma/dbeta [H] fp32 overwritten;
+ * Backward: dy [T,H] dtype_g -> dx [T,H] in dtype_x; dgamma/dbeta [H] fp32 overwritten;
  * part = workspace [apertis_layernorm_bwd_blocks(T,H), 2, H] fp32 (deterministic fold). */
 int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps,
                           void *y, float *mean, float *rstd, int64_t T, int64_t H, int dtype_x,
