@@ -156,6 +156,24 @@ __device__ __forceinline__ void store_tile_lds(char *lds, const uint4 (&regs)[4]
   }
 }
 
+// dgrad epilogue fusion: one 16-byte output chunk of dh is turned into dpre = dh * keep/(1-p) *
+// act'(pre) with the matching chunk of the saved pre-activation (what apertis_act_dropout_bwd does
+// as a separate pass over three [rows, N] tensors)
+template <typename TO, bool FAST>
+__device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row, int64_t col0, int64_t N, int act,
+                                             float drop_p, uint64_t seed, float keep_scale, uint32_t thresh16) {
+  constexpr int NE = 16 / sizeof(TO);
+  union { uint4 u; TO e[NE]; } a, b, o;
+  a.u = dhc; b.u = prec;
+#pragma unroll
+  for (int j = 0; j < NE; ++j) {
+    float g = to_f32(a.e[j]) * act_grad<FAST>(to_f32(b.e[j]), act);
+    if (drop_p > 0.f) g = drop_keep(seed, row, col0 + j, N, thresh16) ? g * keep_scale : 0.f;
+    o.e[j] = from_f32<TO>(g);
+  }
+  return o.u;
+}
+
 // one 1-KiB LDS-DMA piece: 8 tile rows x 128 B.  The LDS image is lane-linear (wave-uniform base +
 // lane*16), so the XOR swizzle is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and
 // again on the fragment read.  Rows past the group's end are clamped to its last row (their
@@ -176,7 +194,8 @@ template <typename T, typename TO, bool GLDS>
 __global__ void __launch_bounds__(NT)
 grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float *__restrict__ bias,
                   const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                  int N, int K, int E, int n_tiles, int act, float drop_p, uint64_t seed) {
+                  const TO *__restrict__ mul_pre, int N, int K, int E, int n_tiles, int act, float drop_p,
+                  uint64_t seed) {
   typedef typename frag_t<T>::type frag;
   constexpr int KPC = 16 / sizeof(T);
   constexpr int BK = ROWB / sizeof(T);
@@ -274,14 +293,19 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
       bv[i][r] = (bias && n < N) ? bias[(int64_t)tc.e * N + n] : 0.f;
     }
   constexpr int CPR = BN * sizeof(TO) / 16;  // 16-byte chunks per output row
-  auto flush_tile = [&](TO *dst) {
+  auto flush_tile = [&](TO *dst, const TO *mulp) {
     __syncthreads();
     for (int q = tid; q < BM * CPR; q += NT) {
       int row = q / CPR, c = q % CPR;
       int ncol = c * (16 / (int)sizeof(TO));
-      if (row < rows_valid && ncol < cols_valid)
-        *reinterpret_cast<uint4 *>(dst + (tc.row0 + row) * N + n0 + ncol) =
-            *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
+      if (row < rows_valid && ncol < cols_valid) {
+        const int64_t g = (tc.row0 + row) * N + n0 + ncol;
+        uint4 v = *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
+        if (mulp)
+          v = actbwd_chunk<TO, sizeof(T) == 2>(v, *reinterpret_cast<const uint4 *>(mulp + g), tc.row0 + row, n0 + ncol,
+                                                N, act, drop_p, seed, keep_scale, thresh16);
+        *reinterpret_cast<uint4 *>(dst + g) = v;
+      }
     }
     __syncthreads();
   };
@@ -295,7 +319,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = from_f32<TO>(acc[i][j][r] + bv[i][r]);
       }
-    flush_tile(pre_act);
+    flush_tile(pre_act, nullptr);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -306,14 +330,16 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[i][r];
-        v = to_f32(from_f32<TO>(v));  // the activation sees the pre-activation as stored (bf16-rounded under bf16)
-        v = act_fwd<sizeof(T) == 2>(v, act);
-        if (drop_p > 0.f)
-          v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+        if (!mul_pre) {
+          v = to_f32(from_f32<TO>(v));  // the activation sees the pre-activation as stored (bf16-rounded under bf16)
+          v = act_fwd<sizeof(T) == 2>(v, act);
+          if (drop_p > 0.f)
+            v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+        }
         p[r] = from_f32<TO>(v);
       }
     }
-  flush_tile(C);
+  flush_tile(C, mul_pre);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -347,8 +373,9 @@ __device__ __forceinline__ TileCoord find_tile256(const int32_t *offsets, int E,
 template <typename TO>
 __global__ void __launch_bounds__(NT2)
 grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
-                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act, int N, int K,
-                     int E, int n_tiles, int act, float drop_p, uint64_t seed) {
+                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
+                     const TO *__restrict__ mul_pre, int N, int K, int E, int n_tiles, int act, float drop_p,
+                     uint64_t seed) {
   typedef bf16_t T;
   typedef bf16x8 frag;
   constexpr int BK = 64;
@@ -426,14 +453,19 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
       bv[i][r] = (bias && n < N) ? bias[(int64_t)tc.e * N + n] : 0.f;
     }
   constexpr int CPR = BN2 * sizeof(TO) / 16;
-  auto flush_tile = [&](TO *dst) {
+  auto flush_tile = [&](TO *dst, const TO *mulp) {
     __syncthreads();
     for (int q = tid; q < BM2 * CPR; q += NT2) {
       int row = q / CPR, c = q % CPR;
       int ncol = c * (16 / (int)sizeof(TO));
-      if (row < rows_valid && ncol < cols_valid)
-        *reinterpret_cast<uint4 *>(dst + (tc.row0 + row) * N + n0 + ncol) =
-            *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
+      if (row < rows_valid && ncol < cols_valid) {
+        const int64_t g = (tc.row0 + row) * N + n0 + ncol;
+        uint4 v = *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
+        if (mulp)
+          v = actbwd_chunk<TO, true>(v, *reinterpret_cast<const uint4 *>(mulp + g), tc.row0 + row, n0 + ncol, N, act,
+                                     drop_p, seed, keep_scale, thresh16);
+        *reinterpret_cast<uint4 *>(dst + g) = v;
+      }
     }
     __syncthreads();
   };
@@ -448,7 +480,7 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = from_f32<TO>(acc[i][j][r] + bv[i][r]);
       }
-    flush_tile(pre_act);
+    flush_tile(pre_act, nullptr);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -459,14 +491,16 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv[i][r];
-        v = to_f32(from_f32<TO>(v));
-        v = act_fwd<true>(v, act);
-        if (drop_p > 0.f)
-          v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+        if (!mul_pre) {
+          v = to_f32(from_f32<TO>(v));
+          v = act_fwd<true>(v, act);
+          if (drop_p > 0.f)
+            v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+        }
         p[r] = from_f32<TO>(v);
       }
     }
-  flush_tile(C);
+  flush_tile(C, mul_pre);
 }
 
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
@@ -782,9 +816,10 @@ template <typename T> bool aligned16(const void *p, int64_t ld) {
 
 template <typename T, typename TO>
 int launch_nt(const void *A, const void *W, const float *bias, const int32_t *offsets, void *C, void *pre_act,
-              int64_t max_rows, int64_t N, int64_t K, int64_t E, int act, float drop_p, uint64_t seed,
+              const void *mul_pre, int64_t max_rows, int64_t N, int64_t K, int64_t E, int act, float drop_p, uint64_t seed,
               hipStream_t st) {
-  if (!aligned16<T>(A, K) || !aligned16<T>(W, K) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)))
+  if (!aligned16<T>(A, K) || !aligned16<T>(W, K) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)) ||
+      (mul_pre && !aligned16<TO>(mul_pre, N)))
     return APERTIS_ERR_UNSUPPORTED;
   const int n_tiles = (int)ceil_div64(N, BN);
   const int64_t m_tiles = ceil_div64(max_rows, BM) + E;  // each group adds at most one partial tile
@@ -799,7 +834,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       auto k2 = grouped_gemm_nt256_k<TO>;
       hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(NT2), lds2, st, (const bf16_t *)A, (const bf16_t *)W, bias,
-                         offsets, (TO *)C, (TO *)pre_act, (int)N, (int)K, (int)E, nt2, act, drop_p, seed);
+                         offsets, (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, nt2, act, drop_p, seed);
       return apertis_check_launch();
     }
   }
@@ -809,13 +844,13 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     auto kern = grouped_gemm_nt_k<T, TO, true>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                       (TO *)pre_act, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
   } else {
     size_t lds = std::max<size_t>(4 * TILE_BYTES, cstage);
     auto kern = grouped_gemm_nt_k<T, TO, false>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                       (TO *)pre_act, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
   }
   return apertis_check_launch();
 }
@@ -823,24 +858,24 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
 }  // namespace
 
 extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias, const int32_t *offsets,
-                                       void *C, void *pre_act, int64_t max_rows, int64_t N, int64_t K, int64_t E,
+                                       void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K, int64_t E,
                                        int act, float drop_p, uint64_t seed, int dtype, int dtype_out, void *stream) {
   if (!A || !W || !offsets || !C || max_rows < 0 || N <= 0 || K <= 0 || E <= 0) return APERTIS_ERR_ARG;
-  if (drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f || (act_bwd_pre && (pre_act || bias))) return APERTIS_ERR_ARG;
   if (max_rows == 0) return APERTIS_OK;
   if (max_rows > 0x7fffffffLL || N > 0x3fffffff || K > 0x3fffffff || E > 4096) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_BF16) {
     if (K % 8 || N % 8) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, max_rows, N, K, E, act, drop_p, seed, st);
+    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, E, act, drop_p, seed, st);
   }
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_F32) {
     if (K % 8 || N % 4) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, max_rows, N, K, E, act, drop_p, seed, st);
+    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, E, act, drop_p, seed, st);
   }
   if (dtype == APERTIS_F32 && dtype_out == APERTIS_F32) {
     if (K % 4 || N % 4) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, max_rows, N, K, E, act, drop_p, seed, st);
+    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, E, act, drop_p, seed, st);
   }
   return APERTIS_ERR_UNSUPPORTED;
 }

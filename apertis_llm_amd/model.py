@@ -384,10 +384,9 @@ class AdaptiveExpertSystem(nn.Module):
                                out_dtype=cd)                                              # core.py:593 + :436
         p_drop = self.hidden_dropout_prob if self.training else 0.0
         seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p_drop > 0 else 0
-        h = ops.grouped_linear(xg, self.expert_w1, self.expert_b1, plan.offsets, plan.max_rows, act=self.activation,
-                               drop_p=p_drop, seed=seed, compute_dtype=cd)                # core.py:437-439
-        yr = ops.grouped_linear(h, self.expert_w2, self.expert_b2, plan.offsets, plan.max_rows,
-                                compute_dtype=cd)                                         # core.py:440
+        yr = ops.expert_mlp(xg, self.expert_w1, self.expert_b1, self.expert_w2, self.expert_b2, plan.offsets,
+                            plan.max_rows, act=self.activation, drop_p=p_drop, seed=seed,
+                            compute_dtype=cd)                                             # core.py:437-440
         out = ops.moe_combine(yr, w, plan, out_dtype=xf.dtype)                            # core.py:594,605
         return out.reshape(B, L, H), lb_loss.to(hidden_states.dtype), rz_loss.to(hidden_states.dtype)
 

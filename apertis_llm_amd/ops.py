@@ -463,7 +463,7 @@ class _GroupedLinear(torch.autograd.Function):
         out = torch.empty(x.shape[0], N, device=x.device, dtype=compute_dtype)
         pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
         _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
-                (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), max_rows, N, K, E, act_code, float(drop_p),
+                (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), None, max_rows, N, K, E, act_code, float(drop_p),
                  int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         ctx.save_for_backward(x, wt, pre, offsets)
         ctx.cfg = (E, N, K, max_rows, act_code, float(drop_p), int(seed), bias is not None, weight.dtype)
@@ -486,7 +486,7 @@ class _GroupedLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
-                    (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, max_rows, K, N, E, _lib.ACT_NONE, 0.0, 0, code,
+                    (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, None, max_rows, K, N, E, _lib.ACT_NONE, 0.0, 0, code,
                      code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
@@ -565,6 +565,85 @@ def layer_norm(x, weight, bias, eps, out_dtype=None):
     """LayerNorm over the last dimension; x fp32/bf16, statistics in fp32, output in out_dtype
     (bf16 under autocast: the following GEMM reads it directly)."""
     return _LayerNorm.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
+FUSE_ACT_BWD = False
+
+
+class _ExpertMLP(torch.autograd.Function):
+    """yr = (dropout(act(xg @ W1[e].T + b1[e]))) @ W2[e].T + b2[e] per group, as ONE autograd node so the
+    backward can fuse act'/dropout into the epilogue of the second layer's data-gradient GEMM."""
+
+    @staticmethod
+    def forward(ctx, xg, w1, b1, w2, b2, offsets, max_rows, act, drop_p, seed, cd):
+        _require_gpu(xg, w1, w2, offsets)
+        lib = _lib.load()
+        E, I, H = w1.shape
+        xg = xg.to(cd).contiguous()
+        need = any(ctx.needs_input_grad[:5])
+        w1c, w1t = cast_transpose(w1, cd, want_transposed=need)
+        w2c, w2t = cast_transpose(w2, cd, want_transposed=need)
+        b1f, b2f = b1.detach().float().contiguous(), b2.detach().float().contiguous()
+        code, act_code = dtype_code(xg), _ACTS[act]
+        R = xg.shape[0]
+        h = torch.empty(R, I, device=xg.device, dtype=cd)
+        pre = torch.empty_like(h) if need else None
+        _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, E, act_code,
+                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
+        yr = torch.empty(R, H, device=xg.device, dtype=cd)
+        _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                (ptr(h), ptr(w2c), ptr(b2f), ptr(offsets), ptr(yr), None, None, max_rows, H, I, E, _lib.ACT_NONE, 0.0, 0,
+                 code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
+        ctx.save_for_backward(xg, pre, h, w1t, w2t, offsets)
+        ctx.cfg = (E, I, H, max_rows, act_code, float(drop_p), int(seed), w1.dtype, w2.dtype)
+        return yr
+
+    @staticmethod
+    def backward(ctx, dyr):
+        lib = _lib.load()
+        xg, pre, h, w1t, w2t, offsets = ctx.saved_tensors
+        E, I, H, max_rows, act_code, drop_p, seed, w1dt, w2dt = ctx.cfg
+        code = dtype_code(xg)
+        dev = xg.device
+        dyr = dyr.to(xg.dtype).contiguous()
+        work = _RowsWork(offsets, E, 2.0 * I * H)
+        dpre = torch.empty_like(h)
+        if FUSE_ACT_BWD:
+            # dpre = (dyr @ W2) * keep/(1-p) * act'(pre): layer 1's activation backward in the dgrad epilogue
+            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, E, act_code, drop_p,
+                     seed, code, code, stream_ptr()), work)
+        else:
+            # measured on MI355X: with one 256x256 work-group per CU nothing overlaps the epilogue, so the
+            # fused form costs more than this separate bandwidth-bound pass (in place on dpre)
+            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, None, max_rows, I, H, E, _lib.ACT_NONE, 0.0, 0,
+                     code, code, stream_ptr()), work)
+            if act_code != _lib.ACT_NONE or drop_p > 0:
+                check(lib.apertis_act_dropout_bwd(ptr(dpre), ptr(pre), ptr(dpre), ptr(offsets), max_rows, I, E, act_code,
+                                                  drop_p, seed, code, stream_ptr()), "apertis_act_dropout_bwd")
+        dw2 = torch.empty(E, H, I, device=dev, dtype=torch.float32)
+        db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
+        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
+                (ptr(dyr), ptr(h), ptr(offsets), ptr(dw2), ptr(db2), max_rows, H, I, E, code, stream_ptr()), work)
+        dxg = None
+        if ctx.needs_input_grad[0]:
+            dxg = torch.empty_like(xg)
+            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+                    (ptr(dpre), ptr(w1t), None, ptr(offsets), ptr(dxg), None, None, max_rows, H, I, E, _lib.ACT_NONE, 0.0, 0,
+                     code, code, stream_ptr()), work)
+        dw1 = torch.empty(E, I, H, device=dev, dtype=torch.float32)
+        db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
+        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
+                (ptr(dpre), ptr(xg), ptr(offsets), ptr(dw1), ptr(db1), max_rows, I, H, E, code, stream_ptr()), work)
+        return dxg, dw1.to(w1dt), db1, dw2.to(w2dt), db2, None, None, None, None, None, None
+
+
+def expert_mlp(xg, w1, b1, w2, b2, offsets, max_rows, act="gelu", drop_p=0.0, seed=0, compute_dtype=None):
+    """Grouped expert MLP (reference core.py:437-440): Linear(H->I) -> act -> Dropout -> Linear(I->H) for
+    expert-sorted rows xg [R,H]; w1 [E,I,H], b1 [E,I], w2 [E,H,I], b2 [E,H] (fp32 masters)."""
+    return _ExpertMLP.apply(xg, w1, b1, w2, b2, offsets, max_rows, act, drop_p, seed, compute_dtype or xg.dtype)
 
 
 def linear_mfma(x, weight, bias=None, act=None, compute_dtype=None):

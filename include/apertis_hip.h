@@ -214,12 +214,16 @@ int apertis_moe_combine_bwd(const void *dout, const void *yr, const int32_t *row
  *        APERTIS_F32  -> fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
  * max_rows bounds the grid (offsets live on the device; no host sync).
  * pre_act (optional, NT only): also stores the pre-activation (needed by the backward).
+ * act_bwd_pre (optional, dgrad fusion; excludes bias/pre_act): C = (A*W^T) (.) keepmask/(1-p) (.)
+ *   act'(act_bwd_pre), i.e. the data gradient w.r.t. the PRE-activation of the producing layer, with
+ *   the same (act, drop_p, seed) that layer's forward used - apertis_act_dropout_bwd fused away.
  * dropout (NT only): if drop_p>0 the activation output is multiplied by a keep mask /(1-p)
  *   from a counter-based hash of (seed, row, col) so the backward can regenerate it
  *   (reference: nn.Dropout inside each expert, core.py:439).
  * ------------------------------------------------------------------------------------------ */
 int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
                             const int32_t *offsets, void *C, void *pre_act,
+                            const void *act_bwd_pre,
                             int64_t max_rows, int64_t N, int64_t K, int64_t E,
                             int act, float drop_p, uint64_t seed,
                             int dtype, int dtype_out, void *stream);

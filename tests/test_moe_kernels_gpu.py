@@ -302,3 +302,45 @@ def test_layer_norm_kernels(dev, T, H, dt_in, dt_out):
     _close(xd.grad, xr.grad, "dx", **tol)
     _close(wd.grad, wr.grad, "dgamma", rtol=1e-3, atol_scale=1e-4 if dt_out == torch.float32 else 1e-2)
     _close(bd.grad, br.grad, "dbeta", rtol=1e-3, atol_scale=1e-4 if dt_out == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dt,sizes,H,I", [(torch.float32, [100, 0, 333, 64], 32, 64), (torch.bfloat16, [3000, 1200, 0, 500], 256, 512)])
+def test_expert_mlp_fused_backward(dev, dt, sizes, H, I):
+    """Expert MLP as one node (dgrad of layer 2 applies act'/dropout of layer 1 in its epilogue)
+    against the two-node composition and, without dropout, against plain torch autograd."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(H)
+    E, R = len(sizes), sum(sizes)
+    x = torch.randn(R, H).to(dt)
+    w1, b1 = torch.randn(E, I, H) / H ** 0.5, torch.randn(E, I) * 0.1
+    w2, b2 = torch.randn(E, H, I) / I ** 0.5, torch.randn(E, H) * 0.1
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    dout = torch.randn(R, H).to(dt).to(dev)
+
+    def run(fn, p, seed):
+        leaves = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        y = fn(leaves, p, seed)
+        y.backward(dout)
+        return [y] + [t.grad for t in leaves]
+    fused = lambda L, p, seed: ops.expert_mlp(L[0], L[1], L[2], L[3], L[4], offs, R, act="gelu", drop_p=p, seed=seed, compute_dtype=dt)
+    two = lambda L, p, seed: ops.grouped_linear(ops.grouped_linear(L[0], L[1], L[2], offs, R, act="gelu", drop_p=p, seed=seed,
+                                                                    compute_dtype=dt), L[3], L[4], offs, R, compute_dtype=dt)
+    tol = dict(rtol=1e-4, atol_scale=1e-5) if dt == torch.float32 else dict(rtol=3e-2, atol_scale=2e-2)
+    for p_drop, fuse in ((0.0, False), (0.25, False), (0.25, True)):
+        ops.FUSE_ACT_BWD = fuse
+        a, b = run(fused, p_drop, 77), run(two, p_drop, 77)
+        ops.FUSE_ACT_BWD = False
+        for u, v, n in zip(a, b, ["y", "dx", "dw1", "db1", "dw2", "db2"]):
+            _close(u, v, f"fused vs two-node {n} (p={p_drop})", **tol)
+    # plain torch reference (no dropout)
+    xr = x.double().requires_grad_(True)
+    W1, B1, W2, B2 = [t.to(dt).double().requires_grad_(True) if t.dim() == 3 else t.double().requires_grad_(True)
+                      for t in (w1, b1, w2, b2)]
+    hmid = _grouped_ref(xr, W1, B1, sizes, "gelu")
+    if dt == torch.bfloat16:
+        hmid = hmid + (hmid.detach().to(dt).double() - hmid.detach())
+    yref = _grouped_ref(hmid, W2, B2, sizes, None)
+    yref.backward(dout.cpu().double())
+    a = run(fused, 0.0, 0)
+    for u, v, n in zip(a, [yref, xr.grad, W1.grad, B1.grad, W2.grad, B2.grad], ["y", "dx", "dw1", "db1", "dw2", "db2"]):
+        _close(u, v, f"fused vs torch {n}", **(tol if dt == torch.float32 else dict(rtol=5e-2, atol_scale=3e-2)))

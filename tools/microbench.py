@@ -64,9 +64,9 @@ def gemm():
         lib = _lib.load()
         P, S = _lib.ptr, _lib.stream_ptr
         def nt():
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, rows, N, K, E, 0, 0.0, 0, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N, K, E, 0, 0.0, 0, 1, 1, S())
         def nt_epi():
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), rows, N, K, E, 1, 0.1, 7, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N, K, E, 1, 0.1, 7, 1, 1, S())
         dw = torch.empty(E, N, K, device=dev)
         def tn():
             lib.apertis_grouped_gemm_tn(P(out), P(x), P(offs), P(dw), None, rows, N, K, E, 1, S())

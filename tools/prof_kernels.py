@@ -36,7 +36,7 @@ if what in ("all", "gemm"):
         pre = torch.empty_like(out)
         dw = torch.empty(E, N_, K_, device=dev)
         for _ in range(reps):
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, rows, N_, K_, E, 0, 0.0, 0, 1, 1, S())
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), rows, N_, K_, E, 1, 0.1, 7, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N_, K_, E, 0, 0.0, 0, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N_, K_, E, 1, 0.1, 7, 1, 1, S())
             lib.apertis_grouped_gemm_tn(P(out), P(x), P(offs), P(dw), None, rows, N_, K_, E, 1, S())
 torch.cuda.synchronize()
