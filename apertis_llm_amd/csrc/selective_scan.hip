@@ -13,8 +13,9 @@
 //   1. tiles of Bt / C / dy are staged HBM -> LDS with the widest loads the slice alignment
 //      allows (16 B per lane when possible), so HBM sees whole row segments;
 //   2. each thread scans its own column of the LDS tile sequentially in fp32 registers;
-//   3. segments are stitched through a 4x64 LDS table, chunks through a [B,nchunks,Dn]
-//      fp32 workspace and a tiny prefix kernel (three launches per direction).
+//   3. segments are stitched through a 4x64 LDS table, chunks through a [B,nchunks,Dn,2]
+//      fp32 aggregate workspace: pass 1 writes every chunk's (prod a, state-from-zero), pass 2
+//      composes its own carry-in from the other chunks' aggregates and replays (two launches).
 //   The backward recomputes the states inside the chunk from the saved chunk carry-in and
 //   runs the adjoint recurrence right-to-left with mu_t = a_t*lambda_t as the carried value.
 #include "common.h"
@@ -120,6 +121,35 @@ struct ScanDims {
   int log2N, HT, nchunks, softplus;
 };
 
+// Carry entering chunk `chunk` for this lane's channel, composed from the aggregates of the
+// other chunks (all final: pass 1 has completed).  The 4 waves split the range, partials meet in
+// a 4x64 LDS table.  forward: chunks [0, chunk) left-to-right from `init`; reverse: chunks
+// (chunk, nchunks) right-to-left from 0.  Replaces a separate prefix launch (which cost as much as
+// the streaming passes at B*L = 32k tokens).  Contains one __syncthreads().
+__device__ __forceinline__ float chunk_carry(const float2 *__restrict__ agg, const float *__restrict__ init, int b,
+                                             int chunk, int c, bool chan_ok, const ScanDims &d, int seg, int lane,
+                                             float2 *lk, bool reverse) {
+  const int lo = reverse ? chunk + 1 : 0, hi = reverse ? d.nchunks : chunk;   // [lo, hi)
+  const int n = hi - lo, q = (n + NSEG - 1) / NSEG;
+  // wave `seg` takes the seg-th sub-range in COMPOSITION order
+  int s0 = lo + seg * q, s1 = min(s0 + q, hi);
+  if (reverse) { s1 = hi - seg * q; s0 = max(s1 - q, lo); }
+  float P = 1.f, S = 0.f;
+  if (chan_ok) {
+    const int64_t base = (int64_t)b * d.nchunks * d.Dn + c;
+    if (!reverse)
+      for (int j = s0; j < s1; ++j) { float2 t = agg[base + (int64_t)j * d.Dn]; S = fmaf(t.x, S, t.y); P *= t.x; }
+    else
+      for (int j = s1 - 1; j >= s0; --j) { float2 t = agg[base + (int64_t)j * d.Dn]; S = fmaf(t.x, S, t.y); P *= t.x; }
+  }
+  lk[seg * TC + lane] = make_float2(P, S);
+  __syncthreads();
+  float carry = (init && chan_ok) ? init[(int64_t)b * d.Dn + c] : 0.f;
+#pragma unroll
+  for (int s = 0; s < NSEG; ++s) { float2 t = lk[s * TC + lane]; carry = fmaf(t.x, carry, t.y); }
+  return carry;
+}
+
 // ---------------------------------------------------------------------------------------
 // pass 1 (forward): per-chunk aggregate (P = prod a, S = state from zero) -> agg[b][j][c]
 template <typename TIN, int VB, int LT>
@@ -170,45 +200,13 @@ scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
   }
 }
 
-// pass 2: exclusive prefix over chunks (reverse != 0: right-to-left).  One thread per (b, channel).
-// The whole column of up to U aggregates is fetched before the serial fma chain starts, so the
-// kernel costs one memory round trip instead of nchunks/8 of them.
-template <int U>
-__global__ void scan_chunk_prefix(const float2 *__restrict__ agg, const float *__restrict__ init,
-                                  float *__restrict__ carry_in, float *__restrict__ last,
-                                  int64_t B, int64_t Dn, int nchunks, int reverse) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * Dn) return;
-  int64_t b = i / Dn, c = i - b * Dn;
-  float carry = init ? init[i] : 0.f;
-  const int64_t base = b * nchunks * Dn + c;
-  for (int j0 = 0; j0 < nchunks; j0 += U) {
-    float2 q[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int j = j0 + u;
-      int jj = reverse ? nchunks - 1 - j : j;
-      q[u] = j < nchunks ? agg[base + (int64_t)jj * Dn] : make_float2(1.f, 0.f);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int j = j0 + u;
-      if (j < nchunks) {
-        int jj = reverse ? nchunks - 1 - j : j;
-        carry_in[base + (int64_t)jj * Dn] = carry;
-        carry = fmaf(q[u].x, carry, q[u].y);
-      }
-    }
-  }
-  if (last) last[i] = carry;
-}
-
-// pass 3 (forward): replay each chunk from its carry-in, write y
+// pass 2 (forward): compose the carry-in from the other chunks' aggregates, replay the chunk, write y
 template <typename TIN, typename TY, int VB, int LT>
 __global__ void __launch_bounds__(NTHREADS)
 scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
                 const TIN *__restrict__ Bt, int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs,
-                const float *__restrict__ h_in, TY *__restrict__ y, int64_t y_rs, ScanDims d) {
+                const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in,
+                float *__restrict__ h_last, TY *__restrict__ y, int64_t y_rs, ScanDims d) {
   constexpr int ROWB = TC * sizeof(TIN);
   constexpr int TS = LT / NSEG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -216,6 +214,7 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   TIN *cc = reinterpret_cast<TIN *>(smem + LT * ROWB);
   float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB);
   float2 *segs = reinterpret_cast<float2 *>(smem + 2 * LT * ROWB + LT * d.HT * 4);
+  float2 *lk = segs + NSEG * TC;
 
   const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
   const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
@@ -234,8 +233,9 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
   const bool chan_ok = c < d.Dn;
   const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
-  float hcar = chan_ok ? h_in[((int64_t)b * d.nchunks + chunk) * d.Dn + c] : 0.f;
-  __syncthreads();
+  // carry-in from the other chunks' aggregates (its barrier also covers the staged tiles)
+  float hcar = chunk_carry(agg, h0, b, chunk, c, chan_ok, d, seg, lane, lk, false);
+  if (seg == 0 && chan_ok) h_in[((int64_t)b * d.nchunks + chunk) * d.Dn + c] = hcar;   // saved for the backward
 
   float a[TS];
   float P = 1.f, S = 0.f;
@@ -282,6 +282,8 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
                             reinterpret_cast<char *>(y + tok0 * y_rs + c0), y_rs * sizeof(TY),
                             rows_valid, ch_valid * (int)sizeof(TY), tid);
   }
+  // final state (padding tokens are identities, so the last segment's state is s_{L-1})
+  if (h_last && chunk == d.nchunks - 1 && seg == NSEG - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -351,7 +353,7 @@ __global__ void __launch_bounds__(NTHREADS)
 scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
                 const TIN *__restrict__ Bt, int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs,
                 const TY *__restrict__ dy, int64_t dy_rs, const float *__restrict__ h_in,
-                const float *__restrict__ mu_in, TIN *__restrict__ dBt, int64_t dbt_rs,
+                const float2 *__restrict__ agg, TIN *__restrict__ dBt, int64_t dbt_rs,
                 TIN *__restrict__ dC, int64_t dc_rs, float *__restrict__ d_dlt,
                 float *__restrict__ dA_part, ScanDims d) {
   constexpr int ROWB = TC * sizeof(TIN);
@@ -364,6 +366,7 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB + LT * ROWY);
   float *ddl = dl + LT * d.HT;
   float *segs = ddl + LT * d.HT;  // [NSEG][TC][3]
+  float2 *lk = reinterpret_cast<float2 *>(segs + NSEG * TC * 3);
 
   const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
   const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
@@ -389,8 +392,8 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   const float A2 = Ac * LOG2E_F;
   const int64_t cidx = ((int64_t)b * d.nchunks + chunk) * d.Dn + c;
   float hcar = chan_ok ? h_in[cidx] : 0.f;
-  float mcar = chan_ok ? mu_in[cidx] : 0.f;
-  __syncthreads();
+  // mu entering from the right: composed from the later chunks' reverse aggregates
+  float mcar = chunk_carry(agg, nullptr, b, chunk, c, chan_ok, d, seg, lane, lk, true);
 
   float a[TS], hs[TS];
   float P = 1.f, S = 0.f, M = 0.f;
@@ -465,18 +468,29 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   }
 }
 
-// column sums of a [rows, cols] fp32 matrix (deterministic order): out[c] = sum_r in[r][c]
-__global__ void __launch_bounds__(NTHREADS)
+// column sums of a [rows, cols] fp32 matrix in a fixed order: out[c] = sum_r in[r][c]
+__global__ void __launch_bounds__(1024)
 colsum_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
-  __shared__ float part[NSEG][TC];
+  __shared__ float part[16][TC];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * TC + lane;
   float s = 0.f;
-  if (c < cols)
-    for (int64_t r = seg; r < rows; r += NSEG) s += in[r * cols + c];
+  if (c < cols) {
+    int64_t r = seg;
+    for (; r + 48 < rows; r += 64) {
+      float a0 = in[r * cols + c], a1 = in[(r + 16) * cols + c], a2 = in[(r + 32) * cols + c], a3 = in[(r + 48) * cols + c];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < rows; r += 16) s += in[r * cols + c];
+  }
   part[seg][lane] = s;
   __syncthreads();
-  if (seg == 0 && c < cols) out[c] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+  if (seg == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][lane];
+    out[c] = t;
+  }
 }
 
 int ilog2_exact(int64_t n) {
@@ -523,18 +537,12 @@ int launch_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
   dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
   size_t dlb = (size_t)LT * d.HT * 4;
   size_t lds1 = LT * TC * sizeof(TIN) + dlb + NSEG * TC * sizeof(float2);
-  size_t lds3 = 2 * LT * TC * sizeof(TIN) + dlb + NSEG * TC * sizeof(float2);
+  size_t lds3 = 2 * LT * TC * sizeof(TIN) + dlb + 2 * NSEG * TC * sizeof(float2);
   hipLaunchKernelGGL((scan_fwd_state<TIN, VB, LT>), grid, block, lds1, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (float2 *)agg, d);
-  int64_t n = d.B * d.Dn;
-  if (d.nchunks <= 64)
-    hipLaunchKernelGGL(scan_chunk_prefix<64>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
-                       (const float2 *)agg, h0, h_in, h_last, d.B, d.Dn, d.nchunks, 0);
-  else
-    hipLaunchKernelGGL(scan_chunk_prefix<16>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
-                       (const float2 *)agg, h0, h_in, h_last, d.B, d.Dn, d.nchunks, 0);
   hipLaunchKernelGGL((scan_fwd_replay<TIN, TY, VB, LT>), grid, block, lds3, st, dlt, A_log,
-                     (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, h_in, (TY *)y, y_rs, d);
+                     (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const float2 *)agg, h0, h_in, h_last, (TY *)y,
+                     y_rs, d);
   return apertis_check_launch();
 }
 
@@ -543,24 +551,19 @@ int launch_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
                int64_t c_rs, const void *dy, int64_t dy_rs, const float *h_in, void *dBt,
                int64_t dbt_rs, void *dC, int64_t dc_rs, float *d_dlt, float *dA_log, float *agg,
                float *mu_in, float *dA_part, const ScanDims &d, hipStream_t st) {
+  (void)mu_in;  // kept in the ABI; the reverse carry is composed in-kernel since r1
   constexpr int LT = LT_DEFAULT;
   dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
   size_t dlb = (size_t)LT * d.HT * 4;
   size_t lds1 = LT * TC * (sizeof(TIN) + sizeof(TY)) + dlb + NSEG * TC * sizeof(float2);
-  size_t lds3 = LT * TC * (2 * sizeof(TIN) + sizeof(TY)) + 2 * dlb + NSEG * TC * 3 * sizeof(float);
+  size_t lds3 = LT * TC * (2 * sizeof(TIN) + sizeof(TY)) + 2 * dlb + NSEG * TC * 3 * sizeof(float) +
+                NSEG * TC * sizeof(float2);
   hipLaunchKernelGGL((scan_bwd_state<TIN, TY, VB, VBY, LT>), grid, block, lds1, st, dlt, A_log,
                      (const TIN *)C, c_rs, (const TY *)dy, dy_rs, (float2 *)agg, d);
-  int64_t n = d.B * d.Dn;
-  if (d.nchunks <= 64)
-    hipLaunchKernelGGL(scan_chunk_prefix<64>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
-                       (const float2 *)agg, (const float *)nullptr, mu_in, (float *)nullptr, d.B, d.Dn, d.nchunks, 1);
-  else
-    hipLaunchKernelGGL(scan_chunk_prefix<16>, dim3((unsigned)ceil_div64(n, 64)), dim3(64), 0, st,
-                       (const float2 *)agg, (const float *)nullptr, mu_in, (float *)nullptr, d.B, d.Dn, d.nchunks, 1);
   hipLaunchKernelGGL((scan_bwd_replay<TIN, TY, VB, VBY, LT>), grid, block, lds3, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const TY *)dy, dy_rs, h_in,
-                     mu_in, (TIN *)dBt, dbt_rs, (TIN *)dC, dc_rs, d_dlt, dA_part, d);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(d.Dn, TC)), dim3(NTHREADS), 0, st,
+                     (const float2 *)agg, (TIN *)dBt, dbt_rs, (TIN *)dC, dc_rs, d_dlt, dA_part, d);
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(d.Dn, TC)), dim3(1024), 0, st,
                      dA_part, dA_log, d.B * d.nchunks, d.Dn);
   return apertis_check_launch();
 }

@@ -80,7 +80,7 @@ int apertis_selective_scan_fwd(const float *dlt, const float *A_log,
  *   dA_log        : [h*N] fp32 (overwritten)
  *   h_in          : saved by the forward
  *   agg           : workspace [B,nchunks,Dn,2] fp32
- *   mu_in         : workspace [B,nchunks,Dn]   fp32
+ *   mu_in         : reserved (ignored; may be NULL... pass a [B,nchunks,Dn] fp32 buffer for ABI stability)
  *   dA_part       : workspace [B*nchunks, Dn]  fp32
  */
 int apertis_selective_scan_bwd(const float *dlt, const float *A_log,
