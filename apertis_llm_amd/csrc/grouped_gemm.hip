@@ -676,9 +676,17 @@ grouped_gemm_tn_k(const T *__restrict__ A, const T *__restrict__ Bm, const int32
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int tn_swz(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
+// One launch can carry TWO weight-gradient problems over the same row grouping (the two expert
+// layers): 2 x 1056 tiles fill 4.1 rounds of the chip instead of 2 x 3 (tile-count quantisation
+// is the largest loss of this kernel at E=8, H=704, I=2816).
+struct TnProblem {
+  const bf16_t *A, *Bm;
+  float *dW, *dbias;
+  int M, N, m_tiles, n_tiles, tiles;
+};
+
 __global__ void __launch_bounds__(NT)
-grouped_gemm_tn2_k(const bf16_t *__restrict__ A, const bf16_t *__restrict__ Bm, const int32_t *__restrict__ offsets,
-                   float *__restrict__ dW, float *__restrict__ dbias, int M, int N, int m_tiles, int n_tiles) {
+grouped_gemm_tn2_k(TnProblem p0, TnProblem p1, const int32_t *__restrict__ offsets) {
   typedef bf16_t T;
   constexpr int BKR = 64;              // rows (K) per step
   constexpr int KROWB = BM * 2;        // 256 B per k-row
@@ -689,7 +697,13 @@ grouped_gemm_tn2_k(const bf16_t *__restrict__ A, const bf16_t *__restrict__ Bm, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const bool second = tile >= p0.tiles;
+  if (second) tile -= p0.tiles;
+  const TnProblem &pp = second ? p1 : p0;
+  const bf16_t *__restrict__ A = pp.A, *__restrict__ Bm = pp.Bm;
+  float *__restrict__ dW = pp.dW, *__restrict__ dbias = pp.dbias;
+  const int M = pp.M, N = pp.N, m_tiles = pp.m_tiles, n_tiles = pp.n_tiles;
   const int e = tile / (m_tiles * n_tiles);
   const int rem = tile - e * m_tiles * n_tiles;
   const int mt = rem / n_tiles, ntile = rem - mt * n_tiles;
@@ -810,6 +824,13 @@ grouped_gemm_tn2_k(const bf16_t *__restrict__ A, const bf16_t *__restrict__ Bm, 
   if (dbias && ntile == 0 && tid < mvalid) dbias[(int64_t)e * M + m0 + tid] = bsum;
 }
 
+int launch_tn2(const TnProblem &q0, const TnProblem &q1, const int32_t *offsets, hipStream_t st) {
+  size_t lds = std::max<size_t>(2 * 2 * 64 * 256, (size_t)BM * (BN * 4 + 16));
+  hipFuncSetAttribute((const void *)grouped_gemm_tn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(grouped_gemm_tn2_k, dim3((unsigned)(q0.tiles + q1.tiles)), dim3(NT), lds, st, q0, q1, offsets);
+  return apertis_check_launch();
+}
+
 template <typename T> bool aligned16(const void *p, int64_t ld) {
   return (((uintptr_t)p) & 15) == 0 && ((ld * sizeof(T)) & 15) == 0;
 }
@@ -892,11 +913,9 @@ extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int3
   if (dtype == APERTIS_BF16) {
     if (M % 8 || N % 8 || !aligned16<bf16_t>(A, M) || !aligned16<bf16_t>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
     if (!getenv("APERTIS_GEMM_TN_V1")) {
-      size_t lds = std::max<size_t>(2 * 2 * 64 * 256, (size_t)BM * (BN * 4 + 16));
-      hipFuncSetAttribute((const void *)grouped_gemm_tn2_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(grouped_gemm_tn2_k, dim3((unsigned)grid), dim3(NT), lds, st, (const bf16_t *)A,
-                         (const bf16_t *)Bm, offsets, dW, dbias, (int)M, (int)N, m_tiles, n_tiles);
-      return apertis_check_launch();
+      TnProblem q0{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, m_tiles, n_tiles, (int)grid};
+      TnProblem q1{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+      return launch_tn2(q0, q1, offsets, st);
     }
     size_t lds = 2 * 32 * (BM * 2 + 16);
     hipLaunchKernelGGL(grouped_gemm_tn_k<bf16_t>, dim3((unsigned)grid), dim3(NT), lds, st, (const bf16_t *)A,
@@ -931,4 +950,25 @@ extern "C" int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void
   else
     return APERTIS_ERR_ARG;
   return apertis_check_launch();
+}
+
+extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, float *dbias0, int64_t M0,
+                                            int64_t N0, const void *A1, const void *B1, float *dW1, float *dbias1,
+                                            int64_t M1, int64_t N1, const int32_t *offsets, int64_t max_rows, int64_t E,
+                                            int dtype, void *stream) {
+  if (!A0 || !B0 || !dW0 || !A1 || !B1 || !dW1 || !offsets || max_rows < 0 || E <= 0) return APERTIS_ERR_ARG;
+  if (dtype != APERTIS_BF16) {   // fp32 parity path: two ordinary launches
+    int rc = apertis_grouped_gemm_tn(A0, B0, offsets, dW0, dbias0, max_rows, M0, N0, E, dtype, stream);
+    return rc ? rc : apertis_grouped_gemm_tn(A1, B1, offsets, dW1, dbias1, max_rows, M1, N1, E, dtype, stream);
+  }
+  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || (M0 | N0 | M1 | N1) % 8) return APERTIS_ERR_UNSUPPORTED;
+  if (!aligned16<bf16_t>(A0, M0) || !aligned16<bf16_t>(B0, N0) || !aligned16<bf16_t>(A1, M1) || !aligned16<bf16_t>(B1, N1))
+    return APERTIS_ERR_UNSUPPORTED;
+  const int mt0 = (int)ceil_div64(M0, BM), nt0 = (int)ceil_div64(N0, BN), mt1 = (int)ceil_div64(M1, BM),
+            nt1 = (int)ceil_div64(N1, BN);
+  const int64_t g0 = E * mt0 * nt0, g1 = E * mt1 * nt1;
+  if (g0 + g1 > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+  TnProblem q0{(const bf16_t *)A0, (const bf16_t *)B0, dW0, dbias0, (int)M0, (int)N0, mt0, nt0, (int)g0};
+  TnProblem q1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, mt1, nt1, (int)g1};
+  return launch_tn2(q0, q1, offsets, (hipStream_t)stream);
 }

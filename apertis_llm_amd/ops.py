@@ -623,20 +623,20 @@ class _ExpertMLP(torch.autograd.Function):
             if act_code != _lib.ACT_NONE or drop_p > 0:
                 check(lib.apertis_act_dropout_bwd(ptr(dpre), ptr(pre), ptr(dpre), ptr(offsets), max_rows, I, E, act_code,
                                                   drop_p, seed, code, stream_ptr()), "apertis_act_dropout_bwd")
-        dw2 = torch.empty(E, H, I, device=dev, dtype=torch.float32)
-        db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
-        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
-                (ptr(dyr), ptr(h), ptr(offsets), ptr(dw2), ptr(db2), max_rows, H, I, E, code, stream_ptr()), work)
         dxg = None
         if ctx.needs_input_grad[0]:
             dxg = torch.empty_like(xg)
             _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
                     (ptr(dpre), ptr(w1t), None, ptr(offsets), ptr(dxg), None, None, max_rows, H, I, E, _lib.ACT_NONE, 0.0, 0,
                      code, code, stream_ptr()), work)
+        # both weight gradients in ONE launch: dW2 = dyr^T h, dW1 = dpre^T xg
+        dw2 = torch.empty(E, H, I, device=dev, dtype=torch.float32)
+        db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
         dw1 = torch.empty(E, I, H, device=dev, dtype=torch.float32)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
-        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
-                (ptr(dpre), ptr(xg), ptr(offsets), ptr(dw1), ptr(db1), max_rows, I, H, E, code, stream_ptr()), work)
+        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair,
+                (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
+                 max_rows, E, code, stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
         return dxg, dw1.to(w1dt), db1, dw2.to(w2dt), db2, None, None, None, None, None, None
 
 

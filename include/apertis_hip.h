@@ -230,6 +230,13 @@ int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
                             int64_t E, int dtype, void *stream);
+/* Two TN problems over the SAME row grouping in one launch (the two expert layers' weight
+ * gradients): halves the tile-count quantisation loss of separate launches. */
+int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, float *dbias0,
+                                 int64_t M0, int64_t N0, const void *A1, const void *B1,
+                                 float *dW1, float *dbias1, int64_t M1, int64_t N1,
+                                 const int32_t *offsets, int64_t max_rows, int64_t E, int dtype,
+                                 void *stream);
 /* Compute copies of fp32 master weights src [E,R,C]: dst [E,R,C] and/or dstT [E,C,R] in
  * dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call. */
 int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R,
