@@ -136,6 +136,14 @@ def main():
     if rank == 0 and timer is not None:
         summ = timer.summary()
         rl = {}
+        # HBM traffic per call from the committed rocprofv3 --pmc passes of the same launches
+        # (tools/run_pmc.sh benchmix -> profiles/r1_pmc_traffic_*.json); only valid for the workload
+        # those passes were taken on, else null
+        traffic = {}
+        tf = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_{args.config}_b{B}.json")
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                traffic = {k: v.get("traffic_bytes_per_call") for k, v in json.load(fh).items()}
         for name, d in summ.items():
             if not d["launches"]:
                 continue
@@ -144,15 +152,15 @@ def main():
             if "gemm" in name:
                 ach = per_launch / (avg_ms * 1e-3) / 1e12
                 rl[name] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "launches": d["launches"],
+                            "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic.get(name), "launches": d["launches"],
                             "avg_ms": avg_ms, "total_ms": d["ms"]}
             else:
                 ach = per_launch / (avg_ms * 1e-3) / 1e9
                 rl[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": d["launches"], "avg_ms": avg_ms,
+                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name), "launches": d["launches"], "avg_ms": avg_ms,
                             "total_ms": d["ms"]}
         if rl:
-            dom = max(rl, key=lambda k: rl[k]["total_ms"])
+            dom = max((k for k in rl if "[dense]" not in k), key=lambda k: rl[k]["total_ms"])
             result["roofline"] = dict(rl[dom], kernel=dom)
             result["roofline_all"] = rl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -15,6 +15,27 @@ P, S = _lib.ptr, _lib.stream_ptr
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 what = sys.argv[2] if len(sys.argv) > 2 else "all"
 
+if what == "benchmix":
+    # exactly the per-layer launches of bench.py's default workload (1.5b-moe, per-GPU batch 8)
+    B, L, h, N, H, I, E = 8, 4096, 11, 16, 704, 2816, 8
+    Dn, R = h * N, 48
+    rows = 40960
+    p = torch.randn(B, L, R + 2 * Dn, device=dev).bfloat16().requires_grad_(True)
+    dl = (torch.randn(B, L, h, device=dev) - 4).requires_grad_(True)
+    A = torch.empty(h, N, device=dev).uniform_(math.log(.5), math.log(.99)).requires_grad_(True)
+    dy = torch.randn(B, L, Dn, device=dev)
+    xg = torch.randn(rows, H, device=dev).bfloat16().requires_grad_(True)
+    w1 = (torch.randn(E, I, H, device=dev) * 0.02).requires_grad_(True)
+    b1 = torch.zeros(E, I, device=dev, requires_grad=True)
+    w2 = (torch.randn(E, H, I, device=dev) * 0.02).requires_grad_(True)
+    b2 = torch.zeros(E, H, device=dev, requires_grad=True)
+    offs = torch.tensor(np.linspace(0, rows, E + 1).astype(np.int32), device=dev)
+    dyr = torch.randn(rows, H, device=dev).bfloat16()
+    for _ in range(reps):
+        y = ops.selective_scan(dl, A, p[..., R:R + Dn], p[..., R + Dn:R + 2 * Dn], delta_softplus=True)
+        y.backward(dy)
+        yr = ops.expert_mlp(xg, w1, b1, w2, b2, offs, rows, act="gelu", drop_p=0.1, seed=5, compute_dtype=torch.bfloat16)
+        yr.backward(dyr)
 if what in ("all", "scan"):
     B, L, h, N = 16, 4096, 11, 16
     Dn, R = h * N, 44

@@ -7,31 +7,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { # name counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 tools/prof_kernels.py 2 "$WHAT" > "$OUT/$name.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 tools/prof_kernels.py 3 "$WHAT" > "$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAIT_INST_LDS
 run sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_LDS_UNALIGNED_STALL
 run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python3 - "$OUT" <<'PY'
-import csv, glob, sys, collections
-out = sys.argv[1]
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(out + "/*/*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:70]
-        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-dur = collections.defaultdict(list)
-for f in glob.glob(out + "/sq1/*/*kernel_trace.csv"):
-    for r in csv.DictReader(open(f)):
-        dur[r["Kernel_Name"][:70]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-with open(out + "/summary.txt", "w") as fo:
-    for k in sorted(agg):
-        if not any(s in k for s in ("scan", "gemm", "colsum", "prefix")):
-            continue
-        d = sorted(dur.get(k, [0]))
-        line = f"{k}\n   launches {len(d)} median_us {d[len(d)//2]:.1f}  " + "  ".join(
-            f"{c}={sorted(v)[len(v)//2]:.4g}" for c, v in sorted(agg[k].items()))
-        print(line); fo.write(line + "\n")
-PY
+python3 tools/pmc_traffic.py "$OUT"
