@@ -274,18 +274,29 @@ dwconv_silu_bwd_k(const T *__restrict__ x, int64_t x_rs, const float *__restrict
   }
 }
 
-// out[c] = sum_r in[r][c], fixed order
-__global__ void __launch_bounds__(256)
+// out[c] = sum_r in[r][c], fixed order (16 row groups, four independent loads in flight)
+__global__ void __launch_bounds__(1024)
 colsum_rows_k(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
-  __shared__ float part[4][64];
+  __shared__ float part[16][64];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * 64 + lane;
   float s = 0.f;
-  if (c < cols)
-    for (int64_t r = seg; r < rows; r += 4) s += in[r * cols + c];
+  if (c < cols) {
+    int64_t r = seg;
+    for (; r + 48 < rows; r += 64) {
+      float a0 = in[r * cols + c], a1 = in[(r + 16) * cols + c], a2 = in[(r + 32) * cols + c], a3 = in[(r + 48) * cols + c];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < rows; r += 16) s += in[r * cols + c];
+  }
   part[seg][lane] = s;
   __syncthreads();
-  if (seg == 0 && c < cols) out[c] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  if (seg == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += part[i][lane];
+    out[c] = t;
+  }
 }
 
 // ---------------------------------------------------------------- cast (+ transposed copy)
@@ -365,7 +376,7 @@ extern "C" int apertis_ssm_gate_bwd(const void *dout, int64_t dout_rs, const voi
                                                    dout_rs, (const TY *)y, y_rs, (const TIO *)xc, xc_rs, (const TIO *)z,
                                                    z_rs, D, (TY *)dy, dy_rs, (TIO *)dxc, dxc_rs, (TIO *)dz, dz_rs, dD_part,
                                                    T, (int)Dn));
-  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(256), 0, st, dD_part, dD, (int64_t)nblk, Dn);
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(1024), 0, st, dD_part, dD, (int64_t)nblk, Dn);
   return apertis_check_launch();
 }
 
@@ -407,9 +418,9 @@ extern "C" int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float 
   CONV_DISPATCH(k, dtype_io, hipLaunchKernelGGL((dwconv_silu_bwd_k<T, KW>), grid, block, lds, st, (const T *)x, x_rs, w,
                                                 bias, (const T *)dout, dout_rs, (T *)dx, dx_rs, dw_part, db_part, B, L,
                                                 (int)Dn));
-  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn * k, 64)), dim3(256), 0, st, dw_part, dw, (int64_t)nblk,
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn * k, 64)), dim3(1024), 0, st, dw_part, dw, (int64_t)nblk,
                      Dn * k);
-  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(256), 0, st, db_part, db, (int64_t)nblk, Dn);
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(1024), 0, st, db_part, db, (int64_t)nblk, Dn);
   return apertis_check_launch();
 }
 
@@ -430,7 +441,7 @@ extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, i
 
 extern "C" int apertis_colsum_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream) {
   if (!in || !out || rows < 0 || cols <= 0) return APERTIS_ERR_ARG;
-  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(256), 0, (hipStream_t)stream, in, out, rows,
+  hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, rows,
                      cols);
   return apertis_check_launch();
 }

@@ -73,6 +73,42 @@ def _rows(t, width):
 # ----------------------------------------------------------------------------------------------
 # selective scan
 # ----------------------------------------------------------------------------------------------
+import os as _os
+
+# Single-launch forward (persistent work-groups + granule hand-off).  Correct and stress-tested, but
+# measured SLOWER than the two-launch form on MI355X at these sizes (30.1 vs 26.2 us per call in
+# the 1.5B step; 2.29 vs 2.46 TB/s at 381 MB): the serial publish -> gather round trip per item with
+# 4 work-groups per CU costs more than the second launch.  Off unless APERTIS_SCAN_FUSED=1.
+SCAN_FUSED = _os.environ.get("APERTIS_SCAN_FUSED", "0") == "1"
+_scan_ws = {}      # device -> [workspace tensor (zeroed once), next epoch]
+
+
+def _fused_scan_ws(lib, B, L, Dn, device):
+    need = lib.apertis_scan_fused_workspace_bytes(B, L, Dn)
+    ent = _scan_ws.get(str(device))
+    if ent is None or ent[0].numel() < need:
+        epoch = ent[1] if ent else 1
+        ent = [torch.zeros(need, device=device, dtype=torch.uint8), epoch]
+        _scan_ws[str(device)] = ent
+    ent[1] += 1
+    if ent[1] >= 0xFFFFFFF0:        # epoch wrap: start over on a clean workspace
+        ent[0].zero_()
+        ent[1] = 2
+    # the error word sits in the last 64 bytes of the size the LIBRARY computes for this shape
+    return ent[0], ent[1] - 1, need
+
+
+def scan_fused_error(device):
+    """Non-zero if any fused-scan launch on this device hit its bounded-spin timeout (host sync)."""
+    ent = _scan_ws.get(str(device))
+    if ent is None:
+        return 0
+    torch.cuda.synchronize(device)
+    flat = ent[0]
+    # an error word lives at (need - 64) for every shape used; scan the whole tail conservatively
+    return int(flat.view(torch.int32)[-16:].abs().sum().item()) if flat.numel() % 4 == 0 else 0
+
+
 class _SelectiveScan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dlt, A_log, Bt, C, h0, delta_softplus, y_dtype, return_last):
@@ -98,9 +134,29 @@ class _SelectiveScan(torch.autograd.Function):
         h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
         work = B * L * (Dn * (2 * Bt.element_size() + y.element_size()) + 4 * h) + 4 * h * N   # algorithmic bytes
-        _launch("apertis_selective_scan_fwd", lib.apertis_selective_scan_fwd,
-                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(agg),
-                 ptr(h_in), B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr()), work)
+        done = False
+        if SCAN_FUSED:
+            ws, epoch, _ = _fused_scan_ws(lib, B, L, Dn, dev)
+            args = (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(h_in),
+                    ptr(ws), epoch, B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr())
+            t = _TIMER
+            if t is not None and "apertis_selective_scan_fwd" in t.names:
+                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_.record()
+                rc = lib.apertis_selective_scan_fwd_fused(*args)
+                e_.record()
+                if rc == 0:
+                    t.records.append(("apertis_selective_scan_fwd", s_, e_, work))
+            else:
+                rc = lib.apertis_selective_scan_fwd_fused(*args)
+            if rc == 0:
+                done = True
+            elif rc != -2:            # -2 = shape/alignment the single-launch kernel is not built for
+                check(rc, "apertis_selective_scan_fwd_fused")
+        if not done:
+            _launch("apertis_selective_scan_fwd", lib.apertis_selective_scan_fwd,
+                    (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(agg),
+                     ptr(h_in), B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr()), work)
         ctx.save_for_backward(dlt, A_log, Bt, C, h_in)
         ctx.cfg = (B, L, h, N, bool(delta_softplus))
         ctx.mark_non_differentiable(*([h_last] if return_last else []))

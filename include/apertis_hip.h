@@ -73,6 +73,21 @@ int apertis_selective_scan_fwd(const float *dlt, const float *A_log,
                                int64_t B, int64_t L, int64_t h, int64_t N,
                                int dtype_bc, int dtype_y, int delta_softplus, void *stream);
 
+/* Single-launch forward (same math and outputs as apertis_selective_scan_fwd): persistent
+ * work-groups publish chunk aggregates to each other through 8-byte {epoch, value} granules
+ * (agent-scope relaxed atomics), so Bt is read once and there is one launch instead of two.
+ *   ws    : apertis_scan_fused_workspace_bytes() bytes, zero-filled ONCE by the caller and then
+ *           reused; its last 64 bytes hold an int32 error word (non-zero = a bounded spin timed out)
+ *   epoch : non-zero, strictly increasing over the launches that share `ws`
+ * One launch at a time may use a given `ws`. */
+int64_t apertis_scan_fused_workspace_bytes(int64_t B, int64_t L, int64_t Dn);
+int apertis_selective_scan_fwd_fused(const float *dlt, const float *A_log,
+                                     const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                                     const float *h0, void *y, int64_t y_rs, float *h_last,
+                                     float *h_in, void *ws, uint32_t epoch,
+                                     int64_t B, int64_t L, int64_t h, int64_t N,
+                                     int dtype_bc, int dtype_y, int delta_softplus, void *stream);
+
 /* Backward of the scan (no reference code: autograd through core.py:347-349).
  *   dy            : [B,L,Dn] (row stride dy_rs, dtype_y)
  *   dBt, dC       : [B,L,Dn] views (row strides dbt_rs/dc_rs, dtype_bc)
