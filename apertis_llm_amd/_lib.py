@@ -42,6 +42,8 @@ SIGNATURES = {
     "apertis_ssm_gate_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64,
                                     _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "apertis_ssm_gate_bwd_blocks": (_i64, [_i64, _i64]),
+    "apertis_dropout_add_fwd": (_i32, [_vp, _vp, _vp, _i64, _f32, _u64, _i32, _i32, _vp]),
+    "apertis_dropout_bwd": (_i32, [_vp, _vp, _i64, _f32, _u64, _i32, _i32, _vp]),
     "apertis_dwconv_silu_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_dwconv_silu_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                        _i64, _i32, _vp]),

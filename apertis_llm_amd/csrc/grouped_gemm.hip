@@ -90,17 +90,6 @@ template <bool FAST> __device__ __forceinline__ float act_grad(float x, int act)
   }
 }
 
-// counter-based keep mask: 16 random bits per element from a 32-bit avalanche of
-// (element pair index, seed); the backward regenerates it from the same (seed,row,col)
-__device__ __forceinline__ bool drop_keep(uint64_t seed, int64_t row, int64_t col, int64_t ncols, uint32_t thresh16) {
-  uint64_t lin = (uint64_t)row * (uint64_t)ncols + (uint64_t)col;
-  uint32_t h = (uint32_t)(lin >> 1) ^ (uint32_t)seed;
-  h += (uint32_t)(lin >> 33) * 0x9E3779B9u + (uint32_t)(seed >> 32);
-  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-  uint32_t r16 = (lin & 1) ? (h >> 16) : (h & 0xffffu);
-  return r16 >= thresh16;
-}
-
 struct TileCoord { int e, m0, rows_left; int64_t row0; bool valid; };
 
 // m-tile index -> (group, first row in group, rows left); mt counts tiles over all groups.

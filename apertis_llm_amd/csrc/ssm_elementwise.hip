@@ -299,6 +299,43 @@ colsum_rows_k(const float *__restrict__ in, float *__restrict__ out, int64_t row
   }
 }
 
+// ---------------------------------------------------------------- residual + dropout
+// y = res + keep/(1-p) * x  (the `output_dropout(block_out) + residual` of every sub-block,
+// reference core.py:836-837,918-919) in one pass; the mask is the counter hash of (seed, index),
+// regenerated by the backward.
+template <typename TX, typename TR>
+__global__ void __launch_bounds__(256)
+dropout_add_fwd_k(const TX *__restrict__ x, const TR *__restrict__ res, TR *__restrict__ y, int64_t n4, float drop_p,
+                  uint64_t seed) {
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t th = (uint32_t)(drop_p * 65536.f);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n4; v += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ld4<TX>(x + v * 4), r = ld4<TR>(res + v * 4);
+    float e[4] = {a.x, a.y, a.z, a.w};
+    if (drop_p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = drop_keep(seed, 0, v * 4 + j, 0, th) ? e[j] * ks : 0.f;
+    }
+    st4<TR>(y + v * 4, make_float4(r.x + e[0], r.y + e[1], r.z + e[2], r.w + e[3]));
+  }
+}
+
+template <typename TG, typename TX>
+__global__ void __launch_bounds__(256)
+dropout_bwd_k(const TG *__restrict__ g, TX *__restrict__ dx, int64_t n4, float drop_p, uint64_t seed) {
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t th = (uint32_t)(drop_p * 65536.f);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < n4; v += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = ld4<TG>(g + v * 4);
+    float e[4] = {a.x, a.y, a.z, a.w};
+    if (drop_p > 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) e[j] = drop_keep(seed, 0, v * 4 + j, 0, th) ? e[j] * ks : 0.f;
+    }
+    st4<TX>(dx + v * 4, make_float4(e[0], e[1], e[2], e[3]));
+  }
+}
+
 // ---------------------------------------------------------------- cast (+ transposed copy)
 template <typename TO>
 __global__ void __launch_bounds__(256)
@@ -443,5 +480,43 @@ extern "C" int apertis_colsum_f32(const float *in, float *out, int64_t rows, int
   if (!in || !out || rows < 0 || cols <= 0) return APERTIS_ERR_ARG;
   hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, (hipStream_t)stream, in, out, rows,
                      cols);
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_dropout_add_fwd(const void *x, const void *res, void *y, int64_t n, float drop_p, uint64_t seed,
+                                       int dtype_x, int dtype_res, void *stream) {
+  if (!x || !res || !y || n < 0 || drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
+  if (n % 4) return APERTIS_ERR_UNSUPPORTED;
+  if (n == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = std::min<int64_t>(ceil_div64(n / 4, 256), 8192);
+  dim3 grid((unsigned)nb), block(256);
+  if (dtype_x == APERTIS_BF16 && dtype_res == APERTIS_F32)
+    hipLaunchKernelGGL((dropout_add_fwd_k<bf16_t, float>), grid, block, 0, st, (const bf16_t *)x, (const float *)res, (float *)y, n / 4, drop_p, seed);
+  else if (dtype_x == APERTIS_F32 && dtype_res == APERTIS_F32)
+    hipLaunchKernelGGL((dropout_add_fwd_k<float, float>), grid, block, 0, st, (const float *)x, (const float *)res, (float *)y, n / 4, drop_p, seed);
+  else if (dtype_x == APERTIS_BF16 && dtype_res == APERTIS_BF16)
+    hipLaunchKernelGGL((dropout_add_fwd_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t *)x, (const bf16_t *)res, (bf16_t *)y, n / 4, drop_p, seed);
+  else
+    return APERTIS_ERR_UNSUPPORTED;
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_dropout_bwd(const void *g, void *dx, int64_t n, float drop_p, uint64_t seed, int dtype_g,
+                                   int dtype_x, void *stream) {
+  if (!g || !dx || n < 0 || drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
+  if (n % 4) return APERTIS_ERR_UNSUPPORTED;
+  if (n == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nb = std::min<int64_t>(ceil_div64(n / 4, 256), 8192);
+  dim3 grid((unsigned)nb), block(256);
+  if (dtype_g == APERTIS_F32 && dtype_x == APERTIS_BF16)
+    hipLaunchKernelGGL((dropout_bwd_k<float, bf16_t>), grid, block, 0, st, (const float *)g, (bf16_t *)dx, n / 4, drop_p, seed);
+  else if (dtype_g == APERTIS_F32 && dtype_x == APERTIS_F32)
+    hipLaunchKernelGGL((dropout_bwd_k<float, float>), grid, block, 0, st, (const float *)g, (float *)dx, n / 4, drop_p, seed);
+  else if (dtype_g == APERTIS_BF16 && dtype_x == APERTIS_BF16)
+    hipLaunchKernelGGL((dropout_bwd_k<bf16_t, bf16_t>), grid, block, 0, st, (const bf16_t *)g, (bf16_t *)dx, n / 4, drop_p, seed);
+  else
+    return APERTIS_ERR_UNSUPPORTED;
   return apertis_check_launch();
 }

@@ -155,6 +155,15 @@ class HipLayerNorm(nn.LayerNorm):
         return super().forward(x)
 
 
+def _dropout_add(drop: nn.Dropout, out, residual):
+    """residual + dropout(out): one HIP kernel on the GPU, stock torch elsewhere."""
+    if out.is_cuda and out.numel() % 4 == 0 and out.shape == residual.shape and \
+            out.dtype in (torch.float32, torch.bfloat16) and residual.dtype in (torch.float32, torch.bfloat16) and \
+            (residual.dtype == torch.float32 or out.dtype == residual.dtype):
+        return ops.dropout_add(out, residual, drop.p, drop.training)
+    return drop(out) + residual
+
+
 def _mfma_linear(x, weight, bias=None):
     """x @ W.T (+b) on the MFMA GEMM tile when the shapes allow 16-byte rows, else stock F.linear
     (both run on the GPU; this is a provider choice, not a fallback to the host)."""
@@ -467,7 +476,7 @@ class ApertisAttention(nn.Module):
                 ctxv = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=att_mask,
                                                       dropout_p=self.attention_dropout.p if self.training else 0.0)
             out = self.out_proj(ctxv.transpose(1, 2).reshape(x.shape[0], Lq, self.hidden_size))
-        return self.output_dropout(out) + hidden_s, proxy, cache
+        return _dropout_add(self.output_dropout, out, hidden_s), proxy, cache
 
 
 class SwiGLUFFN(nn.Module):
@@ -513,7 +522,7 @@ class ApertisFeedForward(nn.Module):
             out, lb, rz = self.ffn(x)
         else:
             out = self.ffn(x)
-        return self.output_dropout(out) + hidden_s, lb, rz
+        return _dropout_add(self.output_dropout, out, hidden_s), lb, rz
 
 
 class ApertisLayer(nn.Module):

@@ -243,6 +243,38 @@ def dwconv_silu(x, weight, bias):
     return _DwConvSilu.apply(x, weight, bias)
 
 
+class _DropoutAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, p, seed):
+        _require_gpu(x, res)
+        lib = _lib.load()
+        x = x.contiguous()
+        res = res.contiguous()
+        y = torch.empty_like(res)
+        check(lib.apertis_dropout_add_fwd(ptr(x), ptr(res), ptr(y), x.numel(), float(p), int(seed), dtype_code(x),
+                                          dtype_code(res), stream_ptr()), "apertis_dropout_add_fwd")
+        ctx.cfg = (float(p), int(seed), x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        p, seed, xdt = ctx.cfg
+        g = g.contiguous()
+        dx = torch.empty(g.shape, device=g.device, dtype=xdt)
+        check(lib.apertis_dropout_bwd(ptr(g), ptr(dx), g.numel(), p, seed, dtype_code(g), dtype_code(dx), stream_ptr()),
+              "apertis_dropout_bwd")
+        return dx, g, None, None
+
+
+def dropout_add(x, residual, p, training):
+    """residual + dropout(x) (reference core.py:836-837, 918-919) in one kernel; the backward regenerates
+    the mask from the seed.  x: block output (compute dtype), residual: the fp32 stream."""
+    p = float(p) if training else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    return _DropoutAdd.apply(x, residual, p, seed)
+
+
 class _SsmGate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, xc, z, D):

@@ -121,6 +121,14 @@ int apertis_ssm_gate_bwd(const void *dout, int64_t dout_rs, const void *y, int64
                          int dtype_io, void *stream);
 int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn);
 
+/* Residual + dropout of every sub-block (core.py:836-837, 918-919): y = res + keep/(1-p) * x over
+ * n elements (n % 4 == 0); mask = counter hash of (seed, element index).  Backward: dx = keep/(1-p)*g
+ * (the residual's gradient is g itself). */
+int apertis_dropout_add_fwd(const void *x, const void *res, void *y, int64_t n, float drop_p,
+                            uint64_t seed, int dtype_x, int dtype_res, void *stream);
+int apertis_dropout_bwd(const void *g, void *dx, int64_t n, float drop_p, uint64_t seed,
+                        int dtype_g, int dtype_x, void *stream);
+
 /* Depthwise causal conv1d (k taps, left pad k-1, keep first L) + SiLU on token-major data
  * (replaces core.py:368-375: transpose -> nn.Conv1d(groups=Dn, padding=k-1)[:, :, :L] ->
  * transpose -> F.silu).  x,out: [B,L,Dn] with row strides; w: [Dn,k] fp32; bias: [Dn] fp32. */

@@ -344,3 +344,24 @@ def test_expert_mlp_fused_backward(dev, dt, sizes, H, I):
     a = run(fused, 0.0, 0)
     for u, v, n in zip(a, [yref, xr.grad, W1.grad, B1.grad, W2.grad, B2.grad], ["y", "dx", "dw1", "db1", "dw2", "db2"]):
         _close(u, v, f"fused vs torch {n}", **(tol if dt == torch.float32 else dict(rtol=5e-2, atol_scale=3e-2)))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dropout_add(dev, dt):
+    from apertis_llm_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(1000, 704, device=dev).to(dt).requires_grad_(True)
+    res = torch.randn(1000, 704, device=dev, requires_grad=True)
+    y0 = ops.dropout_add(x, res, 0.1, training=False)
+    _close(y0, (res.float() + x.float()).cpu(), "eval = plain add", rtol=1e-6)
+    torch.manual_seed(5)
+    y = ops.dropout_add(x, res, 0.1, training=True)
+    d = (y - res).detach()
+    kept = d != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - 0.9) < 0.01, frac
+    _close(d[kept], (x.detach().float() / 0.9)[kept].cpu(), "kept values scaled", rtol=1e-5)
+    g = torch.randn_like(y)
+    y.backward(g)
+    assert torch.equal(res.grad, g)
+    _close(x.grad.float(), (g * kept.float() / 0.9).to(dt).float().cpu(), "dx uses the same mask", rtol=1e-5)
