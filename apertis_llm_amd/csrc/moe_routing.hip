@@ -780,6 +780,158 @@ ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__r
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Router projection: y[T,N] = x[T,K] W[N,K]^T + b, N <= 16 (reference core.py:430,482: H -> num_experts).
+// A GEMM library spends ~115 us on this 0.4 GFLOP product (N=8); it is a bandwidth problem: one
+// wave per row, the weight matrix lives in registers, N dot products are finished with wave
+// reductions.  Backward: dx = dy W (row kernel), dW/db = per-wave register sums over 8 rows ->
+// block partials -> fixed-order fold.
+// ------------------------------------------------------------------------------------------
+constexpr int SK_MAXN = 16;
+
+template <typename TX, int IT, int NN>
+__global__ void __launch_bounds__(256)
+skinny_fwd_k(const TX *__restrict__ x, const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ y,
+             int64_t T, int K) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  float4 w[NN][IT];
+#pragma unroll
+  for (int n = 0; n < NN; ++n)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      w[n][i] = c < K ? load4<float>(W + (int64_t)n * K + c) : make_float4(0, 0, 0, 0);
+    }
+  for (int64_t r = wave; r < T; r += nw) {
+    float4 xv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      xv[i] = c < K ? load4<TX>(x + r * K + c) : make_float4(0, 0, 0, 0);
+    }
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) a += (xv[i].x * w[n][i].x + xv[i].y * w[n][i].y) + (xv[i].z * w[n][i].z + xv[i].w * w[n][i].w);
+      acc[n] = wave_sum(a);
+    }
+    if (lane < NN) {
+      float v = 0.f;
+#pragma unroll
+      for (int n = 0; n < NN; ++n) if (lane == n) v = acc[n];
+      y[r * NN + lane] = v + (b ? b[lane] : 0.f);
+    }
+  }
+}
+
+template <typename TX, int IT, int NN>
+__global__ void __launch_bounds__(256)
+skinny_bwd_k(const TX *__restrict__ x, const float *__restrict__ W, const float *__restrict__ dy, TX *__restrict__ dx,
+             float *__restrict__ part, int64_t T, int K) {
+  // part: [gridDim.x][NN*K + NN] per-block partial sums of dW (row-major [NN][K]) then db
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *red = reinterpret_cast<float4 *>(smem);   // [3 waves][NN][K/4]
+  __shared__ float redb[4][SK_MAXN];
+  constexpr int RPW = 8;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * RPW, r1 = min(r0 + RPW, T);
+  float4 w[NN][IT], aw[NN][IT];
+  float abias[NN];
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    abias[n] = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      w[n][i] = c < K ? load4<float>(W + (int64_t)n * K + c) : make_float4(0, 0, 0, 0);
+      aw[n][i] = make_float4(0, 0, 0, 0);
+    }
+  }
+  for (int64_t r = r0; r < r1; ++r) {
+    float g[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) g[n] = dy[r * NN + n];   // same address in every lane: one broadcast load
+    float4 xv[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      xv[i] = c < K ? load4<TX>(x + r * K + c) : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      float4 d = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        d.x += g[n] * w[n][i].x; d.y += g[n] * w[n][i].y; d.z += g[n] * w[n][i].z; d.w += g[n] * w[n][i].w;
+        aw[n][i].x += g[n] * xv[i].x; aw[n][i].y += g[n] * xv[i].y; aw[n][i].z += g[n] * xv[i].z; aw[n][i].w += g[n] * xv[i].w;
+      }
+      if (c < K) store4<TX>(dx + r * K + c, d);
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) abias[n] += g[n];
+  }
+  const int Q = K / 4;
+  if (wv > 0) {
+#pragma unroll
+    for (int n = 0; n < NN; ++n)
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        int cq = lane + 64 * i;
+        if (cq < Q) red[((wv - 1) * NN + n) * Q + cq] = aw[n][i];
+      }
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int n = 0; n < NN; ++n) redb[wv][n] = abias[n];
+  __syncthreads();
+  float *dst = part + (int64_t)blockIdx.x * (NN * K + NN);
+  if (wv == 0) {
+#pragma unroll
+    for (int n = 0; n < NN; ++n)
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        int cq = lane + 64 * i;
+        if (cq < Q) {
+          float4 a = aw[n][i];
+          for (int w_ = 0; w_ < 3; ++w_) {
+            float4 u = red[(w_ * NN + n) * Q + cq];
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+          }
+          *reinterpret_cast<float4 *>(dst + (int64_t)n * K + cq * 4) = a;
+        }
+      }
+    if (lane < NN) dst[NN * K + lane] = (redb[0][lane] + redb[1][lane]) + (redb[2][lane] + redb[3][lane]);
+  }
+}
+
+// out[c] = sum_r part[r][c] for c < cols (fixed order)
+__global__ void __launch_bounds__(1024)
+fold_rows_k(const float *__restrict__ part, float *__restrict__ out, int64_t nrows, int64_t cols) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (c < cols) {
+    int64_t w = seg;
+    for (; w + 48 < nrows; w += 64)
+      s += (part[w * cols + c] + part[(w + 16) * cols + c]) + (part[(w + 32) * cols + c] + part[(w + 48) * cols + c]);
+    for (; w < nrows; w += 16) s += part[w * cols + c];
+  }
+  red[seg][lane] = s;
+  __syncthreads();
+  if (seg == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][lane];
+    out[c] = t;
+  }
+}
+
 int check_H(int64_t H) { return (H > 0 && H % 4 == 0 && H <= 256 * 16) ? APERTIS_OK : APERTIS_ERR_UNSUPPORTED; }
 
 }  // namespace
@@ -967,5 +1119,62 @@ extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const fl
       (const TA *)x, gamma, mean, rstd, (const TB *)dy, (TA *)dx, part, T, (int)H)));
   hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(1024), 0, st, part, dgamma, dbeta, nblk,
                      (int)H);
+  return apertis_check_launch();
+}
+
+// dispatch on (N, IT): N in {2,4,8,16} compile-time; other N <= 16 are padded by the caller
+#define SKINNY_N(N_, ...)                                              \
+  do {                                                                 \
+    if ((N_) == 2) { constexpr int NN = 2; __VA_ARGS__; }              \
+    else if ((N_) == 4) { constexpr int NN = 4; __VA_ARGS__; }         \
+    else if ((N_) == 8) { constexpr int NN = 8; __VA_ARGS__; }         \
+    else if ((N_) == 16) { constexpr int NN = 16; __VA_ARGS__; }       \
+    else return APERTIS_ERR_UNSUPPORTED;                               \
+  } while (0)
+#define SKINNY_IT(K_, ...)                                             \
+  do {                                                                 \
+    int it_ = (int)ceil_div64((K_), 256);                              \
+    if (it_ <= 1) { constexpr int IT = 1; __VA_ARGS__; }               \
+    else if (it_ <= 2) { constexpr int IT = 2; __VA_ARGS__; }          \
+    else if (it_ <= 3) { constexpr int IT = 3; __VA_ARGS__; }          \
+    else if (it_ <= 4) { constexpr int IT = 4; __VA_ARGS__; }          \
+    else return APERTIS_ERR_UNSUPPORTED;                               \
+  } while (0)
+
+extern "C" int64_t apertis_skinny_linear_bwd_blocks(int64_t T) { return ceil_div64(T > 0 ? T : 1, 32); }
+
+extern "C" int apertis_skinny_linear_fwd(const void *x, const float *W, const float *b, float *y, int64_t T, int64_t K,
+                                         int64_t N, int dtype_x, void *stream) {
+  if (!x || !W || !y || T < 0) return APERTIS_ERR_ARG;
+  if (K <= 0 || K % 4 || K > 1024 || N < 1 || N > SK_MAXN) return APERTIS_ERR_UNSUPPORTED;
+  if (N > 8 && K > 256) return APERTIS_ERR_UNSUPPORTED;   // register budget: N*K/64 weight words per lane
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(T, 8), 4096)), block(256);
+  if (dtype_x == APERTIS_BF16) {
+    SKINNY_N(N, SKINNY_IT(K, hipLaunchKernelGGL((skinny_fwd_k<bf16_t, IT, NN>), grid, block, 0, st, (const bf16_t *)x, W, b, y, T, (int)K)));
+  } else if (dtype_x == APERTIS_F32) {
+    SKINNY_N(N, SKINNY_IT(K, hipLaunchKernelGGL((skinny_fwd_k<float, IT, NN>), grid, block, 0, st, (const float *)x, W, b, y, T, (int)K)));
+  } else return APERTIS_ERR_ARG;
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_skinny_linear_bwd(const void *x, const float *W, const float *dy, void *dx, float *part,
+                                         float *dW_db, int64_t T, int64_t K, int64_t N, int dtype_x, void *stream) {
+  // part: workspace [apertis_skinny_linear_bwd_blocks(T)][N*K + N]; dW_db: out [N*K + N] (dW then db)
+  if (!x || !W || !dy || !dx || !part || !dW_db || T < 0) return APERTIS_ERR_ARG;
+  if (K <= 0 || K % 4 || K > 1024 || N < 1 || N > SK_MAXN) return APERTIS_ERR_UNSUPPORTED;
+  if (N > 8 && K > 256) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = apertis_skinny_linear_bwd_blocks(T);
+  dim3 grid((unsigned)nblk), block(256);
+  const size_t lds = 3 * (size_t)N * K * sizeof(float);
+  if (dtype_x == APERTIS_BF16) {
+    SKINNY_N(N, SKINNY_IT(K, hipLaunchKernelGGL((skinny_bwd_k<bf16_t, IT, NN>), grid, block, lds, st, (const bf16_t *)x, W, dy, (bf16_t *)dx, part, T, (int)K)));
+  } else if (dtype_x == APERTIS_F32) {
+    SKINNY_N(N, SKINNY_IT(K, hipLaunchKernelGGL((skinny_bwd_k<float, IT, NN>), grid, block, lds, st, (const float *)x, W, dy, (float *)dx, part, T, (int)K)));
+  } else return APERTIS_ERR_ARG;
+  const int64_t cols = N * K + N;
+  hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, dW_db, nblk, cols);
   return apertis_check_launch();
 }

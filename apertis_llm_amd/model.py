@@ -365,7 +365,11 @@ class AdaptiveExpertSystem(nn.Module):
         B, L, H = hidden_states.shape
         S, E, K = B * L, self.num_experts, self.experts_per_token
         xf = hidden_states.reshape(S, H)
-        logits = self.router(self.router_norm(xf)).float()                                # core.py:481-482
+        xn = self.router_norm(xf)                                                         # core.py:481
+        if xn.is_cuda and ops.skinny_linear_supported(H, E):
+            logits = ops.skinny_linear(xn, self.router.weight, self.router.bias)          # core.py:482 (fp32 out)
+        else:
+            logits = self.router(xn).float()
         if self.use_noisy_top_k_routing and self.training:                                # core.py:485-488
             logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
         gates, idx, w = ops.moe_gate_topk(logits, K)                                      # core.py:491-492,529

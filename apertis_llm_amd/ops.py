@@ -358,6 +358,50 @@ def moe_gate_topk(logits, K):
     return _GateTopK.apply(logits, K)
 
 
+class _SkinnyLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, weight, bias)
+        lib = _lib.load()
+        x = x.contiguous()
+        T, K = x.shape
+        N = weight.shape[0]
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty(T, N, device=x.device, dtype=torch.float32)
+        check(lib.apertis_skinny_linear_fwd(ptr(x), ptr(w), ptr(b), ptr(y), T, K, N, dtype_code(x), stream_ptr()),
+              "apertis_skinny_linear_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        T, K = x.shape
+        N = w.shape[0]
+        dy = dy.float().contiguous()
+        dx = torch.empty_like(x)
+        nblk = lib.apertis_skinny_linear_bwd_blocks(T)
+        part = torch.empty(nblk, N * K + N, device=x.device, dtype=torch.float32)
+        out = torch.empty(N * K + N, device=x.device, dtype=torch.float32)
+        check(lib.apertis_skinny_linear_bwd(ptr(x), ptr(w), ptr(dy), ptr(dx), ptr(part), ptr(out), T, K, N, dtype_code(x),
+                                            stream_ptr()), "apertis_skinny_linear_bwd")
+        wdt, bdt = ctx.cfg
+        return dx, out[:N * K].reshape(N, K).to(wdt), (out[N * K:].to(bdt) if bdt is not None else None)
+
+
+def skinny_linear_supported(K, N):
+    return N in (2, 4, 8, 16) and K % 4 == 0 and K <= 1024 and (N <= 8 or K <= 256)
+
+
+def skinny_linear(x, weight, bias=None):
+    """fp32 y = x @ W.T + b for a handful of output columns (the MoE router, reference core.py:482):
+    bandwidth-bound row kernel instead of a GEMM-library call."""
+    return _SkinnyLinear.apply(x, weight, bias)
+
+
 class MoePlan:
     """Device-side dispatch plan (reference core.py:547-591), canonical expert-major order."""
     __slots__ = ("offsets", "row_token", "row_k", "slot_of", "S", "E", "K", "max_rows")

@@ -158,6 +158,17 @@ int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx, const floa
                               const float *dgates, float *dlogits,
                               int64_t S, int64_t E, int64_t K, void *stream);
 
+/* Router projection y[T,N] = x[T,K] W[N,K]^T + b for N in {2,4,8,16}, K % 4 == 0, K <= 1024
+ * (core.py:430,482: Linear(hidden -> num_experts)); fp32 weights/outputs, x fp32 or bf16.
+ * Backward: dx [T,K] in x's dtype, dW_db = [N*K dW | N db] fp32; part = workspace
+ * [apertis_skinny_linear_bwd_blocks(T), N*K+N] fp32 (deterministic fold). */
+int apertis_skinny_linear_fwd(const void *x, const float *W, const float *b, float *y, int64_t T,
+                              int64_t K, int64_t N, int dtype_x, void *stream);
+int apertis_skinny_linear_bwd(const void *x, const float *W, const float *dy, void *dx,
+                              float *part, float *dW_db, int64_t T, int64_t K, int64_t N,
+                              int dtype_x, void *stream);
+int64_t apertis_skinny_linear_bwd_blocks(int64_t T);
+
 /* ------------------------------------------------------------------------------------------
  * MoE dispatch plan  (replaces the K x E Python loop core.py:547-591: nonzero / capacity /
  * overflow top-n by gate weight).  Canonical row order: expert-major, then k, then token

@@ -365,3 +365,23 @@ def test_dropout_add(dev, dt):
     y.backward(g)
     assert torch.equal(res.grad, g)
     _close(x.grad.float(), (g * kept.float() / 0.9).to(dt).float().cpu(), "dx uses the same mask", rtol=1e-5)
+
+
+@pytest.mark.parametrize("T,K,N,dt", [(1000, 704, 8, torch.bfloat16), (333, 32, 4, torch.float32), (4097, 256, 16, torch.float32),
+                                      (50, 1024, 2, torch.float32)])
+def test_skinny_linear(dev, T, K, N, dt):
+    from apertis_llm_amd import ops
+    torch.manual_seed(T)
+    x, W, b = torch.randn(T, K).to(dt), torch.randn(N, K) / K ** 0.5, torch.randn(N)
+    dy = torch.randn(T, N)
+    xd, Wd, bd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y = ops.skinny_linear(xd, Wd, bd)
+    assert y.dtype == torch.float32
+    y.backward(dy.to(dev))
+    xr, Wr, br = x.double().requires_grad_(True), W.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.linear(xr, Wr, br)
+    ref.backward(dy.double())
+    _close(y, ref, "y", rtol=1e-4, atol_scale=1e-5)
+    _close(xd.grad, xr.grad, "dx", **(dict(rtol=1e-4, atol_scale=1e-5) if dt == torch.float32 else dict(rtol=1e-2, atol_scale=8e-3)))
+    _close(Wd.grad, Wr.grad, "dW", rtol=1e-4, atol_scale=1e-5)
+    _close(bd.grad, br.grad, "db", rtol=1e-4, atol_scale=1e-5)
