@@ -42,6 +42,9 @@ class BucketedDataParallel(nn.Module):
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reduce_dtype = reduce_dtype
         self._sync = True
+        self._warned_partial = False
+        import os as _os
+        self._force = _os.environ.get("APERTIS_FORCE_DP") == "1"
         params = [p for p in module.parameters() if p.requires_grad]
         self.device = params[0].device
         self._cuda = self.device.type == "cuda"
@@ -95,7 +98,7 @@ class BucketedDataParallel(nn.Module):
                     view.copy_(p.grad)
                 p.grad = view
             b.pending -= 1
-            if b.pending == 0 and self._sync and self.world_size > 1:
+            if b.pending == 0 and self._sync and (self.world_size > 1 or self._force):
                 self._launch(b)
         return hook
 
@@ -123,12 +126,16 @@ class BucketedDataParallel(nn.Module):
 
     def finish(self):
         """Call after backward(), before clipping / optimizer.step(): waits for the reductions."""
-        if self.world_size > 1 and self._sync:
+        if (self.world_size > 1 or self._force) and self._sync:
             for b in self.buckets:
-                if b.pending != 0 and b.pending != len(b.params):
-                    raise RuntimeError("a gradient bucket is partially filled: some parameter received no gradient "
-                                       "(find_unused_parameters=False semantics, reference pipeline.py:463)")
-                if b.pending == len(b.params):   # nothing arrived (e.g. frozen sub-module): still reduce zeros
+                if b.pending != 0:
+                    # some parameter of this bucket received no gradient this step (e.g. the vision tower
+                    # on a text-only batch): its slice of the flat buffer is still zero, reduce it as is
+                    if b.pending != len(b.params) and not self._warned_partial:
+                        self._warned_partial = True
+                        import warnings
+                        warnings.warn("BucketedDataParallel: a bucket was reduced with parameters that got no "
+                                      "gradient this step (their gradients are zeros)")
                     self._launch(b)
             if self._cuda:
                 torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)

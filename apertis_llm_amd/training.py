@@ -9,6 +9,7 @@ needs no loss scaling), and gradients are reduced once per optimizer step (DDP i
 reduces on every micro-step; the results are identical).
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -34,7 +35,9 @@ class TrainStep:
     def __init__(self, model, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0, total_steps=1000, bf16=True,
                  gradient_accumulation_steps=1, bucket_bytes=128 << 20, reduce_dtype=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
-        self.dp = BucketedDataParallel(model, bucket_bytes=bucket_bytes, reduce_dtype=reduce_dtype) if self.world > 1 else None
+        force = os.environ.get("APERTIS_FORCE_DP") == "1" and dist.is_initialized()   # exercise the DP path at world 1
+        self.dp = (BucketedDataParallel(model, bucket_bytes=bucket_bytes, reduce_dtype=reduce_dtype)
+                   if (self.world > 1 or force) else None)
         self.model = model
         self.optimizer = build_optimizer(model, lr, weight_decay)
         total_steps = max(int(total_steps), 2)
