@@ -22,6 +22,7 @@
 // the MFMAs of the current one: one barrier per K step).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -492,6 +493,228 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
   flush_tile(C, mul_pre);
 }
 
+// ------------------------------------------------------------------------------------------
+// Persistent 256 x 256 NT kernel.  grouped_gemm_nt256_k spends 39 us per K=704 tile, ~24 in the K
+// loop: every CU ends its K loop at the same time, so a round's epilogue is one chip-wide burst of
+// output stores with the matrix pipes idle, and the K loops run with HBM idle.  Here one work-group
+// per CU walks its tiles and the output stores drain under the next tile's MFMAs.  vmcnt retires in
+// order, so a wave that has stores in flight cannot wait for a younger LDS-DMA without also waiting
+// for the stores; the roles are therefore split by wave: waves 4-7 ("store waves") issue all output
+// stores of a tile and then sit out the DMA for the first `solo` K steps of the next tile (waves
+// 0-3 issue 16 pieces each instead of 8), never waiting on vmcnt meanwhile; at step `solo` they
+// drain and rejoin.  The next tile's step-0 DMA is issued (by waves 0-3) BEFORE the epilogue, so
+// the per-tile prologue latency disappears as well.  The epilogue converts the accumulators and
+// stages them through ring buffer 1 in two 128-row halves.
+// ------------------------------------------------------------------------------------------
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+struct PTile { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
+
+// raw = the pre-activation pass, r = round; ACT >= 0 fixes the activation and DROP the dropout at
+// compile time (a per-value runtime switch costs more than the conversion itself), ACT < 0 = runtime
+template <typename TO, bool raw, int r, int ACT, bool DROP>
+__device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst,
+                                                const TO *__restrict__ mul_pre, char *stg, const PTile &cur, int N, int act,
+                                                float drop_p, uint64_t seed, float keep_scale, uint32_t thresh16, int tid,
+                                                int wm, int wn, int frow, int fg) {
+  static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
+  // two rounds through the 64 KiB of ring buffer 1: round r carries the m-subtiles j in [4r, 4r+4) of
+  // BOTH wave rows, i.e. 128 tile rows x 512 B, 16-byte chunks XOR-swizzled with the row (no padding
+  // left in the buffer); every wave converts in every round, the store waves issue 16 stores per thread
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = r * 4 + jj;
+        const int srow = wm * 64 + jj * 16 + frow, m = wm * 128 + j * 16 + frow;
+        const int chunk = wn * 8 + i * 2 + (fg >> 1);
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = acc[i][j][q];
+          asm volatile("" : "+v"(a));   // pins the conversion inside its round
+          float v = a + bv[i][q];
+          if (!raw && (ACT >= 0 || !mul_pre)) {
+            if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(from_f32<TO>(v)), ACT >= 0 ? ACT : act);
+            if (ACT >= 0 ? DROP : drop_p > 0.f)
+              v = drop_keep(seed, cur.row0 + m, cur.n0 + wn * 64 + i * 16 + fg * 4 + q, N, thresh16) ? v * keep_scale : 0.f;
+          }
+          o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(v));
+        }
+        *reinterpret_cast<uint2 *>(stg + srow * 512 + ((chunk ^ frow) << 4) + (fg & 1) * 8) =
+            make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+      }
+    __syncthreads();
+    if (tid >= NT2 / 2) {   // store waves
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int c4 = it * (NT2 / 2) + tid - NT2 / 2;
+      const int srow = c4 >> 5, c = c4 & 31;
+      const int row = (srow >> 6) * 128 + (r * 4 + ((srow >> 4) & 3)) * 16 + (srow & 15);
+      const int ncol = c * 8;
+      if (row < cur.rows_valid && ncol < cur.cols_valid) {
+        const int64_t g = (cur.row0 + row) * N + cur.n0 + ncol;
+        uint4 v = *reinterpret_cast<const uint4 *>(stg + srow * 512 + ((c ^ (srow & 15)) << 4));
+        if (ACT < 0 && mul_pre && !raw)
+          v = actbwd_chunk<TO, true>(v, *reinterpret_cast<const uint4 *>(mul_pre + g), cur.row0 + row, cur.n0 + ncol, N, act,
+                                     drop_p, seed, keep_scale, thresh16);
+        *reinterpret_cast<uint4 *>(dst + g) = v;
+      }
+    }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(NT2)
+grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                      const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
+                      const TO *__restrict__ mul_pre, int N, int K, int E, int n_tiles, int total_tiles, int solo,
+                      int act, float drop_p, uint64_t seed) {
+  typedef bf16_t T;
+  typedef bf16x8 frag;
+  constexpr int BK = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *stg = smem + 2 * TILE2_BYTES;                // ring buffer 1 doubles as the C staging area
+  int32_t *s_off = reinterpret_cast<int32_t *>(smem + 4 * TILE2_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int G = gridDim.x;
+  for (int i = tid; i <= E; i += NT2) s_off[i] = offsets[i];
+  __syncthreads();
+
+  // the valid tiles are the first n_valid of the launch grid's (m-tile, n-tile) enumeration
+  int mt_valid = 0;
+  for (int e = 0; e < E; ++e) mt_valid += (s_off[e + 1] - s_off[e] + BM2 - 1) / BM2;
+  const int n_valid = __builtin_amdgcn_readfirstlane(min(total_tiles, mt_valid * n_tiles));
+
+  const int nk = K / BK;
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+
+  f32x4 acc[4][8];
+  PTile cur; cur.valid = 0; cur.e = 0; cur.rows_valid = 0; cur.n0 = 0; cur.cols_valid = 0; cur.row0 = 0;
+  // one pass of this loop = [find + prefetch tile i] [epilogue of tile i-1] [K loop of tile i]; every
+  // piece of code has a single call site
+  for (int t = blockIdx.x;; t += G) {
+    PTile nxt; nxt.valid = 0;
+    if (t < n_valid) {
+      const int r = t / G, within = t - r * G, gr = min(G, n_valid - r * G);
+      const int tile = r * G + xcd_remap(within, gr);
+      const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
+      int accm = 0;
+      for (int e = 0; e < E; ++e) {
+        const int r0 = s_off[e], r1 = s_off[e + 1];
+        const int nt = (r1 - r0 + BM2 - 1) / BM2;
+        if (mt < accm + nt) {
+          const int m0 = (mt - accm) * BM2;
+          // wave-uniform by construction: pin the fields to SGPRs (LDS loads land in VGPRs)
+          nxt.valid = 1;
+          nxt.e = __builtin_amdgcn_readfirstlane(e);
+          nxt.row0 = (int64_t)__builtin_amdgcn_readfirstlane(r0 + m0);
+          nxt.rows_valid = __builtin_amdgcn_readfirstlane(min(BM2, r1 - r0 - m0));
+          nxt.n0 = __builtin_amdgcn_readfirstlane(ntile * BN2);
+          nxt.cols_valid = __builtin_amdgcn_readfirstlane(min(BN2, N - ntile * BN2));
+          break;
+        }
+        accm += nt;
+      }
+    }
+    // the next tile's first DMA goes out before the previous tile's outputs are touched.  Operands
+    // come through raw buffer descriptors sized to the tile's valid rows: the hardware bounds check
+    // zero-fills ragged rows, and a piece's address is one per-lane VGPR (row-in-piece and swizzled
+    // 16-byte chunk, identical for all pieces) + a scalar piece/K-step offset
+    const int ldb = K * (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(X + nxt.row0 * K), 0, nxt.rows_valid * ldb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(W + ((int64_t)nxt.e * N + nxt.n0) * K), 0, nxt.cols_valid * ldb, 0x00020000);
+    const int voff0 = (lane >> 3) * ldb + (((lane & 7) ^ (lane >> 3)) << 4);
+    auto piece = [&](char *xs, int p, int kt) {   // 8 rows x 128 B of both operands
+      const int voff = voff0 + p * 8 * ldb;       // in the VGPR: the range check ignores the scalar offset
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(xs + p * 1024), 16, voff,
+                                               kt * BK * (int)sizeof(T), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(xs + TILE2_BYTES + p * 1024), 16,
+                                               voff, kt * BK * (int)sizeof(T), 0, 0);
+    };
+    // K step kt's operands (32 + 32 pieces): by waves 0-3 alone while kt <= solo
+    auto stage = [&](int buf, int kt) {
+      char *xs = smem + buf * 2 * TILE2_BYTES;
+      if (kt > solo) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) piece(xs, wave * 4 + j, kt);
+      } else if (wave < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) piece(xs, wave * 8 + j, kt);
+      }
+    };
+    if (nxt.valid) stage(0, 0);
+
+    if (cur.valid) {   // epilogue of the previous tile, staged through ring buffer 1
+      float bv[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int n = cur.n0 + wn * 64 + i * 16 + fg * 4 + r;
+          bv[i][r] = (bias && n < N) ? bias[(int64_t)cur.e * N + n] : 0.f;
+        }
+#define OUT_ROUND(RAW, R, A, D, DST) \
+  nt256p_out_round<TO, RAW, R, A, D>(acc, bv, DST, mul_pre, stg, cur, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
+#define OUT_PASS(A, D) { OUT_ROUND(false, 0, A, D, C); OUT_ROUND(false, 1, A, D, C); }
+      if (pre_act) { OUT_ROUND(true, 0, APERTIS_ACT_NONE, false, pre_act); OUT_ROUND(true, 1, APERTIS_ACT_NONE, false, pre_act); }
+      if (mul_pre) OUT_PASS(-1, false)
+      else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT_PASS(APERTIS_ACT_NONE, false)
+      else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT_PASS(APERTIS_ACT_GELU, true)
+      else if (act == APERTIS_ACT_GELU) OUT_PASS(APERTIS_ACT_GELU, false)
+      else OUT_PASS(-1, false)
+#undef OUT_PASS
+#undef OUT_ROUND
+    }
+    if (!nxt.valid) break;
+    cur = nxt;
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      // the wave's share of step kt's DMA has landed; a store wave has none while kt <= solo and
+      // must not wait there (its output stores are still draining)
+      if (wave < 4 || kt > solo) wait_vmcnt<0>();
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      const char *xs = smem + (kt & 1) * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        frag wf[4], xf[8];
+        const int chunk = kk * 4 + fg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int wrow = wn * 64 + i * 16 + frow;
+          wf[i] = *reinterpret_cast<const frag *>(ws + wrow * ROWB + ((chunk ^ (wrow & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int xrow = wm * 128 + j * 16 + frow;
+          xf[j] = *reinterpret_cast<const frag *>(xs + xrow * ROWB + ((chunk ^ (xrow & 7)) << 4));
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) mma(acc[i][j], wf[i], xf[j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    __syncthreads();   // every wave is done with both ring buffers
+  }
+}
+
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
 template <typename T>
 __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict__ pre, T *__restrict__ dpre,
@@ -851,6 +1074,22 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     if (K % 64 == 0 && N >= 512 && max_rows >= 4096 && !getenv("APERTIS_GEMM_TILE128")) {
       const int nt2 = (int)ceil_div64(N, BN2);
       const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;
+      if (!getenv("APERTIS_GEMM_NT256_V1") && E <= 1024 && grid2 < 0x7fffffffLL) {
+        static const int ncu = [] {   // queried once: hipGetDeviceProperties costs ~1 ms of host time per call
+          int n = 256, dev_id = 0;
+          if (hipGetDevice(&dev_id) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id);
+          return n > 0 ? n : 256;
+        }();
+        const int gp = (int)std::min<int64_t>(grid2, ncu);          // one persistent work-group per CU
+        size_t ldsp = 4 * TILE2_BYTES + 4096 + 16;                   // ring + group offsets
+        static const int solo = getenv("APERTIS_GEMM_SOLO") ? atoi(getenv("APERTIS_GEMM_SOLO")) : 4;
+        auto kp = grouped_gemm_nt256p_k<TO>;
+        hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
+        hipLaunchKernelGGL(kp, dim3((unsigned)gp), dim3(NT2), ldsp, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
+                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, nt2, (int)grid2, solo, act,
+                           drop_p, seed);
+        return apertis_check_launch();
+      }
       size_t lds2 = std::max<size_t>(4 * TILE2_BYTES, (size_t)BM2 * (BN2 * sizeof(TO) + 16));
       auto k2 = grouped_gemm_nt256_k<TO>;
       hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
