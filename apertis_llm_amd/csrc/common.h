@@ -46,4 +46,18 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, int64_t row, int64_t co
   return r16 >= thresh16;
 }
 
+// the same mask for 4 consecutive elements starting at a linear index that is a multiple of 4:
+// two hashes instead of four
+__device__ __forceinline__ uint32_t drop_hash_pair(uint64_t seed, uint64_t pair) {
+  uint32_t h = (uint32_t)pair ^ (uint32_t)seed;
+  h += (uint32_t)(pair >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32);
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ void drop_keep4(uint64_t seed, uint64_t lin0, uint32_t thresh16, bool (&keep)[4]) {
+  const uint32_t h0 = drop_hash_pair(seed, lin0 >> 1), h1 = drop_hash_pair(seed, (lin0 >> 1) + 1);
+  keep[0] = (h0 & 0xffffu) >= thresh16; keep[1] = (h0 >> 16) >= thresh16;
+  keep[2] = (h1 & 0xffffu) >= thresh16; keep[3] = (h1 >> 16) >= thresh16;
+}
+
 #define LOG2E_F 1.4426950408889634f

@@ -73,9 +73,25 @@ template <bool FAST> __device__ __forceinline__ float exp_t(float x) {
   else return expf(x);
 }
 
+// gelu(x) = x * Phi(x) with the same 7.1.26 erf, folded: with u = |x|/sqrt2, t = 1/(1 + p*u),
+// erfc(u) = poly(t) * t * exp(-u^2), so gelu = max(x,0) - |x| * (poly/2)(t) * t * exp2(-x^2 * log2e/2)
+// (13 VALU ops, two of them transcendental, instead of ~20)
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * LOG2E_F));
+  return fmaf(-ax, p * t * e, fmaxf(x, 0.f));
+}
+
 template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
-    case APERTIS_ACT_GELU: return 0.5f * x * (1.f + erf_t<FAST>(x * 0.70710678118654752f));
+    case APERTIS_ACT_GELU:
+      if constexpr (FAST) return gelu_fast(x);
+      else return 0.5f * x * (1.f + erf_t<FAST>(x * 0.70710678118654752f));
     case APERTIS_ACT_RELU: return x > 0.f ? x : 0.f;
     case APERTIS_ACT_SILU: return x / (1.f + exp_t<FAST>(-x));
     default: return x;
@@ -530,6 +546,9 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
         const int srow = wm * 64 + jj * 16 + frow, m = wm * 128 + j * 16 + frow;
         const int chunk = wn * 8 + i * 2 + (fg >> 1);
         uint32_t o[4];
+        bool keep[4] = {true, true, true, true};
+        if (!raw && (ACT >= 0 ? DROP : (!mul_pre && drop_p > 0.f)))
+          drop_keep4(seed, (uint64_t)(cur.row0 + m) * (uint64_t)N + (uint64_t)(cur.n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float a = acc[i][j][q];
@@ -537,8 +556,7 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
           float v = a + bv[i][q];
           if (!raw && (ACT >= 0 || !mul_pre)) {
             if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(from_f32<TO>(v)), ACT >= 0 ? ACT : act);
-            if (ACT >= 0 ? DROP : drop_p > 0.f)
-              v = drop_keep(seed, cur.row0 + m, cur.n0 + wn * 64 + i * 16 + fg * 4 + q, N, thresh16) ? v * keep_scale : 0.f;
+            v = keep[q] ? v * keep_scale : 0.f;   // keep_scale is 1 without dropout
           }
           o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(v));
         }
@@ -1054,6 +1072,270 @@ int launch_tn2(const TnProblem &q0, const TnProblem &q1, const int32_t *offsets,
   return apertis_check_launch();
 }
 
+// ------------------------------------------------------------------------------------------
+// TN v3 (bf16): 256 x 256 output tiles, 512 threads (2(M) x 4(N) waves of 128 x 64), one persistent
+// work-group per CU.  What bounded v2 on the expert weight gradients (E=8, 2816 x 704): (a) tile
+// count quantisation - 2 x 1056 tiles of 128^2 on 512 slots is 4.1 rounds, run as 5; (b) operand
+// re-fetch - a 128^2 tile needs 64 flop per L2 byte and the 132 tiles of one (problem, expert) are
+// spread over two or three XCDs, each fetching the same rows into its own L2 (PMC: 2.4x the
+// algorithmic HBM bytes).  Here the CUs are dealt out in equal shares to the (problem, expert)
+// groups - a group's CUs are neighbours on one XCD (xcd_remap) - and a group's tiles are processed
+// in lock-step rounds of `cpg` tiles, all walking the group's rows together, so a row block is
+// fetched into that XCD's L2 once per round.  The tiles left over after the full rounds are not
+// given a round of their own: each is split along the rows into cpg/rem slices, one per CU, whose
+// partial tiles go to the caller's workspace and are summed in slice order by tn3_fold_k
+// (deterministic; no atomics).  With E=1 this is an ordinary split-K GEMM.
+// Operand images As[64 k][256 m], Bs[64 k][256 n] (512-byte k-rows) arrive by buffer_load...lds
+// through descriptors sized to the group's rows - rows past the end read as zero, so there is no
+// tail path - double-buffered (2 x 64 KiB); the transposed fragment reads and the 32-byte window
+// swizzle are v2's.  The bias gradient (column sums of A) comes from the matrix pipe as well: one
+// extra MFMA per k-block against an all-ones fragment, two m-subtiles per wave.
+// ------------------------------------------------------------------------------------------
+struct Tn3Problem {
+  const bf16_t *A, *Bm;
+  float *dW, *dbias;
+  int M, N, m_tiles, n_tiles;
+};
+struct Tn3Args {
+  Tn3Problem p0, p1;
+  int nprob, E, cpg;   // cpg = CUs (work-groups) per (problem, expert) group
+  float *ws;           // [grid][TN3_SLOT] partial tiles (+ 256 partial bias sums each)
+};
+constexpr int TN3_SLOT = 256 * 256 + 256;
+
+// the part of the schedule the GEMM and the fold kernel must agree on
+struct Tn3Sched { int T, full, rem, s; };
+__host__ __device__ inline Tn3Sched tn3_sched(int m_tiles, int n_tiles, int cpg) {
+  Tn3Sched c;
+  c.T = m_tiles * n_tiles;
+  c.full = c.T / cpg;
+  c.rem = c.T - c.full * cpg;
+  c.s = c.rem ? cpg / c.rem : 0;
+  return c;
+}
+
+__global__ void __launch_bounds__(NT2)
+grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
+  typedef bf16_t T;
+  constexpr int BKR = 64, KROWB = 512, OPB = BKR * KROWB;   // 32 KiB per operand image
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int g = id / a.cpg, j = id - g * a.cpg;
+  const bool second = g >= a.E;
+  const int e = second ? g - a.E : g;
+  const T *__restrict__ A = second ? a.p1.A : a.p0.A, *__restrict__ Bm = second ? a.p1.Bm : a.p0.Bm;
+  float *__restrict__ dW = second ? a.p1.dW : a.p0.dW, *__restrict__ dbias = second ? a.p1.dbias : a.p0.dbias;
+  const int M = second ? a.p1.M : a.p0.M, N = second ? a.p1.N : a.p0.N;
+  const int n_tiles = second ? a.p1.n_tiles : a.p0.n_tiles;
+  const Tn3Sched sc = tn3_sched(second ? a.p1.m_tiles : a.p0.m_tiles, n_tiles, a.cpg);
+  const int r_begin = offsets[e], rows = offsets[e + 1] - r_begin;
+  const int nsteps = (rows + BKR - 1) / BKR;
+  const int ldA = M * (int)sizeof(T), ldB = N * (int)sizeof(T);
+
+  // per-lane parts of the addresses.  DMA piece p (two k-rows) is handled by wave p & 7: the
+  // swizzle key of its rows, f(k) = (k&3) | ((k>>3)&1)<<2 with k = 2p + (lane>>5), then only
+  // depends on the wave and the lane
+  const int hi = lane >> 5;
+  const int chunk = (lane & 31) ^ (hi << 1) ^ ((wave & 1) << 2) ^ (((wave >> 2) & 1) << 3);
+  const uint32_t va0 = (uint32_t)(hi * ldA + chunk * 16), vb0 = (uint32_t)(hi * ldB + chunk * 16);
+  const int frow = lane & 15, fg = lane >> 4;
+  const int trow = frow >> 2, tcol4 = (frow & 3) * 4;
+  const int lane_sw = trow | ((fg & 1) << 2);
+  const int rd0 = (8 * fg + trow) * KROWB + tcol4 * 2;
+  bf16x8 ones;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ones[q] = (bf16_t)1.0f;
+  const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+
+  for (int it = 0; it <= sc.full; ++it) {
+    int tile, s0 = 0, s1 = nsteps;
+    bool partial = false;
+    if (it < sc.full) {
+      tile = it * a.cpg + j;
+    } else {
+      if (!sc.rem) break;
+      const int ri = j / sc.s;
+      if (ri >= sc.rem) break;
+      const int sl = j - ri * sc.s, per = (nsteps + sc.s - 1) / sc.s;
+      tile = sc.full * a.cpg + ri;
+      s0 = min(sl * per, nsteps);
+      s1 = min(s0 + per, nsteps);
+      partial = sc.s > 1;
+    }
+    const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+    const int m0 = mt * 256, n0 = nt * 256;
+    const bool want_bias = dbias != nullptr && nt == 0;
+    // descriptors from the tile's first column of the group's first row to the end of its last row
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(A + (int64_t)r_begin * M + m0), 0, rows > 0 ? rows * ldA - m0 * (int)sizeof(T) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(Bm + (int64_t)r_begin * N + n0), 0, rows > 0 ? rows * ldB - n0 * (int)sizeof(T) : 0, 0x00020000);
+    auto stage = [&](int buf, int step) {
+      char *as = smem + buf * 2 * OPB, *bs = as + OPB;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int p = jj * 8 + wave;
+        const uint32_t row = (uint32_t)(step * BKR + 2 * p);   // in the VGPR offset: the range check ignores the scalar one
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(as + p * 1024), 16,
+                                                 va0 + row * (uint32_t)ldA, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void *)(bs + p * 1024), 16,
+                                                 vb0 + row * (uint32_t)ldB, 0, 0, 0);
+      }
+    };
+
+    f32x4 acc[4][8];   // [n-subtile][m-subtile]
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int im = 0; im < 8; ++im) acc[jn][im] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+
+    if (s0 < s1) stage(0, s0);
+    for (int st = s0; st < s1; ++st) {
+      wait_vmcnt<0>();
+      __syncthreads();
+      if (st + 1 < s1) stage((st + 1 - s0) & 1, st + 1);
+      const char *as = smem + ((st - s0) & 1) * 2 * OPB, *bs = as + OPB;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16x8 af[8], bf[4];
+#pragma unroll
+        for (int im = 0; im < 8; ++im) {
+          union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+                as + rd0 + (((wm * 8 + im) ^ lane_sw) << 5) + (kb * 32 + 4 * hh) * KROWB));
+          af[im] = u.v;
+        }
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+          union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+                bs + rd0 + (((wn * 4 + jn) ^ lane_sw) << 5) + (kb * 32 + 4 * hh) * KROWB));
+          bf[jn] = u.v;
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+          for (int im = 0; im < 8; ++im) mma(acc[jn][im], bf[jn], af[im]);
+        if (want_bias) {
+          // this wave's two m-subtiles, picked without indexing the register array.  wn_u is in an
+          // SGPR on purpose: MFMA ignores EXEC, and hipcc drops the execz skip around a short
+          // divergent block, so an `if (lane-derived wn == ...)` here runs the MFMA in every wave
+#pragma unroll
+          for (int im = 0; im < 8; ++im)
+            if ((im >> 1) == wn_u) mma(accb[im & 1], ones, af[im]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    __syncthreads();   // the ring is free again before the next item's first DMA
+
+    // D rows = n (fg*4 + r within subtile jn), D cols = m (frow within subtile im)
+    float *out;
+    int64_t ldo;
+    bool bounded;
+    if (partial) { out = a.ws + (int64_t)id * TN3_SLOT; ldo = 256; bounded = false; }
+    else { out = dW + (int64_t)e * M * N + (int64_t)m0 * N + n0; ldo = N; bounded = true; }
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+      for (int im = 0; im < 8; ++im) {
+        const int m = wm * 128 + im * 16 + frow, n = wn * 64 + jn * 16 + fg * 4;
+        if (!bounded || (m0 + m < M && n0 + n < N)) *reinterpret_cast<f32x4 *>(out + (int64_t)m * ldo + n) = acc[jn][im];
+      }
+    if (want_bias && fg == 0) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int m = wm * 128 + (2 * wn + ii) * 16 + frow;
+        if (partial) a.ws[(int64_t)id * TN3_SLOT + 256 * 256 + m] = accb[ii][0];
+        else if (m0 + m < M) dbias[(int64_t)e * M + m0 + m] = accb[ii][0];
+      }
+    }
+  }
+}
+
+// sums the row-slices of the split tiles in slice order.  grid = (groups * max(1, cpg/2), 16)
+__global__ void __launch_bounds__(256) tn3_fold_k(Tn3Args a) {
+  const int half = max(1, a.cpg / 2);
+  const int g = blockIdx.x / half, ri = blockIdx.x - g * half;
+  const bool second = g >= a.E;
+  const int e = second ? g - a.E : g;
+  const Tn3Problem &pp = second ? a.p1 : a.p0;
+  const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, a.cpg);
+  if (ri >= sc.rem || sc.s <= 1) return;
+  const int tile = sc.full * a.cpg + ri;
+  const int mt = tile / pp.n_tiles, nt = tile - mt * pp.n_tiles;
+  const int m0 = mt * 256, n0 = nt * 256;
+  const float *src = a.ws + (int64_t)(g * a.cpg + ri * sc.s) * TN3_SLOT;
+  float *out = pp.dW + (int64_t)e * pp.M * pp.N;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = (blockIdx.y * 1024 + q * 256 + threadIdx.x) * 4;
+    const int m = idx >> 8, n = idx & 255;
+    if (m0 + m >= pp.M || n0 + n >= pp.N) continue;
+    float4 sum = *reinterpret_cast<const float4 *>(src + idx);
+    for (int sl = 1; sl < sc.s; ++sl) {
+      const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)sl * TN3_SLOT + idx);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + (int64_t)(m0 + m) * pp.N + n0 + n) = sum;
+  }
+  if (pp.dbias && nt == 0 && blockIdx.y == 0 && m0 + (int)threadIdx.x < pp.M) {
+    float sum = src[256 * 256 + threadIdx.x];
+    for (int sl = 1; sl < sc.s; ++sl) sum += src[(int64_t)sl * TN3_SLOT + 256 * 256 + threadIdx.x];
+    pp.dbias[(int64_t)e * pp.M + m0 + threadIdx.x] = sum;
+  }
+}
+
+int device_cu_count() {
+  static const int ncu = [] {   // queried once: hipGetDeviceProperties costs ~1 ms of host time per call
+    int n = 256, dev_id = 0;
+    if (hipGetDevice(&dev_id) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id);
+    return n > 0 ? n : 256;
+  }();
+  return ncu;
+}
+
+// returns APERTIS_ERR_UNSUPPORTED when the shape does not fit v3's assumptions (the caller falls back to v2)
+int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t max_rows, const int32_t *offsets, float *ws,
+               int64_t ws_bytes, hipStream_t st) {
+  const int nprob = q1 ? 2 : 1;
+  const int64_t groups = nprob * E;
+  const int ncu = device_cu_count();
+  if (!ws || groups > ncu) return APERTIS_ERR_UNSUPPORTED;
+  // short groups: a 256-row-deep slice per CU does not amortise the tile prologue/epilogue and the fold
+  if (max_rows / E < 2048 && !getenv("APERTIS_GEMM_TN_V3")) return APERTIS_ERR_UNSUPPORTED;
+  const int cpg = (int)(ncu / groups);
+  const int grid = (int)(groups * cpg);
+  if (ws_bytes < (int64_t)grid * TN3_SLOT * (int64_t)sizeof(float) || (((uintptr_t)ws) & 15)) return APERTIS_ERR_UNSUPPORTED;
+  const int64_t ldmax = std::max<int64_t>(std::max(q0.M, q0.N), q1 ? std::max(q1->M, q1->N) : 0) * 2;
+  if ((max_rows + 256) * ldmax >= 0xffffffffLL) return APERTIS_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  Tn3Args a;
+  a.p0 = q0;
+  a.p1 = q1 ? *q1 : Tn3Problem{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  a.nprob = nprob; a.E = (int)E; a.cpg = cpg; a.ws = ws;
+  const size_t lds = 4 * 64 * 512;
+  hipFuncSetAttribute((const void *)grouped_gemm_tn3_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(grouped_gemm_tn3_k, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
+  bool split = false;
+  for (int q = 0; q < nprob; ++q) {
+    const Tn3Problem &pp = q ? a.p1 : a.p0;
+    const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, cpg);
+    split |= sc.rem && sc.s > 1;
+  }
+  if (split) hipLaunchKernelGGL(tn3_fold_k, dim3((unsigned)(groups * std::max(1, cpg / 2)), 16), dim3(256), 0, st, a);
+  return apertis_check_launch();
+}
+
 template <typename T> bool aligned16(const void *p, int64_t ld) {
   return (((uintptr_t)p) & 15) == 0 && ((ld * sizeof(T)) & 15) == 0;
 }
@@ -1075,11 +1357,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       const int nt2 = (int)ceil_div64(N, BN2);
       const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;
       if (!getenv("APERTIS_GEMM_NT256_V1") && E <= 1024 && grid2 < 0x7fffffffLL) {
-        static const int ncu = [] {   // queried once: hipGetDeviceProperties costs ~1 ms of host time per call
-          int n = 256, dev_id = 0;
-          if (hipGetDevice(&dev_id) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id);
-          return n > 0 ? n : 256;
-        }();
+        const int ncu = device_cu_count();
         const int gp = (int)std::min<int64_t>(grid2, ncu);          // one persistent work-group per CU
         size_t ldsp = 4 * TILE2_BYTES + 4096 + 16;                   // ring + group offsets
         static const int solo = getenv("APERTIS_GEMM_SOLO") ? atoi(getenv("APERTIS_GEMM_SOLO")) : 4;
@@ -1140,9 +1418,17 @@ extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float
   return APERTIS_ERR_UNSUPPORTED;
 }
 
+extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems) {
+  if (E <= 0 || n_problems < 1 || n_problems > 2) return 0;
+  const int ncu = device_cu_count();
+  const int64_t groups = E * n_problems;
+  if (groups > ncu) return 0;   // v3 does not apply; no workspace needed
+  return (ncu / groups) * groups * (int64_t)TN3_SLOT * (int64_t)sizeof(float);
+}
+
 extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets, float *dW,
-                                       float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, int dtype,
-                                       void *stream) {
+                                       float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, void *ws,
+                                       int64_t ws_bytes, int dtype, void *stream) {
   if (!A || !Bm || !offsets || !dW || max_rows < 0 || M <= 0 || N <= 0 || E <= 0) return APERTIS_ERR_ARG;
   if (M > 0x3fffffff || N > 0x3fffffff || max_rows > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -1151,6 +1437,12 @@ extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int3
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   if (dtype == APERTIS_BF16) {
     if (M % 8 || N % 8 || !aligned16<bf16_t>(A, M) || !aligned16<bf16_t>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
+    if (ws && !getenv("APERTIS_GEMM_TN_V2") && !getenv("APERTIS_GEMM_TN_V1")) {
+      Tn3Problem q{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, (int)ceil_div64(M, 256),
+                   (int)ceil_div64(N, 256)};
+      const int rc = launch_tn3(q, nullptr, E, max_rows, offsets, (float *)ws, ws_bytes, st);
+      if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
+    }
     if (!getenv("APERTIS_GEMM_TN_V1")) {
       TnProblem q0{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, m_tiles, n_tiles, (int)grid};
       TnProblem q1{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
@@ -1194,15 +1486,23 @@ extern "C" int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void
 extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, float *dbias0, int64_t M0,
                                             int64_t N0, const void *A1, const void *B1, float *dW1, float *dbias1,
                                             int64_t M1, int64_t N1, const int32_t *offsets, int64_t max_rows, int64_t E,
-                                            int dtype, void *stream) {
+                                            void *ws, int64_t ws_bytes, int dtype, void *stream) {
   if (!A0 || !B0 || !dW0 || !A1 || !B1 || !dW1 || !offsets || max_rows < 0 || E <= 0) return APERTIS_ERR_ARG;
   if (dtype != APERTIS_BF16) {   // fp32 parity path: two ordinary launches
-    int rc = apertis_grouped_gemm_tn(A0, B0, offsets, dW0, dbias0, max_rows, M0, N0, E, dtype, stream);
-    return rc ? rc : apertis_grouped_gemm_tn(A1, B1, offsets, dW1, dbias1, max_rows, M1, N1, E, dtype, stream);
+    int rc = apertis_grouped_gemm_tn(A0, B0, offsets, dW0, dbias0, max_rows, M0, N0, E, nullptr, 0, dtype, stream);
+    return rc ? rc : apertis_grouped_gemm_tn(A1, B1, offsets, dW1, dbias1, max_rows, M1, N1, E, nullptr, 0, dtype, stream);
   }
   if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || (M0 | N0 | M1 | N1) % 8) return APERTIS_ERR_UNSUPPORTED;
   if (!aligned16<bf16_t>(A0, M0) || !aligned16<bf16_t>(B0, N0) || !aligned16<bf16_t>(A1, M1) || !aligned16<bf16_t>(B1, N1))
     return APERTIS_ERR_UNSUPPORTED;
+  if (ws && !getenv("APERTIS_GEMM_TN_V2") && max_rows <= 0x7fffffffLL && std::max(std::max(M0, N0), std::max(M1, N1)) < 0x3fffffff) {
+    Tn3Problem p0{(const bf16_t *)A0, (const bf16_t *)B0, dW0, dbias0, (int)M0, (int)N0, (int)ceil_div64(M0, 256),
+                  (int)ceil_div64(N0, 256)};
+    Tn3Problem p1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, (int)ceil_div64(M1, 256),
+                  (int)ceil_div64(N1, 256)};
+    const int rc = launch_tn3(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, (hipStream_t)stream);
+    if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
+  }
   const int mt0 = (int)ceil_div64(M0, BM), nt0 = (int)ceil_div64(N0, BN), mt1 = (int)ceil_div64(M1, BM),
             nt1 = (int)ceil_div64(N1, BN);
   const int64_t g0 = E * mt0 * nt0, g1 = E * mt1 * nt1;

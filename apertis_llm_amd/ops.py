@@ -572,6 +572,22 @@ _ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "rel
          "silu": _lib.ACT_SILU, "swish": _lib.ACT_SILU}
 
 
+_TN_WS = {}
+
+
+def _tn_workspace(E, n_problems, device):
+    """Scratch for the split tiles of the weight-gradient GEMM: one buffer per (device, stream),
+    sized by the library, contents don't care (apertis_hip.h: TN workspace)."""
+    nbytes = _lib.load().apertis_grouped_gemm_tn_workspace_bytes(E, n_problems)
+    if nbytes <= 0:
+        return None, 0
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _TN_WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _TN_WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    return buf, nbytes
+
+
 class _GroupedLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype):
@@ -624,13 +640,15 @@ class _GroupedLinear(torch.autograd.Function):
             if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
                 # dense layer: the K dimension of the weight gradient is ALL rows; cut it into
                 # pseudo-groups of _SPLITK_ROWS rows so the grid fills the chip, then fold the
-                # partials in a fixed order (deterministic split-K, no atomics)
+                # partials in a fixed order (deterministic split-K, no atomics).  The dense layers of
+                # this model are narrow (352 / 704 wide): 128x128 tiles waste 8 % of the MFMA work on
+                # them where the 256x256 split-K kernel wastes 37 % (measured 322 vs 144 TF)
                 G = -(-max_rows // _SPLITK_ROWS)
                 soffs = _splitk_offsets(max_rows, G, x.device)
                 part = torch.empty(G, N, K, device=x.device, dtype=torch.float32)
                 bpart = torch.empty(G, N, device=x.device, dtype=torch.float32) if has_bias else None
                 _launch("apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
-                        (ptr(dpre), ptr(x), ptr(soffs), ptr(part), ptr(bpart), max_rows, N, K, G, code, stream_ptr()),
+                        (ptr(dpre), ptr(x), ptr(soffs), ptr(part), ptr(bpart), max_rows, N, K, G, None, 0, code, stream_ptr()),
                         2.0 * max_rows * N * K)
                 dw = torch.empty(1, N, K, device=x.device, dtype=torch.float32)
                 check(lib.apertis_colsum_f32(ptr(part), ptr(dw), G, N * K, stream_ptr()), "apertis_colsum_f32")
@@ -641,9 +659,10 @@ class _GroupedLinear(torch.autograd.Function):
             else:
                 dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
                 db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
-                _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn,
-                        (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, code, stream_ptr()),
-                        _RowsWork(offsets, E, 2.0 * N * K))
+                ws, ws_bytes = _tn_workspace(E, 1, x.device)
+                _launch("apertis_grouped_gemm_tn" if E > 1 else "apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
+                        (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, ptr(ws), ws_bytes, code,
+                         stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
             dw = dw.to(wdtype)
         return dx, dw, db, None, None, None, None, None, None
 
@@ -766,9 +785,10 @@ class _ExpertMLP(torch.autograd.Function):
         db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
         dw1 = torch.empty(E, I, H, device=dev, dtype=torch.float32)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
+        ws, ws_bytes = _tn_workspace(E, 2, dev)
         _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair,
                 (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
-                 max_rows, E, code, stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
+                 max_rows, E, ptr(ws), ws_bytes, code, stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
         return dxg, dw1.to(w1dt), db1, dw2.to(w2dt), db2, None, None, None, None, None, None
 
 

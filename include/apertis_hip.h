@@ -261,16 +261,22 @@ int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
                             int64_t max_rows, int64_t N, int64_t K, int64_t E,
                             int act, float drop_p, uint64_t seed,
                             int dtype, int dtype_out, void *stream);
+/* TN workspace (bf16 only): the 256x256-tile kernel deals the CUs out to the (problem, group)
+ * pairs and splits the tiles left after the full rounds along the rows; the partial tiles live
+ * in a caller-owned scratch buffer `ws` (16-byte aligned, apertis_grouped_gemm_tn_workspace_bytes
+ * bytes, contents don't care) and are summed in a fixed order.  ws == NULL, a too-small buffer
+ * or E * n_problems > #CUs select the 128x128-tile kernel, which needs none. */
+int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
-                            int64_t E, int dtype, void *stream);
+                            int64_t E, void *ws, int64_t ws_bytes, int dtype, void *stream);
 /* Two TN problems over the SAME row grouping in one launch (the two expert layers' weight
- * gradients): halves the tile-count quantisation loss of separate launches. */
+ * gradients): one schedule over both, so neither pays tile-count quantisation alone. */
 int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, float *dbias0,
                                  int64_t M0, int64_t N0, const void *A1, const void *B1,
                                  float *dW1, float *dbias1, int64_t M1, int64_t N1,
-                                 const int32_t *offsets, int64_t max_rows, int64_t E, int dtype,
-                                 void *stream);
+                                 const int32_t *offsets, int64_t max_rows, int64_t E,
+                                 void *ws, int64_t ws_bytes, int dtype, void *stream);
 /* Compute copies of fp32 master weights src [E,R,C]: dst [E,R,C] and/or dstT [E,C,R] in
  * dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call. */
 int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R,

@@ -385,3 +385,72 @@ def test_skinny_linear(dev, T, K, N, dt):
     _close(xd.grad, xr.grad, "dx", **(dict(rtol=1e-4, atol_scale=1e-5) if dt == torch.float32 else dict(rtol=1e-2, atol_scale=8e-3)))
     _close(Wd.grad, Wr.grad, "dW", rtol=1e-4, atol_scale=1e-5)
     _close(bd.grad, br.grad, "db", rtol=1e-4, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------ weight-gradient GEMM (TN) through the C ABI
+def _tn_call(dev, A, Bm, offsets, E, with_bias, ws_mode, R=None):
+    from apertis_llm_amd import _lib
+    lib = _lib.load()
+    R, M = A.shape[0] if R is None else R, A.shape[1]
+    N = Bm.shape[1]
+    dW = torch.full((E, M, N), float("nan"), device=dev)
+    db = torch.full((E, M), float("nan"), device=dev) if with_bias else None
+    nbytes = lib.apertis_grouped_gemm_tn_workspace_bytes(E, 1)
+    ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8) if ws_mode else None
+    import os
+    os.environ["APERTIS_GEMM_TN_V3"] = "1"      # the 256x256-tile kernel also for groups the library would call too short for it
+    try:
+        rc = lib.apertis_grouped_gemm_tn(_lib.ptr(A), _lib.ptr(Bm), _lib.ptr(offsets), _lib.ptr(dW), _lib.ptr(db), R, M, N, E,
+                                         _lib.ptr(ws), nbytes if ws_mode else 0, _lib.BF16, _lib.stream_ptr())
+    finally:
+        del os.environ["APERTIS_GEMM_TN_V3"]
+    assert rc == 0, _lib.load().apertis_strerror(rc)
+    torch.cuda.synchronize()
+    return dW, db
+
+
+@pytest.mark.parametrize("sizes,M,N", [
+    ([700, 100, 0, 513], 256, 128),          # empty group, one tile per group -> every tile is row-split 64 ways
+    ([4000, 3000, 5000, 2000, 1, 63, 64, 65], 704, 2816),   # the expert shapes: 33 tiles on 32 CUs, one split 32 ways
+    ([9000], 352, 704),                       # dense split-K (E = 1), ragged last m-tile
+    ([300, 5], 8, 520),                       # tiny M, N not a multiple of 256
+    ([0, 0, 0], 64, 64),                      # nothing to sum: zeros
+])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_grouped_gemm_tn_bf16(dev, sizes, M, N, with_bias):
+    """dW[e] = A[rows_e]^T @ B[rows_e], dbias[e] = column sums of A[rows_e]; the 256x256-tile kernel
+    (with workspace) and the 128x128-tile kernel (without) against an fp64 product of the same bf16 values."""
+    torch.manual_seed(len(sizes) * 1000 + M + N)
+    E, R = len(sizes), sum(sizes)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=dev)
+    A = torch.randn(R + 7, M, device=dev).bfloat16()      # rows past the last group exist but are never read
+    Bm = torch.randn(R + 7, N, device=dev).bfloat16()
+    ref_w = torch.zeros(E, M, N, dtype=torch.float64)
+    ref_b = torch.zeros(E, M, dtype=torch.float64)
+    Ac, Bc = A.double().cpu(), Bm.double().cpu()
+    for e in range(E):
+        r0, r1 = int(offs[e]), int(offs[e + 1])
+        ref_w[e] = Ac[r0:r1].T @ Bc[r0:r1]
+        ref_b[e] = Ac[r0:r1].sum(0)
+    scale = max(1.0, float(max(sizes)) ** 0.5)
+    for ws_mode in (True, False):
+        dW, db = _tn_call(dev, A, Bm, offs, E, with_bias, ws_mode, R=R)
+        assert torch.isfinite(dW).all(), "every output element must be written"
+        err = (dW.double().cpu() - ref_w).abs().max().item()
+        assert err <= 2e-5 * scale * 8, f"ws={ws_mode}: max abs err {err:.3e}"   # fp32 accumulation of exact bf16 products
+        if with_bias:
+            assert torch.isfinite(db).all()
+            errb = (db.double().cpu() - ref_b).abs().max().item()
+            assert errb <= 2e-5 * scale * 8, f"ws={ws_mode}: bias max abs err {errb:.3e}"
+
+
+def test_grouped_gemm_tn_is_deterministic(dev):
+    torch.manual_seed(5)
+    sizes = [4000, 3000, 5000, 2000]
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=dev)
+    A = torch.randn(sum(sizes), 704, device=dev).bfloat16()
+    Bm = torch.randn(sum(sizes), 512, device=dev).bfloat16()
+    first = _tn_call(dev, A, Bm, offs, 4, True, True)
+    for _ in range(3):
+        again = _tn_call(dev, A, Bm, offs, 4, True, True)
+        assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
