@@ -509,6 +509,50 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
   flush_tile(C, mul_pre);
 }
 
+// LDS-DMA through inline asm.  hipcc tracks an LDS-DMA builtin as a store to LDS and puts
+// `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint - every
+// ds_read_b64_tr_b16 - which serialises the double buffer (the DMA of step k+1 would be waited for
+// before the MFMAs of step k start).  The ordering is done by hand here (vmcnt(0) + barrier at the
+// top of each step), so the DMA is kept out of the compiler's sight.
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i raw_buffer_rsrc(const void *base, uint32_t bytes) {
+  const uint64_t a = (uint64_t)base;
+  v4i r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));   // stride 0: raw buffer
+  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                              // num_records: reads past it return 0
+  r[3] = 0x00020000;
+  return r;
+}
+// the same buffer seen from `off` bytes in (scalar arithmetic only; keeps the zero-fill past the end)
+__device__ __forceinline__ v4i rsrc_advance(const v4i &r, uint32_t off) {
+  const uint64_t base = (((uint64_t)(uint32_t)r[1] << 32) | (uint32_t)r[0]) + off;
+  v4i o;
+  o[0] = (int)(uint32_t)base;
+  o[1] = (int)(uint32_t)(base >> 32);
+  o[2] = (uint32_t)r[2] > off ? (int)((uint32_t)r[2] - off) : 0;
+  o[3] = r[3];
+  return o;
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+// 64 lanes x 16 B from buffer offset voff (per lane) to LDS lds_addr + 16 * lane (lds_addr wave-uniform)
+__device__ __forceinline__ void lds_dma16(const v4i &rs, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs) : "memory", "m0");
+}
+// 64 lanes x 4 B
+__device__ __forceinline__ void lds_dma4(const v4i &rs, uint32_t lds_addr, uint32_t voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs) : "memory", "m0");
+}
+// same, from a per-lane global address
+__device__ __forceinline__ void lds_dma16_global(const void *src, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(src) : "memory", "m0");
+}
+
 // ------------------------------------------------------------------------------------------
 // Persistent 256 x 256 NT kernel.  grouped_gemm_nt256_k spends 39 us per K=704 tile, ~24 in the K
 // loop: every CU ends its K loop at the same time, so a round's epilogue is one chip-wide burst of
@@ -969,10 +1013,8 @@ grouped_gemm_tn2_k(TnProblem p0, TnProblem p1, const int32_t *__restrict__ offse
       const int ca = min(csrc * 8, mvalid - 8), cb = min(csrc * 8, nvalid - 8);   // clamp column chunk (masked at store)
       const T *pa = A + (r0 + krow) * M + m0 + ca;
       const T *pb = Bm + (r0 + krow) * N + n0 + cb;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pa,
-                                       (__attribute__((address_space(3))) void *)(as + piece * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)pb,
-                                       (__attribute__((address_space(3))) void *)(bs + piece * 1024), 16, 0, 0);
+      lds_dma16_global(pa, lds_addr_of(as + piece * 1024));
+      lds_dma16_global(pb, lds_addr_of(bs + piece * 1024));
     }
   };
   // register-staged, zero-filled tail step (rows >= r_end contribute nothing)
@@ -1105,6 +1147,13 @@ constexpr int TN3_SLOT = 256 * 256 + 256;
 
 // the part of the schedule the GEMM and the fold kernel must agree on
 struct Tn3Sched { int T, full, rem, s; };
+// tile index -> (m-tile, n-tile), the dimension with FEWER tiles fastest: the cpg tiles of a round
+// then cover all blocks of the narrow operand but only ~cpg/min(m_tiles, n_tiles) blocks of the wide
+// one, so per round the wide operand is fetched once and only the narrow one again
+__host__ __device__ inline void tn3_tile_coord(int tile, int m_tiles, int n_tiles, int &mt, int &nt) {
+  if (m_tiles < n_tiles) { nt = tile / m_tiles; mt = tile - nt * m_tiles; }
+  else { mt = tile / n_tiles; nt = tile - mt * n_tiles; }
+}
 __host__ __device__ inline Tn3Sched tn3_sched(int m_tiles, int n_tiles, int cpg) {
   Tn3Sched c;
   c.T = m_tiles * n_tiles;
@@ -1130,8 +1179,8 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
   const T *__restrict__ A = second ? a.p1.A : a.p0.A, *__restrict__ Bm = second ? a.p1.Bm : a.p0.Bm;
   float *__restrict__ dW = second ? a.p1.dW : a.p0.dW, *__restrict__ dbias = second ? a.p1.dbias : a.p0.dbias;
   const int M = second ? a.p1.M : a.p0.M, N = second ? a.p1.N : a.p0.N;
-  const int n_tiles = second ? a.p1.n_tiles : a.p0.n_tiles;
-  const Tn3Sched sc = tn3_sched(second ? a.p1.m_tiles : a.p0.m_tiles, n_tiles, a.cpg);
+  const int m_tiles = second ? a.p1.m_tiles : a.p0.m_tiles, n_tiles = second ? a.p1.n_tiles : a.p0.n_tiles;
+  const Tn3Sched sc = tn3_sched(m_tiles, n_tiles, a.cpg);
   const int r_begin = offsets[e], rows = offsets[e + 1] - r_begin;
   const int nsteps = (rows + BKR - 1) / BKR;
   const int ldA = M * (int)sizeof(T), ldB = N * (int)sizeof(T);
@@ -1166,24 +1215,22 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
       s1 = min(s0 + per, nsteps);
       partial = sc.s > 1;
     }
-    const int mt = tile / n_tiles, nt = tile - mt * n_tiles;
+    int mt, nt;
+    tn3_tile_coord(tile, m_tiles, n_tiles, mt, nt);
     const int m0 = mt * 256, n0 = nt * 256;
     const bool want_bias = dbias != nullptr && nt == 0;
     // descriptors from the tile's first column of the group's first row to the end of its last row
-    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T *>(A + (int64_t)r_begin * M + m0), 0, rows > 0 ? rows * ldA - m0 * (int)sizeof(T) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T *>(Bm + (int64_t)r_begin * N + n0), 0, rows > 0 ? rows * ldB - n0 * (int)sizeof(T) : 0, 0x00020000);
+    const v4i ars = raw_buffer_rsrc(A + (int64_t)r_begin * M + m0, rows > 0 ? (uint32_t)(rows * ldA - m0 * (int)sizeof(T)) : 0u);
+    const v4i brs = raw_buffer_rsrc(Bm + (int64_t)r_begin * N + n0, rows > 0 ? (uint32_t)(rows * ldB - n0 * (int)sizeof(T)) : 0u);
+    const uint32_t lds0 = lds_addr_of(smem);
     auto stage = [&](int buf, int step) {
-      char *as = smem + buf * 2 * OPB, *bs = as + OPB;
+      const uint32_t as = lds0 + buf * 2 * OPB, bs = as + OPB;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int p = jj * 8 + wave;
         const uint32_t row = (uint32_t)(step * BKR + 2 * p);   // in the VGPR offset: the range check ignores the scalar one
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void *)(as + p * 1024), 16,
-                                                 va0 + row * (uint32_t)ldA, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void *)(bs + p * 1024), 16,
-                                                 vb0 + row * (uint32_t)ldB, 0, 0, 0);
+        lds_dma16(ars, as + p * 1024, va0 + row * (uint32_t)ldA);
+        lds_dma16(brs, bs + p * 1024, vb0 + row * (uint32_t)ldB);
       }
     };
 
@@ -1273,7 +1320,8 @@ __global__ void __launch_bounds__(256) tn3_fold_k(Tn3Args a) {
   const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, a.cpg);
   if (ri >= sc.rem || sc.s <= 1) return;
   const int tile = sc.full * a.cpg + ri;
-  const int mt = tile / pp.n_tiles, nt = tile - mt * pp.n_tiles;
+  int mt, nt;
+  tn3_tile_coord(tile, pp.m_tiles, pp.n_tiles, mt, nt);
   const int m0 = mt * 256, n0 = nt * 256;
   const float *src = a.ws + (int64_t)(g * a.cpg + ri * sc.s) * TN3_SLOT;
   float *out = pp.dW + (int64_t)e * pp.M * pp.N;
