@@ -772,6 +772,8 @@ class ApertisForCausalLM(nn.Module):
             n = min(sl.shape[1], tl.shape[1])
             if n == 0:
                 loss = torch.zeros((), device=logits.device, requires_grad=self.training)
+            elif ops.shifted_cross_entropy_supported(logits, labels):
+                loss = ops.shifted_cross_entropy(logits, labels, ignore_index=-100)     # core.py:1407-1416, one pass
             else:
                 loss = F.cross_entropy(sl[:, :n].reshape(-1, sl.shape[-1]).float(), tl[:, :n].reshape(-1),
                                        ignore_index=-100)

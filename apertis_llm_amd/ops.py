@@ -798,6 +798,52 @@ def expert_mlp(xg, w1, b1, w2, b2, offsets, max_rows, act="gelu", drop_p=0.0, se
     return _ExpertMLP.apply(xg, w1, b1, w2, b2, offsets, max_rows, act, drop_p, seed, compute_dtype or xg.dtype)
 
 
+class _ShiftedCrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, n_pos, ignore_index):
+        _require_gpu(logits, labels)
+        lib = _lib.load()
+        B, L, V = logits.shape
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        lse = torch.empty(B * L, device=logits.device, dtype=torch.float32)
+        row_loss = torch.empty(B * L, device=logits.device, dtype=torch.float32)
+        check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(labels), ptr(lse), ptr(row_loss), B, L, V, labels.shape[1], n_pos,
+                                            ignore_index, dtype_code(logits), stream_ptr()), "apertis_cross_entropy_fwd")
+        count = (labels[:, 1:n_pos + 1] != ignore_index).sum().to(torch.float32)   # 0 targets -> nan, like F.cross_entropy
+        ctx.save_for_backward(logits, labels, lse, count)
+        ctx.cfg = (n_pos, ignore_index)
+        return row_loss.sum() / count
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        logits, labels, lse, count = ctx.saved_tensors
+        n_pos, ignore_index = ctx.cfg
+        B, L, V = logits.shape
+        gscale = (dloss.to(torch.float32) / count).reshape(1).contiguous()
+        dlogits = torch.empty_like(logits)
+        check(lib.apertis_cross_entropy_bwd(ptr(logits), ptr(labels), ptr(lse), ptr(gscale), ptr(dlogits), B, L, V,
+                                            labels.shape[1], n_pos, ignore_index, dtype_code(logits), stream_ptr()),
+              "apertis_cross_entropy_bwd")
+        return dlogits, None, None, None
+
+
+def shifted_cross_entropy_supported(logits, labels):
+    V = logits.shape[-1]
+    return (logits.is_cuda and labels.is_cuda and logits.dim() == 3 and labels.dim() == 2 and labels.dtype == torch.int64 and
+            logits.shape[0] == labels.shape[0] and logits.dtype in (torch.float32, torch.bfloat16) and
+            V % (8 if logits.dtype == torch.bfloat16 else 4) == 0 and logits.shape[0] * logits.shape[1] < 2 ** 31)
+
+
+def shifted_cross_entropy(logits, labels, ignore_index=-100):
+    """mean_{valid (b,l)} CE(logits[b, l, :], labels[b, l+1]) for l < min(L, L_labels) - 1, fp32 math on the
+    logits as stored: the reference's shift + CrossEntropyLoss(ignore_index) (core.py:1407-1416) without the
+    shifted / fp32 copies of the [B, L, V] tensor.  Labels must be in [0, V) or ignore_index."""
+    n_pos = min(logits.shape[1], labels.shape[1]) - 1
+    return _ShiftedCrossEntropy.apply(logits, labels, n_pos, ignore_index)
+
+
 def linear_mfma(x, weight, bias=None, act=None, compute_dtype=None):
     """Dense act(x @ W.T + b) through the same MFMA tile (one group).  Used for the patch-embed
     GEMM and vision_projection (reference multimodal/module.py:102, core.py:1209)."""

@@ -289,6 +289,27 @@ int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void *dpre,
                             const int32_t *offsets, int64_t max_rows, int64_t N, int64_t E,
                             int act, float drop_p, uint64_t seed, int dtype, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Next-token cross entropy straight on the LM head's logits  (reference core.py:1407-1416:
+ * CrossEntropyLoss(ignore_index=-100) over logits[..., :-1, :] vs labels[..., 1:], fp32 math).
+ * logits [B, L, V] row-major (bf16 or fp32, V % 8 == 0 / V % 4 == 0, 16-byte aligned); labels
+ * int64 [B, label_stride]; the target of row (b, l) is labels[b, l + 1] for l < n_pos
+ * (n_pos <= L, n_pos + 1 <= label_stride).  Rows with l >= n_pos or target == ignore_index carry
+ * no loss; any other target must lie in [0, V).
+ * fwd: lse[b*L + l] = log sum exp(row), row_loss = lse - row[target] (0 for rows without loss);
+ *      the caller reduces row_loss (sum / number of targets).
+ * bwd: dlogits = (softmax(row) - onehot(target)) * gscale[0] (device scalar = dLoss / number of
+ *      targets), zero rows where there is no loss; dlogits has the logits' dtype and layout.
+ * ------------------------------------------------------------------------------------------ */
+int apertis_cross_entropy_fwd(const void *logits, const int64_t *labels, float *lse,
+                              float *row_loss, int64_t B, int64_t L, int64_t V,
+                              int64_t label_stride, int64_t n_pos, int64_t ignore_index, int dtype,
+                              void *stream);
+int apertis_cross_entropy_bwd(const void *logits, const int64_t *labels, const float *lse,
+                              const float *gscale, void *dlogits, int64_t B, int64_t L, int64_t V,
+                              int64_t label_stride, int64_t n_pos, int64_t ignore_index, int dtype,
+                              void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@ import json
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import load_golden
 
@@ -190,3 +191,41 @@ def test_train_step_bf16_autocast_runs(dev):
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
     for n, p in model.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+
+
+# ------------------------------------------------------------------ loss
+@pytest.mark.parametrize("dt,B,L,V,Ll", [(torch.bfloat16, 3, 17, 512, 17), (torch.float32, 2, 9, 100, 9),
+                                          (torch.bfloat16, 2, 33, 32000, 33), (torch.bfloat16, 2, 12, 256, 8),
+                                          (torch.float32, 1, 2, 8, 2)])
+def test_shifted_cross_entropy_matches_reference_formula(dev, dt, B, L, V, Ll):
+    """ops.shifted_cross_entropy vs the reference's shift + CrossEntropyLoss(ignore_index=-100) in fp32
+    (core.py:1407-1416) on the same stored logits: loss to 1e-5, gradient to the output dtype's rounding."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(B * 1000 + L + V)
+    logits = (torch.randn(B, L, V) * 3).to(dt)
+    labels = torch.randint(0, V, (B, Ll))
+    if Ll > 4:
+        labels[0, 3] = -100
+    if Ll > 5:
+        labels[-1, 5] = -100
+    n = min(L, Ll) - 1
+    ref_in = logits.float().clone().requires_grad_(True)
+    ref = F.cross_entropy(ref_in[:, :n].reshape(-1, V), labels[:, 1:n + 1].reshape(-1), ignore_index=-100)
+    (ref * 1.7).backward()
+    x = logits.to(dev).requires_grad_(True)
+    assert ops.shifted_cross_entropy_supported(x, labels.to(dev))
+    loss = ops.shifted_cross_entropy(x, labels.to(dev))
+    (loss * 1.7).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert x.grad.dtype == dt and x.grad.shape == x.shape
+    tol = 1e-6 if dt == torch.float32 else 2 ** -8
+    diff = (x.grad.float().cpu() - ref_in.grad).abs()
+    assert float((diff - tol * ref_in.grad.abs()).max()) <= 1e-7 + (0 if dt == torch.float32 else 1e-9), float(diff.max())
+    assert float(x.grad[:, n:].abs().max()) == 0.0     # positions without a target get an exact zero gradient
+
+
+def test_shifted_cross_entropy_all_ignored_is_nan_like_torch(dev):
+    from apertis_llm_amd import ops
+    logits = torch.randn(1, 4, 16, device=dev)
+    labels = torch.full((1, 4), -100, device=dev)
+    assert torch.isnan(ops.shifted_cross_entropy(logits, labels))
