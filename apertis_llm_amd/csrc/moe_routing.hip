@@ -932,6 +932,95 @@ fold_rows_k(const float *__restrict__ part, float *__restrict__ out, int64_t nro
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tiny linear: y[T,N] = x[T,:K] W[N,K]^T + b with K <= 64, N <= 16 - the SSM's dt_proj_head
+// (Linear(dt_rank -> heads), reference core.py:361,382), whose input is a column slice of the
+// x_param_proj output (row stride ldx).  A GEMM library pays ~20 us forward and ~270 us backward
+// (a [11 x 98304] x [98304 x 22] weight gradient on 16x16 macro tiles plus a separate bias
+// reduction) for 4 MB of traffic.  One row per thread; W and b sit in LDS (broadcast reads).
+// Backward: dx per row, and dW/db as per-block partial sums over a row tile staged in LDS
+// (entry q < N*K is dW[q], the next N are db; thread p owns q = p, p + 128, ...), folded in a fixed order.
+// ------------------------------------------------------------------------------------------
+constexpr int TL_MAXK = 64, TL_MAXN = 16, TL_ROWS = 128;
+constexpr int TL_ACC = (TL_MAXN * TL_MAXK + TL_MAXN + TL_ROWS - 1) / TL_ROWS;   // dW/db entries per thread
+
+template <typename TX>
+__global__ void __launch_bounds__(TL_ROWS)
+tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ b,
+                  float *__restrict__ y, int64_t T, int K, int N) {
+  __shared__ float sW[TL_MAXN * TL_MAXK + TL_MAXN];
+  for (int i = threadIdx.x; i < N * K; i += TL_ROWS) sW[i] = W[i];
+  for (int i = threadIdx.x; i < N; i += TL_ROWS) sW[N * K + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  for (int64_t t = (int64_t)blockIdx.x * TL_ROWS + threadIdx.x; t < T; t += (int64_t)gridDim.x * TL_ROWS) {
+    float xr[TL_MAXK];
+#pragma unroll
+    for (int r = 0; r < TL_MAXK; ++r) xr[r] = r < K ? to_f32(x[t * ldx + r]) : 0.f;
+    for (int j = 0; j < N; ++j) {
+      float a = sW[N * K + j];
+#pragma unroll
+      for (int r = 0; r < TL_MAXK; ++r)
+        if (r < K) a = fmaf(xr[r], sW[j * K + r], a);
+      y[t * N + j] = a;
+    }
+  }
+}
+
+template <typename TX>
+__global__ void __launch_bounds__(TL_ROWS)
+tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ dy,
+                  TX *__restrict__ dx, int64_t lddx, float *__restrict__ part, int64_t T, int K, int N) {
+  __shared__ float sW[TL_MAXN * TL_MAXK];
+  __shared__ float sx[TL_ROWS][TL_MAXK + 1], sdy[TL_ROWS][TL_MAXN + 1];
+  for (int i = threadIdx.x; i < N * K; i += TL_ROWS) sW[i] = W[i];
+  const int nq = N * K + N;
+  float acc[TL_ACC];
+#pragma unroll
+  for (int a = 0; a < TL_ACC; ++a) acc[a] = 0.f;
+  for (int64_t t0 = (int64_t)blockIdx.x * TL_ROWS; t0 < T; t0 += (int64_t)gridDim.x * TL_ROWS) {
+    const int64_t t = t0 + threadIdx.x;
+    const bool live = t < T;
+    __syncthreads();   // sW loaded / the previous tile is no longer read
+#pragma unroll
+    for (int r = 0; r < TL_MAXK; ++r) sx[threadIdx.x][r] = (live && r < K) ? to_f32(x[t * ldx + r]) : 0.f;
+    float dyr[TL_MAXN];
+#pragma unroll
+    for (int j = 0; j < TL_MAXN; ++j) {
+      dyr[j] = (live && j < N) ? dy[t * N + j] : 0.f;
+      sdy[threadIdx.x][j] = dyr[j];
+    }
+    if (live) {
+      for (int r = 0; r < K; ++r) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < TL_MAXN; ++j)
+          if (j < N) a = fmaf(dyr[j], sW[j * K + r], a);
+        dx[t * lddx + r] = from_f32<TX>(a);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < TL_ACC; ++a) {
+      const int q = threadIdx.x + a * TL_ROWS;
+      if (q < N * K) {
+        const int qj = q / K, qr = q - qj * K;
+        float v = acc[a];
+        for (int row = 0; row < TL_ROWS; ++row) v = fmaf(sdy[row][qj], sx[row][qr], v);
+        acc[a] = v;
+      } else if (q < nq) {
+        float v = acc[a];
+        for (int row = 0; row < TL_ROWS; ++row) v += sdy[row][q - N * K];
+        acc[a] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < TL_ACC; ++a) {
+    const int q = threadIdx.x + a * TL_ROWS;
+    if (q < nq) part[(int64_t)blockIdx.x * nq + q] = acc[a];
+  }
+}
+
 int check_H(int64_t H) { return (H > 0 && H % 4 == 0 && H <= 256 * 16) ? APERTIS_OK : APERTIS_ERR_UNSUPPORTED; }
 
 }  // namespace
@@ -1174,6 +1263,46 @@ extern "C" int apertis_skinny_linear_bwd(const void *x, const float *W, const fl
   } else if (dtype_x == APERTIS_F32) {
     SKINNY_N(N, SKINNY_IT(K, hipLaunchKernelGGL((skinny_bwd_k<float, IT, NN>), grid, block, lds, st, (const float *)x, W, dy, (float *)dx, part, T, (int)K)));
   } else return APERTIS_ERR_ARG;
+  const int64_t cols = N * K + N;
+  hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, dW_db, nblk, cols);
+  return apertis_check_launch();
+}
+
+extern "C" int64_t apertis_tiny_linear_bwd_blocks(int64_t T) {
+  return std::min<int64_t>(ceil_div64(T > 0 ? T : 1, TL_ROWS), 1024);
+}
+
+extern "C" int apertis_tiny_linear_fwd(const void *x, int64_t ldx, const float *W, const float *b, float *y, int64_t T,
+                                       int64_t K, int64_t N, int dtype_x, void *stream) {
+  if (!x || !W || !y || T < 0 || ldx < K) return APERTIS_ERR_ARG;
+  if (K < 1 || K > TL_MAXK || N < 1 || N > TL_MAXN) return APERTIS_ERR_UNSUPPORTED;
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(T, TL_ROWS), 4096)), block(TL_ROWS);
+  if (dtype_x == APERTIS_BF16)
+    hipLaunchKernelGGL(tiny_linear_fwd_k<bf16_t>, grid, block, 0, st, (const bf16_t *)x, ldx, W, b, y, T, (int)K, (int)N);
+  else if (dtype_x == APERTIS_F32)
+    hipLaunchKernelGGL(tiny_linear_fwd_k<float>, grid, block, 0, st, (const float *)x, ldx, W, b, y, T, (int)K, (int)N);
+  else return APERTIS_ERR_ARG;
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *W, const float *dy, void *dx, int64_t lddx,
+                                       float *part, float *dW_db, int64_t T, int64_t K, int64_t N, int dtype_x,
+                                       void *stream) {
+  // part: workspace [apertis_tiny_linear_bwd_blocks(T)][N*K + N]; dW_db: out [N*K + N] (dW then db)
+  if (!x || !W || !dy || !dx || !part || !dW_db || T < 0 || ldx < K || lddx < K) return APERTIS_ERR_ARG;
+  if (K < 1 || K > TL_MAXK || N < 1 || N > TL_MAXN) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = apertis_tiny_linear_bwd_blocks(T);
+  dim3 grid((unsigned)nblk), block(TL_ROWS);
+  if (dtype_x == APERTIS_BF16)
+    hipLaunchKernelGGL(tiny_linear_bwd_k<bf16_t>, grid, block, 0, st, (const bf16_t *)x, ldx, W, dy, (bf16_t *)dx, lddx, part, T,
+                       (int)K, (int)N);
+  else if (dtype_x == APERTIS_F32)
+    hipLaunchKernelGGL(tiny_linear_bwd_k<float>, grid, block, 0, st, (const float *)x, ldx, W, dy, (float *)dx, lddx, part, T,
+                       (int)K, (int)N);
+  else return APERTIS_ERR_ARG;
   const int64_t cols = N * K + N;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, dW_db, nblk, cols);
   return apertis_check_launch();

@@ -254,7 +254,7 @@ class SelectiveLinearAttention(nn.Module):
         # in_proj_x and in_proj_z share their input: one GEMM with the stacked weight, outputs are
         # column views (core.py:366-367)
         xz = _mfma_linear(hidden_states, torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
-        xp, z = xz[..., :Dn], xz[..., Dn:]
+        xp, z = ops.split_cols(xz, (Dn, Dn))
         conv_in = xp
         if conv_prev is not None and use_cache and conv_prev.shape[1] == Dn and conv_prev.shape[2] == kw - 1:
             # the reference prepends the cached window and keeps the FIRST L conv outputs
@@ -269,11 +269,15 @@ class SelectiveLinearAttention(nn.Module):
         if pad:
             wp = torch.cat([wp, wp.new_zeros(pad, wp.shape[1])], dim=0)
         p = _mfma_linear(xc, wp)                                             # [B,L,R+2Dn(+pad)]
-        dt_logits = self.dt_proj_head(p[..., :R]).float()                    # [B,L,h]    core.py:382
+        # dt / Bt / C are column slices of p taken in place (core.py:382-385)
+        dt_in, Bt, Cm = ops.split_cols(p, (R, Dn, Dn, pad))[:3]
+        if ops.tiny_linear_supported(dt_in, R, self.num_heads):
+            dt_logits = ops.tiny_linear(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias)   # [B,L,h] fp32
+        else:
+            dt_logits = self.dt_proj_head(dt_in).float()
         h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None
-        # Bt/C are column slices of p taken in place (core.py:384-385); softplus (core.py:383)
-        # is applied inside the scan kernel
-        res = ops.selective_scan(dt_logits, self.A_log, p[..., R:R + Dn], p[..., R + Dn:R + 2 * Dn], h0=h0,
+        # softplus (core.py:383) is applied inside the scan kernel
+        res = ops.selective_scan(dt_logits, self.A_log, Bt, Cm, h0=h0,
                                  delta_softplus=True, y_dtype=torch.float32, return_last=use_cache)
         y, h_last = res if use_cache else (res, None)
         gated = ops.ssm_gate(y, xc, z, self.D)                               # core.py:395-396

@@ -392,6 +392,75 @@ class _SkinnyLinear(torch.autograd.Function):
         return dx, out[:N * K].reshape(N, K).to(wdt), (out[N * K:].to(bdt) if bdt is not None else None)
 
 
+class _TinyLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_gpu(x, weight, bias)
+        lib = _lib.load()
+        K, N = x.shape[-1], weight.shape[0]
+        x3 = x if x.dim() == 3 else x.reshape(1, -1, K)
+        xr, ldx = _rows(x3, K)
+        T = x.numel() // K
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+        check(lib.apertis_tiny_linear_fwd(ptr(xr), ldx, ptr(w), ptr(b), ptr(y), T, K, N, dtype_code(xr), stream_ptr()),
+              "apertis_tiny_linear_fwd")
+        ctx.save_for_backward(xr, w)
+        ctx.cfg = (ldx, T, tuple(x.shape), weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xr, w = ctx.saved_tensors
+        ldx, T, xshape, wdt, bdt = ctx.cfg
+        N, K = w.shape
+        dy = dy.float().contiguous()
+        dx = torch.empty(xshape, device=xr.device, dtype=xr.dtype)
+        nblk = lib.apertis_tiny_linear_bwd_blocks(T)
+        part = torch.empty(nblk, N * K + N, device=xr.device, dtype=torch.float32)
+        out = torch.empty(N * K + N, device=xr.device, dtype=torch.float32)
+        check(lib.apertis_tiny_linear_bwd(ptr(xr), ldx, ptr(w), ptr(dy), ptr(dx), K, ptr(part), ptr(out), T, K, N,
+                                          dtype_code(xr), stream_ptr()), "apertis_tiny_linear_bwd")
+        return dx, out[:N * K].reshape(N, K).to(wdt), (out[N * K:].to(bdt) if bdt is not None else None)
+
+
+def tiny_linear_supported(x, K, N):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and 1 <= K <= 64 and 1 <= N <= 16
+
+
+def tiny_linear(x, weight, bias=None):
+    """fp32 y = x @ W.T + b for K <= 64 inputs and N <= 16 outputs, x read in place when it is a column
+    slice (the SSM's dt_proj_head on p[..., :dt_rank], reference core.py:382)."""
+    return _TinyLinear.apply(x, weight, bias)
+
+
+class _SplitCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.sizes = sizes
+        outs, a = [], 0
+        for n in sizes:
+            outs.append(x[..., a:a + n])
+            a += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros(*ref.shape[:-1], n) for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, dim=-1),) + (None,) * len(ctx.sizes)
+
+
+def split_cols(x, sizes):
+    """Column views x[..., a:b] of consecutive widths `sizes` (summing to x.shape[-1]) whose backward
+    assembles the input gradient with ONE concatenation; slicing leaves autograd to zero-fill, copy and
+    add a full-width tensor per slice."""
+    assert sum(sizes) == x.shape[-1]
+    return _SplitCols.apply(x, *sizes)
+
+
 def skinny_linear_supported(K, N):
     return N in (2, 4, 8, 16) and K % 4 == 0 and K <= 1024 and (N <= 8 or K <= 256)
 

@@ -169,6 +169,18 @@ int apertis_skinny_linear_bwd(const void *x, const float *W, const float *dy, vo
                               int dtype_x, void *stream);
 int64_t apertis_skinny_linear_bwd_blocks(int64_t T);
 
+/* Tiny linear y[T,N] = x[T,:K] W[N,K]^T + b for K <= 64, N <= 16: the SSM's
+ * dt_proj_head (core.py:361,382) applied to a column slice of the x_param_proj output, read in
+ * place (row stride ldx elements).  fp32 W/b/y, x fp32 or bf16.  Backward: dx rows (row stride lddx,
+ * x's dtype), dW_db = [N*K dW | N db] fp32; part = workspace [apertis_tiny_linear_bwd_blocks(T),
+ * N*K+N] fp32 (fixed-order fold). */
+int apertis_tiny_linear_fwd(const void *x, int64_t ldx, const float *W, const float *b, float *y,
+                            int64_t T, int64_t K, int64_t N, int dtype_x, void *stream);
+int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *W, const float *dy, void *dx,
+                            int64_t lddx, float *part, float *dW_db, int64_t T, int64_t K,
+                            int64_t N, int dtype_x, void *stream);
+int64_t apertis_tiny_linear_bwd_blocks(int64_t T);
+
 /* ------------------------------------------------------------------------------------------
  * MoE dispatch plan  (replaces the K x E Python loop core.py:547-591: nonzero / capacity /
  * overflow top-n by gate weight).  Canonical row order: expert-major, then k, then token

@@ -197,3 +197,48 @@ def test_scan_fused_single_launch_stress(dev):
             _close(y1, y2.cpu(), f"fused vs two-launch y {B,L,h,N}", rtol=2e-5, atol_scale=2e-6)
             _close(l1, l2.cpu(), "final state", rtol=2e-5, atol_scale=2e-6)
     assert ops.scan_fused_error(dev) == 0
+
+
+# ------------------------------------------------------------------ dt_proj_head / column split
+@pytest.mark.parametrize("dt,B,L,K,N,ld", [(torch.float32, 2, 300, 22, 11, 64), (torch.bfloat16, 3, 257, 22, 11, 368),
+                                            (torch.float32, 1, 5, 1, 1, 1), (torch.bfloat16, 2, 1000, 32, 7, 32),
+                                            (torch.float32, 1, 70000, 8, 16, 24), (torch.bfloat16, 2, 700, 44, 11, 400),
+                                            (torch.float32, 1, 130, 64, 16, 64)])
+def test_tiny_linear_on_a_column_slice(dev, dt, B, L, K, N, ld):
+    """ops.tiny_linear (dt_proj_head, reference core.py:382) on p[..., :K] read in place vs F.linear in fp32."""
+    import torch.nn.functional as F
+    from apertis_llm_amd import ops
+    torch.manual_seed(K * 100 + N)
+    p_full = torch.randn(B, L, ld).to(dt)
+    W, b = torch.randn(N, K) * 0.3, torch.randn(N)
+    gy = torch.randn(B, L, N)
+    xr = p_full[..., :K].float().clone().requires_grad_(True)
+    Wr, br = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.linear(xr, Wr, br) * gy).sum().backward()
+    pg = p_full.to(dev).requires_grad_(True)
+    Wg, bg = W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    x = pg[..., :K]
+    assert ops.tiny_linear_supported(x, K, N)
+    y = ops.tiny_linear(x, Wg, bg)
+    assert y.dtype == torch.float32 and y.shape == (B, L, N)
+    (y * gy.to(dev)).sum().backward()
+    ref_y = F.linear(p_full[..., :K].float(), W, b)
+    assert torch.allclose(y.cpu(), ref_y, rtol=1e-5, atol=1e-5)
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert torch.allclose(pg.grad[..., :K].float().cpu(), xr.grad, rtol=tol, atol=tol)
+    assert float(pg.grad[..., K:].abs().max()) == 0.0 if ld > K else True
+    scale = (B * L) ** 0.5
+    assert torch.allclose(Wg.grad.cpu(), Wr.grad, rtol=1e-4, atol=1e-4 * scale)
+    assert torch.allclose(bg.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * scale)
+
+
+def test_split_cols_backward_is_one_concatenation(dev):
+    from apertis_llm_amd import ops
+    x = torch.randn(2, 7, 20, device=dev, requires_grad=True)
+    a, b, c, d = ops.split_cols(x, (3, 8, 8, 1))
+    assert a.shape[-1] == 3 and d.shape[-1] == 1 and a.data_ptr() == x.data_ptr()
+    (a.sum() * 2 + (c * c).sum()).backward()          # b and d get no gradient at all
+    ref = torch.zeros_like(x)
+    ref[..., :3] = 2
+    ref[..., 11:19] = 2 * x.detach()[..., 11:19]
+    assert torch.equal(x.grad, ref)
