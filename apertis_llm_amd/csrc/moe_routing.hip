@@ -668,8 +668,8 @@ constexpr int LN_RPW = 8;
 template <typename TX, typename TG, int IT>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean_i,
-                const float *__restrict__ rstd_i, const TG *__restrict__ dy, TX *__restrict__ dx,
-                float *__restrict__ part, int64_t T, int H) {
+                const float *__restrict__ rstd_i, const TG *__restrict__ dy, const TX *__restrict__ dres,
+                TX *__restrict__ dx, float *__restrict__ part, int64_t T, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [3 waves][2][H/4]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -720,9 +720,13 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         int c = (lane + 64 * i) * 4;
-        if (c < H)
-          store4<TX>(dst + c, make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2), rstd[q] * (gd[i].y - m1 - xh[i].y * m2),
-                                          rstd[q] * (gd[i].z - m1 - xh[i].z * m2), rstd[q] * (gd[i].w - m1 - xh[i].w * m2)));
+        if (c < H) {
+          // dres: the gradient arriving on the residual branch that bypasses this norm (pre-norm block
+          // y = x + f(LN(x))): added here instead of in a separate full-width pass
+          const float4 rr = dres ? load4<TX>(dres + (r + q) * H + c) : make_float4(0, 0, 0, 0);
+          store4<TX>(dst + c, make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2) + rr.x, rstd[q] * (gd[i].y - m1 - xh[i].y * m2) + rr.y,
+                                          rstd[q] * (gd[i].z - m1 - xh[i].z * m2) + rr.z, rstd[q] * (gd[i].w - m1 - xh[i].w * m2) + rr.w));
+        }
       }
     }
   }
@@ -1196,8 +1200,8 @@ extern "C" int apertis_layernorm_fwd(const void *x, const float *gamma, const fl
 }
 
 extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean, const float *rstd,
-                                     const void *dy, void *dx, float *part, float *dgamma, float *dbeta, int64_t T,
-                                     int64_t H, int dtype_x, int dtype_g, void *stream) {
+                                     const void *dy, const void *dres, void *dx, float *part, float *dgamma, float *dbeta,
+                                     int64_t T, int64_t H, int dtype_x, int dtype_g, void *stream) {
   if (!x || !gamma || !mean || !rstd || !dy || !dx || !part || !dgamma || !dbeta || T < 0) return APERTIS_ERR_ARG;
   if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -1205,7 +1209,7 @@ extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const fl
   dim3 grid((unsigned)nblk), block(256);
   const size_t lds = 3 * 2 * (size_t)H * sizeof(float);
   DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((layernorm_bwd_k<TA, TB, IT>), grid, block, lds, st,
-      (const TA *)x, gamma, mean, rstd, (const TB *)dy, (TA *)dx, part, T, (int)H)));
+      (const TA *)x, gamma, mean, rstd, (const TB *)dy, (const TA *)dres, (TA *)dx, part, T, (int)H)));
   hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(1024), 0, st, part, dgamma, dbeta, nblk,
                      (int)H);
   return apertis_check_launch();

@@ -154,6 +154,18 @@ class HipLayerNorm(nn.LayerNorm):
             return ops.layer_norm(x, self.weight, self.bias, self.eps, out_dtype=_compute_dtype(x))
         return super().forward(x)
 
+    def forward_pass(self, x):
+        """(LayerNorm(x), x) for a pre-norm residual block: adding the residual through the returned x lets
+        the backward kernel fold the residual gradient into dx (ops.layer_norm_pass)."""
+        H = x.shape[-1]
+        if x.is_cuda and H % 4 == 0 and H <= 4096 and x.dtype in (torch.float32, torch.bfloat16):
+            return ops.layer_norm_pass(x, self.weight, self.bias, self.eps, out_dtype=_compute_dtype(x))
+        return self.forward(x), x
+
+
+def _norm_pass(norm, x):
+    return norm.forward_pass(x) if isinstance(norm, HipLayerNorm) else (norm(x), x)
+
 
 def _dropout_add(drop: nn.Dropout, out, residual):
     """residual + dropout(out): one HIP kernel on the GPU, stock torch elsewhere."""
@@ -455,7 +467,7 @@ class ApertisAttention(nn.Module):
         return t.view(B, L, self.num_attention_heads, self.attention_head_size).transpose(1, 2)
 
     def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False):
-        x = self.pre_norm(hidden_s)
+        x, hidden_s = _norm_pass(self.pre_norm, hidden_s)
         if self._ssm:
             out, proxy, cache = self.attention_mechanism_impl(x, attention_mask=att_mask, position_ids=pos_ids,
                                                               past_key_value=past_kv, output_attentions=output_att,
@@ -524,7 +536,7 @@ class ApertisFeedForward(nn.Module):
         self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_s):
-        x = self.pre_norm(hidden_s)
+        x, hidden_s = _norm_pass(self.pre_norm, hidden_s)
         lb = rz = hidden_s.new_zeros(())
         if self.is_expert_system:
             out, lb, rz = self.ffn(x)

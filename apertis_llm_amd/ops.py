@@ -766,25 +766,46 @@ class _LayerNorm(torch.autograd.Function):
         return y.reshape(shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         lib = _lib.load()
         x2, g, mean, rstd = ctx.saved_tensors
         T, H = x2.shape
+        if dy is None:      # the normalised output was not used: only the pass-through carries gradient
+            return dres, None, None, None, None
         dy2 = dy.reshape(T, H).contiguous()
+        if dres is not None:
+            dres = dres.reshape(T, H).to(x2.dtype).contiguous()
         dx = torch.empty(T, H, device=x2.device, dtype=x2.dtype)
         nw = lib.apertis_layernorm_bwd_blocks(T, H)
         part = torch.empty(nw, 2, H, device=x2.device, dtype=torch.float32)
         dg = torch.empty(H, device=x2.device, dtype=torch.float32)
         db = torch.empty(H, device=x2.device, dtype=torch.float32)
-        check(lib.apertis_layernorm_bwd(ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dy2), ptr(dx), ptr(part), ptr(dg), ptr(db),
-                                        T, H, dtype_code(x2), dtype_code(dy2), stream_ptr()), "apertis_layernorm_bwd")
+        check(lib.apertis_layernorm_bwd(ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dy2), ptr(dres), ptr(dx), ptr(part), ptr(dg),
+                                        ptr(db), T, H, dtype_code(x2), dtype_code(dy2), stream_ptr()), "apertis_layernorm_bwd")
         return dx.reshape(ctx.shape), dg.to(ctx.pdtypes[0]), db.to(ctx.pdtypes[1]), None, None
+
+
+class _LayerNormPass(_LayerNorm):
+    """LayerNorm that also hands its input through: (LN(x), x).  In a pre-norm residual block
+    y = x + f(LN(x)) the residual add reads the pass-through, so both gradients reach this node together
+    and the backward kernel adds them (dx = LN backward + dres) instead of autograd running a separate
+    full-width add."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, out_dtype):
+        y = _LayerNorm.forward(ctx, x, weight, bias, eps, out_dtype)
+        return y, x.view_as(x)
 
 
 def layer_norm(x, weight, bias, eps, out_dtype=None):
     """LayerNorm over the last dimension; x fp32/bf16, statistics in fp32, output in out_dtype
     (bf16 under autocast: the following GEMM reads it directly)."""
     return _LayerNorm.apply(x, weight, bias, eps, out_dtype or x.dtype)
+
+
+def layer_norm_pass(x, weight, bias, eps, out_dtype=None):
+    """(LayerNorm(x), x): see _LayerNormPass."""
+    return _LayerNormPass.apply(x, weight, bias, eps, out_dtype or x.dtype)
 
 
 FUSE_ACT_BWD = False

@@ -221,12 +221,14 @@ int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
 /* Plain LayerNorm over the last dimension on the same row kernels (pre-norms and final norm,
  * core.py:669,695,847,888,1040,1294): x [T,H] dtype_x -> y [T,H] dtype_y, mean/rstd [T] fp32.
  * Backward: dy [T,H] dtype_g -> dx [T,H] in dtype_x; dgamma/dbeta [H] fp32 overwritten;
- * part = workspace [apertis_layernorm_bwd_blocks(T,H), 2, H] fp32 (deterministic fold). */
+ * part = workspace [apertis_layernorm_bwd_blocks(T,H), 2, H] fp32 (deterministic fold).
+ * dres (optional, [T,H] dtype_x): gradient arriving on the residual branch around the norm
+ * (pre-norm block y = x + f(LN(x)), core.py:667-700,845-890); dx = LN backward + dres. */
 int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps,
                           void *y, float *mean, float *rstd, int64_t T, int64_t H, int dtype_x,
                           int dtype_y, void *stream);
 int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean,
-                          const float *rstd, const void *dy, void *dx, float *part,
+                          const float *rstd, const void *dy, const void *dres, void *dx, float *part,
                           float *dgamma, float *dbeta, int64_t T, int64_t H, int dtype_x,
                           int dtype_g, void *stream);
 int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H);

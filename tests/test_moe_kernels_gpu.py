@@ -454,3 +454,32 @@ def test_grouped_gemm_tn_is_deterministic(dev):
     for _ in range(3):
         again = _tn_call(dev, A, Bm, offs, 4, True, True)
         assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
+
+
+@pytest.mark.parametrize("T,H,dt_in,dt_out", [(1000, 704, torch.float32, torch.bfloat16), (77, 32, torch.float32, torch.float32),
+                                               (513, 256, torch.bfloat16, torch.bfloat16)])
+def test_layer_norm_pass_folds_residual_gradient(dev, T, H, dt_in, dt_out):
+    """(LN(x), x) = ops.layer_norm_pass(x): the gradient arriving on the pass-through is added inside the
+    LayerNorm backward kernel; same numbers as autograd's separate add."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(T + H)
+    x = torch.randn(T, H).to(dt_in)
+    w, b = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    gy, gp = torch.randn(T, H).to(dt_out).float(), torch.randn(T, H).to(dt_in).float()   # exactly representable upstream grads
+    xr = x.float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    (F.layer_norm(xr, (H,), wr, br, 1e-5) * gy).sum().backward()
+    ref_dx = xr.grad + gp
+    xd = x.to(dev).requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    y, xp = ops.layer_norm_pass(xd, wd, bd, 1e-5, out_dtype=dt_out)
+    assert xp.data_ptr() == xd.data_ptr() and y.dtype == dt_out
+    ((y.float() * gy.to(dev)).sum() + (xp.float() * gp.to(dev)).sum()).backward()
+    tol = 2e-5 if dt_in == torch.float32 else 3e-2
+    assert torch.allclose(xd.grad.float().cpu(), ref_dx, rtol=tol, atol=tol * float(ref_dx.abs().max()))
+    assert torch.allclose(wd.grad.cpu(), wr.grad, rtol=1e-4, atol=1e-4 * T ** 0.5)
+    # only the pass-through used: the gradient is handed on untouched
+    xd2 = x.to(dev).requires_grad_(True)
+    _, xp2 = ops.layer_norm_pass(xd2, wd, bd, 1e-5, out_dtype=dt_out)
+    (xp2.float() * gp.to(dev)).sum().backward()
+    assert torch.allclose(xd2.grad.float().cpu(), gp.to(dt_in).float(), rtol=1e-6, atol=1e-6)
