@@ -937,6 +937,205 @@ fold_rows_k(const float *__restrict__ part, float *__restrict__ out, int64_t nro
 }
 
 // ------------------------------------------------------------------------------------------
+// Router projection with its LayerNorm fused in: logits = Linear(LayerNorm(x))  (reference
+// core.py:481-482).  As two ops the normalised [T,H] tensor is written and read back, and the
+// backward moves [T,H] five more times (skinny dx, LN dx, the add with the expert path's gradient):
+// 536 us per layer at T=98304, H=704 for a layer that has 8 outputs.  Fused: the forward reads x
+// once; the backward reads x and the gradient arriving on the pass-through of x (`dres`, the
+// expert path) once and writes dx once.  Forward: wave per row, lanes over H as in the LayerNorm kernels.
+// part: [gridDim.x][NN*H + NN + 2H] per-block sums of dW, db, dgamma, dbeta, folded in a fixed order.
+// ------------------------------------------------------------------------------------------
+template <typename TX> struct raw4;
+template <> struct raw4<float> { typedef float4 type; };
+template <> struct raw4<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 raw_to_f4(const float4 &v) { return v; }
+__device__ __forceinline__ float4 raw_to_f4(const uint2 &u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+
+template <typename TX, int IT, int NN>
+__global__ void __launch_bounds__(256)
+router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+             const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ logits,
+             float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t T, int H) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *sW = reinterpret_cast<float4 *>(smem);   // [NN][H/4]: in registers the weight would cost NN*IT*4 VGPRs and two waves per SIMD
+  const int lane = threadIdx.x & 63, Q = H / 4;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  for (int i = threadIdx.x; i < NN * Q; i += 256) sW[i] = reinterpret_cast<const float4 *>(W)[i];
+  float4 g4[IT], b4[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    g4[i] = c < H ? load4<float>(gamma + c) : make_float4(0, 0, 0, 0);
+    b4[i] = c < H ? load4<float>(beta + c) : make_float4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  typedef typename raw4<TX>::type raw_t;
+  raw_t cur[IT], nxt[IT];
+  auto fetch = [&](raw_t (&o)[IT], int64_t r) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      o[i] = (c < H && r < T) ? *reinterpret_cast<const raw_t *>(x + r * H + c) : raw_t{};
+    }
+  };
+  if (wave < T) fetch(cur, wave);
+  for (int64_t r = wave; r < T; r += nw) {
+    fetch(nxt, r + nw);   // the wave's next row is in flight while this one is reduced
+    float4 v[IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      v[i] = raw_to_f4(cur[i]);
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + bb * bb) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) cur[i] = nxt[i];
+#pragma unroll
+    for (int i = 0; i < IT; ++i)   // padding lanes: g4 = b4 = 0, so xn = 0 there
+      v[i] = make_float4((v[i].x - mean) * rstd * g4[i].x + b4[i].x, (v[i].y - mean) * rstd * g4[i].y + b4[i].y,
+                         (v[i].z - mean) * rstd * g4[i].z + b4[i].z, (v[i].w - mean) * rstd * g4[i].w + b4[i].w);
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const float4 wn = lane + 64 * i < Q ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
+        a += (v[i].x * wn.x + v[i].y * wn.y) + (v[i].z * wn.z + v[i].w * wn.w);
+      }
+      acc[n] = wave_sum(a);
+    }
+    if (lane < NN) {
+      float o = 0.f;
+#pragma unroll
+      for (int n = 0; n < NN; ++n) if (lane == n) o = acc[n];
+      logits[r * NN + lane] = o + (b ? b[lane] : 0.f);
+    }
+    if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+  }
+}
+
+// Backward, columns split over the block's four waves: a lane owns ONE 4-column chunk (q = wave * Qw +
+// lane, Qw = ceil(H/16) <= 64), so the router weight and every accumulator of its columns (dW[NN], dgamma,
+// dbeta) are 4-float registers and nothing is reduced across waves at the end; only the two LayerNorm
+// row sums cross waves, through LDS, once per tile of RT_R rows.  The next tile's rows are fetched
+// while the current one is computed (a row-per-wave form with the NN x H/64 dW accumulators in
+// registers ran at 2 waves per SIMD with one row in flight each: 510 us, latency-bound).
+constexpr int RT_R = 4;
+
+template <typename TX, int NN>
+__global__ void __launch_bounds__(256)
+router_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+             const float *__restrict__ mean_i, const float *__restrict__ rstd_i, const float *__restrict__ W,
+             const float *__restrict__ dlogits, const TX *__restrict__ dres, TX *__restrict__ dx,
+             float *__restrict__ part, int64_t T, int H) {
+  typedef typename raw4<TX>::type raw_t;
+  __shared__ float2 s_part[2][4][RT_R];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int Q = H / 4, Qw = (Q + 3) / 4;
+  const int q = wv * Qw + lane;
+  const bool act = lane < Qw && q < Q;
+  const int c = q * 4;
+  float4 w[NN], aw[NN], g4, b4, ag = make_float4(0, 0, 0, 0), ab = make_float4(0, 0, 0, 0);
+  float abias[NN];
+  g4 = act ? load4<float>(gamma + c) : make_float4(0, 0, 0, 0);
+  b4 = act ? load4<float>(beta + c) : make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int n = 0; n < NN; ++n) {
+    w[n] = act ? load4<float>(W + (int64_t)n * H + c) : make_float4(0, 0, 0, 0);
+    aw[n] = make_float4(0, 0, 0, 0);
+    abias[n] = 0.f;
+  }
+  const int64_t ntiles = ceil_div64(T, RT_R);
+  raw_t xr[RT_R], rr[RT_R], xr_next[RT_R], rr_next[RT_R];
+  auto fetch = [&](raw_t (&xo)[RT_R], raw_t (&ro)[RT_R], int64_t tile) {
+#pragma unroll
+    for (int j = 0; j < RT_R; ++j) {
+      const int64_t row = tile * RT_R + j;
+      const bool ok = act && row < T;
+      xo[j] = ok ? *reinterpret_cast<const raw_t *>(x + row * H + c) : raw_t{};
+      ro[j] = (ok && dres) ? *reinterpret_cast<const raw_t *>(dres + row * H + c) : raw_t{};
+    }
+  };
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) fetch(xr, rr, tile);
+  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
+    // the next tile's rows are requested before this tile is touched: a full iteration to arrive
+    fetch(xr_next, rr_next, tile + gridDim.x);
+    float4 xh[RT_R], dn[RT_R], rv[RT_R];
+    float rstd[RT_R];
+    float2 ps[RT_R];
+#pragma unroll
+    for (int j = 0; j < RT_R; ++j) {
+      const int64_t row = min(tile * RT_R + j, T - 1);
+      const bool live = tile * RT_R + j < T;
+      const float mean = mean_i[row];
+      rstd[j] = rstd_i[row];
+      const float4 xv = raw_to_f4(xr[j]);
+      rv[j] = raw_to_f4(rr[j]);
+      xh[j] = act ? make_float4((xv.x - mean) * rstd[j], (xv.y - mean) * rstd[j], (xv.z - mean) * rstd[j], (xv.w - mean) * rstd[j])
+                  : make_float4(0, 0, 0, 0);
+      const float4 xn = make_float4(xh[j].x * g4.x + b4.x, xh[j].y * g4.y + b4.y, xh[j].z * g4.z + b4.z, xh[j].w * g4.w + b4.w);
+      float4 d = make_float4(0, 0, 0, 0);   // dxn = dlogits @ W on this lane's columns
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        const float g = live ? dlogits[row * NN + n] : 0.f;   // wave-uniform address
+        d.x += g * w[n].x; d.y += g * w[n].y; d.z += g * w[n].z; d.w += g * w[n].w;
+        aw[n].x += g * xn.x; aw[n].y += g * xn.y; aw[n].z += g * xn.z; aw[n].w += g * xn.w;
+        abias[n] += g;
+      }
+      ag.x += d.x * xh[j].x; ag.y += d.y * xh[j].y; ag.z += d.z * xh[j].z; ag.w += d.w * xh[j].w;
+      ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
+      dn[j] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
+      ps[j].x = wave_sum((dn[j].x + dn[j].y) + (dn[j].z + dn[j].w));
+      ps[j].y = wave_sum((dn[j].x * xh[j].x + dn[j].y * xh[j].y) + (dn[j].z * xh[j].z + dn[j].w * xh[j].w));
+    }
+    if (lane == 0)
+#pragma unroll
+      for (int j = 0; j < RT_R; ++j) s_part[it & 1][wv][j] = ps[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RT_R; ++j) {
+      const float2 p0 = s_part[it & 1][0][j], p1 = s_part[it & 1][1][j], p2 = s_part[it & 1][2][j], p3 = s_part[it & 1][3][j];
+      const float m1 = ((p0.x + p1.x) + (p2.x + p3.x)) / (float)H, m2 = ((p0.y + p1.y) + (p2.y + p3.y)) / (float)H;
+      const int64_t row = tile * RT_R + j;
+      if (act && row < T)
+        store4<TX>(dx + row * H + c, make_float4(rstd[j] * (dn[j].x - m1 - xh[j].x * m2) + rv[j].x, rstd[j] * (dn[j].y - m1 - xh[j].y * m2) + rv[j].y,
+                                                  rstd[j] * (dn[j].z - m1 - xh[j].z * m2) + rv[j].z, rstd[j] * (dn[j].w - m1 - xh[j].w * m2) + rv[j].w));
+    }
+#pragma unroll
+    for (int j = 0; j < RT_R; ++j) { xr[j] = xr_next[j]; rr[j] = rr_next[j]; }
+  }
+  float *dst = part + (int64_t)blockIdx.x * (NN * H + NN + 2 * H);
+  if (act) {
+#pragma unroll
+    for (int n = 0; n < NN; ++n) *reinterpret_cast<float4 *>(dst + (int64_t)n * H + c) = aw[n];
+    *reinterpret_cast<float4 *>(dst + NN * H + NN + c) = ag;
+    *reinterpret_cast<float4 *>(dst + NN * H + NN + H + c) = ab;
+  }
+  if (wv == 0 && lane < NN) {
+    float o = 0.f;
+#pragma unroll
+    for (int n = 0; n < NN; ++n) if (lane == n) o = abias[n];
+    dst[NN * H + lane] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Tiny linear: y[T,N] = x[T,:K] W[N,K]^T + b with K <= 64, N <= 16 - the SSM's dt_proj_head
 // (Linear(dt_rank -> heads), reference core.py:361,382), whose input is a column slice of the
 // x_param_proj output (row stride ldx).  A GEMM library pays ~20 us forward and ~270 us backward
@@ -1309,5 +1508,42 @@ extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *
   else return APERTIS_ERR_ARG;
   const int64_t cols = N * K + N;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, dW_db, nblk, cols);
+  return apertis_check_launch();
+}
+
+extern "C" int64_t apertis_router_bwd_blocks(int64_t T) { return std::min<int64_t>(ceil_div64(T > 0 ? T : 1, RT_R), 512); }
+
+extern "C" int apertis_router_fwd(const void *x, const float *gamma, const float *beta, float eps, const float *W,
+                                  const float *b, float *logits, float *mean, float *rstd, int64_t T, int64_t H, int64_t N,
+                                  int dtype_x, void *stream) {
+  if (!x || !gamma || !beta || !W || !logits || !mean || !rstd || T < 0) return APERTIS_ERR_ARG;
+  if (H <= 0 || H % 4 || H > 1024 || N < 1 || N > 8) return APERTIS_ERR_UNSUPPORTED;
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(T, 8), 1024)), block(256);   // every block stages W once
+  if (dtype_x == APERTIS_BF16) {
+    SKINNY_N(N, SKINNY_IT(H, hipLaunchKernelGGL((router_fwd_k<bf16_t, IT, NN>), grid, block, (size_t)(N * H * 4), st, (const bf16_t *)x, gamma, beta, eps, W, b, logits, mean, rstd, T, (int)H)));
+  } else if (dtype_x == APERTIS_F32) {
+    SKINNY_N(N, SKINNY_IT(H, hipLaunchKernelGGL((router_fwd_k<float, IT, NN>), grid, block, (size_t)(N * H * 4), st, (const float *)x, gamma, beta, eps, W, b, logits, mean, rstd, T, (int)H)));
+  } else return APERTIS_ERR_ARG;
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
+                                  const float *W, const float *dlogits, const void *dres, void *dx, float *part,
+                                  float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
+  // part: workspace [apertis_router_bwd_blocks(T)][N*H + N + 2H]; grads: out [N*H dW | N db | H dgamma | H dbeta]
+  if (!x || !gamma || !beta || !mean || !rstd || !W || !dlogits || !dx || !part || !grads || T < 0) return APERTIS_ERR_ARG;
+  if (H <= 0 || H % 4 || H > 1024 || N < 1 || N > 8) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = apertis_router_bwd_blocks(T);
+  dim3 grid((unsigned)nblk), block(256);
+  if (dtype_x == APERTIS_BF16) {
+    SKINNY_N(N, hipLaunchKernelGGL((router_bwd_k<bf16_t, NN>), grid, block, 0, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H));
+  } else if (dtype_x == APERTIS_F32) {
+    SKINNY_N(N, hipLaunchKernelGGL((router_bwd_k<float, NN>), grid, block, 0, st, (const float *)x, gamma, beta, mean, rstd, W, dlogits, (const float *)dres, (float *)dx, part, T, (int)H));
+  } else return APERTIS_ERR_ARG;
+  const int64_t cols = N * H + N + 2 * H;
+  hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, grads, nblk, cols);
   return apertis_check_launch();
 }

@@ -381,11 +381,16 @@ class AdaptiveExpertSystem(nn.Module):
         B, L, H = hidden_states.shape
         S, E, K = B * L, self.num_experts, self.experts_per_token
         xf = hidden_states.reshape(S, H)
-        xn = self.router_norm(xf)                                                         # core.py:481
-        if xn.is_cuda and ops.skinny_linear_supported(H, E):
-            logits = ops.skinny_linear(xn, self.router.weight, self.router.bias)          # core.py:482 (fp32 out)
+        if ops.router_ln_linear_supported(xf, H, E):
+            # core.py:481-482 in one pass over x; xf comes back as the pass-through the expert path reads
+            logits, xf = ops.router_ln_linear(xf, self.router_norm.weight, self.router_norm.bias, self.router_norm.eps,
+                                              self.router.weight, self.router.bias)
         else:
-            logits = self.router(xn).float()
+            xn = self.router_norm(xf)                                                     # core.py:481
+            if xn.is_cuda and ops.skinny_linear_supported(H, E):
+                logits = ops.skinny_linear(xn, self.router.weight, self.router.bias)      # core.py:482 (fp32 out)
+            else:
+                logits = self.router(xn).float()
         if self.use_noisy_top_k_routing and self.training:                                # core.py:485-488
             logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
         gates, idx, w = ops.moe_gate_topk(logits, K)                                      # core.py:491-492,529

@@ -461,6 +461,63 @@ def split_cols(x, sizes):
     return _SplitCols.apply(x, *sizes)
 
 
+class _RouterLN(torch.autograd.Function):
+    """(Linear(LayerNorm(x)), x): the router projection with its norm fused in, handing x through so the
+    gradient of x's other consumers (the expert path) is added inside the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, eps, weight, bias):
+        _require_gpu(x, ln_w, ln_b, weight, bias)
+        lib = _lib.load()
+        x = x.contiguous()
+        T, H = x.shape
+        N = weight.shape[0]
+        g, be = ln_w.detach().float().contiguous(), ln_b.detach().float().contiguous()
+        w = weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        logits = torch.empty(T, N, device=x.device, dtype=torch.float32)
+        mean = torch.empty(T, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(T, device=x.device, dtype=torch.float32)
+        check(lib.apertis_router_fwd(ptr(x), ptr(g), ptr(be), float(eps), ptr(w), ptr(b), ptr(logits), ptr(mean), ptr(rstd),
+                                     T, H, N, dtype_code(x), stream_ptr()), "apertis_router_fwd")
+        ctx.save_for_backward(x, g, be, mean, rstd, w)
+        ctx.cfg = (ln_w.dtype, ln_b.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return logits, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dlogits, dpass):
+        lib = _lib.load()
+        x, g, be, mean, rstd, w = ctx.saved_tensors
+        T, H = x.shape
+        N = w.shape[0]
+        if dlogits is None:
+            return dpass, None, None, None, None, None
+        dlogits = dlogits.float().contiguous()
+        if dpass is not None:
+            dpass = dpass.to(x.dtype).contiguous()
+        dx = torch.empty_like(x)
+        nblk = lib.apertis_router_bwd_blocks(T)
+        cols = N * H + N + 2 * H
+        part = torch.empty(nblk, cols, device=x.device, dtype=torch.float32)
+        out = torch.empty(cols, device=x.device, dtype=torch.float32)
+        check(lib.apertis_router_bwd(ptr(x), ptr(g), ptr(be), ptr(mean), ptr(rstd), ptr(w), ptr(dlogits), ptr(dpass), ptr(dx),
+                                     ptr(part), ptr(out), T, H, N, dtype_code(x), stream_ptr()), "apertis_router_bwd")
+        gdt, bedt, wdt, bdt = ctx.cfg
+        dW, db = out[:N * H].reshape(N, H), out[N * H:N * H + N]
+        dg, dbe = out[N * H + N:N * H + N + H], out[N * H + N + H:]
+        return dx, dg.to(gdt), dbe.to(bedt), None, dW.to(wdt), (db.to(bdt) if bdt is not None else None)
+
+
+def router_ln_linear_supported(x, H, N):
+    return x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and N in (2, 4, 8) and H % 4 == 0 and H <= 1024
+
+
+def router_ln_linear(x, ln_weight, ln_bias, eps, weight, bias=None):
+    """(fp32 logits [T,N], x) with logits = Linear(LayerNorm(x)) (reference core.py:481-482) in one pass over
+    x; route x's other uses through the returned x so their gradient is folded into this op's backward."""
+    return _RouterLN.apply(x, ln_weight, ln_bias, eps, weight, bias)
+
+
 def skinny_linear_supported(K, N):
     return N in (2, 4, 8, 16) and K % 4 == 0 and K <= 1024 and (N <= 8 or K <= 256)
 

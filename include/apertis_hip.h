@@ -169,6 +169,21 @@ int apertis_skinny_linear_bwd(const void *x, const float *W, const float *dy, vo
                               int dtype_x, void *stream);
 int64_t apertis_skinny_linear_bwd_blocks(int64_t T);
 
+/* Router with its LayerNorm fused in (core.py:481-482): logits[T,N] = Linear(LayerNorm(x[T,H])),
+ * N in {2,4,8}, H % 4 == 0, H <= 1024; x fp32 or bf16, everything else fp32; mean/rstd [T] saved.
+ * Backward: dx [T,H] (x's dtype) = gradient through LN and the projection + dres (optional [T,H],
+ * x's dtype: the gradient arriving on the other consumers of x, i.e. the expert path);
+ * grads = [N*H dW | N db | H dgamma | H dbeta] fp32; part = workspace
+ * [apertis_router_bwd_blocks(T), N*H + N + 2H] fp32 (fixed-order fold). */
+int apertis_router_fwd(const void *x, const float *gamma, const float *beta, float eps,
+                       const float *W, const float *b, float *logits, float *mean, float *rstd,
+                       int64_t T, int64_t H, int64_t N, int dtype_x, void *stream);
+int apertis_router_bwd(const void *x, const float *gamma, const float *beta, const float *mean,
+                       const float *rstd, const float *W, const float *dlogits, const void *dres,
+                       void *dx, float *part, float *grads, int64_t T, int64_t H, int64_t N,
+                       int dtype_x, void *stream);
+int64_t apertis_router_bwd_blocks(int64_t T);
+
 /* Tiny linear y[T,N] = x[T,:K] W[N,K]^T + b for K <= 64, N <= 16: the SSM's
  * dt_proj_head (core.py:361,382) applied to a column slice of the x_param_proj output, read in
  * place (row stride ldx elements).  fp32 W/b/y, x fp32 or bf16.  Backward: dx rows (row stride lddx,

@@ -483,3 +483,29 @@ def test_layer_norm_pass_folds_residual_gradient(dev, T, H, dt_in, dt_out):
     _, xp2 = ops.layer_norm_pass(xd2, wd, bd, 1e-5, out_dtype=dt_out)
     (xp2.float() * gp.to(dev)).sum().backward()
     assert torch.allclose(xd2.grad.float().cpu(), gp.to(dt_in).float(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("T,H,N,dt", [(1000, 704, 8, torch.float32), (333, 32, 4, torch.float32), (4097, 256, 2, torch.bfloat16),
+                                       (5000, 704, 8, torch.bfloat16), (1, 1024, 8, torch.float32)])
+def test_router_ln_linear(dev, T, H, N, dt):
+    """Fused router: logits = Linear(LayerNorm(x)) (core.py:481-482) and its backward with the pass-through
+    gradient folded in, against the two stock torch ops in fp32."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(T + H + N)
+    x = (torch.randn(T, H) * 2 + 0.3).to(dt)
+    lw, lb = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    W, b = torch.randn(N, H) * 0.05, torch.randn(N) * 0.1
+    gl, gp = torch.randn(T, N), torch.randn(T, H).to(dt).float()
+    ref = [t.clone().requires_grad_(True) for t in (x.float(), lw, lb, W, b)]
+    ref_logits = F.linear(F.layer_norm(ref[0], (H,), ref[1], ref[2], 1e-5), ref[3], ref[4])
+    ((ref_logits * gl).sum() + (ref[0] * gp).sum()).backward()
+    dv = [t.to(dev).requires_grad_(True) for t in (x, lw, lb, W, b)]
+    assert ops.router_ln_linear_supported(dv[0], H, N)
+    logits, xp = ops.router_ln_linear(dv[0], dv[1], dv[2], 1e-5, dv[3], dv[4])
+    assert logits.dtype == torch.float32 and xp.data_ptr() == dv[0].data_ptr()
+    ((logits * gl.to(dev)).sum() + (xp.float() * gp.to(dev)).sum()).backward()
+    _close(logits, ref_logits, "logits", rtol=1e-4, atol_scale=1e-5)
+    rt = 1e-4 if dt == torch.float32 else 2e-2
+    _close(dv[0].grad.float(), ref[0].grad, "dx", rtol=rt, atol_scale=1e-5 if dt == torch.float32 else 1e-2)
+    for i, name in ((1, "dgamma"), (2, "dbeta"), (3, "dW"), (4, "db")):
+        _close(dv[i].grad, ref[i].grad, name, rtol=2e-4, atol_scale=2e-5)

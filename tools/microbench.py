@@ -77,9 +77,40 @@ def gemm():
               f"{fl/t2/1e9:6.0f} TF  TN {t3*1e3:7.1f} us {fl/t3/1e9:6.0f} TF")
 
 
+def rows():
+    """Row kernels of the MoE / SSM glue at the bench shapes: time and algorithmic GB/s (fwd+bwd separately)."""
+    T, H, E = 24 * 4096, 704, 8
+    x = torch.randn(T, H, device=dev).bfloat16().requires_grad_(True)
+    lw, lb = torch.ones(H, device=dev, requires_grad=True), torch.zeros(H, device=dev, requires_grad=True)
+    W, b = (torch.randn(E, H, device=dev) * 0.02).requires_grad_(True), torch.zeros(E, device=dev, requires_grad=True)
+    gl, gp = torch.randn(T, E, device=dev), torch.randn(T, H, device=dev).bfloat16()
+
+    def fwd_bwd(make, grads, nbytes_f, nbytes_b, name):
+        outs = make()
+        tf = timeit(make)
+        def bw():
+            torch.autograd.backward(outs, grads, retain_graph=True)
+        tb = timeit(bw)
+        print(f"{name:28s} fwd {tf*1e3:7.1f} us {nbytes_f/tf/1e6:7.0f} GB/s   bwd {tb*1e3:7.1f} us {nbytes_b/tb/1e6:7.0f} GB/s")
+
+    fwd_bwd(lambda: ops.router_ln_linear(x, lw, lb, 1e-5, W, b), [gl, gp], T * H * 2, T * H * 2 * 3, "router_ln_linear")
+    xf = torch.randn(T, H, device=dev, requires_grad=True)
+    gy = torch.randn(T, H, device=dev).bfloat16()
+    gpf = torch.randn(T, H, device=dev)
+    fwd_bwd(lambda: ops.layer_norm_pass(xf, lw, lb, 1e-5, out_dtype=torch.bfloat16), [gy, gpf], T * H * 6, T * H * 14,
+            "layer_norm_pass f32->bf16")
+    R, h, ld = 44, 11, 400
+    p = torch.randn(24, 4096, ld, device=dev).bfloat16().requires_grad_(True)
+    Wd, bd = (torch.randn(h, R, device=dev) * 0.1).requires_grad_(True), torch.zeros(h, device=dev, requires_grad=True)
+    gd = torch.randn(24, 4096, h, device=dev)
+    fwd_bwd(lambda: (ops.tiny_linear(p[..., :R], Wd, bd),), [gd], T * (R * 2 + h * 4), T * (R * 4 + h * 4), "tiny_linear 44->11")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("scan", "all"):
         scan()
     if what in ("gemm", "all"):
         gemm()
+    if what in ("rows", "all"):
+        rows()
