@@ -24,8 +24,8 @@ CONFIGS = {
     # name: (target params, moe, multimodal, seq, default per-GPU batch)   BASELINE.json configs[1..4]
     "125m": ("125M", False, False, 2048, 32),
     "350m-moe": ("350M", True, False, 4096, 16),
-    # per-GPU batch 24 x 4096 tokens: 167 GiB of the 288 GB HBM3E (measured); B=8 gives 153k tok/s, 24: 188k, 32: 193k
-    "1.5b-moe": ("1.5B", True, False, 4096, 24),
+    # per-GPU batch 32 x 4096 tokens: 181 GiB of the 288 GB HBM3E (measured); B=24 gives 244k tok/s, 32: 249k
+    "1.5b-moe": ("1.5B", True, False, 4096, 32),
     "1.5b-moe-mm": ("1.5B", True, True, 2048, 16),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
