@@ -64,12 +64,12 @@ SIGNATURES = {
     "apertis_moe_combine_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_moe_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _i32, _i32, _vp]),
-    "apertis_grouped_gemm_nt": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
+    "apertis_grouped_gemm_nt": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
                                        _i32, _i32, _vp]),
     "apertis_grouped_gemm_tn_workspace_bytes": (_i64, [_i64, _i32]),
     "apertis_grouped_gemm_tn_pair": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                             _vp, _i64, _i32, _vp]),
-    "apertis_cast_transpose": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_cast_transpose": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _vp]),
     "apertis_router_fwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_router_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),

@@ -200,7 +200,7 @@ template <typename T, typename TO, bool GLDS>
 __global__ void __launch_bounds__(NT)
 grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float *__restrict__ bias,
                   const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                  const TO *__restrict__ mul_pre, int N, int K, int E, int n_tiles, int act, float drop_p,
+                  const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act, float drop_p,
                   uint64_t seed) {
   typedef typename frag_t<T>::type frag;
   constexpr int KPC = 16 / sizeof(T);
@@ -219,7 +219,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
   const int rows_valid = min(BM, tc.rows_left);
   const int cols_valid = min(BN, N - n0);
   const T *xbase = X + tc.row0 * K;
-  const T *wbase = W + ((int64_t)tc.e * N + n0) * K;
+  const T *wbase = W + ((int64_t)tc.e * N + n0) * ldw;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -256,7 +256,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
       for (int j = 0; j < 4; ++j) {
         const int piece = wave * 4 + j;   // 16 pieces of 8 rows per operand tile
         glds_piece<T>(xs + piece * 1024, xbase, K, piece * 8, rows_valid, kt * BK, lane);
-        glds_piece<T>(ws + piece * 1024, wbase, K, piece * 8, cols_valid, kt * BK, lane);
+        glds_piece<T>(ws + piece * 1024, wbase, ldw, piece * 8, cols_valid, kt * BK, lane);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -266,7 +266,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
   } else {
     uint4 xr[4], wr[4];
     load_tile_regs<T>(xr, xbase, K, rows_valid, 0, K, tid);
-    load_tile_regs<T>(wr, wbase, K, cols_valid, 0, K, tid);
+    load_tile_regs<T>(wr, wbase, ldw, cols_valid, 0, K, tid);
     store_tile_lds(smem, xr, tid);
     store_tile_lds(smem + TILE_BYTES, wr, tid);
     __syncthreads();
@@ -275,7 +275,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
       char *ws = xs + TILE_BYTES;
       if (kt + 1 < nk) {
         load_tile_regs<T>(xr, xbase, K, rows_valid, (kt + 1) * BK, K, tid);
-        load_tile_regs<T>(wr, wbase, K, cols_valid, (kt + 1) * BK, K, tid);
+        load_tile_regs<T>(wr, wbase, ldw, cols_valid, (kt + 1) * BK, K, tid);
       }
       compute_tile(xs, ws);
       if (kt + 1 < nk) {
@@ -380,7 +380,7 @@ template <typename TO>
 __global__ void __launch_bounds__(NT2)
 grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                      const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                     const TO *__restrict__ mul_pre, int N, int K, int E, int n_tiles, int act, float drop_p,
+                     const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act, float drop_p,
                      uint64_t seed) {
   typedef bf16_t T;
   typedef bf16x8 frag;
@@ -399,7 +399,7 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
   const int rows_valid = min(BM2, tc.rows_left);
   const int cols_valid = min(BN2, N - n0);
   const T *xbase = X + tc.row0 * K;
-  const T *wbase = W + ((int64_t)tc.e * N + n0) * K;
+  const T *wbase = W + ((int64_t)tc.e * N + n0) * ldw;
 
   f32x4 acc[4][8];  // [n-subtile][m-subtile]
 #pragma unroll
@@ -415,7 +415,7 @@ grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W,
     for (int j = 0; j < 4; ++j) {
       const int piece = wave * 4 + j;  // 32 pieces of 8 rows per operand tile
       glds_piece<T>(xs + piece * 1024, xbase, K, piece * 8, rows_valid, kt * BK, lane);
-      glds_piece<T>(ws + piece * 1024, wbase, K, piece * 8, cols_valid, kt * BK, lane);
+      glds_piece<T>(ws + piece * 1024, wbase, ldw, piece * 8, cols_valid, kt * BK, lane);
     }
   };
   stage(0, 0);
@@ -629,12 +629,14 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
   }
 }
 
-template <typename TO>
+// RAGGED: K % 64 != 0 or W has its own row pitch (the dense projections); otherwise ldw == K and both
+// operands share one lane offset
+template <typename TO, bool RAGGED>
 __global__ void __launch_bounds__(NT2)
 grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                       const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                      const TO *__restrict__ mul_pre, int N, int K, int E, int n_tiles, int total_tiles, int solo,
-                      int act, float drop_p, uint64_t seed) {
+                      const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int total_tiles,
+                      int solo, int act, float drop_p, uint64_t seed) {
   typedef bf16_t T;
   typedef bf16x8 frag;
   constexpr int BK = 64;
@@ -654,7 +656,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
   for (int e = 0; e < E; ++e) mt_valid += (s_off[e + 1] - s_off[e] + BM2 - 1) / BM2;
   const int n_valid = __builtin_amdgcn_readfirstlane(min(total_tiles, mt_valid * n_tiles));
 
-  const int nk = K / BK;
+  const int nk = (K + BK - 1) / BK;
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
 
@@ -690,18 +692,28 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     // come through raw buffer descriptors sized to the tile's valid rows: the hardware bounds check
     // zero-fills ragged rows, and a piece's address is one per-lane VGPR (row-in-piece and swizzled
     // 16-byte chunk, identical for all pieces) + a scalar piece/K-step offset
-    const int ldb = K * (int)sizeof(T);
+    // K need not be a multiple of 64: the last K step then reads past a row's end - the next row's
+    // first columns, or zeros past the tile's last valid row (the K-step offset is part of the
+    // range-checked lane offset) - and W carries zero columns there (row pitch ldw >= the K steps)
+    const int ldb = K * (int)sizeof(T), ldwb = ldw * (int)sizeof(T);
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<T *>(X + nxt.row0 * K), 0, nxt.rows_valid * ldb, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T *>(W + ((int64_t)nxt.e * N + nxt.n0) * K), 0, nxt.cols_valid * ldb, 0x00020000);
-    const int voff0 = (lane >> 3) * ldb + (((lane & 7) ^ (lane >> 3)) << 4);
+        const_cast<T *>(W + ((int64_t)nxt.e * N + nxt.n0) * ldw), 0, nxt.cols_valid * ldwb, 0x00020000);
+    // a piece's address = one per-lane VGPR per operand (row-in-piece and swizzled 16-byte chunk) + scalar
+    // terms.  The hardware range check covers the lane offset only, so the piece's row offset always
+    // goes there; the K-step offset rides in the (unchecked) scalar offset unless K is ragged
+    const int chunk_sw = ((lane & 7) ^ (lane >> 3)) << 4;
+    const int voffx0 = (lane >> 3) * ldb + chunk_sw, voffw0 = RAGGED ? (lane >> 3) * ldwb + chunk_sw : voffx0;
     auto piece = [&](char *xs, int p, int kt) {   // 8 rows x 128 B of both operands
-      const int voff = voff0 + p * 8 * ldb;       // in the VGPR: the range check ignores the scalar offset
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(xs + p * 1024), 16, voff,
-                                               kt * BK * (int)sizeof(T), 0, 0);
+      const int kbytes = kt * BK * (int)sizeof(T);
+      // (a runtime select in the ragged variant: hipcc spills 75 VGPRs when it is folded, 25 when it is not)
+      const bool ktail = RAGGED && (K & (BK - 1)) != 0;
+      const int kv = ktail ? kbytes : 0, ks = ktail ? 0 : kbytes;
+      const int vx = voffx0 + (p * 8 * ldb + kv), vw = RAGGED ? voffw0 + (p * 8 * ldwb + kv) : vx;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(xs + p * 1024), 16, vx, ks, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(xs + TILE2_BYTES + p * 1024), 16,
-                                               voff, kt * BK * (int)sizeof(T), 0, 0);
+                                               vw, ks, 0, 0);
     };
     // K step kt's operands (32 + 32 pieces): by waves 0-3 alone while kt <= solo
     auto stage = [&](int buf, int kt) {
@@ -1390,9 +1402,9 @@ template <typename T> bool aligned16(const void *p, int64_t ld) {
 
 template <typename T, typename TO>
 int launch_nt(const void *A, const void *W, const float *bias, const int32_t *offsets, void *C, void *pre_act,
-              const void *mul_pre, int64_t max_rows, int64_t N, int64_t K, int64_t E, int act, float drop_p, uint64_t seed,
-              hipStream_t st) {
-  if (!aligned16<T>(A, K) || !aligned16<T>(W, K) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)) ||
+              const void *mul_pre, int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E, int act, float drop_p,
+              uint64_t seed, hipStream_t st) {
+  if (!aligned16<T>(A, K) || !aligned16<T>(W, ldw) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)) ||
       (mul_pre && !aligned16<TO>(mul_pre, N)))
     return APERTIS_ERR_UNSUPPORTED;
   const int n_tiles = (int)ceil_div64(N, BN);
@@ -1401,26 +1413,31 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   constexpr int BK = ROWB / sizeof(T);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
-    if (K % 64 == 0 && N >= 512 && max_rows >= 4096 && !getenv("APERTIS_GEMM_TILE128")) {
+    // the 256x256 kernels step K in 64s: K itself may be ragged when W's rows are zero-padded to the step.
+    // One group (dense projection) takes them at any width: narrow outputs are HBM-bound and the
+    // persistent kernel's cross-tile prefetch matters more than the MFMA work a partial n-tile wastes
+    const bool kpad_ok = K % 64 == 0 || ldw >= ceil_div64(K, 64) * 64;
+    if (kpad_ok && (N >= 512 || (E == 1 && N >= 128)) && max_rows >= 4096 && !getenv("APERTIS_GEMM_TILE128")) {
       const int nt2 = (int)ceil_div64(N, BN2);
       const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;
-      if (!getenv("APERTIS_GEMM_NT256_V1") && E <= 1024 && grid2 < 0x7fffffffLL) {
+      if ((K % 64 || !getenv("APERTIS_GEMM_NT256_V1")) && E <= 1024 && grid2 < 0x7fffffffLL) {
         const int ncu = device_cu_count();
         const int gp = (int)std::min<int64_t>(grid2, ncu);          // one persistent work-group per CU
         size_t ldsp = 4 * TILE2_BYTES + 4096 + 16;                   // ring + group offsets
         static const int solo = getenv("APERTIS_GEMM_SOLO") ? atoi(getenv("APERTIS_GEMM_SOLO")) : 4;
-        auto kp = grouped_gemm_nt256p_k<TO>;
+        auto kp = (K % 64 == 0 && ldw == K) ? grouped_gemm_nt256p_k<TO, false> : grouped_gemm_nt256p_k<TO, true>;
         hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         hipLaunchKernelGGL(kp, dim3((unsigned)gp), dim3(NT2), ldsp, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
-                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, nt2, (int)grid2, solo, act,
-                           drop_p, seed);
+                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt2, (int)grid2, solo,
+                           act, drop_p, seed);
         return apertis_check_launch();
       }
+      if (K % 64) return APERTIS_ERR_UNSUPPORTED;   // only reachable with E > 1024 groups
       size_t lds2 = std::max<size_t>(4 * TILE2_BYTES, (size_t)BM2 * (BN2 * sizeof(TO) + 16));
       auto k2 = grouped_gemm_nt256_k<TO>;
       hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
       hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(NT2), lds2, st, (const bf16_t *)A, (const bf16_t *)W, bias,
-                         offsets, (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, nt2, act, drop_p, seed);
+                         offsets, (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt2, act, drop_p, seed);
       return apertis_check_launch();
     }
   }
@@ -1430,13 +1447,13 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     auto kern = grouped_gemm_nt_k<T, TO, true>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, n_tiles, act, drop_p, seed);
   } else {
     size_t lds = std::max<size_t>(4 * TILE_BYTES, cstage);
     auto kern = grouped_gemm_nt_k<T, TO, false>;
     if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)E, n_tiles, act, drop_p, seed);
+                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, n_tiles, act, drop_p, seed);
   }
   return apertis_check_launch();
 }
@@ -1444,24 +1461,26 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
 }  // namespace
 
 extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias, const int32_t *offsets,
-                                       void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K, int64_t E,
-                                       int act, float drop_p, uint64_t seed, int dtype, int dtype_out, void *stream) {
-  if (!A || !W || !offsets || !C || max_rows < 0 || N <= 0 || K <= 0 || E <= 0) return APERTIS_ERR_ARG;
+                                       void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K,
+                                       int64_t ldw, int64_t E, int act, float drop_p, uint64_t seed, int dtype, int dtype_out,
+                                       void *stream) {
+  if (!A || !W || !offsets || !C || max_rows < 0 || N <= 0 || K <= 0 || E <= 0 || (ldw != 0 && ldw < K)) return APERTIS_ERR_ARG;
+  if (ldw == 0) ldw = K;
   if (drop_p < 0.f || drop_p >= 1.f || (act_bwd_pre && (pre_act || bias))) return APERTIS_ERR_ARG;
   if (max_rows == 0) return APERTIS_OK;
-  if (max_rows > 0x7fffffffLL || N > 0x3fffffff || K > 0x3fffffff || E > 4096) return APERTIS_ERR_UNSUPPORTED;
+  if (max_rows > 0x7fffffffLL || N > 0x3fffffff || K > 0x3fffffff || ldw > 0x3fffffff || E > 4096) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_BF16) {
     if (K % 8 || N % 8) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, E, act, drop_p, seed, st);
+    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, st);
   }
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_F32) {
     if (K % 8 || N % 4) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, E, act, drop_p, seed, st);
+    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, st);
   }
   if (dtype == APERTIS_F32 && dtype_out == APERTIS_F32) {
     if (K % 4 || N % 4) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, E, act, drop_p, seed, st);
+    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, st);
   }
   return APERTIS_ERR_UNSUPPORTED;
 }

@@ -339,7 +339,8 @@ dropout_bwd_k(const TG *__restrict__ g, TX *__restrict__ dx, int64_t n4, float d
 // ---------------------------------------------------------------- cast (+ transposed copy)
 template <typename TO>
 __global__ void __launch_bounds__(256)
-cast_transpose_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__restrict__ dstT, int R, int C) {
+cast_transpose_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__restrict__ dstT, int R, int C, int ld_dst,
+                 int ld_dstT) {
   __shared__ float tile[64][65];
   const int64_t e = blockIdx.z;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -349,13 +350,13 @@ cast_transpose_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__rest
     int r = r0 + i, c = c0 + tx;
     float v = (r < R && c < C) ? s[(int64_t)r * C + c] : 0.f;
     tile[i][tx] = v;
-    if (dst && r < R && c < C) dst[e * (int64_t)R * C + (int64_t)r * C + c] = from_f32<TO>(v);
+    if (dst && r < R && c < ld_dst) dst[e * (int64_t)R * ld_dst + (int64_t)r * ld_dst + c] = from_f32<TO>(v);   // pad columns: 0
   }
   __syncthreads();
   if (dstT)
     for (int i = ty; i < 64; i += 4) {
       int c = c0 + i, r = r0 + tx;
-      if (r < R && c < C) dstT[e * (int64_t)R * C + (int64_t)c * R + r] = from_f32<TO>(tile[tx][i]);
+      if (r < ld_dstT && c < C) dstT[e * (int64_t)C * ld_dstT + (int64_t)c * ld_dstT + r] = from_f32<TO>(tile[tx][i]);
     }
 }
 
@@ -462,15 +463,21 @@ extern "C" int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float 
 }
 
 extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R, int64_t C,
-                                      int dtype_out, void *stream) {
+                                      int64_t ld_dst, int64_t ld_dstT, int dtype_out, void *stream) {
   if (!src || (!dst && !dstT) || E <= 0 || R <= 0 || C <= 0) return APERTIS_ERR_ARG;
+  if (ld_dst == 0) ld_dst = C;
+  if (ld_dstT == 0) ld_dstT = R;
+  // the pad columns are written by the 64-wide tile that holds the last real column
+  if (ld_dst < C || ld_dst > ceil_div64(C, 64) * 64 || ld_dstT < R || ld_dstT > ceil_div64(R, 64) * 64) return APERTIS_ERR_ARG;
   if (R > 0x3fffffff || C > 0x3fffffff || E > 65535 || ceil_div64(R, 64) > 65535) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)ceil_div64(C, 64), (unsigned)ceil_div64(R, 64), (unsigned)E), block(256);
   if (dtype_out == APERTIS_BF16)
-    hipLaunchKernelGGL(cast_transpose_k<bf16_t>, grid, block, 0, st, src, (bf16_t *)dst, (bf16_t *)dstT, (int)R, (int)C);
+    hipLaunchKernelGGL(cast_transpose_k<bf16_t>, grid, block, 0, st, src, (bf16_t *)dst, (bf16_t *)dstT, (int)R, (int)C, (int)ld_dst,
+                       (int)ld_dstT);
   else if (dtype_out == APERTIS_F32)
-    hipLaunchKernelGGL(cast_transpose_k<float>, grid, block, 0, st, src, (float *)dst, (float *)dstT, (int)R, (int)C);
+    hipLaunchKernelGGL(cast_transpose_k<float>, grid, block, 0, st, src, (float *)dst, (float *)dstT, (int)R, (int)C, (int)ld_dst,
+                       (int)ld_dstT);
   else
     return APERTIS_ERR_ARG;
   return apertis_check_launch();

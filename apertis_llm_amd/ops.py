@@ -642,7 +642,9 @@ def moe_combine(yr, w, plan, out_dtype=None):
 
 
 def cast_transpose(w, dtype, want_plain=True, want_transposed=True):
-    """Compute copies of an fp32 master weight [E,R,C]: ([E,R,C], [E,C,R]) in `dtype`."""
+    """Compute copies of an fp32 master weight [E,R,C]: ([E,R,C'], [E,C,R']) in `dtype`.  In bf16 the
+    last dimension is zero-padded to a multiple of 64 (C', R'): the GEMM's W operand then has whole
+    64-wide K steps whatever K is; pass `.shape[-1]` as its row pitch (ldw)."""
     _require_gpu(w)
     lib = _lib.load()
     w = w.detach()
@@ -650,10 +652,13 @@ def cast_transpose(w, dtype, want_plain=True, want_transposed=True):
         w = w.float()
     w = w.contiguous()
     E, R, C = w.shape
-    plain = torch.empty(E, R, C, device=w.device, dtype=dtype) if want_plain else None
-    tr = torch.empty(E, C, R, device=w.device, dtype=dtype) if want_transposed else None
+    pad = dtype == torch.bfloat16
+    Cp, Rp = (-(-C // 64) * 64, -(-R // 64) * 64) if pad else (C, R)
+    plain = torch.empty(E, R, Cp, device=w.device, dtype=dtype) if want_plain else None
+    tr = torch.empty(E, C, Rp, device=w.device, dtype=dtype) if want_transposed else None
     code = _lib.BF16 if dtype == torch.bfloat16 else _lib.F32
-    check(lib.apertis_cast_transpose(ptr(w), ptr(plain), ptr(tr), E, R, C, code, stream_ptr()), "apertis_cast_transpose")
+    check(lib.apertis_cast_transpose(ptr(w), ptr(plain), ptr(tr), E, R, C, Cp, Rp, code, stream_ptr()),
+          "apertis_cast_transpose")
     return plain, tr
 
 
@@ -737,8 +742,8 @@ class _GroupedLinear(torch.autograd.Function):
         out = torch.empty(x.shape[0], N, device=x.device, dtype=compute_dtype)
         pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
         _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
-                (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), None, max_rows, N, K, E, act_code, float(drop_p),
-                 int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
+                (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), None, max_rows, N, K, wc.shape[-1], E, act_code,
+                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         ctx.save_for_backward(x, wt, pre, offsets)
         ctx.cfg = (E, N, K, max_rows, act_code, float(drop_p), int(seed), bias is not None, weight.dtype)
         return out
@@ -760,8 +765,8 @@ class _GroupedLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
-                    (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, None, max_rows, K, N, E, _lib.ACT_NONE, 0.0, 0, code,
-                     code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
+                    (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, None, max_rows, K, N, wt.shape[-1], E, _lib.ACT_NONE,
+                     0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
                 # dense layer: the K dimension of the weight gradient is ALL rows; cut it into
@@ -887,12 +892,12 @@ class _ExpertMLP(torch.autograd.Function):
         h = torch.empty(R, I, device=xg.device, dtype=cd)
         pre = torch.empty_like(h) if need else None
         _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
-                (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, E, act_code,
+                (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, w1c.shape[-1], E, act_code,
                  float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
         yr = torch.empty(R, H, device=xg.device, dtype=cd)
         _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
-                (ptr(h), ptr(w2c), ptr(b2f), ptr(offsets), ptr(yr), None, None, max_rows, H, I, E, _lib.ACT_NONE, 0.0, 0,
-                 code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
+                (ptr(h), ptr(w2c), ptr(b2f), ptr(offsets), ptr(yr), None, None, max_rows, H, I, w2c.shape[-1], E, _lib.ACT_NONE,
+                 0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
         ctx.save_for_backward(xg, pre, h, w1t, w2t, offsets)
         ctx.cfg = (E, I, H, max_rows, act_code, float(drop_p), int(seed), w1.dtype, w2.dtype)
         return yr
@@ -910,14 +915,14 @@ class _ExpertMLP(torch.autograd.Function):
         if FUSE_ACT_BWD:
             # dpre = (dyr @ W2) * keep/(1-p) * act'(pre): layer 1's activation backward in the dgrad epilogue
             _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
-                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, E, act_code, drop_p,
-                     seed, code, code, stream_ptr()), work)
+                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, w2t.shape[-1], E, act_code,
+                     drop_p, seed, code, code, stream_ptr()), work)
         else:
             # measured on MI355X: with one 256x256 work-group per CU nothing overlaps the epilogue, so the
             # fused form costs more than this separate bandwidth-bound pass (in place on dpre)
             _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
-                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, None, max_rows, I, H, E, _lib.ACT_NONE, 0.0, 0,
-                     code, code, stream_ptr()), work)
+                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, None, max_rows, I, H, w2t.shape[-1], E, _lib.ACT_NONE,
+                     0.0, 0, code, code, stream_ptr()), work)
             if act_code != _lib.ACT_NONE or drop_p > 0:
                 check(lib.apertis_act_dropout_bwd(ptr(dpre), ptr(pre), ptr(dpre), ptr(offsets), max_rows, I, E, act_code,
                                                   drop_p, seed, code, stream_ptr()), "apertis_act_dropout_bwd")
@@ -925,8 +930,8 @@ class _ExpertMLP(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dxg = torch.empty_like(xg)
             _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
-                    (ptr(dpre), ptr(w1t), None, ptr(offsets), ptr(dxg), None, None, max_rows, H, I, E, _lib.ACT_NONE, 0.0, 0,
-                     code, code, stream_ptr()), work)
+                    (ptr(dpre), ptr(w1t), None, ptr(offsets), ptr(dxg), None, None, max_rows, H, I, w1t.shape[-1], E, _lib.ACT_NONE,
+                     0.0, 0, code, code, stream_ptr()), work)
         # both weight gradients in ONE launch: dW2 = dyr^T h, dW1 = dpre^T xg
         dw2 = torch.empty(E, H, I, device=dev, dtype=torch.float32)
         db2 = torch.empty(E, H, device=dev, dtype=torch.float32)

@@ -276,6 +276,8 @@ int apertis_moe_combine_bwd(const void *dout, const void *yr, const int32_t *row
  * dtype: APERTIS_BF16 -> bf16 operands, fp32 accumulate on v_mfma_f32_16x16x32_bf16;
  *        APERTIS_F32  -> fp32 operands on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
  * max_rows bounds the grid (offsets live on the device; no host sync).
+ * ldw (NT): row pitch of W in elements, 0 = K.  With ldw >= K rounded up to 64 and the pad columns
+ *   zero (apertis_cast_transpose writes them), the 256x256 bf16 kernels also take K % 64 != 0.
  * pre_act (optional, NT only): also stores the pre-activation (needed by the backward).
  * act_bwd_pre (optional, dgrad fusion; excludes bias/pre_act): C = (A*W^T) (.) keepmask/(1-p) (.)
  *   act'(act_bwd_pre), i.e. the data gradient w.r.t. the PRE-activation of the producing layer, with
@@ -287,7 +289,7 @@ int apertis_moe_combine_bwd(const void *dout, const void *yr, const int32_t *row
 int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
                             const int32_t *offsets, void *C, void *pre_act,
                             const void *act_bwd_pre,
-                            int64_t max_rows, int64_t N, int64_t K, int64_t E,
+                            int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E,
                             int act, float drop_p, uint64_t seed,
                             int dtype, int dtype_out, void *stream);
 /* TN workspace (bf16 only): the 256x256-tile kernel deals the CUs out to the (problem, group)
@@ -306,10 +308,12 @@ int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, flo
                                  float *dW1, float *dbias1, int64_t M1, int64_t N1,
                                  const int32_t *offsets, int64_t max_rows, int64_t E,
                                  void *ws, int64_t ws_bytes, int dtype, void *stream);
-/* Compute copies of fp32 master weights src [E,R,C]: dst [E,R,C] and/or dstT [E,C,R] in
- * dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call. */
+/* Compute copies of fp32 master weights src [E,R,C]: dst [E,R,ld_dst] and/or dstT [E,C,ld_dstT]
+ * in dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call.
+ * ld_dst in [C, C rounded up to 64], ld_dstT in [R, R rounded up to 64] (0 = unpadded); pad columns
+ * are written as zero - the form apertis_grouped_gemm_nt wants for K % 64 != 0. */
 int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R,
-                           int64_t C, int dtype_out, void *stream);
+                           int64_t C, int64_t ld_dst, int64_t ld_dstT, int dtype_out, void *stream);
 /* out[c] = sum_r in[r,c] over a row-major fp32 [rows, cols] matrix, fixed summation order
  * (folds split-K partial weight gradients and per-block partial sums deterministically). */
 int apertis_colsum_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream);

@@ -53,7 +53,10 @@ def scan():
 def gemm():
     import numpy as np
     for (rows, N, K, E) in [(40960, 2816, 704, 8), (40960, 704, 2816, 8), (81920, 2816, 704, 8), (81920, 704, 2816, 8),
-                            (10240, 1024, 256, 8), (65536, 4096, 4096, 8), (32768, 352, 704, 1), (32768, 704, 176, 1)]:
+                            (10240, 1024, 256, 8), (65536, 4096, 4096, 8), (32768, 352, 704, 1), (32768, 704, 176, 1),
+                            # the SSM block's dense projections and their data gradients at the bench shape
+                            (131072, 352, 704, 1), (131072, 400, 176, 1), (131072, 704, 176, 1), (131072, 176, 704, 1),
+                            (131072, 176, 400, 1), (131072, 704, 352, 1)]:
         x = torch.randn(rows, K, device=dev).bfloat16()
         W = torch.randn(E, N, K, device=dev) / K ** 0.5
         offs = torch.tensor(np.linspace(0, rows, E + 1).astype(np.int32), device=dev)
@@ -64,9 +67,9 @@ def gemm():
         lib = _lib.load()
         P, S = _lib.ptr, _lib.stream_ptr
         def nt():
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N, K, E, 0, 0.0, 0, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N, K, wc.shape[-1], E, 0, 0.0, 0, 1, 1, S())
         def nt_epi():
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N, K, E, 1, 0.1, 7, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N, K, wc.shape[-1], E, 1, 0.1, 7, 1, 1, S())
         dw = torch.empty(E, N, K, device=dev)
         ws = torch.empty(max(16, _lib.load().apertis_grouped_gemm_tn_workspace_bytes(E, 1)), device=dev, dtype=torch.uint8)
         def tn():

@@ -59,7 +59,7 @@ if what in ("all", "gemm"):
         dw = torch.empty(E, N_, K_, device=dev)
         ws = torch.empty(max(16, lib.apertis_grouped_gemm_tn_workspace_bytes(E, 1)), device=dev, dtype=torch.uint8)
         for _ in range(reps):
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N_, K_, E, 0, 0.0, 0, 1, 1, S())
-            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N_, K_, E, 1, 0.1, 7, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N_, K_, wc.shape[-1], E, 0, 0.0, 0, 1, 1, S())
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N_, K_, wc.shape[-1], E, 1, 0.1, 7, 1, 1, S())
             lib.apertis_grouped_gemm_tn(P(out), P(x), P(offs), P(dw), None, rows, N_, K_, E, P(ws), ws.numel(), 1, S())
 torch.cuda.synchronize()
