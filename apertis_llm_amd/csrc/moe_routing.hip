@@ -937,6 +937,156 @@ fold_rows_k(const float *__restrict__ part, float *__restrict__ out, int64_t nro
 }
 
 // ------------------------------------------------------------------------------------------
+// gate + auxiliary losses in one pass (training): besides gates / top-K / weights, the per-row
+// log-sum-exp and the three reductions the two router losses need - column sums of the gates,
+// assignment counts per expert, sum of lse^2 - as per-block partials, folded in block order by
+// gate_aux_fold_k, which also evaluates (reference core.py:499-505, 524-526)
+//   lb = lb_coef * E * sum_e (count_e / S) * (colsum_e / S),   rz = rz_coef * sum_s lse_s^2 / S.
+// As stock tensor ops the two losses are ~35 launches forward and ~25 backward per layer, 4-5 us each
+// on [S, 8] tensors, plus a 47 us index_add.  stats out: [lb, rz, frac_0..frac_{E-1}].
+// ------------------------------------------------------------------------------------------
+template <int EC>
+__global__ void __launch_bounds__(256)
+gate_topk_aux_fwd_k(const float *__restrict__ logits, float *__restrict__ gates, int32_t *__restrict__ idx,
+                    float *__restrict__ w, float *__restrict__ lse, float *__restrict__ part, int64_t S, int E_rt, int K) {
+  constexpr int CAP = EC > 0 ? EC : MAXE;
+  const int E = EC > 0 ? EC : E_rt;
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = s < S;
+  float v[CAP];
+  float cnt[CAP];
+  float l2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CAP; ++i) { v[i] = 0.f; cnt[i] = 0.f; }
+  if (live) {
+    const float *row = logits + s * E;
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (i < E) { v[i] = row[i]; m = fmaxf(m, v[i]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (i < E) { v[i] = expf(v[i] - m); sum += v[i]; }
+    const float l = m + logf(sum);
+    lse[s] = l;
+    l2 = l * l;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (i < E) { v[i] = v[i] / sum; gates[s * E + i] = v[i]; }
+    uint64_t chosen = 0;
+    float p[MAXK];
+    float psum = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      if (k < K) {
+        float best = -1.f;
+        int bi = 0;
+#pragma unroll
+        for (int i = 0; i < CAP; ++i)
+          if (i < E && !((chosen >> i) & 1) && v[i] > best) { best = v[i]; bi = i; }
+        chosen |= 1ull << bi;
+        idx[s * K + k] = bi;
+        p[k] = best;
+        psum += best;
+      }
+    }
+    const float den = psum + 1e-6f;  // core.py:529
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < K) w[s * K + k] = p[k] / den;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (i < E) cnt[i] = (float)((chosen >> i) & 1);
+  }
+  // block partials: [colsum(gates) E | counts E | sum lse^2]
+  __shared__ float red[4][2 * MAXE + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < CAP; ++i) {
+    if (i < E) {
+      const float a = wave_sum(v[i]), b = wave_sum(cnt[i]);
+      if (lane == 0) { red[wv][i] = a; red[wv][E + i] = b; }
+    }
+  }
+  l2 = wave_sum(l2);
+  if (lane == 0) red[wv][2 * E] = l2;
+  __syncthreads();
+  if (threadIdx.x < 2 * E + 1)
+    part[(int64_t)blockIdx.x * (2 * E + 1) + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(64)
+gate_aux_fold_k(const float *__restrict__ part, float *__restrict__ stats, int64_t nblk, int64_t S, int E, float lb_coef,
+                float rz_coef) {
+  __shared__ float tot[2 * MAXE + 1];
+  const int c = threadIdx.x;
+  const int cols = 2 * E + 1;
+  for (int cc = c; cc < cols; cc += 64) {
+    float a = 0.f;
+    for (int64_t b = 0; b < nblk; ++b) a += part[b * cols + cc];
+    tot[cc] = a;
+  }
+  __syncthreads();
+  if (c == 0) {
+    float lb = 0.f;
+    for (int e = 0; e < E; ++e) lb += (tot[E + e] / (float)S) * (tot[e] / (float)S);
+    stats[0] = lb_coef * (float)E * lb;
+    stats[1] = rz_coef * tot[2 * E] / (float)S;
+  }
+  if (c < E) stats[2 + c] = tot[E + c] / (float)S;
+}
+
+// backward of gate + losses: dgates[s,e] = dlb * lb_coef * E * frac_e / S (the load-balancing loss through the
+// gate means), dlogits += drz * rz_coef * 2 lse_s / S * gates[s,e] (d lse / d logits = softmax)
+template <int EC>
+__global__ void gate_topk_aux_bwd_k(const float *__restrict__ gates, const int32_t *__restrict__ idx,
+                                    const float *__restrict__ dw, const float *__restrict__ lse,
+                                    const float *__restrict__ stats, const float *__restrict__ dlb,
+                                    const float *__restrict__ drz, float lb_coef, float rz_coef,
+                                    float *__restrict__ dlogits, int64_t S, int E_rt, int K) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  constexpr int CAP = EC > 0 ? EC : MAXE;
+  const int E = EC > 0 ? EC : E_rt;
+  const float glb = dlb ? dlb[0] * lb_coef * (float)E / (float)S : 0.f;
+  const float grz = drz ? drz[0] * rz_coef * 2.f * lse[s] / (float)S : 0.f;
+  float g[CAP], dg[CAP];
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) { g[i] = gates[s * E + i]; dg[i] = glb * stats[2 + i]; }
+  if (dw) {
+    float psum = 0.f, dot = 0.f;
+    for (int k = 0; k < K; ++k) {
+      int e = idx[s * K + k];
+      float pe = 0.f;
+#pragma unroll
+      for (int i = 0; i < CAP; ++i)
+        if (i == e) pe = g[i];
+      psum += pe;
+      dot += dw[s * K + k] * pe;
+    }
+    const float den = psum + 1e-6f;
+    const float corr = dot / (den * den);
+    for (int k = 0; k < K; ++k) {
+      int e = idx[s * K + k];
+      float dp = dw[s * K + k] / den - corr;
+#pragma unroll
+      for (int i = 0; i < CAP; ++i)
+        if (i == e) dg[i] += dp;
+    }
+  }
+  float inner = 0.f;
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) inner += dg[i] * g[i];
+#pragma unroll
+  for (int i = 0; i < CAP; ++i)
+    if (i < E) dlogits[s * E + i] = g[i] * (dg[i] - inner) + grz * g[i];
+}
+
+// ------------------------------------------------------------------------------------------
 // Router projection with its LayerNorm fused in: logits = Linear(LayerNorm(x))  (reference
 // core.py:481-482).  As two ops the normalised [T,H] tensor is written and read back, and the
 // backward moves [T,H] five more times (skinny dx, LN dx, the add with the expert path's gradient):
@@ -1545,5 +1695,37 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
   } else return APERTIS_ERR_ARG;
   const int64_t cols = N * H + N + 2 * H;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, grads, nblk, cols);
+  return apertis_check_launch();
+}
+
+extern "C" int64_t apertis_moe_gate_aux_blocks(int64_t S) { return ceil_div64(S > 0 ? S : 1, 256); }
+
+extern "C" int apertis_moe_gate_topk_aux_fwd(const float *logits, float *gates, int32_t *idx, float *w, float *lse,
+                                             float *part, float *stats, int64_t S, int64_t E, int64_t K, float lb_coef,
+                                             float rz_coef, void *stream) {
+  // part: workspace [apertis_moe_gate_aux_blocks(S)][2E+1]; stats: out [2 + E] = [lb, rz, frac_e]
+  if (!logits || !gates || !idx || !w || !lse || !part || !stats || S <= 0) return APERTIS_ERR_ARG;
+  if (E < 1 || E > MAXE || K < 1 || K > MAXK || K > E) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = apertis_moe_gate_aux_blocks(S);
+  dim3 grid((unsigned)nblk), block(256);
+#define GO(EC) hipLaunchKernelGGL(gate_topk_aux_fwd_k<EC>, grid, block, 0, st, logits, gates, idx, w, lse, part, S, (int)E, (int)K)
+  if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
+#undef GO
+  hipLaunchKernelGGL(gate_aux_fold_k, dim3(1), dim3(64), 0, st, part, stats, nblk, S, (int)E, lb_coef, rz_coef);
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *idx, const float *dw, const float *lse,
+                                             const float *stats, const float *dlb, const float *drz, float lb_coef,
+                                             float rz_coef, float *dlogits, int64_t S, int64_t E, int64_t K, void *stream) {
+  if (!gates || !idx || !lse || !stats || !dlogits || S < 0) return APERTIS_ERR_ARG;
+  if (E < 1 || E > MAXE || K < 1 || K > MAXK || K > E) return APERTIS_ERR_UNSUPPORTED;
+  if (S == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(S, 256)), block(256);
+#define GO(EC) hipLaunchKernelGGL(gate_topk_aux_bwd_k<EC>, grid, block, 0, st, gates, idx, dw, lse, stats, dlb, drz, lb_coef, rz_coef, dlogits, S, (int)E, (int)K)
+  if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
+#undef GO
   return apertis_check_launch();
 }

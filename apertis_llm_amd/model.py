@@ -393,12 +393,22 @@ class AdaptiveExpertSystem(nn.Module):
                 logits = self.router(xn).float()
         if self.use_noisy_top_k_routing and self.training:                                # core.py:485-488
             logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
-        gates, idx, w = ops.moe_gate_topk(logits, K)                                      # core.py:491-492,529
         lb_loss, rz_loss = zero, zero
-        if self.use_load_balancing_loss and self.training and self.load_balancing_loss_coef > 0:   # :499-505
-            frac = torch.zeros(E, device=xf.device).index_add_(0, idx.reshape(-1).long(),
-                                                               torch.ones(S * K, device=xf.device)) / S
-            lb_loss = self.load_balancing_loss_coef * E * torch.sum(frac * gates.mean(dim=0))
+        lb_coef = self.load_balancing_loss_coef if (self.use_load_balancing_loss and self.training) else 0.0
+        rz_coef = self.router_z_loss_coef if (self.use_router_z_loss and self.training) else 0.0
+        if logits.is_cuda and S > 0 and (lb_coef > 0 or rz_coef > 0):
+            # gate + both auxiliary losses in one pass (core.py:491-505, 524-529)
+            idx, w, lb, rz = ops.moe_gate_topk_aux(logits, K, lb_coef, rz_coef)
+            lb_loss = lb if lb_coef > 0 else zero
+            rz_loss = rz if rz_coef > 0 else zero
+        else:
+            gates, idx, w = ops.moe_gate_topk(logits, K)                                  # core.py:491-492,529
+            if lb_coef > 0:                                                               # core.py:499-505
+                frac = torch.zeros(E, device=xf.device).index_add_(0, idx.reshape(-1).long(),
+                                                                   torch.ones(S * K, device=xf.device)) / S
+                lb_loss = lb_coef * E * torch.sum(frac * gates.mean(dim=0))
+            if rz_coef > 0:                                                               # core.py:524-526
+                rz_loss = rz_coef * torch.mean(torch.logsumexp(logits, dim=-1) ** 2)
         capacity = None
         if self.use_expert_capacity_limit and self.training:                              # core.py:508-511
             capacity = max(1, math.floor((S / E) * self.expert_capacity_factor)) if S > 0 else 0
@@ -409,9 +419,6 @@ class AdaptiveExpertSystem(nn.Module):
                 active = torch.ones(E, dtype=torch.bool)
                 active[torch.randperm(E)[:n_drop]] = False
                 active = active.to(xf.device)
-        if self.use_router_z_loss and self.training and self.router_z_loss_coef > 0:      # core.py:524-526
-            rz_loss = self.router_z_loss_coef * torch.mean(torch.logsumexp(logits, dim=-1) ** 2)
-
         cd = _compute_dtype(xf)
         plan = ops.moe_plan(idx, w, E, capacity, active)                                  # core.py:547-591
         xg = ops.moe_gather_ln(xf, self.expert_ln_weight, self.expert_ln_bias, plan, self.config.layer_norm_eps,

@@ -351,6 +351,51 @@ class _GateTopK(torch.autograd.Function):
         return dlogits, None
 
 
+class _GateTopKAux(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, K, lb_coef, rz_coef):
+        _require_gpu(logits)
+        lib = _lib.load()
+        logits = logits.float().contiguous()
+        S, E = logits.shape
+        dev = logits.device
+        gates = torch.empty(S, E, device=dev, dtype=torch.float32)
+        idx = torch.empty(S, K, device=dev, dtype=torch.int32)
+        w = torch.empty(S, K, device=dev, dtype=torch.float32)
+        lse = torch.empty(S, device=dev, dtype=torch.float32)
+        part = torch.empty(lib.apertis_moe_gate_aux_blocks(S), 2 * E + 1, device=dev, dtype=torch.float32)
+        stats = torch.empty(2 + E, device=dev, dtype=torch.float32)
+        check(lib.apertis_moe_gate_topk_aux_fwd(ptr(logits), ptr(gates), ptr(idx), ptr(w), ptr(lse), ptr(part), ptr(stats),
+                                                S, E, K, float(lb_coef), float(rz_coef), stream_ptr()),
+              "apertis_moe_gate_topk_aux_fwd")
+        ctx.save_for_backward(gates, idx, lse, stats)
+        ctx.cfg = (K, float(lb_coef), float(rz_coef))
+        ctx.mark_non_differentiable(idx)
+        return idx, w, stats[0], stats[1]
+
+    @staticmethod
+    def backward(ctx, _didx, dw, dlb, drz):
+        lib = _lib.load()
+        gates, idx, lse, stats = ctx.saved_tensors
+        K, lb_coef, rz_coef = ctx.cfg
+        S, E = gates.shape
+        dw = None if dw is None else dw.float().contiguous()
+        dlb = None if dlb is None else dlb.float().reshape(1).contiguous()
+        drz = None if drz is None else drz.float().reshape(1).contiguous()
+        dlogits = torch.empty_like(gates)
+        check(lib.apertis_moe_gate_topk_aux_bwd(ptr(gates), ptr(idx), ptr(dw), ptr(lse), ptr(stats), ptr(dlb), ptr(drz),
+                                                lb_coef, rz_coef, ptr(dlogits), S, E, K, stream_ptr()),
+              "apertis_moe_gate_topk_aux_bwd")
+        return dlogits, None, None, None
+
+
+def moe_gate_topk_aux(logits, K, lb_coef, rz_coef):
+    """moe_gate_topk plus the router's two auxiliary losses in the same pass (reference core.py:491-505,
+    524-529): returns idx [S,K] int32, w [S,K] fp32, lb_loss and rz_loss (fp32 scalars on the device; a
+    coefficient of 0 switches a loss off)."""
+    return _GateTopKAux.apply(logits, K, lb_coef, rz_coef)
+
+
 def moe_gate_topk(logits, K):
     """softmax -> top-K -> renormalised weights (reference core.py:491-492,529).
     Returns gates [S,E] fp32, idx [S,K] int32 (descending probability, ties lowest index),

@@ -158,6 +158,21 @@ int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx, const floa
                               const float *dgates, float *dlogits,
                               int64_t S, int64_t E, int64_t K, void *stream);
 
+/* The same gate with the two router losses fused in (training, core.py:499-505, 524-526):
+ *   stats[0] = lb_coef * E * sum_e (count_e / S) * mean_s gates[s,e]      (load balancing)
+ *   stats[1] = rz_coef * mean_s logsumexp(logits[s,:])^2                  (router z-loss)
+ *   stats[2..2+E) = count_e / S;  lse [S] = logsumexp per row (saved for the backward)
+ * part = workspace [apertis_moe_gate_aux_blocks(S), 2E+1] fp32 (fixed-order fold).  Backward: dlb / drz are
+ * DEVICE scalars (gradients of the two losses, NULL = 0); dw as above; returns dlogits. */
+int apertis_moe_gate_topk_aux_fwd(const float *logits, float *gates, int32_t *idx, float *w,
+                                  float *lse, float *part, float *stats, int64_t S, int64_t E,
+                                  int64_t K, float lb_coef, float rz_coef, void *stream);
+int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *idx, const float *dw,
+                                  const float *lse, const float *stats, const float *dlb,
+                                  const float *drz, float lb_coef, float rz_coef, float *dlogits,
+                                  int64_t S, int64_t E, int64_t K, void *stream);
+int64_t apertis_moe_gate_aux_blocks(int64_t S);
+
 /* Router projection y[T,N] = x[T,K] W[N,K]^T + b for N in {2,4,8,16}, K % 4 == 0, K <= 1024
  * (core.py:430,482: Linear(hidden -> num_experts)); fp32 weights/outputs, x fp32 or bf16.
  * Backward: dx [T,K] in x's dtype, dW_db = [N*K dW | N db] fp32; part = workspace

@@ -509,3 +509,30 @@ def test_router_ln_linear(dev, T, H, N, dt):
     _close(dv[0].grad.float(), ref[0].grad, "dx", rtol=rt, atol_scale=1e-5 if dt == torch.float32 else 1e-2)
     for i, name in ((1, "dgamma"), (2, "dbeta"), (3, "dW"), (4, "db")):
         _close(dv[i].grad, ref[i].grad, name, rtol=2e-4, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("S,E,K", [(1000, 8, 2), (77, 4, 1), (4097, 16, 3), (300, 5, 2)])
+def test_gate_topk_aux_losses(dev, S, E, K):
+    """Gate + load-balancing + router-z losses in one pass vs the reference formulas (core.py:491-505,524-529)
+    written with stock torch ops on the CPU; indices exact, losses and dlogits to fp32 rounding."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(S * 7 + E)
+    logits = torch.randn(S, E) * 2
+    lb_coef, rz_coef = 0.01, 0.001
+    gw = torch.randn(S, K)
+    lo = logits.clone().requires_grad_(True)
+    gates = torch.softmax(lo, dim=-1)
+    p, idx_ref = torch.topk(gates, K, dim=-1)
+    w_ref = p / (p.sum(-1, keepdim=True) + 1e-6)
+    frac = torch.zeros(E).index_add_(0, idx_ref.reshape(-1), torch.ones(S * K)) / S
+    lb_ref = lb_coef * E * torch.sum(frac * gates.mean(dim=0))
+    rz_ref = rz_coef * torch.mean(torch.logsumexp(lo, dim=-1) ** 2)
+    ((w_ref * gw).sum() + 3.0 * lb_ref + 0.5 * rz_ref).backward()
+    ld = logits.to(dev).requires_grad_(True)
+    idx, w, lb, rz = ops.moe_gate_topk_aux(ld, K, lb_coef, rz_coef)
+    ((w * gw.to(dev)).sum() + 3.0 * lb + 0.5 * rz).backward()
+    assert torch.equal(idx.cpu().long(), idx_ref)
+    _close(w, w_ref, "w", rtol=1e-5)
+    assert abs(float(lb) - float(lb_ref)) <= 1e-5 * abs(float(lb_ref)) and abs(float(rz) - float(rz_ref)) <= 1e-5 * abs(float(rz_ref))
+    # K == 1: w = p / (p + 1e-6) is flat, its two gradient terms cancel to ~1e-4 of their size -> absolute floor
+    assert torch.allclose(ld.grad.cpu(), lo.grad, rtol=1e-4, atol=3e-7), float((ld.grad.cpu() - lo.grad).abs().max())
