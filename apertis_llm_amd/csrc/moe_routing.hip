@@ -201,11 +201,20 @@ plan_select_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     const uint32_t prefix = s_prefix, mask = s_mask;
-    for (int64_t s = threadIdx.x; s < S; s += blockDim.x) {
-      if (idx[s * K + k] == e) {
-        uint32_t bits = __float_as_uint(wk[s * K + k]);
-        if ((bits & mask) == prefix) atomicAdd(&hist[(bits >> shift) & 255], 1);
+    // 8 tokens per thread and trip, all 16 loads issued before the first use: one block per (e,k) walks
+    // all S tokens four times, and with one dependent load pair per trip that walk was pure latency (200 us)
+    for (int64_t s0 = threadIdx.x; s0 < S; s0 += (int64_t)blockDim.x * 8) {
+      int32_t ei[8];
+      uint32_t bi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t s = s0 + (int64_t)u * blockDim.x;
+        ei[u] = s < S ? idx[s * K + k] : -1;
+        bi[u] = s < S ? __float_as_uint(wk[s * K + k]) : 0u;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (ei[u] == e && (bi[u] & mask) == prefix) atomicAdd(&hist[(bi[u] >> shift) & 255], 1);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1017,25 +1026,26 @@ gate_topk_aux_fwd_k(const float *__restrict__ logits, float *__restrict__ gates,
         (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(1024)
 gate_aux_fold_k(const float *__restrict__ part, float *__restrict__ stats, int64_t nblk, int64_t S, int E, float lb_coef,
                 float rz_coef) {
   __shared__ float tot[2 * MAXE + 1];
-  const int c = threadIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int cols = 2 * E + 1;
-  for (int cc = c; cc < cols; cc += 64) {
+  for (int cc = wv; cc < cols; cc += 16) {     // a wave per column: lane-strided partial sums, then the wave (fixed order)
     float a = 0.f;
-    for (int64_t b = 0; b < nblk; ++b) a += part[b * cols + cc];
-    tot[cc] = a;
+    for (int64_t b = lane; b < nblk; b += 64) a += part[b * cols + cc];
+    a = wave_sum(a);
+    if (lane == 0) tot[cc] = a;
   }
   __syncthreads();
-  if (c == 0) {
+  if (threadIdx.x == 0) {
     float lb = 0.f;
     for (int e = 0; e < E; ++e) lb += (tot[E + e] / (float)S) * (tot[e] / (float)S);
     stats[0] = lb_coef * (float)E * lb;
     stats[1] = rz_coef * tot[2 * E] / (float)S;
   }
-  if (c < E) stats[2 + c] = tot[E + c] / (float)S;
+  if (threadIdx.x < E) stats[2 + threadIdx.x] = tot[E + threadIdx.x] / (float)S;
 }
 
 // backward of gate + losses: dgates[s,e] = dlb * lb_coef * E * frac_e / S (the load-balancing loss through the
@@ -1285,6 +1295,151 @@ router_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
   }
 }
 
+// Backward, one wave per row (every lane busy, per-row scalar work done once): W in LDS, the dW / dgamma /
+// dbeta accumulators in registers (2 waves per SIMD), the wave's next row prefetched while this one is
+// computed.  ~350 wave-instructions per row against ~700 per row for the column-split form above.
+template <typename TX, int IT, int NN>
+__global__ void __launch_bounds__(256)
+router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+              const float *__restrict__ mean_i, const float *__restrict__ rstd_i, const float *__restrict__ W,
+              const float *__restrict__ dlogits, const TX *__restrict__ dres, TX *__restrict__ dx,
+              float *__restrict__ part, int64_t T, int H) {
+  typedef typename raw4<TX>::type raw_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *sW = reinterpret_cast<float4 *>(smem);                 // [NN][H/4]
+  float4 *red = sW + NN * (H / 4);                               // [NN + 2][H/4], one wave at a time
+  __shared__ float redb[4][SK_MAXN];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, Q = H / 4;
+  for (int i = threadIdx.x; i < NN * Q; i += 256) sW[i] = reinterpret_cast<const float4 *>(W)[i];
+  float4 aw[NN][IT], ag[IT], ab[IT], g4[IT], b4[IT];
+  float abias = 0.f;   // lane n < NN accumulates db[n]
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    g4[i] = c < H ? load4<float>(gamma + c) : make_float4(0, 0, 0, 0);
+    b4[i] = c < H ? load4<float>(beta + c) : make_float4(0, 0, 0, 0);
+    ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < NN; ++n) aw[n][i] = make_float4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+  raw_t xc[IT], rc[IT], xn_[IT], rn_[IT];
+  auto fetch = [&](raw_t (&xo)[IT], raw_t (&ro)[IT], int64_t r) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      const bool ok = c < H && r < T;
+      xo[i] = ok ? *reinterpret_cast<const raw_t *>(x + r * H + c) : raw_t{};
+      ro[i] = (ok && dres) ? *reinterpret_cast<const raw_t *>(dres + r * H + c) : raw_t{};
+    }
+  };
+  // the row's scalars - NN logit gradients, mean, rstd - ride in ONE register: lane n < NN holds dlogits[r][n],
+  // lanes NN / NN+1 hold mean / rstd; fetched a row ahead like x, read back with v_readlane.  (As per-row
+  // broadcast loads they were ten dependent memory round trips per row and bounded the kernel.)
+  auto fetch_meta = [&](int64_t r) -> float {
+    if (r >= T) return 0.f;
+    const float *p = lane < NN ? dlogits + r * NN + lane : (lane == NN ? mean_i + r : rstd_i + r);
+    return lane < NN + 2 ? *p : 0.f;
+  };
+  auto lane_val = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+  float meta = 0.f, meta_next = 0.f;
+  if (wave < T) { fetch(xc, rc, wave); meta = fetch_meta(wave); }
+  for (int64_t r = wave; r < T; r += nw) {
+    fetch(xn_, rn_, r + nw);
+    meta_next = fetch_meta(r + nw);
+    float g[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) g[n] = lane_val(meta, n);
+    if (lane < NN) abias += meta;
+    const float mean = lane_val(meta, NN), rstd = lane_val(meta, NN + 1);
+    float4 xh[IT], dn[IT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const bool in = lane + 64 * i < Q;
+      const float4 xv = raw_to_f4(xc[i]);
+      xh[i] = in ? make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd)
+                 : make_float4(0, 0, 0, 0);
+      const float4 xn = make_float4(xh[i].x * g4[i].x + b4[i].x, xh[i].y * g4[i].y + b4[i].y, xh[i].z * g4[i].z + b4[i].z,
+                                    xh[i].w * g4[i].w + b4[i].w);
+      float4 d = make_float4(0, 0, 0, 0);   // dxn = dlogits @ W
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        const float4 wn = in ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
+        d.x += g[n] * wn.x; d.y += g[n] * wn.y; d.z += g[n] * wn.z; d.w += g[n] * wn.w;
+        aw[n][i].x += g[n] * xn.x; aw[n][i].y += g[n] * xn.y; aw[n][i].z += g[n] * xn.z; aw[n][i].w += g[n] * xn.w;
+      }
+      ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+      ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      dn[i] = make_float4(d.x * g4[i].x, d.y * g4[i].y, d.z * g4[i].z, d.w * g4[i].w);
+      s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
+      s2 += (dn[i].x * xh[i].x + dn[i].y * xh[i].y) + (dn[i].z * xh[i].z + dn[i].w * xh[i].w);
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 rr = raw_to_f4(rc[i]);
+        store4<TX>(dx + r * H + c, make_float4(rstd * (dn[i].x - m1 - xh[i].x * m2) + rr.x, rstd * (dn[i].y - m1 - xh[i].y * m2) + rr.y,
+                                                rstd * (dn[i].z - m1 - xh[i].z * m2) + rr.z, rstd * (dn[i].w - m1 - xh[i].w * m2) + rr.w));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { xc[i] = xn_[i]; rc[i] = rn_[i]; }
+    meta = meta_next;
+  }
+  // block reduction in wave order (waves 1..3 take turns in one LDS buffer), then one partial row per block
+  if (lane < NN) redb[wv][lane] = abias;
+  for (int turn = 1; turn < 4; ++turn) {
+    __syncthreads();
+    if (wv == turn) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int cq = lane + 64 * i;
+        if (cq < Q) {
+#pragma unroll
+          for (int n = 0; n < NN; ++n) red[n * Q + cq] = aw[n][i];
+          red[NN * Q + cq] = ag[i];
+          red[(NN + 1) * Q + cq] = ab[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int cq = lane + 64 * i;
+        if (cq < Q) {
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            const float4 u = red[n * Q + cq];
+            aw[n][i].x += u.x; aw[n][i].y += u.y; aw[n][i].z += u.z; aw[n][i].w += u.w;
+          }
+          const float4 u = red[NN * Q + cq], v = red[(NN + 1) * Q + cq];
+          ag[i].x += u.x; ag[i].y += u.y; ag[i].z += u.z; ag[i].w += u.w;
+          ab[i].x += v.x; ab[i].y += v.y; ab[i].z += v.z; ab[i].w += v.w;
+        }
+      }
+    }
+  }
+  float *dst = part + (int64_t)blockIdx.x * (NN * H + NN + 2 * H);
+  if (wv == 0) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int cq = lane + 64 * i;
+      if (cq < Q) {
+#pragma unroll
+        for (int n = 0; n < NN; ++n) *reinterpret_cast<float4 *>(dst + (int64_t)n * H + cq * 4) = aw[n][i];
+        *reinterpret_cast<float4 *>(dst + NN * H + NN + cq * 4) = ag[i];
+        *reinterpret_cast<float4 *>(dst + NN * H + NN + H + cq * 4) = ab[i];
+      }
+    }
+    if (lane < NN) dst[NN * H + lane] = (redb[0][lane] + redb[1][lane]) + (redb[2][lane] + redb[3][lane]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Tiny linear: y[T,N] = x[T,:K] W[N,K]^T + b with K <= 64, N <= 16 - the SSM's dt_proj_head
 // (Linear(dt_rank -> heads), reference core.py:361,382), whose input is a column slice of the
@@ -1297,7 +1452,42 @@ router_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
 constexpr int TL_MAXK = 64, TL_MAXN = 16, TL_ROWS = 128;
 constexpr int TL_ACC = (TL_MAXN * TL_MAXK + TL_MAXN + TL_ROWS - 1) / TL_ROWS;   // dW/db entries per thread
 
-template <typename TX>
+// a thread's K-element row slice -> floats.  VEC: 16-byte loads (row start 16-byte aligned, the slice rounded
+// up to whole chunks stays inside the row); lanes hold different rows ~ld apart, so every load instruction
+// touches 64 cache lines whatever its width - six 16-byte loads instead of 44 two-byte ones
+template <typename TX, bool VEC>
+__device__ __forceinline__ void tl_load_row(const TX *row, int K, float (&xr)[TL_MAXK]) {
+  constexpr int EPC = 16 / (int)sizeof(TX);
+  if constexpr (VEC) {
+#pragma unroll
+    for (int ch = 0; ch < TL_MAXK / EPC; ++ch) {
+      if (ch * EPC < K) {
+        float4 lo, hi = make_float4(0, 0, 0, 0);
+        if constexpr (sizeof(TX) == 2) {
+          const uint4 u = *reinterpret_cast<const uint4 *>(row + ch * EPC);
+          lo = raw_to_f4(make_uint2(u.x, u.y));
+          hi = raw_to_f4(make_uint2(u.z, u.w));
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+          for (int u8 = 0; u8 < 8; ++u8) xr[ch * 8 + u8] = ch * 8 + u8 < K ? v[u8] : 0.f;
+        } else {
+          lo = *reinterpret_cast<const float4 *>(row + ch * EPC);
+          const float v[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+          for (int u4 = 0; u4 < 4; ++u4) xr[ch * 4 + u4] = ch * 4 + u4 < K ? v[u4] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < EPC; ++u) xr[ch * EPC + u] = 0.f;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < TL_MAXK; ++r) xr[r] = r < K ? to_f32(row[r]) : 0.f;
+  }
+}
+
+template <typename TX, bool VEC>
 __global__ void __launch_bounds__(TL_ROWS)
 tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ b,
                   float *__restrict__ y, int64_t T, int K, int N) {
@@ -1307,8 +1497,7 @@ tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
   __syncthreads();
   for (int64_t t = (int64_t)blockIdx.x * TL_ROWS + threadIdx.x; t < T; t += (int64_t)gridDim.x * TL_ROWS) {
     float xr[TL_MAXK];
-#pragma unroll
-    for (int r = 0; r < TL_MAXK; ++r) xr[r] = r < K ? to_f32(x[t * ldx + r]) : 0.f;
+    tl_load_row<TX, VEC>(x + t * ldx, K, xr);
     for (int j = 0; j < N; ++j) {
       float a = sW[N * K + j];
 #pragma unroll
@@ -1319,7 +1508,7 @@ tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
   }
 }
 
-template <typename TX>
+template <typename TX, bool VEC>
 __global__ void __launch_bounds__(TL_ROWS)
 tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ dy,
                   TX *__restrict__ dx, int64_t lddx, float *__restrict__ part, int64_t T, int K, int N) {
@@ -1334,8 +1523,12 @@ tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
     const int64_t t = t0 + threadIdx.x;
     const bool live = t < T;
     __syncthreads();   // sW loaded / the previous tile is no longer read
+    {
+      float xr[TL_MAXK];
+      if (live) tl_load_row<TX, VEC>(x + t * ldx, K, xr);
 #pragma unroll
-    for (int r = 0; r < TL_MAXK; ++r) sx[threadIdx.x][r] = (live && r < K) ? to_f32(x[t * ldx + r]) : 0.f;
+      for (int r = 0; r < TL_MAXK; ++r) sx[threadIdx.x][r] = live ? xr[r] : 0.f;
+    }
     float dyr[TL_MAXN];
 #pragma unroll
     for (int j = 0; j < TL_MAXN; ++j) {
@@ -1343,12 +1536,33 @@ tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
       sdy[threadIdx.x][j] = dyr[j];
     }
     if (live) {
-      for (int r = 0; r < K; ++r) {
-        float a = 0.f;
+      constexpr int EPC = 16 / (int)sizeof(TX);
+      TX *drow = dx + t * lddx;
+      for (int r0 = 0; r0 < K; r0 += EPC) {
+        float a[EPC];
 #pragma unroll
-        for (int j = 0; j < TL_MAXN; ++j)
-          if (j < N) a = fmaf(dyr[j], sW[j * K + r], a);
-        dx[t * lddx + r] = from_f32<TX>(a);
+        for (int u = 0; u < EPC; ++u) {
+          a[u] = 0.f;
+#pragma unroll
+          for (int j = 0; j < TL_MAXN; ++j)
+            if (j < N && r0 + u < K) a[u] = fmaf(dyr[j], sW[j * K + r0 + u], a[u]);
+        }
+        if (VEC && r0 + EPC <= K) {      // whole 16-byte chunk (the output rows are 16-byte aligned when VEC)
+          if constexpr (sizeof(TX) == 2) {
+            uint32_t wq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              wq[u] = (uint32_t)__builtin_bit_cast(uint16_t, from_f32<TX>(a[2 * u])) |
+                      ((uint32_t)__builtin_bit_cast(uint16_t, from_f32<TX>(a[2 * u + 1])) << 16);
+            *reinterpret_cast<uint4 *>(drow + r0) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+          } else {
+            *reinterpret_cast<float4 *>(drow + r0) = make_float4(a[0], a[1], a[2], a[3]);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < EPC; ++u)
+            if (r0 + u < K) drow[r0 + u] = from_f32<TX>(a[u]);
+        }
       }
     }
     __syncthreads();
@@ -1632,11 +1846,13 @@ extern "C" int apertis_tiny_linear_fwd(const void *x, int64_t ldx, const float *
   if (T == 0) return APERTIS_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)std::min<int64_t>(ceil_div64(T, TL_ROWS), 4096)), block(TL_ROWS);
-  if (dtype_x == APERTIS_BF16)
-    hipLaunchKernelGGL(tiny_linear_fwd_k<bf16_t>, grid, block, 0, st, (const bf16_t *)x, ldx, W, b, y, T, (int)K, (int)N);
-  else if (dtype_x == APERTIS_F32)
-    hipLaunchKernelGGL(tiny_linear_fwd_k<float>, grid, block, 0, st, (const float *)x, ldx, W, b, y, T, (int)K, (int)N);
-  else return APERTIS_ERR_ARG;
+  if (dtype_x != APERTIS_BF16 && dtype_x != APERTIS_F32) return APERTIS_ERR_ARG;
+  const int64_t esz = dtype_x == APERTIS_BF16 ? 2 : 4, epc = 16 / esz;
+  const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx * esz) % 16 == 0 && ceil_div64(K, epc) * epc <= ldx;
+#define GO(TX, V) hipLaunchKernelGGL((tiny_linear_fwd_k<TX, V>), grid, block, 0, st, (const TX *)x, ldx, W, b, y, T, (int)K, (int)N)
+  if (dtype_x == APERTIS_BF16) { if (vec) GO(bf16_t, true); else GO(bf16_t, false); }
+  else { if (vec) GO(float, true); else GO(float, false); }
+#undef GO
   return apertis_check_launch();
 }
 
@@ -1649,13 +1865,14 @@ extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *
   hipStream_t st = (hipStream_t)stream;
   const int64_t nblk = apertis_tiny_linear_bwd_blocks(T);
   dim3 grid((unsigned)nblk), block(TL_ROWS);
-  if (dtype_x == APERTIS_BF16)
-    hipLaunchKernelGGL(tiny_linear_bwd_k<bf16_t>, grid, block, 0, st, (const bf16_t *)x, ldx, W, dy, (bf16_t *)dx, lddx, part, T,
-                       (int)K, (int)N);
-  else if (dtype_x == APERTIS_F32)
-    hipLaunchKernelGGL(tiny_linear_bwd_k<float>, grid, block, 0, st, (const float *)x, ldx, W, dy, (float *)dx, lddx, part, T,
-                       (int)K, (int)N);
-  else return APERTIS_ERR_ARG;
+  if (dtype_x != APERTIS_BF16 && dtype_x != APERTIS_F32) return APERTIS_ERR_ARG;
+  const int64_t esz = dtype_x == APERTIS_BF16 ? 2 : 4, epc = 16 / esz;
+  const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx * esz) % 16 == 0 && ceil_div64(K, epc) * epc <= ldx &&
+                   (((uintptr_t)dx) & 15) == 0 && (lddx * esz) % 16 == 0;
+#define GO(TX, V) hipLaunchKernelGGL((tiny_linear_bwd_k<TX, V>), grid, block, 0, st, (const TX *)x, ldx, W, dy, (TX *)dx, lddx, part, T, (int)K, (int)N)
+  if (dtype_x == APERTIS_BF16) { if (vec) GO(bf16_t, true); else GO(bf16_t, false); }
+  else { if (vec) GO(float, true); else GO(float, false); }
+#undef GO
   const int64_t cols = N * K + N;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, dW_db, nblk, cols);
   return apertis_check_launch();
@@ -1688,6 +1905,14 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
   hipStream_t st = (hipStream_t)stream;
   const int64_t nblk = apertis_router_bwd_blocks(T);
   dim3 grid((unsigned)nblk), block(256);
+  const size_t lds3 = (size_t)(2 * N + 2) * H * sizeof(float);
+  if (!getenv("APERTIS_ROUTER_BWD_V2")) {
+    if (dtype_x == APERTIS_BF16) {
+      SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<bf16_t, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<bf16_t, IT, NN>), grid, block, lds3, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H)));
+    } else if (dtype_x == APERTIS_F32) {
+      SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<float, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<float, IT, NN>), grid, block, lds3, st, (const float *)x, gamma, beta, mean, rstd, W, dlogits, (const float *)dres, (float *)dx, part, T, (int)H)));
+    } else return APERTIS_ERR_ARG;
+  } else
   if (dtype_x == APERTIS_BF16) {
     SKINNY_N(N, hipLaunchKernelGGL((router_bwd_k<bf16_t, NN>), grid, block, 0, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H));
   } else if (dtype_x == APERTIS_F32) {
@@ -1712,7 +1937,7 @@ extern "C" int apertis_moe_gate_topk_aux_fwd(const float *logits, float *gates, 
 #define GO(EC) hipLaunchKernelGGL(gate_topk_aux_fwd_k<EC>, grid, block, 0, st, logits, gates, idx, w, lse, part, S, (int)E, (int)K)
   if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
 #undef GO
-  hipLaunchKernelGGL(gate_aux_fold_k, dim3(1), dim3(64), 0, st, part, stats, nblk, S, (int)E, lb_coef, rz_coef);
+  hipLaunchKernelGGL(gate_aux_fold_k, dim3(1), dim3(1024), 0, st, part, stats, nblk, S, (int)E, lb_coef, rz_coef);
   return apertis_check_launch();
 }
 

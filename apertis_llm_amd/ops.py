@@ -462,11 +462,13 @@ class _TinyLinear(torch.autograd.Function):
         ldx, T, xshape, wdt, bdt = ctx.cfg
         N, K = w.shape
         dy = dy.float().contiguous()
-        dx = torch.empty(xshape, device=xr.device, dtype=xr.dtype)
+        Kp = -(-K // 8) * 8     # 16-byte row pitch: the kernel stores whole 16-byte chunks
+        dxp = torch.empty(*xshape[:-1], Kp, device=xr.device, dtype=xr.dtype)
+        dx = dxp[..., :K]
         nblk = lib.apertis_tiny_linear_bwd_blocks(T)
         part = torch.empty(nblk, N * K + N, device=xr.device, dtype=torch.float32)
         out = torch.empty(N * K + N, device=xr.device, dtype=torch.float32)
-        check(lib.apertis_tiny_linear_bwd(ptr(xr), ldx, ptr(w), ptr(dy), ptr(dx), K, ptr(part), ptr(out), T, K, N,
+        check(lib.apertis_tiny_linear_bwd(ptr(xr), ldx, ptr(w), ptr(dy), ptr(dxp), Kp, ptr(part), ptr(out), T, K, N,
                                           dtype_code(xr), stream_ptr()), "apertis_tiny_linear_bwd")
         return dx, out[:N * K].reshape(N, K).to(wdt), (out[N * K:].to(bdt) if bdt is not None else None)
 
