@@ -637,9 +637,13 @@ class _GatherLN(torch.autograd.Function):
         dxr = torch.empty_like(dxg)
         dgamma = torch.zeros(plan.E, H, device=dev, dtype=torch.float32)
         dbeta = torch.zeros(plan.E, H, device=dev, dtype=torch.float32)
+        nblk = lib.apertis_moe_gather_ln_bwd_blocks(plan.max_rows)
+        part = torch.empty(nblk, 2 * H, device=dev, dtype=torch.float32)
+        blk_e = torch.empty(nblk, device=dev, dtype=torch.int32)
         check(lib.apertis_moe_gather_ln_bwd(ptr(x), ptr(plan.row_token), ptr(plan.offsets), ptr(g), ptr(mean), ptr(rstd),
-                                            ptr(dxg), ptr(dxr), ptr(dgamma), ptr(dbeta), plan.max_rows, H, plan.E,
-                                            dtype_code(x), dtype_code(dxg), stream_ptr()), "apertis_moe_gather_ln_bwd")
+                                            ptr(dxg), ptr(dxr), ptr(dgamma), ptr(dbeta), ptr(part), ptr(blk_e), plan.max_rows,
+                                            H, plan.E, dtype_code(x), dtype_code(dxg), stream_ptr()),
+              "apertis_moe_gather_ln_bwd")
         dx = torch.empty(S, H, device=dev, dtype=x.dtype)
         check(lib.apertis_moe_combine_fwd(ptr(dxr), ptr(plan.slot_of), None, ptr(dx), S, H, plan.K, 0, dtype_code(dxr),
                                           dtype_code(dx), stream_ptr()), "apertis_moe_combine_fwd(scatter)")

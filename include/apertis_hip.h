@@ -238,15 +238,19 @@ int apertis_moe_gather_ln_fwd(const void *x, const int32_t *row_token,
                               const float *beta, float eps, void *xg, float *mean, float *rstd,
                               int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_out,
                               void *stream);
-/* Backward: dxg [rows,H] -> per-row dx contribution dxr [rows,H] (LayerNorm backward); the
- * affine gradients are ACCUMULATED into dgamma/dbeta [E,H] fp32 (caller zero-fills) with float
- * atomics.  The rows are later scattered to tokens by apertis_moe_combine_fwd(with_weights=0). */
+/* Backward: dxg [rows,H] -> per-row dx contribution dxr [rows,H] (LayerNorm backward; dxr may be
+ * NULL); the affine gradients are ADDED into dgamma/dbeta [E,H] fp32 (caller zero-fills): 32-row
+ * blocks that lie inside one expert go through per-block partial sums (part, blk_expert: workspaces of
+ * apertis_moe_gather_ln_bwd_blocks(max_rows) x 2H floats / ints) folded per expert in block order;
+ * only blocks straddling an expert boundary use float atomics.  The rows are later scattered to
+ * tokens by apertis_moe_combine_fwd(with_weights=0). */
 int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
                               const int32_t *expert_offsets, const float *gamma,
                               const float *mean, const float *rstd, const void *dxg,
-                              void *dxr, float *dgamma, float *dbeta,
+                              void *dxr, float *dgamma, float *dbeta, float *part, int32_t *blk_expert,
                               int64_t max_rows, int64_t H, int64_t E, int dtype_x, int dtype_g,
                               void *stream);
+int64_t apertis_moe_gather_ln_bwd_blocks(int64_t max_rows);
 
 /* Plain LayerNorm over the last dimension on the same row kernels (pre-norms and final norm,
  * core.py:669,695,847,888,1040,1294): x [T,H] dtype_x -> y [T,H] dtype_y, mean/rstd [T] fp32.
