@@ -409,82 +409,8 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
   if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
 }
 
-// LayerNorm backward per row; dgamma/dbeta accumulated per wave over RPW consecutive rows and
-// flushed with float atomics when the expert changes (rows are expert-sorted)
-template <typename TX, typename TG, int IT>
-__global__ void __launch_bounds__(256)
-gather_ln_bwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
-                const int32_t *__restrict__ offsets, const float *__restrict__ gamma,
-                const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
-                const TG *__restrict__ dxg, TG *__restrict__ dxr, float *__restrict__ dgamma,
-                float *__restrict__ dbeta, float *__restrict__ part, int64_t max_rows, int H, int E, int RPW) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t total = offsets ? min((int64_t)offsets[E], max_rows) : max_rows;
-  int64_t r0 = wave * RPW, r1 = min(r0 + RPW, total);
-  float4 ag[IT], ab[IT];
-#pragma unroll
-  for (int i = 0; i < IT; ++i) { ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0); }
-  if (part) {
-    // single-group mode: this wave's sums go to part[wave][2][H] (zeros if it has no rows) and a
-    // fixed-order column sum folds them - deterministic, no atomic contention on 2H addresses
-    if (r0 >= total) r1 = r0;
-  } else if (r0 >= total) {
-    return;
-  }
-  int e = (offsets && r0 < total) ? expert_of_row(offsets, E, (int)r0) : 0;
-  auto flush = [&](int ee) {
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      int c = (lane + 64 * i) * 4;
-      if (c < H && part) {
-        *reinterpret_cast<float4 *>(part + (wave * 2 + 0) * H + c) = ag[i];
-        *reinterpret_cast<float4 *>(part + (wave * 2 + 1) * H + c) = ab[i];
-      } else if (c < H) {
-        float *dg = dgamma + (int64_t)ee * H + c, *db = dbeta + (int64_t)ee * H + c;
-        atomicAdd(dg + 0, ag[i].x); atomicAdd(dg + 1, ag[i].y); atomicAdd(dg + 2, ag[i].z); atomicAdd(dg + 3, ag[i].w);
-        atomicAdd(db + 0, ab[i].x); atomicAdd(db + 1, ab[i].y); atomicAdd(db + 2, ab[i].z); atomicAdd(db + 3, ab[i].w);
-      }
-      ag[i] = make_float4(0, 0, 0, 0); ab[i] = make_float4(0, 0, 0, 0);
-    }
-  };
-  for (int64_t r = r0; r < r1; ++r) {
-    while (offsets && e + 1 < E && offsets[e + 1] <= r) { flush(e); ++e; }
-    const TX *src = x + (row_token ? (int64_t)row_token[r] : r) * H;
-    const TG *dsrc = dxg + r * H;
-    const float mean = mean_i[r], rstd = rstd_i[r];
-    const float *ga = gamma + (int64_t)e * H;
-    float4 xh[IT], gd[IT];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      int c = (lane + 64 * i) * 4;
-      if (c < H) {
-        float4 xv = load4<TX>(src + c), dv = load4<TG>(dsrc + c), g4 = load4<float>(ga + c);
-        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
-        gd[i] = make_float4(dv.x * g4.x, dv.y * g4.y, dv.z * g4.z, dv.w * g4.w);
-        ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
-        ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
-        s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
-        s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
-      } else { xh[i] = make_float4(0, 0, 0, 0); gd[i] = make_float4(0, 0, 0, 0); }
-    }
-    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
-    TG *dst = dxr + r * H;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      int c = (lane + 64 * i) * 4;
-      if (c < H)
-        store4<TG>(dst + c, make_float4(rstd * (gd[i].x - m1 - xh[i].x * m2), rstd * (gd[i].y - m1 - xh[i].y * m2),
-                                        rstd * (gd[i].z - m1 - xh[i].z * m2), rstd * (gd[i].w - m1 - xh[i].w * m2)));
-    }
-  }
-  flush(e);
-}
-
-// Gather-LayerNorm backward, v2: same math as gather_ln_bwd_k, restructured like layernorm_bwd_k
-// (8 rows per wave, two rows in flight, 16 waves per CU) because the one-row-at-a-time loop was
-// latency-bound (180 us for 41k rows of 704).  Affine gradients: per-wave register sums are
+// Gather-LayerNorm backward per row, structured like layernorm_bwd_k (8 rows per wave, two rows in
+// flight, 16 waves per CU; a one-row-at-a-time loop was latency-bound: 180 us for 41k rows of 704).  Affine gradients: per-wave register sums are
 // flushed with float atomics when the expert changes inside the wave's rows (rare: rows are
 // expert-sorted); at the end the block's four waves are combined in LDS first when they all ended
 // in the same expert, so the common case issues one set of atomics per 32 rows.
@@ -1227,115 +1153,10 @@ router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
   }
 }
 
-// Backward, columns split over the block's four waves: a lane owns ONE 4-column chunk (q = wave * Qw +
-// lane, Qw = ceil(H/16) <= 64), so the router weight and every accumulator of its columns (dW[NN], dgamma,
-// dbeta) are 4-float registers and nothing is reduced across waves at the end; only the two LayerNorm
-// row sums cross waves, through LDS, once per tile of RT_R rows.  The next tile's rows are fetched
-// while the current one is computed (a row-per-wave form with the NN x H/64 dW accumulators in
-// registers ran at 2 waves per SIMD with one row in flight each: 510 us, latency-bound).
-constexpr int RT_R = 4;
-
-template <typename TX, int NN>
-__global__ void __launch_bounds__(256)
-router_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
-             const float *__restrict__ mean_i, const float *__restrict__ rstd_i, const float *__restrict__ W,
-             const float *__restrict__ dlogits, const TX *__restrict__ dres, TX *__restrict__ dx,
-             float *__restrict__ part, int64_t T, int H) {
-  typedef typename raw4<TX>::type raw_t;
-  __shared__ float2 s_part[2][4][RT_R];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int Q = H / 4, Qw = (Q + 3) / 4;
-  const int q = wv * Qw + lane;
-  const bool act = lane < Qw && q < Q;
-  const int c = q * 4;
-  float4 w[NN], aw[NN], g4, b4, ag = make_float4(0, 0, 0, 0), ab = make_float4(0, 0, 0, 0);
-  float abias[NN];
-  g4 = act ? load4<float>(gamma + c) : make_float4(0, 0, 0, 0);
-  b4 = act ? load4<float>(beta + c) : make_float4(0, 0, 0, 0);
-#pragma unroll
-  for (int n = 0; n < NN; ++n) {
-    w[n] = act ? load4<float>(W + (int64_t)n * H + c) : make_float4(0, 0, 0, 0);
-    aw[n] = make_float4(0, 0, 0, 0);
-    abias[n] = 0.f;
-  }
-  const int64_t ntiles = ceil_div64(T, RT_R);
-  raw_t xr[RT_R], rr[RT_R], xr_next[RT_R], rr_next[RT_R];
-  auto fetch = [&](raw_t (&xo)[RT_R], raw_t (&ro)[RT_R], int64_t tile) {
-#pragma unroll
-    for (int j = 0; j < RT_R; ++j) {
-      const int64_t row = tile * RT_R + j;
-      const bool ok = act && row < T;
-      xo[j] = ok ? *reinterpret_cast<const raw_t *>(x + row * H + c) : raw_t{};
-      ro[j] = (ok && dres) ? *reinterpret_cast<const raw_t *>(dres + row * H + c) : raw_t{};
-    }
-  };
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) fetch(xr, rr, tile);
-  for (int it = 0; tile < ntiles; tile += gridDim.x, ++it) {
-    // the next tile's rows are requested before this tile is touched: a full iteration to arrive
-    fetch(xr_next, rr_next, tile + gridDim.x);
-    float4 xh[RT_R], dn[RT_R], rv[RT_R];
-    float rstd[RT_R];
-    float2 ps[RT_R];
-#pragma unroll
-    for (int j = 0; j < RT_R; ++j) {
-      const int64_t row = min(tile * RT_R + j, T - 1);
-      const bool live = tile * RT_R + j < T;
-      const float mean = mean_i[row];
-      rstd[j] = rstd_i[row];
-      const float4 xv = raw_to_f4(xr[j]);
-      rv[j] = raw_to_f4(rr[j]);
-      xh[j] = act ? make_float4((xv.x - mean) * rstd[j], (xv.y - mean) * rstd[j], (xv.z - mean) * rstd[j], (xv.w - mean) * rstd[j])
-                  : make_float4(0, 0, 0, 0);
-      const float4 xn = make_float4(xh[j].x * g4.x + b4.x, xh[j].y * g4.y + b4.y, xh[j].z * g4.z + b4.z, xh[j].w * g4.w + b4.w);
-      float4 d = make_float4(0, 0, 0, 0);   // dxn = dlogits @ W on this lane's columns
-#pragma unroll
-      for (int n = 0; n < NN; ++n) {
-        const float g = live ? dlogits[row * NN + n] : 0.f;   // wave-uniform address
-        d.x += g * w[n].x; d.y += g * w[n].y; d.z += g * w[n].z; d.w += g * w[n].w;
-        aw[n].x += g * xn.x; aw[n].y += g * xn.y; aw[n].z += g * xn.z; aw[n].w += g * xn.w;
-        abias[n] += g;
-      }
-      ag.x += d.x * xh[j].x; ag.y += d.y * xh[j].y; ag.z += d.z * xh[j].z; ag.w += d.w * xh[j].w;
-      ab.x += d.x; ab.y += d.y; ab.z += d.z; ab.w += d.w;
-      dn[j] = make_float4(d.x * g4.x, d.y * g4.y, d.z * g4.z, d.w * g4.w);
-      ps[j].x = wave_sum((dn[j].x + dn[j].y) + (dn[j].z + dn[j].w));
-      ps[j].y = wave_sum((dn[j].x * xh[j].x + dn[j].y * xh[j].y) + (dn[j].z * xh[j].z + dn[j].w * xh[j].w));
-    }
-    if (lane == 0)
-#pragma unroll
-      for (int j = 0; j < RT_R; ++j) s_part[it & 1][wv][j] = ps[j];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < RT_R; ++j) {
-      const float2 p0 = s_part[it & 1][0][j], p1 = s_part[it & 1][1][j], p2 = s_part[it & 1][2][j], p3 = s_part[it & 1][3][j];
-      const float m1 = ((p0.x + p1.x) + (p2.x + p3.x)) / (float)H, m2 = ((p0.y + p1.y) + (p2.y + p3.y)) / (float)H;
-      const int64_t row = tile * RT_R + j;
-      if (act && row < T)
-        store4<TX>(dx + row * H + c, make_float4(rstd[j] * (dn[j].x - m1 - xh[j].x * m2) + rv[j].x, rstd[j] * (dn[j].y - m1 - xh[j].y * m2) + rv[j].y,
-                                                  rstd[j] * (dn[j].z - m1 - xh[j].z * m2) + rv[j].z, rstd[j] * (dn[j].w - m1 - xh[j].w * m2) + rv[j].w));
-    }
-#pragma unroll
-    for (int j = 0; j < RT_R; ++j) { xr[j] = xr_next[j]; rr[j] = rr_next[j]; }
-  }
-  float *dst = part + (int64_t)blockIdx.x * (NN * H + NN + 2 * H);
-  if (act) {
-#pragma unroll
-    for (int n = 0; n < NN; ++n) *reinterpret_cast<float4 *>(dst + (int64_t)n * H + c) = aw[n];
-    *reinterpret_cast<float4 *>(dst + NN * H + NN + c) = ag;
-    *reinterpret_cast<float4 *>(dst + NN * H + NN + H + c) = ab;
-  }
-  if (wv == 0 && lane < NN) {
-    float o = 0.f;
-#pragma unroll
-    for (int n = 0; n < NN; ++n) if (lane == n) o = abias[n];
-    dst[NN * H + lane] = o;
-  }
-}
-
 // Backward, one wave per row (every lane busy, per-row scalar work done once): W in LDS, the dW / dgamma /
 // dbeta accumulators in registers (2 waves per SIMD), the wave's next row prefetched while this one is
-// computed.  ~350 wave-instructions per row against ~700 per row for the column-split form above.
+// computed.  (A form with the columns split over the block's waves - small accumulators, more waves - ran
+// twice the instructions per row and was no faster: 304 vs 276 us at 98k rows.)
 template <typename TX, int IT, int NN>
 __global__ void __launch_bounds__(256)
 router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -1923,7 +1744,7 @@ extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *
   return apertis_check_launch();
 }
 
-extern "C" int64_t apertis_router_bwd_blocks(int64_t T) { return std::min<int64_t>(ceil_div64(T > 0 ? T : 1, RT_R), 512); }
+extern "C" int64_t apertis_router_bwd_blocks(int64_t T) { return std::min<int64_t>(ceil_div64(T > 0 ? T : 1, 4), 512); }
 
 extern "C" int apertis_router_fwd(const void *x, const float *gamma, const float *beta, float eps, const float *W,
                                   const float *b, float *logits, float *mean, float *rstd, int64_t T, int64_t H, int64_t N,
@@ -1951,17 +1772,10 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
   const int64_t nblk = apertis_router_bwd_blocks(T);
   dim3 grid((unsigned)nblk), block(256);
   const size_t lds3 = (size_t)(2 * N + 2) * H * sizeof(float);
-  if (!getenv("APERTIS_ROUTER_BWD_V2")) {
-    if (dtype_x == APERTIS_BF16) {
-      SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<bf16_t, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<bf16_t, IT, NN>), grid, block, lds3, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H)));
-    } else if (dtype_x == APERTIS_F32) {
-      SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<float, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<float, IT, NN>), grid, block, lds3, st, (const float *)x, gamma, beta, mean, rstd, W, dlogits, (const float *)dres, (float *)dx, part, T, (int)H)));
-    } else return APERTIS_ERR_ARG;
-  } else
   if (dtype_x == APERTIS_BF16) {
-    SKINNY_N(N, hipLaunchKernelGGL((router_bwd_k<bf16_t, NN>), grid, block, 0, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H));
+    SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<bf16_t, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<bf16_t, IT, NN>), grid, block, lds3, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H)));
   } else if (dtype_x == APERTIS_F32) {
-    SKINNY_N(N, hipLaunchKernelGGL((router_bwd_k<float, NN>), grid, block, 0, st, (const float *)x, gamma, beta, mean, rstd, W, dlogits, (const float *)dres, (float *)dx, part, T, (int)H));
+    SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<float, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<float, IT, NN>), grid, block, lds3, st, (const float *)x, gamma, beta, mean, rstd, W, dlogits, (const float *)dres, (float *)dx, part, T, (int)H)));
   } else return APERTIS_ERR_ARG;
   const int64_t cols = N * H + N + 2 * H;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, grads, nblk, cols);
