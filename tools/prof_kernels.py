@@ -16,10 +16,10 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 what = sys.argv[2] if len(sys.argv) > 2 else "all"
 
 if what == "benchmix":
-    # exactly the per-layer launches of bench.py's default workload (1.5b-moe, per-GPU batch 8)
-    B = int(sys.argv[3]) if len(sys.argv) > 3 else 24
+    # exactly the per-layer hot-kernel launches of bench.py's default workload (1.5b-moe, per-GPU batch 32)
+    B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     L, h, N, H, I, E = 4096, 11, 16, 704, 2816, 8
-    Dn, R = h * N, 48
+    Dn, R = h * N, 48      # dt_rank 44 + pad to a 16-byte row
     rows = E * int((B * L / E) * 1.25)      # capacity-limited rows of the train step
     p = torch.randn(B, L, R + 2 * Dn, device=dev).bfloat16().requires_grad_(True)
     dl = (torch.randn(B, L, h, device=dev) - 4).requires_grad_(True)

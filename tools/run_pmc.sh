@@ -2,7 +2,7 @@
 # PMC passes for the hot kernels (separate rocprofv3 runs per counter group; never combined with
 # tracing other than --kernel-trace).  Usage on the GPU box: bash tools/run_pmc.sh <outdir> <what>
 set -u
-OUT=${1:-gpurun_out/pmc}; WHAT=${2:-all}; BATCH=${3:-24}
+OUT=${1:-gpurun_out/pmc}; WHAT=${2:-all}; BATCH=${3:-32}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { # name counters...
