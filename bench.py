@@ -181,11 +181,19 @@ def main():
         except Exception as exc:  # timeout / parse error: report it, never fail the bench line
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "port",
                                       "sample": f"oracle run did not finish: {type(exc).__name__}"}
-    if rank == 0:
-        print(json.dumps(result))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to stdout through C stdio (flushed at exit): push it out first so the
+        # JSON line is the LAST line of stdout whatever else the runtime printed
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
