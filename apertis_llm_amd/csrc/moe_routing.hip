@@ -638,11 +638,72 @@ combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int3
 // partial row per block, folded in a fixed order by ln_fold_k (deterministic, no atomics).
 constexpr int LN_RPW = 8;
 
+// Block boundary of the pre-norm stack, forward: y = res + dropout(blk) (the residual stream, core.py:698,888)
+// and xn = LayerNorm(y) (the next sub-block's pre-norm, core.py:667,847) in one pass: as two kernels y is
+// written by the first and read back by the second (T*H*4 bytes each way).  Wave per row; the mask is the
+// counter hash of (seed, linear index) that apertis_dropout_add_fwd uses, so the backward regenerates it.
+template <typename TX, typename TO, int IT>
+__global__ void __launch_bounds__(256)
+dropadd_ln_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, const float *__restrict__ gamma,
+                 const float *__restrict__ beta, float eps, TX *__restrict__ y, TO *__restrict__ xn,
+                 float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t T, int H, float drop_p, uint64_t seed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= T) return;
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t th = (uint32_t)(drop_p * 65536.f);
+  float4 v[IT];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const float4 a = load4<TO>(blk + r * H + c), rr = load4<TX>(res + r * H + c);
+      float e[4] = {a.x, a.y, a.z, a.w};
+      if (drop_p > 0.f) {
+        bool keep[4];
+        drop_keep4(seed, (uint64_t)r * (uint64_t)H + (uint64_t)c, th, keep);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
+      }
+      v[i] = make_float4(rr.x + e[0], rr.y + e[1], rr.z + e[2], rr.w + e[3]);
+      store4<TX>(y + r * H + c, v[i]);
+      // the norm sees y as stored (a no-op for the fp32 stream)
+      v[i] = make_float4(to_f32(from_f32<TX>(v[i].x)), to_f32(from_f32<TX>(v[i].y)), to_f32(from_f32<TX>(v[i].z)), to_f32(from_f32<TX>(v[i].w)));
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    } else {
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const float mean = wave_sum(sum) / (float)H;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      sq += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+      const float4 g4 = load4<float>(gamma + c), b4 = load4<float>(beta + c);
+      store4<TO>(xn + r * H + c, make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                                             (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w));
+    }
+  }
+  if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+}
+
 template <typename TX, typename TG, int IT>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean_i,
                 const float *__restrict__ rstd_i, const TG *__restrict__ dy, const TX *__restrict__ dres,
-                TX *__restrict__ dx, float *__restrict__ part, int64_t T, int H) {
+                TX *__restrict__ dx, TG *__restrict__ dblk, float drop_p, uint64_t seed, float *__restrict__ part,
+                int64_t T, int H) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [3 waves][2][H/4]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -697,8 +758,24 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
           // dres: the gradient arriving on the residual branch that bypasses this norm (pre-norm block
           // y = x + f(LN(x))): added here instead of in a separate full-width pass
           const float4 rr = dres ? load4<TX>(dres + (r + q) * H + c) : make_float4(0, 0, 0, 0);
-          store4<TX>(dst + c, make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2) + rr.x, rstd[q] * (gd[i].y - m1 - xh[i].y * m2) + rr.y,
-                                          rstd[q] * (gd[i].z - m1 - xh[i].z * m2) + rr.z, rstd[q] * (gd[i].w - m1 - xh[i].w * m2) + rr.w));
+          const float4 dt = make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2) + rr.x, rstd[q] * (gd[i].y - m1 - xh[i].y * m2) + rr.y,
+                                        rstd[q] * (gd[i].z - m1 - xh[i].z * m2) + rr.z, rstd[q] * (gd[i].w - m1 - xh[i].w * m2) + rr.w);
+          store4<TX>(dst + c, dt);
+          if (dblk) {
+            // block boundary, backward: x was res + dropout(blk), so the block output's gradient is the masked
+            // copy of this row's total gradient (what apertis_dropout_bwd computes in a pass of its own)
+            float e[4] = {dt.x, dt.y, dt.z, dt.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = to_f32(from_f32<TX>(e[j]));
+            if (drop_p > 0.f) {
+              bool keep[4];
+              drop_keep4(seed, (uint64_t)(r + q) * (uint64_t)H + (uint64_t)c, (uint32_t)(drop_p * 65536.f), keep);
+              const float ks = 1.f / (1.f - drop_p);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
+            }
+            store4<TG>(dblk + (r + q) * H + c, make_float4(e[0], e[1], e[2], e[3]));
+          }
         }
       }
     }
@@ -1629,16 +1706,18 @@ extern "C" int apertis_layernorm_fwd(const void *x, const float *gamma, const fl
 }
 
 extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean, const float *rstd,
-                                     const void *dy, const void *dres, void *dx, float *part, float *dgamma, float *dbeta,
-                                     int64_t T, int64_t H, int dtype_x, int dtype_g, void *stream) {
+                                     const void *dy, const void *dres, void *dx, void *dblk, float drop_p, uint64_t seed,
+                                     float *part, float *dgamma, float *dbeta, int64_t T, int64_t H, int dtype_x,
+                                     int dtype_g, void *stream) {
   if (!x || !gamma || !mean || !rstd || !dy || !dx || !part || !dgamma || !dbeta || T < 0) return APERTIS_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
   if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nblk = apertis_layernorm_bwd_blocks(T, H);
   dim3 grid((unsigned)nblk), block(256);
   const size_t lds = 3 * 2 * (size_t)H * sizeof(float);
   DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((layernorm_bwd_k<TA, TB, IT>), grid, block, lds, st,
-      (const TA *)x, gamma, mean, rstd, (const TB *)dy, (const TA *)dres, (TA *)dx, part, T, (int)H)));
+      (const TA *)x, gamma, mean, rstd, (const TB *)dy, (const TA *)dres, (TA *)dx, (TB *)dblk, drop_p, seed, part, T, (int)H)));
   hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(1024), 0, st, part, dgamma, dbeta, nblk,
                      (int)H);
   return apertis_check_launch();
@@ -1811,5 +1890,20 @@ extern "C" int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *
 #define GO(EC) hipLaunchKernelGGL(gate_topk_aux_bwd_k<EC>, grid, block, 0, st, gates, idx, dw, lse, stats, dlb, drz, lb_coef, rz_coef, dlogits, S, (int)E, (int)K)
   if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
 #undef GO
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_dropout_add_layernorm_fwd(const void *blk, const void *res, const float *gamma, const float *beta,
+                                                 float eps, void *y, void *xn, float *mean, float *rstd, int64_t T,
+                                                 int64_t H, float drop_p, uint64_t seed, int dtype_x, int dtype_y,
+                                                 void *stream) {
+  if (!blk || !res || !gamma || !beta || !y || !xn || !mean || !rstd || T < 0 || drop_p < 0.f || drop_p >= 1.f)
+    return APERTIS_ERR_ARG;
+  if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(T, 4)), block(256);
+  DISPATCH_2T(dtype_x, dtype_y, DISPATCH_IT(H, hipLaunchKernelGGL((dropadd_ln_fwd_k<TA, TB, IT>), grid, block, 0, st,
+      (const TB *)blk, (const TA *)res, gamma, beta, eps, (TA *)y, (TB *)xn, mean, rstd, T, (int)H, drop_p, seed)));
   return apertis_check_launch();
 }

@@ -167,6 +167,34 @@ def _norm_pass(norm, x):
     return norm.forward_pass(x) if isinstance(norm, HipLayerNorm) else (norm(x), x)
 
 
+class _Pending:
+    """A sub-block's output that has not been added to the residual stream yet: the consumer either resolves
+    it (`residual + dropout(out)`) or folds the add into its own pre-norm (`_enter_block`)."""
+    __slots__ = ("out", "res", "drop")
+
+    def __init__(self, out, res, drop):
+        self.out, self.res, self.drop = out, res, drop
+
+    def resolve(self):
+        return _dropout_add(self.drop, self.out, self.res)
+
+
+def _enter_block(norm, h):
+    """(normalised input, residual) of a pre-norm sub-block.  When `h` is a _Pending boundary and the norm is a
+    HipLayerNorm on the GPU, the residual add, its dropout and the norm run as ONE kernel in each direction."""
+    if isinstance(h, _Pending):
+        out, res = h.out, h.res
+        H = res.shape[-1]
+        cd = _compute_dtype(res)
+        if (isinstance(norm, HipLayerNorm) and res.is_cuda and out.shape == res.shape and H % 4 == 0 and H <= 4096 and
+                res.dtype in (torch.float32, torch.bfloat16) and (res.dtype == torch.float32 or cd == res.dtype)):
+            y, xn = ops.dropout_add_layer_norm(out, res, norm.weight, norm.bias, norm.eps, h.drop.p, h.drop.training,
+                                               out_dtype=cd)
+            return xn, y
+        h = h.resolve()
+    return _norm_pass(norm, h)
+
+
 def _dropout_add(drop: nn.Dropout, out, residual):
     """residual + dropout(out): one HIP kernel on the GPU, stock torch elsewhere."""
     if out.is_cuda and out.numel() % 4 == 0 and out.shape == residual.shape and \
@@ -478,8 +506,10 @@ class ApertisAttention(nn.Module):
         B, L, _ = t.shape
         return t.view(B, L, self.num_attention_heads, self.attention_head_size).transpose(1, 2)
 
-    def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False):
-        x, hidden_s = _norm_pass(self.pre_norm, hidden_s)
+    def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False, defer=False):
+        """hidden_s: the residual stream, or the previous sub-block's _Pending output (its residual add is then
+        folded into this block's pre-norm).  defer=True returns this block's output as a _Pending too."""
+        x, hidden_s = _enter_block(self.pre_norm, hidden_s)
         if self._ssm:
             out, proxy, cache = self.attention_mechanism_impl(x, attention_mask=att_mask, position_ids=pos_ids,
                                                               past_key_value=past_kv, output_attentions=output_att,
@@ -508,6 +538,8 @@ class ApertisAttention(nn.Module):
                 ctxv = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=att_mask,
                                                       dropout_p=self.attention_dropout.p if self.training else 0.0)
             out = self.out_proj(ctxv.transpose(1, 2).reshape(x.shape[0], Lq, self.hidden_size))
+        if defer:
+            return _Pending(out, hidden_s, self.output_dropout), proxy, cache
         return _dropout_add(self.output_dropout, out, hidden_s), proxy, cache
 
 
@@ -547,13 +579,15 @@ class ApertisFeedForward(nn.Module):
                                      nn.Linear(config.intermediate_size, config.hidden_size))
         self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
 
-    def forward(self, hidden_s):
-        x, hidden_s = _norm_pass(self.pre_norm, hidden_s)
+    def forward(self, hidden_s, defer=False):
+        x, hidden_s = _enter_block(self.pre_norm, hidden_s)
         lb = rz = hidden_s.new_zeros(())
         if self.is_expert_system:
             out, lb, rz = self.ffn(x)
         else:
             out = self.ffn(x)
+        if defer:
+            return _Pending(out, hidden_s, self.output_dropout), lb, rz
         return _dropout_add(self.output_dropout, out, hidden_s), lb, rz
 
 
@@ -564,9 +598,11 @@ class ApertisLayer(nn.Module):
         self.attention = ApertisAttention(config)
         self.feed_forward = ApertisFeedForward(config)
 
-    def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False):
-        x, att_w, cache = self.attention(hidden_s, att_mask, pos_ids, past_kv, output_att, use_c)
-        x, lb, rz = self.feed_forward(x)
+    def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False, defer=False):
+        """defer=True (the model's layer loop): the layer accepts and returns a _Pending boundary, so every
+        residual add of the stack is fused with the pre-norm that follows it (ops.dropout_add_layer_norm)."""
+        x, att_w, cache = self.attention(hidden_s, att_mask, pos_ids, past_kv, output_att, use_c, defer=True)
+        x, lb, rz = self.feed_forward(x, defer=defer)
         return x, att_w, cache, lb, rz
 
 
@@ -709,14 +745,15 @@ class ApertisModel(nn.Module):
                 x, att_w, cache, lb, rz = torch.utils.checkpoint.checkpoint(layer, x, mask, pos_layers, past, out_att,
                                                                             use_c, use_reentrant=False)
             else:
-                x, att_w, cache, lb, rz = layer(x, mask, pos_layers, past, out_att, use_c)
+                # hidden states are only materialised at layer boundaries when somebody asked for them
+                x, att_w, cache, lb, rz = layer(x, mask, pos_layers, past, out_att, use_c, defer=not out_hs)
             if out_att:
                 all_att.append(att_w)
             if use_c:
                 all_cache.append(cache)
             if cfg.use_expert_system:
                 lb_tot, rz_tot = lb_tot + lb, rz_tot + rz
-        x = self.final_post_norm(x)
+        x, _ = _enter_block(self.final_post_norm, x)
         if out_hs:
             all_hs.append(x)
         return (x, tuple(all_hs) if out_hs and all_hs else None, tuple(all_att) if out_att and all_att else None,

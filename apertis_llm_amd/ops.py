@@ -893,8 +893,9 @@ class _LayerNorm(torch.autograd.Function):
         part = torch.empty(nw, 2, H, device=x2.device, dtype=torch.float32)
         dg = torch.empty(H, device=x2.device, dtype=torch.float32)
         db = torch.empty(H, device=x2.device, dtype=torch.float32)
-        check(lib.apertis_layernorm_bwd(ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dy2), ptr(dres), ptr(dx), ptr(part), ptr(dg),
-                                        ptr(db), T, H, dtype_code(x2), dtype_code(dy2), stream_ptr()), "apertis_layernorm_bwd")
+        check(lib.apertis_layernorm_bwd(ptr(x2), ptr(g), ptr(mean), ptr(rstd), ptr(dy2), ptr(dres), ptr(dx), None, 0.0, 0,
+                                        ptr(part), ptr(dg), ptr(db), T, H, dtype_code(x2), dtype_code(dy2), stream_ptr()),
+              "apertis_layernorm_bwd")
         return dx.reshape(ctx.shape), dg.to(ctx.pdtypes[0]), db.to(ctx.pdtypes[1]), None, None
 
 
@@ -908,6 +909,68 @@ class _LayerNormPass(_LayerNorm):
     def forward(ctx, x, weight, bias, eps, out_dtype):
         y = _LayerNorm.forward(ctx, x, weight, bias, eps, out_dtype)
         return y, x.view_as(x)
+
+
+class _DropoutAddLN(torch.autograd.Function):
+    """(y, xn) = (res + dropout(blk), LayerNorm(y)): the boundary between two pre-norm sub-blocks as one
+    node.  Forward: y is written once and normalised in the same pass; backward: the gradients of y (the
+    residual path) and xn arrive together, one kernel writes d_res = LN backward + dy and d_blk = its masked
+    copy."""
+
+    @staticmethod
+    def forward(ctx, blk, res, weight, bias, eps, p, seed, out_dtype):
+        _require_gpu(blk, res, weight, bias)
+        lib = _lib.load()
+        shape = res.shape
+        H = shape[-1]
+        blk2 = blk.reshape(-1, H).to(out_dtype).contiguous()
+        res2 = res.reshape(-1, H).contiguous()
+        T = res2.shape[0]
+        g = weight.detach().float().contiguous()
+        b = bias.detach().float().contiguous()
+        y = torch.empty_like(res2)
+        xn = torch.empty(T, H, device=res.device, dtype=out_dtype)
+        mean = torch.empty(T, device=res.device, dtype=torch.float32)
+        rstd = torch.empty(T, device=res.device, dtype=torch.float32)
+        check(lib.apertis_dropout_add_layernorm_fwd(ptr(blk2), ptr(res2), ptr(g), ptr(b), float(eps), ptr(y), ptr(xn), ptr(mean),
+                                                    ptr(rstd), T, H, float(p), int(seed), dtype_code(res2), dtype_code(xn),
+                                                    stream_ptr()), "apertis_dropout_add_layernorm_fwd")
+        ctx.save_for_backward(y, g, mean, rstd)
+        ctx.cfg = (shape, float(p), int(seed), weight.dtype, bias.dtype, blk.dtype, out_dtype)
+        return y.reshape(shape), xn.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy, dxn):
+        lib = _lib.load()
+        y, g, mean, rstd = ctx.saved_tensors
+        shape, p, seed, wdt, bdt, blkdt, odt = ctx.cfg
+        T, H = y.shape
+        if dxn is None:      # the normalised output was not used: only the residual path carries gradient
+            dy2 = dy.reshape(T, H).contiguous()
+            dblk = torch.empty(T, H, device=y.device, dtype=odt)
+            check(lib.apertis_dropout_bwd(ptr(dy2), ptr(dblk), dy2.numel(), p, seed, dtype_code(dy2), dtype_code(dblk), stream_ptr()),
+                  "apertis_dropout_bwd")
+            return dblk.reshape(shape).to(blkdt), dy, None, None, None, None, None, None
+        dxn2 = dxn.reshape(T, H).to(odt).contiguous()
+        dres = None if dy is None else dy.reshape(T, H).to(y.dtype).contiguous()
+        dx = torch.empty_like(y)
+        dblk = torch.empty(T, H, device=y.device, dtype=odt)
+        nw = lib.apertis_layernorm_bwd_blocks(T, H)
+        part = torch.empty(nw, 2, H, device=y.device, dtype=torch.float32)
+        dg = torch.empty(H, device=y.device, dtype=torch.float32)
+        db = torch.empty(H, device=y.device, dtype=torch.float32)
+        check(lib.apertis_layernorm_bwd(ptr(y), ptr(g), ptr(mean), ptr(rstd), ptr(dxn2), ptr(dres), ptr(dx), ptr(dblk), p, seed,
+                                        ptr(part), ptr(dg), ptr(db), T, H, dtype_code(y), dtype_code(dxn2), stream_ptr()),
+              "apertis_layernorm_bwd")
+        return dblk.reshape(shape).to(blkdt), dx.reshape(shape), dg.to(wdt), db.to(bdt), None, None, None, None
+
+
+def dropout_add_layer_norm(blk, residual, weight, bias, eps, p, training, out_dtype=None):
+    """(residual + dropout(blk), LayerNorm(of that)) in one pass each way (reference core.py:698 + :847, :888 +
+    :667 of the next layer, :1294)."""
+    p = float(p) if training else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    return _DropoutAddLN.apply(blk, residual, weight, bias, eps, p, seed, out_dtype or residual.dtype)
 
 
 def layer_norm(x, weight, bias, eps, out_dtype=None):

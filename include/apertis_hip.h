@@ -257,15 +257,25 @@ int64_t apertis_moe_gather_ln_bwd_blocks(int64_t max_rows);
  * Backward: dy [T,H] dtype_g -> dx [T,H] in dtype_x; dgamma/dbeta [H] fp32 overwritten;
  * part = workspace [apertis_layernorm_bwd_blocks(T,H), 2, H] fp32 (deterministic fold).
  * dres (optional, [T,H] dtype_x): gradient arriving on the residual branch around the norm
- * (pre-norm block y = x + f(LN(x)), core.py:667-700,845-890); dx = LN backward + dres. */
+ * (pre-norm block y = x + f(LN(x)), core.py:667-700,845-890); dx = LN backward + dres.
+ * dblk (optional, [T,H] dtype_g) with (drop_p, seed): when x itself was res + dropout(blk) - made by
+ * apertis_dropout_add_layernorm_fwd - also writes blk's gradient, the masked copy of dx. */
 int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps,
                           void *y, float *mean, float *rstd, int64_t T, int64_t H, int dtype_x,
                           int dtype_y, void *stream);
 int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean,
-                          const float *rstd, const void *dy, const void *dres, void *dx, float *part,
+                          const float *rstd, const void *dy, const void *dres, void *dx,
+                          void *dblk, float drop_p, uint64_t seed, float *part,
                           float *dgamma, float *dbeta, int64_t T, int64_t H, int dtype_x,
                           int dtype_g, void *stream);
 int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H);
+/* Block boundary of the pre-norm stack in one pass: y = res + dropout(blk) (core.py:698,888; the mask of
+ * apertis_dropout_add_fwd) and xn = LayerNorm(y) (the next sub-block's pre-norm).  res, y: dtype_x;
+ * blk, xn: dtype_y.  Backward: apertis_layernorm_bwd with dblk. */
+int apertis_dropout_add_layernorm_fwd(const void *blk, const void *res, const float *gamma,
+                                      const float *beta, float eps, void *y, void *xn, float *mean,
+                                      float *rstd, int64_t T, int64_t H, float drop_p, uint64_t seed,
+                                      int dtype_x, int dtype_y, void *stream);
 
 /* Combine (core.py:594,605 weights * expert_output, index_add_):
  *   out[s,:] = sum_{k asc, slot_of[s,k]>=0} wk[s,k] * yr[slot_of[s,k],:]   (zeros if none)

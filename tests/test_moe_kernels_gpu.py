@@ -536,3 +536,31 @@ def test_gate_topk_aux_losses(dev, S, E, K):
     assert abs(float(lb) - float(lb_ref)) <= 1e-5 * abs(float(lb_ref)) and abs(float(rz) - float(rz_ref)) <= 1e-5 * abs(float(rz_ref))
     # K == 1: w = p / (p + 1e-6) is flat, its two gradient terms cancel to ~1e-4 of their size -> absolute floor
     assert torch.allclose(ld.grad.cpu(), lo.grad, rtol=1e-4, atol=3e-7), float((ld.grad.cpu() - lo.grad).abs().max())
+
+
+@pytest.mark.parametrize("T,H,dt_res,dt_blk,p", [(1000, 704, torch.float32, torch.bfloat16, 0.1), (333, 32, torch.float32, torch.float32, 0.0),
+                                                  (513, 256, torch.float32, torch.float32, 0.25), (77, 64, torch.bfloat16, torch.bfloat16, 0.1)])
+def test_dropout_add_layer_norm_boundary(dev, T, H, dt_res, dt_blk, p):
+    """(res + dropout(blk), LayerNorm(that)) as one node vs the two ops it fuses (same seed => same mask):
+    forward bit-identical, backward to rounding; both gradients (residual path and block output) checked."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(T + H)
+    blk, res = torch.randn(T, H).to(dt_blk), torch.randn(T, H).to(dt_res)
+    w, b = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    gy, gn = torch.randn(T, H).to(dt_res), torch.randn(T, H).to(dt_blk)
+    seed = 1234567
+
+    def run(fused):
+        L = [t.to(dev).requires_grad_(True) for t in (blk, res, w, b)]
+        if fused:
+            y, xn = ops._DropoutAddLN.apply(L[0], L[1], L[2], L[3], 1e-5, p, seed, dt_blk)
+        else:
+            y = ops._DropoutAdd.apply(L[0], L[1], p, seed)
+            xn = ops.layer_norm(y, L[2], L[3], 1e-5, out_dtype=dt_blk)
+        ((y.float() * gy.to(dev).float()).sum() + (xn.float() * gn.to(dev).float()).sum()).backward()
+        return [y, xn] + [t.grad for t in L]
+    a, c = run(True), run(False)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), "forward must match the two-op form bit for bit"
+    tol = dict(rtol=1e-5, atol_scale=1e-6) if dt_res == torch.float32 and dt_blk == torch.float32 else dict(rtol=2e-2, atol_scale=1e-2)
+    for u, v, n in zip(a[2:], c[2:], ["dblk", "dres", "dgamma", "dbeta"]):
+        _close(u.float(), v.float(), n, **tol)
