@@ -112,7 +112,8 @@ __global__ void gate_topk_bwd_k(const float *__restrict__ gates, const int32_t *
 // ------------------------------------------------------------------------------------------
 struct PlanWs {
   int32_t *total, *keep, *mode, *quota, *seg_start;
-  uint32_t *thr;
+  uint32_t *thr, *smask;   // radix select: prefix found so far / bits already fixed
+  int32_t *ghist;          // [P][256] digit histogram of the current radix pass
   int32_t *cnt_g, *cnt_t;  // [P][NCH]
   int P, NCH;
 };
@@ -128,6 +129,8 @@ PlanWs carve_ws(void *ws, int64_t S, int64_t E, int64_t K) {
   w.quota = p; p += w.P;
   w.seg_start = p; p += w.P;
   w.thr = (uint32_t *)p; p += w.P;
+  w.smask = (uint32_t *)p; p += w.P;
+  w.ghist = p; p += (int64_t)w.P * 256;
   w.cnt_g = p; p += (int64_t)w.P * w.NCH;
   w.cnt_t = p;
   return w;
@@ -167,8 +170,9 @@ __global__ void plan_capacity_k(PlanWs w, const uint8_t *__restrict__ active, in
       }
       w.keep[p] = (int)keep;
       w.mode[p] = keep == 0 ? 0 : (keep == tot ? 1 : 2);
-      w.quota[p] = 0;
+      w.quota[p] = (int)keep;   // radix select: how many of the slot's candidates are still to be taken
       w.thr[p] = 0;
+      w.smask[p] = 0;
       load += keep;
     }
   }
@@ -232,6 +236,75 @@ plan_select_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict
     __syncthreads();
   }
   if (threadIdx.x == 0) { w.thr[p] = s_prefix; w.quota[p] = s_need; }
+}
+
+// The same radix select spread over the chip (one launch pair per 8-bit digit): every work-group histograms
+// its share of the tokens for ALL overflowing slots in LDS and adds the non-empty bins to the global
+// histogram (integer atomics: exact, order-free); plan_sel_pick_k then fixes the digit per slot.  The
+// one-block-per-slot kernel above walks all S tokens four times with at most E*K blocks busy (154 us at
+// S = 131k with 8 overflowing slots); kept for P > 32 slots (LDS).
+__global__ void __launch_bounds__(256)
+plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk, int64_t S, int E, int K, int shift) {
+  extern __shared__ int32_t lh[];   // [P][256]
+  const int P = w.P;
+  for (int i = threadIdx.x; i < P * 256; i += 256) lh[i] = 0;
+  __syncthreads();
+  const int64_t SK = S * K;
+  for (int64_t a0 = (int64_t)blockIdx.x * 256 + threadIdx.x; a0 < SK; a0 += (int64_t)gridDim.x * 256 * 4) {
+    int32_t ei[4];
+    uint32_t bi[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t a = a0 + (int64_t)u * gridDim.x * 256;
+      ei[u] = a < SK ? idx[a] : -1;
+      bi[u] = a < SK ? __float_as_uint(wk[a]) : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t a = a0 + (int64_t)u * gridDim.x * 256;
+      if (ei[u] >= 0 && ei[u] < E) {
+        const int p = ei[u] * K + (int)(a % K);
+        if (w.mode[p] == 2 && (bi[u] & w.smask[p]) == w.thr[p]) atomicAdd(&lh[p * 256 + ((bi[u] >> shift) & 255)], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * 256; i += 256)
+    if (lh[i]) atomicAdd(&w.ghist[i], lh[i]);
+}
+
+// one wave per slot: the bucket (from the top) where the running count reaches the slot's remaining need
+__global__ void __launch_bounds__(64)
+plan_sel_pick_k(PlanWs w, int shift) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  if (w.mode[p] != 2) return;
+  int32_t *h = w.ghist + p * 256;
+  // lane l owns bins 255-4l .. 252-4l (descending)
+  int c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = h[255 - 4 * lane - j];
+  const int mine = (c[0] + c[1]) + (c[2] + c[3]);
+  int incl = mine;   // inclusive prefix over lanes 0..l
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int need = w.quota[p];
+  const int before = incl - mine;
+  if (before < need && incl >= need) {   // exactly one lane
+    int cum = before, b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cum < need && cum + c[j] >= need) { b = 255 - 4 * lane - j; break; }
+      cum += c[j];
+    }
+    w.quota[p] = need - cum;
+    w.thr[p] = w.thr[p] | ((uint32_t)b << shift);
+    w.smask[p] = w.smask[p] | (255u << shift);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[255 - 4 * lane - j] = 0;   // ready for the next digit
 }
 
 __device__ __forceinline__ void plan_flags(const PlanWs &w, const int32_t *idx, const float *wk, int64_t s,
@@ -1580,7 +1653,7 @@ extern "C" int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx,
 
 extern "C" int64_t apertis_moe_plan_workspace_bytes(int64_t S, int64_t E, int64_t K) {
   int64_t P = E * K, NCH = ceil_div64(S > 0 ? S : 1, 64);
-  return (6 * P + 2 * P * NCH) * 4 + 64;
+  return (7 * P + 256 * P + 2 * P * NCH) * 4 + 64;
 }
 
 extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_t *active,
@@ -1600,8 +1673,19 @@ extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_
   }
   hipLaunchKernelGGL(plan_capacity_k, dim3(1), dim3(64), 0, st, pw, active, capacity, expert_offsets, (int)E, (int)K);
   if (S > 0) {
-    if (capacity > 0)
-      hipLaunchKernelGGL(plan_select_k, dim3(pw.P), dim3(1024), 0, st, pw, idx, w, S, (int)K);
+    if (capacity > 0) {
+      if (pw.P <= 32) {
+        hipMemsetAsync(pw.ghist, 0, sizeof(int32_t) * pw.P * 256, st);
+        const unsigned nbh = (unsigned)std::min<int64_t>(ceil_div64(S * K, 1024), 512);
+        for (int shift = 24; shift >= 0; shift -= 8) {
+          hipLaunchKernelGGL(plan_sel_hist_k, dim3(nbh), dim3(256), (size_t)pw.P * 256 * sizeof(int32_t), st, pw, idx, w, S,
+                             (int)E, (int)K, shift);
+          hipLaunchKernelGGL(plan_sel_pick_k, dim3(pw.P), dim3(64), 0, st, pw, shift);
+        }
+      } else {
+        hipLaunchKernelGGL(plan_select_k, dim3(pw.P), dim3(1024), 0, st, pw, idx, w, S, (int)K);
+      }
+    }
     dim3 cgrid((unsigned)ceil_div64(pw.NCH, 4)), cblock(256);
     hipLaunchKernelGGL(plan_count_k, cgrid, cblock, 0, st, pw, idx, w, S, (int)E, (int)K);
     hipLaunchKernelGGL(plan_scan_k, dim3(2 * pw.P), dim3(256), 0, st, pw);
