@@ -1370,16 +1370,20 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       const float4 xv = raw_to_f4(xc[i]);
       xh[i] = in ? make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd)
                  : make_float4(0, 0, 0, 0);
-      const float4 xn = make_float4(xh[i].x * g4[i].x + b4[i].x, xh[i].y * g4[i].y + b4[i].y, xh[i].z * g4[i].z + b4[i].z,
-                                    xh[i].w * g4[i].w + b4[i].w);
+      const float4 xn = make_float4(fmaf(xh[i].x, g4[i].x, b4[i].x), fmaf(xh[i].y, g4[i].y, b4[i].y), fmaf(xh[i].z, g4[i].z, b4[i].z),
+                                    fmaf(xh[i].w, g4[i].w, b4[i].w));
       float4 d = make_float4(0, 0, 0, 0);   // dxn = dlogits @ W
 #pragma unroll
       for (int n = 0; n < NN; ++n) {
         const float4 wn = in ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
-        d.x += g[n] * wn.x; d.y += g[n] * wn.y; d.z += g[n] * wn.z; d.w += g[n] * wn.w;
-        aw[n][i].x += g[n] * xn.x; aw[n][i].y += g[n] * xn.y; aw[n][i].z += g[n] * xn.z; aw[n][i].w += g[n] * xn.w;
+        // explicit FMAs: the file is built with -ffp-contract=off (parity kernels), which would make every
+        // accumulation here a multiply and an add - 2x the instructions of a VALU-bound kernel
+        d.x = fmaf(g[n], wn.x, d.x); d.y = fmaf(g[n], wn.y, d.y); d.z = fmaf(g[n], wn.z, d.z); d.w = fmaf(g[n], wn.w, d.w);
+        aw[n][i].x = fmaf(g[n], xn.x, aw[n][i].x); aw[n][i].y = fmaf(g[n], xn.y, aw[n][i].y);
+        aw[n][i].z = fmaf(g[n], xn.z, aw[n][i].z); aw[n][i].w = fmaf(g[n], xn.w, aw[n][i].w);
       }
-      ag[i].x += d.x * xh[i].x; ag[i].y += d.y * xh[i].y; ag[i].z += d.z * xh[i].z; ag[i].w += d.w * xh[i].w;
+      ag[i].x = fmaf(d.x, xh[i].x, ag[i].x); ag[i].y = fmaf(d.y, xh[i].y, ag[i].y);
+      ag[i].z = fmaf(d.z, xh[i].z, ag[i].z); ag[i].w = fmaf(d.w, xh[i].w, ag[i].w);
       ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
       dn[i] = make_float4(d.x * g4[i].x, d.y * g4[i].y, d.z * g4[i].z, d.w * g4[i].w);
       s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
