@@ -126,6 +126,7 @@ class _SelectiveScan(torch.autograd.Function):
         A_log = A_log.float().contiguous()
         if h0 is not None:
             h0 = h0.float().reshape(B, Dn).contiguous()
+        ctx.slots = (_slot_of(Bt), _slot_of(C))
         (Bt, bt_rs), (C, c_rs) = _rows(Bt, Dn), _rows(C, Dn)
         nch = lib.apertis_scan_num_chunks(B, L, Dn)
         dev = dlt.device
@@ -173,8 +174,8 @@ class _SelectiveScan(torch.autograd.Function):
         nch = h_in.shape[1]
         # dBt/dC keep the layout of the forward views when those are slices of one projection
         # output, so autograd's slice-backward sees dense tensors of the expected shape
-        dBt = torch.empty(B, L, Dn, device=dev, dtype=Bt.dtype)
-        dC = torch.empty(B, L, Dn, device=dev, dtype=C.dtype)
+        dBt, dbt_rs = _grad_out(ctx.slots[0], (B, L), Dn, Bt.dtype, dev)
+        dC, dc_rs = _grad_out(ctx.slots[1], (B, L), Dn, C.dtype, dev)
         d_dlt = torch.empty(B, L, h, device=dev, dtype=torch.float32)
         dA_log = torch.empty(h, N, device=dev, dtype=torch.float32)
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
@@ -182,8 +183,8 @@ class _SelectiveScan(torch.autograd.Function):
         dA_part = torch.empty(B * nch, Dn, device=dev, dtype=torch.float32)
         work = B * L * (Dn * (4 * Bt.element_size() + dy.element_size()) + 8 * h) + 8 * h * N  # algorithmic bytes
         _launch("apertis_selective_scan_bwd", lib.apertis_selective_scan_bwd,
-                (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(dy), Dn, ptr(h_in), ptr(dBt), Dn,
-                 ptr(dC), Dn, ptr(d_dlt), ptr(dA_log), ptr(agg), ptr(mu_in), ptr(dA_part), B, L, h, N, dtype_code(Bt),
+                (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(dy), Dn, ptr(h_in), ptr(dBt), dbt_rs,
+                 ptr(dC), dc_rs, ptr(d_dlt), ptr(dA_log), ptr(agg), ptr(mu_in), ptr(dA_part), B, L, h, N, dtype_code(Bt),
                  dtype_code(dy), int(sp), stream_ptr()), work)
         return d_dlt, dA_log, dBt, dC, None, None, None, None
 
@@ -206,6 +207,7 @@ class _DwConvSilu(torch.autograd.Function):
         _require_gpu(x, w, b)
         lib = _lib.load()
         B, L, Dn = x.shape
+        ctx.slot = _slot_of(x)
         x, x_rs = _rows(x, Dn)
         w2 = w.detach().float().reshape(Dn, -1).contiguous()
         b2 = b.detach().float().contiguous()
@@ -226,12 +228,12 @@ class _DwConvSilu(torch.autograd.Function):
         dout = dout.contiguous()
         nblk = lib.apertis_dwconv_bwd_blocks(B, L, Dn)
         dev = x.device
-        dx = torch.empty(B, L, Dn, device=dev, dtype=x.dtype)
+        dx, dx_rs = _grad_out(ctx.slot, (B, L), Dn, x.dtype, dev)
         dw_part = torch.empty(nblk, Dn, k, device=dev, dtype=torch.float32)
         db_part = torch.empty(nblk, Dn, device=dev, dtype=torch.float32)
         dw = torch.empty(Dn, k, device=dev, dtype=torch.float32)
         db = torch.empty(Dn, device=dev, dtype=torch.float32)
-        check(lib.apertis_dwconv_silu_bwd(ptr(x), x.stride(-2), ptr(w2), ptr(b2), ptr(dout), Dn, ptr(dx), Dn,
+        check(lib.apertis_dwconv_silu_bwd(ptr(x), x.stride(-2), ptr(w2), ptr(b2), ptr(dout), Dn, ptr(dx), dx_rs,
                                           ptr(dw_part), ptr(db_part), ptr(dw), ptr(db), B, L, Dn, k, dtype_code(x),
                                           stream_ptr()), "apertis_dwconv_silu_bwd")
         return dx, dw.reshape(ctx.wshape), db
@@ -281,6 +283,7 @@ class _SsmGate(torch.autograd.Function):
         _require_gpu(y, xc, z, D)
         lib = _lib.load()
         B, L, Dn = y.shape
+        ctx.zslot = _slot_of(z)
         y, y_rs = _rows(y, Dn)
         xc, xc_rs = _rows(xc, Dn)
         z, z_rs = _rows(z, Dn)
@@ -303,11 +306,11 @@ class _SsmGate(torch.autograd.Function):
         nblk = lib.apertis_ssm_gate_bwd_blocks(B * L, Dn)
         dy = torch.empty(B, L, Dn, device=dev, dtype=y.dtype)
         dxc = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
-        dz = torch.empty(B, L, Dn, device=dev, dtype=z.dtype)
+        dz, dz_rs = _grad_out(ctx.zslot, (B, L), Dn, z.dtype, dev)
         part = torch.empty(nblk, Dn, device=dev, dtype=torch.float32)
         dD = torch.empty(Dn, device=dev, dtype=torch.float32)
         check(lib.apertis_ssm_gate_bwd(ptr(dout), Dn, ptr(y), y.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
-                                       ptr(Df), ptr(dy), Dn, ptr(dxc), Dn, ptr(dz), Dn, ptr(part), ptr(dD), B * L, Dn,
+                                       ptr(Df), ptr(dy), Dn, ptr(dxc), Dn, ptr(dz), dz_rs, ptr(part), ptr(dD), B * L, Dn,
                                        dtype_code(y), dtype_code(xc), stream_ptr()), "apertis_ssm_gate_bwd")
         return dy, dxc, dz, dD
 
@@ -443,6 +446,7 @@ class _TinyLinear(torch.autograd.Function):
         _require_gpu(x, weight, bias)
         lib = _lib.load()
         K, N = x.shape[-1], weight.shape[0]
+        ctx.slot = _slot_of(x)
         x3 = x if x.dim() == 3 else x.reshape(1, -1, K)
         xr, ldx = _rows(x3, K)
         T = x.numel() // K
@@ -462,9 +466,13 @@ class _TinyLinear(torch.autograd.Function):
         ldx, T, xshape, wdt, bdt = ctx.cfg
         N, K = w.shape
         dy = dy.float().contiguous()
-        Kp = -(-K // 8) * 8     # 16-byte row pitch: the kernel stores whole 16-byte chunks
-        dxp = torch.empty(*xshape[:-1], Kp, device=xr.device, dtype=xr.dtype)
-        dx = dxp[..., :K]
+        if ctx.slot is not None and ctx.slot[0].widths[ctx.slot[1]] == K:
+            dx, Kp = ctx.slot[0].out(ctx.slot[1], xshape[:-1], xr.dtype, xr.device)   # a column range of the shared buffer
+            dxp = dx
+        else:
+            Kp = -(-K // 8) * 8     # 16-byte row pitch: the kernel stores whole 16-byte chunks
+            dxp = torch.empty(*xshape[:-1], Kp, device=xr.device, dtype=xr.dtype)
+            dx = dxp[..., :K]
         nblk = lib.apertis_tiny_linear_bwd_blocks(T)
         part = torch.empty(nblk, N * K + N, device=xr.device, dtype=torch.float32)
         out = torch.empty(N * K + N, device=xr.device, dtype=torch.float32)
@@ -483,29 +491,80 @@ def tiny_linear(x, weight, bias=None):
     return _TinyLinear.apply(x, weight, bias)
 
 
+class _ColSlot:
+    """Gradient buffer shared by the column views of one split_cols call.  Ops of this module that consume such a
+    view (`x._apertis_slot = (slot, i)`) write their input gradient straight into columns [off_i, off_i + w_i)
+    of `buf` (their kernels take an output row stride), so split_cols' backward is the buffer itself instead of
+    a concatenation."""
+    __slots__ = ("widths", "offsets", "total", "buf", "claimed")
+
+    def __init__(self, widths):
+        self.widths = tuple(widths)
+        self.offsets = tuple(sum(widths[:i]) for i in range(len(widths)))
+        self.total = sum(widths)
+        self.buf = None
+        self.claimed = set()
+
+    def out(self, i, lead_shape, dtype, device):
+        """(gradient tensor for view i, its row stride in elements).  A view's columns are handed out once per
+        backward pass: a second consumer of the same view gets a tensor of its own and autograd adds the two."""
+        if self.buf is None:
+            self.buf = torch.empty(*lead_shape, self.total, device=device, dtype=dtype)
+            self.claimed = set()
+        if i in self.claimed or self.buf.dtype != dtype or tuple(self.buf.shape[:-1]) != tuple(lead_shape):
+            return torch.empty(*lead_shape, self.widths[i], device=device, dtype=dtype), self.widths[i]
+        self.claimed.add(i)
+        return self.buf[..., self.offsets[i]:self.offsets[i] + self.widths[i]], self.total
+
+
+def _slot_of(t):
+    return getattr(t, "_apertis_slot", None)
+
+
+def _grad_out(slot, lead_shape, width, dtype, device):
+    """Gradient buffer for an input that may be a split_cols view: (tensor [..., width], row stride)."""
+    if slot is not None and slot[0].widths[slot[1]] == width:
+        return slot[0].out(slot[1], lead_shape, dtype, device)
+    return torch.empty(*lead_shape, width, device=device, dtype=dtype), width
+
+
 class _SplitCols(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, *sizes):
-        ctx.sizes = sizes
-        outs, a = [], 0
-        for n in sizes:
-            outs.append(x[..., a:a + n])
-            a += n
-        return tuple(outs)
+    def forward(ctx, x, slot):
+        ctx.slot = slot
+        return tuple(x[..., a:a + n] for a, n in zip(slot.offsets, slot.widths))
 
     @staticmethod
     def backward(ctx, *grads):
-        ref = next(g for g in grads if g is not None)
-        parts = [g if g is not None else ref.new_zeros(*ref.shape[:-1], n) for g, n in zip(grads, ctx.sizes)]
-        return (torch.cat(parts, dim=-1),) + (None,) * len(ctx.sizes)
+        slot = ctx.slot
+        buf, slot.buf = slot.buf, None
+        if buf is None:
+            ref = next(g for g in grads if g is not None)
+            parts = [g if g is not None else ref.new_zeros(*ref.shape[:-1], n) for g, n in zip(grads, slot.widths)]
+            return torch.cat(parts, dim=-1), None
+        es = buf.element_size()
+        for g, off, n in zip(grads, slot.offsets, slot.widths):
+            if n == 0:
+                continue
+            dst = buf[..., off:off + n]
+            if g is None:
+                dst.zero_()
+            elif not (g.data_ptr() == buf.data_ptr() + off * es and g.stride() == dst.stride()):
+                dst.copy_(g)      # produced by an op that does not know the protocol
+        return buf, None
 
 
 def split_cols(x, sizes):
-    """Column views x[..., a:b] of consecutive widths `sizes` (summing to x.shape[-1]) whose backward
-    assembles the input gradient with ONE concatenation; slicing leaves autograd to zero-fill, copy and
+    """Column views x[..., a:b] of consecutive widths `sizes` (summing to x.shape[-1]).  The backward assembles the
+    input gradient without a pass of its own when the consumers are ops of this module (they write into one shared
+    buffer, see _ColSlot), with one concatenation otherwise; plain slicing leaves autograd to zero-fill, copy and
     add a full-width tensor per slice."""
     assert sum(sizes) == x.shape[-1]
-    return _SplitCols.apply(x, *sizes)
+    slot = _ColSlot(sizes)
+    outs = _SplitCols.apply(x, slot)
+    for i, o in enumerate(outs):
+        o._apertis_slot = (slot, i)
+    return outs
 
 
 class _RouterLN(torch.autograd.Function):

@@ -242,3 +242,31 @@ def test_split_cols_backward_is_one_concatenation(dev):
     ref[..., :3] = 2
     ref[..., 11:19] = 2 * x.detach()[..., 11:19]
     assert torch.equal(x.grad, ref)
+
+
+def test_split_cols_shared_gradient_buffer(dev):
+    """Consumers from this module write their input gradients into one buffer (no concatenation); a view used
+    twice, a view used by a stock op and an unused view still give the right total gradient."""
+    import torch.nn.functional as F
+    from apertis_llm_amd import ops
+    torch.manual_seed(3)
+    B, L, Dn, R = 2, 70, 16, 6
+    base = torch.randn(B, L, R + 2 * Dn + 2)
+    W, bb = torch.randn(5, R) * 0.3, torch.randn(5)
+    wc, bc = torch.randn(Dn, 1, 3) * 0.3, torch.randn(Dn) * 0.1
+
+    def loss(p, split):
+        a, b, c, d = split(p)
+        y1 = ops.tiny_linear(a, W.to(p.device), bb.to(p.device))            # protocol consumer
+        y2 = ops.dwconv_silu(b, wc.to(p.device), bc.to(p.device))           # protocol consumer ...
+        y3 = ops.dwconv_silu(b, wc.to(p.device) * 0.5, bc.to(p.device))     # ... of the same view, a second time
+        return y1.sum() * 0.7 + (y2 * y2).sum() + y3.sum() + torch.tanh(c).sum()   # c: stock op; d: unused
+    ref = base.clone().requires_grad_(True)
+    a, b, c, d = ref[..., :R], ref[..., R:R + Dn], ref[..., R + Dn:R + 2 * Dn], ref[..., R + 2 * Dn:]
+    y1 = F.linear(a, W, bb)
+    def conv(x, w, bias):
+        return F.silu(F.conv1d(x.transpose(1, 2), w, bias, groups=Dn, padding=2)[..., :L].transpose(1, 2))
+    (y1.sum() * 0.7 + (conv(b, wc, bc) ** 2).sum() + conv(b, wc * 0.5, bc).sum() + torch.tanh(c).sum()).backward()
+    p = base.to(dev).requires_grad_(True)
+    loss(p, lambda t: ops.split_cols(t, (R, Dn, Dn, 2))).backward()
+    assert torch.allclose(p.grad.cpu(), ref.grad, rtol=1e-4, atol=1e-5), float((p.grad.cpu() - ref.grad).abs().max())
