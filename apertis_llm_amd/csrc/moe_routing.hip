@@ -717,9 +717,10 @@ constexpr int LN_RPW = 8;
 // counter hash of (seed, linear index) that apertis_dropout_add_fwd uses, so the backward regenerates it.
 template <typename TX, typename TO, int IT>
 __global__ void __launch_bounds__(256)
-dropadd_ln_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, const float *__restrict__ gamma,
-                 const float *__restrict__ beta, float eps, TX *__restrict__ y, TO *__restrict__ xn,
-                 float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t T, int H, float drop_p, uint64_t seed) {
+dropadd_ln_fwd_k(const TO *__restrict__ blk, const int32_t *__restrict__ slot_of, const float *__restrict__ wk, int K,
+                 const TX *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                 TX *__restrict__ y, TO *__restrict__ xn, float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t T,
+                 int H, float drop_p, uint64_t seed) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= T) return;
@@ -731,7 +732,23 @@ dropadd_ln_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, const f
   for (int i = 0; i < IT; ++i) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
-      const float4 a = load4<TO>(blk + r * H + c), rr = load4<TX>(res + r * H + c);
+      float4 a;
+      if (slot_of) {
+        // blk is the expert output [rows,H]: the token's row is the MoE combine (apertis_moe_combine_fwd: k
+        // ascending, multiply then add, rounded to the block dtype) computed here instead of in a pass of its own
+        float4 acc = make_float4(0, 0, 0, 0);
+        for (int k = 0; k < K; ++k) {
+          const int slot = slot_of[r * K + k];
+          if (slot < 0) continue;
+          const float wv = wk[r * K + k];
+          const float4 v = load4<TO>(blk + (int64_t)slot * H + c);
+          acc.x += v.x * wv; acc.y += v.y * wv; acc.z += v.z * wv; acc.w += v.w * wv;
+        }
+        a = make_float4(to_f32(from_f32<TO>(acc.x)), to_f32(from_f32<TO>(acc.y)), to_f32(from_f32<TO>(acc.z)), to_f32(from_f32<TO>(acc.w)));
+      } else {
+        a = load4<TO>(blk + r * H + c);
+      }
+      const float4 rr = load4<TX>(res + r * H + c);
       float e[4] = {a.x, a.y, a.z, a.w};
       if (drop_p > 0.f) {
         bool keep[4];
@@ -1981,17 +1998,19 @@ extern "C" int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *
   return apertis_check_launch();
 }
 
-extern "C" int apertis_dropout_add_layernorm_fwd(const void *blk, const void *res, const float *gamma, const float *beta,
-                                                 float eps, void *y, void *xn, float *mean, float *rstd, int64_t T,
-                                                 int64_t H, float drop_p, uint64_t seed, int dtype_x, int dtype_y,
-                                                 void *stream) {
+extern "C" int apertis_dropout_add_layernorm_fwd(const void *blk, const int32_t *slot_of, const float *wk, int64_t K,
+                                                 const void *res, const float *gamma, const float *beta, float eps, void *y,
+                                                 void *xn, float *mean, float *rstd, int64_t T, int64_t H, float drop_p,
+                                                 uint64_t seed, int dtype_x, int dtype_y, void *stream) {
   if (!blk || !res || !gamma || !beta || !y || !xn || !mean || !rstd || T < 0 || drop_p < 0.f || drop_p >= 1.f)
     return APERTIS_ERR_ARG;
+  if (slot_of && (!wk || K < 1 || K > MAXK)) return APERTIS_ERR_ARG;
   if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
   if (T == 0) return APERTIS_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)ceil_div64(T, 4)), block(256);
   DISPATCH_2T(dtype_x, dtype_y, DISPATCH_IT(H, hipLaunchKernelGGL((dropadd_ln_fwd_k<TA, TB, IT>), grid, block, 0, st,
-      (const TB *)blk, (const TA *)res, gamma, beta, eps, (TA *)y, (TB *)xn, mean, rstd, T, (int)H, drop_p, seed)));
+      (const TB *)blk, slot_of, wk, (int)K, (const TA *)res, gamma, beta, eps, (TA *)y, (TB *)xn, mean, rstd, T, (int)H, drop_p,
+      seed)));
   return apertis_check_launch();
 }

@@ -167,6 +167,19 @@ def _norm_pass(norm, x):
     return norm.forward_pass(x) if isinstance(norm, HipLayerNorm) else (norm(x), x)
 
 
+class _LazyCombine:
+    """The MoE block's output before its combine (reference core.py:594,605): expert rows yr [rows,H], gate
+    weights w [S,K] and the dispatch plan.  `_enter_block` forms the combine inside the boundary kernel;
+    `materialise()` is the stand-alone combine."""
+    __slots__ = ("yr", "w", "plan", "shape", "dtype")
+
+    def __init__(self, yr, w, plan, shape, dtype):
+        self.yr, self.w, self.plan, self.shape, self.dtype = yr, w, plan, shape, dtype
+
+    def materialise(self):
+        return ops.moe_combine(self.yr, self.w, self.plan, out_dtype=self.dtype).reshape(self.shape)
+
+
 class _Pending:
     """A sub-block's output that has not been added to the residual stream yet: the consumer either resolves
     it (`residual + dropout(out)`) or folds the add into its own pre-norm (`_enter_block`)."""
@@ -176,7 +189,8 @@ class _Pending:
         self.out, self.res, self.drop = out, res, drop
 
     def resolve(self):
-        return _dropout_add(self.drop, self.out, self.res)
+        out = self.out.materialise() if isinstance(self.out, _LazyCombine) else self.out
+        return _dropout_add(self.drop, out, self.res)
 
 
 def _enter_block(norm, h):
@@ -186,10 +200,16 @@ def _enter_block(norm, h):
         out, res = h.out, h.res
         H = res.shape[-1]
         cd = _compute_dtype(res)
-        if (isinstance(norm, HipLayerNorm) and res.is_cuda and out.shape == res.shape and H % 4 == 0 and H <= 4096 and
-                res.dtype in (torch.float32, torch.bfloat16) and (res.dtype == torch.float32 or cd == res.dtype)):
-            y, xn = ops.dropout_add_layer_norm(out, res, norm.weight, norm.bias, norm.eps, h.drop.p, h.drop.training,
-                                               out_dtype=cd)
+        lazy = out if isinstance(out, _LazyCombine) else None
+        if (isinstance(norm, HipLayerNorm) and res.is_cuda and tuple(out.shape) == tuple(res.shape) and H % 4 == 0 and
+                H <= 4096 and res.dtype in (torch.float32, torch.bfloat16) and
+                (res.dtype == torch.float32 or cd == res.dtype) and (lazy is None or lazy.dtype == lazy.yr.dtype == cd)):
+            if lazy is not None:
+                y, xn = ops.dropout_add_layer_norm(lazy.yr, res, norm.weight, norm.bias, norm.eps, h.drop.p,
+                                                   h.drop.training, out_dtype=cd, combine=(lazy.w, lazy.plan))
+            else:
+                y, xn = ops.dropout_add_layer_norm(out, res, norm.weight, norm.bias, norm.eps, h.drop.p,
+                                                   h.drop.training, out_dtype=cd)
             return xn, y
         h = h.resolve()
     return _norm_pass(norm, h)
@@ -402,7 +422,7 @@ class AdaptiveExpertSystem(nn.Module):
             self.expert_ln_weight.fill_(1.0)
             self.expert_ln_bias.zero_()
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, lazy_combine=False):
         zero = hidden_states.new_zeros(())
         if self.num_experts <= 0 or self.router is None:
             return hidden_states, zero, zero
@@ -456,8 +476,10 @@ class AdaptiveExpertSystem(nn.Module):
         yr = ops.expert_mlp(xg, self.expert_w1, self.expert_b1, self.expert_w2, self.expert_b2, plan.offsets,
                             plan.max_rows, act=self.activation, drop_p=p_drop, seed=seed,
                             compute_dtype=cd)                                             # core.py:437-440
-        out = ops.moe_combine(yr, w, plan, out_dtype=xf.dtype)                            # core.py:594,605
-        return out.reshape(B, L, H), lb_loss.to(hidden_states.dtype), rz_loss.to(hidden_states.dtype)
+        out = _LazyCombine(yr, w, plan, (B, L, H), xf.dtype)                              # core.py:594,605
+        if not lazy_combine:
+            out = out.materialise()
+        return out, lb_loss.to(hidden_states.dtype), rz_loss.to(hidden_states.dtype)
 
 
 class StateTrackingRecurrentCell(nn.Module):
@@ -583,7 +605,7 @@ class ApertisFeedForward(nn.Module):
         x, hidden_s = _enter_block(self.pre_norm, hidden_s)
         lb = rz = hidden_s.new_zeros(())
         if self.is_expert_system:
-            out, lb, rz = self.ffn(x)
+            out, lb, rz = self.ffn(x, lazy_combine=defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"))
         else:
             out = self.ffn(x)
         if defer:

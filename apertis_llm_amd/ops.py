@@ -977,7 +977,8 @@ class _DropoutAddLN(torch.autograd.Function):
     copy."""
 
     @staticmethod
-    def forward(ctx, blk, res, weight, bias, eps, p, seed, out_dtype):
+    def forward(ctx, blk, res, weight, bias, eps, p, seed, out_dtype, wk=None, plan=None):
+        """plan/wk given: blk is the MoE expert output [rows,H] and the block output is its combine."""
         _require_gpu(blk, res, weight, bias)
         lib = _lib.load()
         shape = res.shape
@@ -985,31 +986,55 @@ class _DropoutAddLN(torch.autograd.Function):
         blk2 = blk.reshape(-1, H).to(out_dtype).contiguous()
         res2 = res.reshape(-1, H).contiguous()
         T = res2.shape[0]
+        wf = None if plan is None else wk.float().contiguous()
         g = weight.detach().float().contiguous()
         b = bias.detach().float().contiguous()
         y = torch.empty_like(res2)
         xn = torch.empty(T, H, device=res.device, dtype=out_dtype)
         mean = torch.empty(T, device=res.device, dtype=torch.float32)
         rstd = torch.empty(T, device=res.device, dtype=torch.float32)
-        check(lib.apertis_dropout_add_layernorm_fwd(ptr(blk2), ptr(res2), ptr(g), ptr(b), float(eps), ptr(y), ptr(xn), ptr(mean),
-                                                    ptr(rstd), T, H, float(p), int(seed), dtype_code(res2), dtype_code(xn),
-                                                    stream_ptr()), "apertis_dropout_add_layernorm_fwd")
-        ctx.save_for_backward(y, g, mean, rstd)
-        ctx.cfg = (shape, float(p), int(seed), weight.dtype, bias.dtype, blk.dtype, out_dtype)
+        check(lib.apertis_dropout_add_layernorm_fwd(ptr(blk2), None if plan is None else ptr(plan.slot_of), ptr(wf),
+                                                    0 if plan is None else plan.K, ptr(res2), ptr(g), ptr(b), float(eps), ptr(y),
+                                                    ptr(xn), ptr(mean), ptr(rstd), T, H, float(p), int(seed), dtype_code(res2),
+                                                    dtype_code(xn), stream_ptr()), "apertis_dropout_add_layernorm_fwd")
+        if plan is None:
+            ctx.save_for_backward(y, g, mean, rstd)
+        else:
+            ctx.save_for_backward(y, g, mean, rstd, blk2, wf)
+        ctx.plan = plan
+        ctx.cfg = (shape, float(p), int(seed), weight.dtype, bias.dtype, blk.dtype, out_dtype, tuple(blk.shape))
         return y.reshape(shape), xn.reshape(shape)
+
+    @staticmethod
+    def _to_inputs(ctx, dblk):
+        """Gradient of the block-output argument(s) from the token-major dblk [T,H]."""
+        lib = _lib.load()
+        shape, _p, _seed, _wdt, _bdt, blkdt, _odt, blkshape = ctx.cfg
+        plan = ctx.plan
+        if plan is None:
+            return dblk.reshape(shape).to(blkdt), None
+        yr, wf = ctx.saved_tensors[4], ctx.saved_tensors[5]
+        H = yr.shape[1]
+        dyr = torch.empty_like(yr)
+        dw = torch.zeros(plan.S, plan.K, device=yr.device, dtype=torch.float32)
+        check(lib.apertis_moe_combine_bwd(ptr(dblk), ptr(yr), ptr(plan.row_token), ptr(plan.row_k), ptr(plan.offsets),
+                                          ptr(wf), ptr(dyr), ptr(dw), plan.max_rows, plan.S, H, plan.K, plan.E,
+                                          dtype_code(dblk), dtype_code(yr), stream_ptr()), "apertis_moe_combine_bwd")
+        return dyr.reshape(blkshape).to(blkdt), dw
 
     @staticmethod
     def backward(ctx, dy, dxn):
         lib = _lib.load()
-        y, g, mean, rstd = ctx.saved_tensors
-        shape, p, seed, wdt, bdt, blkdt, odt = ctx.cfg
+        y, g, mean, rstd = ctx.saved_tensors[:4]
+        shape, p, seed, wdt, bdt, blkdt, odt, _ = ctx.cfg
         T, H = y.shape
         if dxn is None:      # the normalised output was not used: only the residual path carries gradient
             dy2 = dy.reshape(T, H).contiguous()
             dblk = torch.empty(T, H, device=y.device, dtype=odt)
             check(lib.apertis_dropout_bwd(ptr(dy2), ptr(dblk), dy2.numel(), p, seed, dtype_code(dy2), dtype_code(dblk), stream_ptr()),
                   "apertis_dropout_bwd")
-            return dblk.reshape(shape).to(blkdt), dy, None, None, None, None, None, None
+            dblk_in, dwk = _DropoutAddLN._to_inputs(ctx, dblk)
+            return dblk_in, dy, None, None, None, None, None, None, dwk, None
         dxn2 = dxn.reshape(T, H).to(odt).contiguous()
         dres = None if dy is None else dy.reshape(T, H).to(y.dtype).contiguous()
         dx = torch.empty_like(y)
@@ -1021,15 +1046,18 @@ class _DropoutAddLN(torch.autograd.Function):
         check(lib.apertis_layernorm_bwd(ptr(y), ptr(g), ptr(mean), ptr(rstd), ptr(dxn2), ptr(dres), ptr(dx), ptr(dblk), p, seed,
                                         ptr(part), ptr(dg), ptr(db), T, H, dtype_code(y), dtype_code(dxn2), stream_ptr()),
               "apertis_layernorm_bwd")
-        return dblk.reshape(shape).to(blkdt), dx.reshape(shape), dg.to(wdt), db.to(bdt), None, None, None, None
+        dblk_in, dwk = _DropoutAddLN._to_inputs(ctx, dblk)
+        return dblk_in, dx.reshape(shape), dg.to(wdt), db.to(bdt), None, None, None, None, dwk, None
 
 
-def dropout_add_layer_norm(blk, residual, weight, bias, eps, p, training, out_dtype=None):
+def dropout_add_layer_norm(blk, residual, weight, bias, eps, p, training, out_dtype=None, combine=None):
     """(residual + dropout(blk), LayerNorm(of that)) in one pass each way (reference core.py:698 + :847, :888 +
-    :667 of the next layer, :1294)."""
+    :667 of the next layer, :1294).  combine=(w, plan): blk is the MoE expert output [rows,H] and the block output
+    its weighted combine (core.py:594,605), formed inside the same forward pass."""
     p = float(p) if training else 0.0
     seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
-    return _DropoutAddLN.apply(blk, residual, weight, bias, eps, p, seed, out_dtype or residual.dtype)
+    wk, plan = combine if combine is not None else (None, None)
+    return _DropoutAddLN.apply(blk, residual, weight, bias, eps, p, seed, out_dtype or residual.dtype, wk, plan)
 
 
 def layer_norm(x, weight, bias, eps, out_dtype=None):

@@ -271,8 +271,11 @@ int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean,
 int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H);
 /* Block boundary of the pre-norm stack in one pass: y = res + dropout(blk) (core.py:698,888; the mask of
  * apertis_dropout_add_fwd) and xn = LayerNorm(y) (the next sub-block's pre-norm).  res, y: dtype_x;
- * blk, xn: dtype_y.  Backward: apertis_layernorm_bwd with dblk. */
-int apertis_dropout_add_layernorm_fwd(const void *blk, const void *res, const float *gamma,
+ * blk, xn: dtype_y.  With slot_of [T,K] / wk [T,K] (else NULL) blk is the MoE expert output [rows,H] and the
+ * token's row is the combine sum_k wk*blk[slot_of] (apertis_moe_combine_fwd's arithmetic) taken on the fly.
+ * Backward: apertis_layernorm_bwd with dblk (then apertis_moe_combine_bwd on dblk in the MoE form). */
+int apertis_dropout_add_layernorm_fwd(const void *blk, const int32_t *slot_of, const float *wk, int64_t K,
+                                      const void *res, const float *gamma,
                                       const float *beta, float eps, void *y, void *xn, float *mean,
                                       float *rstd, int64_t T, int64_t H, float drop_p, uint64_t seed,
                                       int dtype_x, int dtype_y, void *stream);

@@ -564,3 +564,36 @@ def test_dropout_add_layer_norm_boundary(dev, T, H, dt_res, dt_blk, p):
     tol = dict(rtol=1e-5, atol_scale=1e-6) if dt_res == torch.float32 and dt_blk == torch.float32 else dict(rtol=2e-2, atol_scale=1e-2)
     for u, v, n in zip(a[2:], c[2:], ["dblk", "dres", "dgamma", "dbeta"]):
         _close(u.float(), v.float(), n, **tol)
+
+
+@pytest.mark.parametrize("S,H,E,K,dt,p,cap", [(1000, 704, 8, 2, torch.bfloat16, 0.1, 200), (257, 64, 4, 1, torch.float32, 0.0, None),
+                                               (512, 256, 8, 3, torch.float32, 0.2, 100)])
+def test_boundary_with_moe_combine(dev, S, H, E, K, dt, p, cap):
+    """MoE combine formed inside the boundary kernel vs moe_combine -> dropout_add -> layer_norm: forward
+    bit-identical (incl. capacity-dropped tokens = exact zero rows), all five gradients to rounding."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(S + H + K)
+    logits = torch.randn(S, E, device=dev)
+    _, idx, w0 = ops.moe_gate_topk(logits, K)
+    plan = ops.moe_plan(idx, w0, E, cap, None)
+    rows = int(plan.max_rows)
+    yr0, res0 = torch.randn(rows, H).to(dt), torch.randn(S, H)
+    g0, b0 = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    gy, gn = torch.randn(S, H, device=dev), torch.randn(S, H, device=dev).to(dt)
+    seed = 424242
+
+    def run(fused):
+        L = [t.detach().clone().to(dev).requires_grad_(True) for t in (yr0, w0, res0, g0, b0)]
+        if fused:
+            y, xn = ops._DropoutAddLN.apply(L[0], L[2], L[3], L[4], 1e-5, p, seed, dt, L[1], plan)
+        else:
+            out = ops.moe_combine(L[0], L[1], plan, out_dtype=dt)
+            y = ops._DropoutAdd.apply(out, L[2], p, seed)
+            xn = ops.layer_norm(y, L[3], L[4], 1e-5, out_dtype=dt)
+        ((y * gy).sum() + (xn.float() * gn.float()).sum()).backward()
+        return [y, xn] + [t.grad for t in L]
+    a, c = run(True), run(False)
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), "forward must match the three-op form bit for bit"
+    tol = dict(rtol=1e-5, atol_scale=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol_scale=1e-2)
+    for u, v, n in zip(a[2:], c[2:], ["dyr", "dw", "dres", "dgamma", "dbeta"]):
+        _close(u.float(), v.float(), n, **tol)
