@@ -789,6 +789,202 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 128 NT kernel, TWO work-groups per CU.  The persistent kernel above runs a tile's epilogue
+// (VALU: activation, dropout hash, conversions; then the output stores) with the matrix pipes idle and
+// its K loop with the VALU idle, and keeps at most one 64 KiB stage of operands in flight per CU.  Here
+// a work-group is 4 waves (one per SIMD; wave tile 128 x 64 as above) with its own 72 KiB ring of three
+// 32-deep stages, so two independent work-groups share a CU: one's epilogue runs under the other's
+// MFMAs, and 2 x 48 KiB of LDS-DMA are in flight per CU.  Inside a wave the fragments of sub-step s+1
+// are read from LDS under the MFMAs of sub-step s (X fragments in place once their four MFMAs have
+// issued, W fragments into a second set).  Rows are 64 B per stage; the 16-byte chunk c of row r sits
+// at chunk position c ^ F[(r >> 2) & 3], F = {0,3,2,1}, which makes both the 1 KiB DMA pieces (16 rows)
+// and the ds_read_b128 fragment reads (lane groups of MI355X_MICROARCH.md's LDS table) conflict-free.
+// ------------------------------------------------------------------------------------------
+constexpr int NT3 = 256, BM3 = 256, BN3 = 128, ROWB3 = 64;
+constexpr int SLOT3 = (BM3 + BN3) * ROWB3;   // 24 KiB: X rows, then W rows
+constexpr int RING3 = 3 * SLOT3;
+
+__device__ __forceinline__ void lds_dma16s(const v4i &rs, uint32_t lds_addr, uint32_t voff, uint32_t soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+
+// one staging pass of the 256 x 128 tile through the ring (256-byte rows, 16-byte chunks XOR-swizzled with
+// the row) and out to `dst`; raw = the pre-activation pass
+template <typename TO, bool raw, int ACT, bool DROP>
+__device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst, char *stg,
+                                         int64_t row0, int rows_valid, int n0, int cols_valid, int N, int act, float drop_p,
+                                         uint64_t seed, float keep_scale, uint32_t thresh16, int tid, int wm, int wn,
+                                         int frow, int fg) {
+  static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = wm * 128 + j * 16 + frow;
+      const int chunk = wn * 8 + i * 2 + (fg >> 1);
+      uint32_t o[4];
+      bool keep[4] = {true, true, true, true};
+      if (!raw && (ACT >= 0 ? DROP : drop_p > 0.f))
+        drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = acc[i][j][q] + bv[i][q];
+        if (!raw) {
+          if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(from_f32<TO>(v)), ACT >= 0 ? ACT : act);
+          v = keep[q] ? v * keep_scale : 0.f;   // keep_scale is 1 without dropout
+        }
+        o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(v));
+      }
+      *reinterpret_cast<uint2 *>(stg + m * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8) =
+          make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    }
+  __syncthreads();
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int c4 = it * NT3 + tid;
+    const int row = c4 >> 4, c = c4 & 15;
+    if (row < rows_valid && c * 8 < cols_valid)
+      *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
+          *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
+  }
+  __syncthreads();
+}
+
+template <typename TO>
+__global__ void __launch_bounds__(NT3, 2)
+grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                    const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act, int N, int K, int ldw,
+                    int E, int n_tiles, int act, float drop_p, uint64_t seed) {
+  typedef bf16x8 frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+
+  // tile of this work-group (XCD-aware order; n fastest so neighbours share activation rows)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
+  int e = -1, rows_valid = 0, accm = 0;
+  int64_t row0 = 0;
+  for (int g = 0; g < E; ++g) {
+    const int r0 = offsets[g], r1 = offsets[g + 1];
+    const int nt = (r1 - r0 + BM3 - 1) / BM3;
+    if (mt < accm + nt) {
+      const int m0 = (mt - accm) * BM3;
+      e = g; row0 = r0 + m0; rows_valid = min(BM3, r1 - r0 - m0);
+      break;
+    }
+    accm += nt;
+  }
+  if (e < 0) return;
+  e = __builtin_amdgcn_readfirstlane(e);
+  rows_valid = __builtin_amdgcn_readfirstlane(rows_valid);
+  row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)row0);
+  const int n0 = ntile * BN3, cols_valid = min(BN3, N - n0);
+
+  // operands through raw buffer descriptors sized to the tile's valid rows (zero fill past them); a lane's
+  // offset = row-in-piece and swizzled chunk, the K offset of the sub-step rides in the scalar offset
+  const int ldb = K * 2, ldwb = ldw * 2;
+  const v4i xrs = raw_buffer_rsrc(X + row0 * K, (uint32_t)rows_valid * (uint32_t)ldb);
+  const v4i wrs = raw_buffer_rsrc(W + ((int64_t)e * N + n0) * ldw, (uint32_t)cols_valid * (uint32_t)ldwb);
+  const int fsw = (4 - ((lane >> 4) & 3)) & 3;                       // F[(row >> 2) & 3] for row = lane >> 2
+  const uint32_t vx0 = (uint32_t)((wave * 64 + (lane >> 2)) * ldb + (((lane & 3) ^ fsw) << 4));
+  const uint32_t vw0 = (uint32_t)((wave * 32 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
+  const uint32_t lds0 = lds_addr_of(smem);
+  auto issue = [&](uint32_t slot_off, int s) {   // sub-step s: this wave's 4 X pieces and 2 W pieces
+    const uint32_t kb = (uint32_t)s * ROWB3, base = lds0 + slot_off;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lds_dma16s(xrs, base + (wave * 4 + j) * 1024, vx0 + (uint32_t)(j * 16 * ldb), kb);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + j) * 1024, vw0 + (uint32_t)(j * 16 * ldwb), kb);
+  };
+  const int nk = K / 32;   // >= 3 (launcher)
+  issue(0, 0); issue(SLOT3, 1); issue(2 * SLOT3, 2);
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: the lane part is the same for every 16-row sub-tile
+  const int frd = frow * ROWB3 + ((fg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
+  const char *xbase = smem + wm * 128 * ROWB3 + frd, *wbase = smem + BM3 * ROWB3 + wn * 64 * ROWB3 + frd;
+  frag wf[2][4], xf[8];
+  auto load_w = [&](frag (&dst)[4], int slot_off) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const frag *>(wbase + slot_off + i * 16 * ROWB3);
+  };
+  // 32 MFMAs on (wcur, xf) while (wnxt, xf) are refilled from the slot at nxt_off
+  auto sub_step = [&](const frag (&wcur)[4], frag (&wnxt)[4], int nxt_off) {
+    load_w(wnxt, nxt_off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mma(acc[i][j], wcur[i], xf[j]);
+      xf[j] = *reinterpret_cast<const frag *>(xbase + nxt_off + j * 16 * ROWB3);
+    }
+    // issue order: 4 MFMAs, then the LDS reads whose registers they freed (hipcc otherwise sinks the reads to
+    // the end of the MFMA run, where their latency is exposed)
+#define SGB(nr) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, nr, 0);
+    SGB(3) SGB(3) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1)
+#undef SGB
+  };
+  wait_vmcnt<12>();   // stage 0 (vmcnt retires in order)
+  __syncthreads();
+  load_w(wf[0], 0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const frag *>(xbase + j * 16 * ROWB3);
+  int cur = 0;   // LDS offset of sub-step s's slot
+  for (int s = 0; s < nk; s += 2) {
+    // top of a sub-step: this wave holds the fragments of s (slot s is free once every wave says so) and its
+    // share of stage s+1 has landed; behind the barrier stage s+1 is complete and stage s+3 may overwrite s
+#define SUB(S, WC, WN)                                                                                   \
+    {                                                                                                    \
+      const int nxt = cur + SLOT3 == RING3 ? 0 : cur + SLOT3;                                            \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+      if ((S) + 2 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();                                           \
+      __syncthreads();                                                                                   \
+      if ((S) + 3 < nk) issue((uint32_t)cur, (S) + 3);                                                   \
+      __builtin_amdgcn_s_setprio(1);                                                                     \
+      sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
+      __builtin_amdgcn_s_setprio(0);                                                                     \
+      cur = nxt;                                                                                         \
+    }
+    SUB(s, wf[0], wf[1])
+    if (s + 1 < nk) SUB(s + 1, wf[1], wf[0])
+    else {   // odd nk: keep the register roles of the loop
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wf[0][i] = wf[1][i];
+    }
+#undef SUB
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();   // every wave is done with the ring: it becomes the output staging area
+
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+  float bv[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
+      bv[i][r] = (bias && n < N) ? bias[(int64_t)e * N + n] : 0.f;
+    }
+#define OUT(RAW, A, D, DST) \
+  nt2x_out<TO, RAW, A, D>(acc, bv, DST, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
+  if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);
+  if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
+  else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C);
+  else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C);
+  else OUT(false, -1, false, C);
+#undef OUT
+}
+
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
 template <typename T>
 __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict__ pre, T *__restrict__ dpre,
@@ -1417,6 +1613,21 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // One group (dense projection) takes them at any width: narrow outputs are HBM-bound and the
     // persistent kernel's cross-tile prefetch matters more than the MFMA work a partial n-tile wastes
     const bool kpad_ok = K % 64 == 0 || ldw >= ceil_div64(K, 64) * 64;
+    // two work-groups per CU pay off when the epilogue is heavy next to the K loop (activation / dropout /
+    // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop)
+    static const int force2x = getenv("APERTIS_GEMM_NT2X") ? atoi(getenv("APERTIS_GEMM_NT2X")) : -1;
+    const bool use2x = force2x >= 0 ? force2x != 0 : ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act) && K <= 1024 && N >= 512);
+    if (use2x && !mul_pre && K % 32 == 0 && K >= 96 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
+      const int nt3 = (int)ceil_div64(N, BN3);
+      const int64_t grid3 = (ceil_div64(max_rows, BM3) + E) * nt3;
+      if (grid3 < 0x7fffffffLL) {
+        auto k3 = grouped_gemm_nt2x_k<TO>;
+        hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        hipLaunchKernelGGL(k3, dim3((unsigned)grid3), dim3(NT3), RING3, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
+                           (TO *)C, (TO *)pre_act, (int)N, (int)K, (int)ldw, (int)E, nt3, act, drop_p, seed);
+        return apertis_check_launch();
+      }
+    }
     if (kpad_ok && (N >= 512 || (E == 1 && N >= 128)) && max_rows >= 4096 && !getenv("APERTIS_GEMM_TILE128")) {
       const int nt2 = (int)ceil_div64(N, BN2);
       const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;

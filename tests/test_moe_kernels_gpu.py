@@ -597,3 +597,36 @@ def test_boundary_with_moe_combine(dev, S, H, E, K, dt, p, cap):
     tol = dict(rtol=1e-5, atol_scale=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol_scale=1e-2)
     for u, v, n in zip(a[2:], c[2:], ["dyr", "dw", "dres", "dgamma", "dbeta"]):
         _close(u.float(), v.float(), n, **tol)
+
+
+@pytest.mark.parametrize("sizes,N,K", [([4100, 0, 90, 513], 576, 96), ([2000, 2300], 512, 160), ([5000, 300, 0, 1], 1024, 704)])
+def test_grouped_gemm_nt_two_per_cu_kernel(dev, sizes, N, K):
+    """The 256x128 two-work-groups-per-CU NT kernel (taken for an activation / second-output epilogue on a short K)
+    against the plain-epilogue path on the same operands: the pre-activation output is bit-identical (same K order),
+    the activated output is gelu of it, and dropout only zeroes / rescales it.  Ragged groups, an empty group, a
+    partial n-tile, odd and minimal numbers of 32-deep K steps."""
+    from apertis_llm_amd import _lib
+    lib, P, S = _lib.load(), _lib.ptr, _lib.stream_ptr
+    torch.manual_seed(N + K)
+    E, R = len(sizes), sum(sizes)
+    x = torch.randn(R, K, device=dev).bfloat16()
+    W = (torch.randn(E, N, K, device=dev) / K ** 0.5).bfloat16()
+    b = torch.randn(E, N, device=dev)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    plain, pre, act, drop = (torch.full((R, N), float("nan"), device=dev, dtype=torch.bfloat16) for _ in range(4))
+    pre2 = torch.empty_like(pre)
+
+    def nt(out, pre_out, a, p):
+        rc = lib.apertis_grouped_gemm_nt(P(x), P(W), P(b), P(offs), P(out), P(pre_out), None, R, N, K, K, E, a, p, 77, 1, 1, S())
+        assert rc == 0
+    nt(plain, None, 0, 0.0)
+    nt(act, pre, 1, 0.0)
+    nt(drop, pre2, 1, 0.25)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, pre) and torch.equal(pre, pre2), "pre-activation output must match the plain path bit for bit"
+    ref = torch.nn.functional.gelu(pre.float())
+    _close(act.float(), ref, "gelu(pre)", rtol=8e-3, atol_scale=1e-5)
+    kept = drop != 0
+    frac = float((kept & (act != 0)).sum()) / max(1.0, float((act != 0).sum()))
+    assert abs(frac - 0.75) < 0.01, frac
+    _close(drop.float()[kept], (act.float() / 0.75)[kept], "kept values rescaled", rtol=8e-3, atol_scale=1e-5)

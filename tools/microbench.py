@@ -52,7 +52,7 @@ def scan():
 
 def gemm():
     import numpy as np
-    for (rows, N, K, E) in [(40960, 2816, 704, 8), (40960, 704, 2816, 8), (81920, 2816, 704, 8), (81920, 704, 2816, 8),
+    for (rows, N, K, E) in [(163840, 2816, 704, 8), (163840, 704, 2816, 8), (40960, 2816, 704, 8), (40960, 704, 2816, 8), (81920, 2816, 704, 8), (81920, 704, 2816, 8),
                             (10240, 1024, 256, 8), (65536, 4096, 4096, 8), (32768, 352, 704, 1), (32768, 704, 176, 1),
                             # the SSM block's dense projections and their data gradients at the bench shape
                             (131072, 352, 704, 1), (131072, 400, 176, 1), (131072, 704, 176, 1), (131072, 176, 704, 1),
