@@ -171,11 +171,16 @@ __device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row
   constexpr int NE = 16 / sizeof(TO);
   union { uint4 u; TO e[NE]; } a, b, o;
   a.u = dhc; b.u = prec;
+  static_assert(NE % 4 == 0, "keep bits come four at a time");
 #pragma unroll
-  for (int j = 0; j < NE; ++j) {
-    float g = to_f32(a.e[j]) * act_grad<FAST>(to_f32(b.e[j]), act);
-    if (drop_p > 0.f) g = drop_keep(seed, row, col0 + j, N, thresh16) ? g * keep_scale : 0.f;
-    o.e[j] = from_f32<TO>(g);
+  for (int j4 = 0; j4 < NE; j4 += 4) {
+    bool keep[4] = {true, true, true, true};
+    if (drop_p > 0.f) drop_keep4(seed, (uint64_t)row * (uint64_t)N + (uint64_t)(col0 + j4), thresh16, keep);
+#pragma unroll
+    for (int j = j4; j < j4 + 4; ++j) {
+      const float g = to_f32(a.e[j]) * act_grad<FAST>(to_f32(b.e[j]), act);
+      o.e[j] = from_f32<TO>(keep[j - j4] ? g * keep_scale : 0.f);
+    }
   }
   return o.u;
 }
@@ -812,12 +817,24 @@ __device__ __forceinline__ void lds_dma16s(const v4i &rs, uint32_t lds_addr, uin
 
 // one staging pass of the 256 x 128 tile through the ring (256-byte rows, 16-byte chunks XOR-swizzled with
 // the row) and out to `dst`; raw = the pre-activation pass
-template <typename TO, bool raw, int ACT, bool DROP>
-__device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst, char *stg,
-                                         int64_t row0, int rows_valid, int n0, int cols_valid, int N, int act, float drop_p,
+template <typename TO, bool raw, int ACT, bool DROP, bool MULPRE = false>
+__device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst,
+                                         const TO *__restrict__ mul_pre, char *stg, int64_t row0, int rows_valid, int n0, int cols_valid, int N, int act, float drop_p,
                                          uint64_t seed, float keep_scale, uint32_t thresh16, int tid, int wm, int wn,
                                          int frow, int fg) {
   static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
+  // dgrad fusion (MULPRE): the saved pre-activation chunks this thread will need are fetched first, under the
+  // conversions; the tile is staged as plain dh and turned into dpre chunk by chunk on the way out
+  uint4 pc[MULPRE ? 16 : 1];
+  if (MULPRE) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int c4 = it * NT3 + tid;
+      const int row = c4 >> 4, c = c4 & 15;
+      pc[it] = (row < rows_valid && c * 8 < cols_valid) ? *reinterpret_cast<const uint4 *>(mul_pre + (row0 + row) * N + n0 + c * 8)
+                                                          : make_uint4(0, 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -826,12 +843,12 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
       const int chunk = wn * 8 + i * 2 + (fg >> 1);
       uint32_t o[4];
       bool keep[4] = {true, true, true, true};
-      if (!raw && (ACT >= 0 ? DROP : drop_p > 0.f))
+      if (!raw && !MULPRE && (ACT >= 0 ? DROP : drop_p > 0.f))
         drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float v = acc[i][j][q] + bv[i][q];
-        if (!raw) {
+        if (!raw && !MULPRE) {
           if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(from_f32<TO>(v)), ACT >= 0 ? ACT : act);
           v = keep[q] ? v * keep_scale : 0.f;   // keep_scale is 1 without dropout
         }
@@ -841,13 +858,15 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
           make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
   __syncthreads();
-#pragma unroll 4
+#pragma unroll
   for (int it = 0; it < 16; ++it) {
     const int c4 = it * NT3 + tid;
     const int row = c4 >> 4, c = c4 & 15;
-    if (row < rows_valid && c * 8 < cols_valid)
-      *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
-          *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
+    if (row < rows_valid && c * 8 < cols_valid) {
+      uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
+      if (MULPRE) v = actbwd_chunk<TO, true>(v, pc[it], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16);
+      *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) = v;
+    }
   }
   __syncthreads();
 }
@@ -855,8 +874,9 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
 template <typename TO>
 __global__ void __launch_bounds__(NT3, 2)
 grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
-                    const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act, int N, int K, int ldw,
-                    int E, int n_tiles, int act, float drop_p, uint64_t seed) {
+                    const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
+                    const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act, float drop_p,
+                    uint64_t seed) {
   typedef bf16x8 frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -975,10 +995,11 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
       bv[i][r] = (bias && n < N) ? bias[(int64_t)e * N + n] : 0.f;
     }
-#define OUT(RAW, A, D, DST) \
-  nt2x_out<TO, RAW, A, D>(acc, bv, DST, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
+#define OUT(RAW, A, D, DST, ...) \
+  nt2x_out<TO, RAW, A, D, ##__VA_ARGS__>(acc, bv, DST, mul_pre, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
   if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);
-  if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
+  if (mul_pre) OUT(false, -1, false, C, true);
+  else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
   else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C);
   else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C);
   else OUT(false, -1, false, C);
@@ -1616,15 +1637,15 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // two work-groups per CU pay off when the epilogue is heavy next to the K loop (activation / dropout /
     // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop)
     static const int force2x = getenv("APERTIS_GEMM_NT2X") ? atoi(getenv("APERTIS_GEMM_NT2X")) : -1;
-    const bool use2x = force2x >= 0 ? force2x != 0 : ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act) && K <= 1024 && N >= 512);
-    if (use2x && !mul_pre && K % 32 == 0 && K >= 96 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
+    const bool use2x = force2x >= 0 ? force2x != 0 : ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512);
+    if (use2x && K % 32 == 0 && K >= 96 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);
       const int64_t grid3 = (ceil_div64(max_rows, BM3) + E) * nt3;
       if (grid3 < 0x7fffffffLL) {
         auto k3 = grouped_gemm_nt2x_k<TO>;
         hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         hipLaunchKernelGGL(k3, dim3((unsigned)grid3), dim3(NT3), RING3, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
-                           (TO *)C, (TO *)pre_act, (int)N, (int)K, (int)ldw, (int)E, nt3, act, drop_p, seed);
+                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act, drop_p, seed);
         return apertis_check_launch();
       }
     }

@@ -1071,7 +1071,7 @@ def layer_norm_pass(x, weight, bias, eps, out_dtype=None):
     return _LayerNormPass.apply(x, weight, bias, eps, out_dtype or x.dtype)
 
 
-FUSE_ACT_BWD = False
+FUSE_ACT_BWD = not _os.environ.get("APERTIS_NO_FUSE_ACT_BWD")
 
 
 class _ExpertMLP(torch.autograd.Function):
