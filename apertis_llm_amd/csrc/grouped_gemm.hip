@@ -87,6 +87,20 @@ __device__ __forceinline__ float gelu_fast(float x) {
   return fmaf(-ax, p * t * e, fmaxf(x, 0.f));
 }
 
+// d/dx gelu(x) = Phi(x) + x * phi(x) on the same folded 7.1.26 terms: q = Phi(-|x|) = (poly/2)(t) * t * e with
+// e = exp(-x^2/2), which is phi(x) * sqrt(2 pi) as well - one rcp and one exp2 instead of three transcendentals
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * LOG2E_F));
+  const float q = p * t * e;
+  return fmaf(x * 0.3989422804014327f, e, x >= 0.f ? 1.f - q : q);
+}
+
 template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
@@ -100,7 +114,8 @@ template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) 
 template <bool FAST> __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
-      return 0.5f * (1.f + erf_t<FAST>(x * 0.70710678118654752f)) + x * 0.3989422804014327f * exp_t<FAST>(-0.5f * x * x);
+      if constexpr (FAST) return gelu_grad_fast(x);
+      else return 0.5f * (1.f + erf_t<FAST>(x * 0.70710678118654752f)) + x * 0.3989422804014327f * exp_t<FAST>(-0.5f * x * x);
     case APERTIS_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case APERTIS_ACT_SILU: { float s = 1.f / (1.f + exp_t<FAST>(-x)); return s * (1.f + x * (1.f - s)); }
     default: return 1.f;
@@ -165,24 +180,43 @@ __device__ __forceinline__ void store_tile_lds(char *lds, const uint4 (&regs)[4]
 // dgrad epilogue fusion: one 16-byte output chunk of dh is turned into dpre = dh * keep/(1-p) *
 // act'(pre) with the matching chunk of the saved pre-activation (what apertis_act_dropout_bwd does
 // as a separate pass over three [rows, N] tensors)
-template <typename TO, bool FAST>
-__device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row, int64_t col0, int64_t N, int act,
-                                             float drop_p, uint64_t seed, float keep_scale, uint32_t thresh16) {
-  constexpr int NE = 16 / sizeof(TO);
-  union { uint4 u; TO e[NE]; } a, b, o;
-  a.u = dhc; b.u = prec;
-  static_assert(NE % 4 == 0, "keep bits come four at a time");
+template <typename TO, bool FAST, int ACT = -1, bool DROP = true>
+__device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row, int64_t col0, int64_t N, int act_rt,
+                                             float drop_p_rt, uint64_t seed, float keep_scale, uint32_t thresh16) {
+  // ACT >= 0 fixes the activation (and DROP the dropout) at compile time: a per-value runtime switch breaks the
+  // instruction stream into branchy blocks that cost more than the arithmetic
+  const int act = ACT >= 0 ? ACT : act_rt;
+  const float drop_p = ACT >= 0 ? (DROP ? 1.f : 0.f) : drop_p_rt;
+  if constexpr (sizeof(TO) == 2) {   // bf16: unpacked with shifts, no byte-addressed temporaries
+    const uint32_t a[4] = {dhc.x, dhc.y, dhc.z, dhc.w}, b[4] = {prec.x, prec.y, prec.z, prec.w};
+    uint32_t o[4];
 #pragma unroll
-  for (int j4 = 0; j4 < NE; j4 += 4) {
-    bool keep[4] = {true, true, true, true};
-    if (drop_p > 0.f) drop_keep4(seed, (uint64_t)row * (uint64_t)N + (uint64_t)(col0 + j4), thresh16, keep);
+    for (int h = 0; h < 2; ++h) {
+      bool keep[4] = {true, true, true, true};
+      if (drop_p > 0.f) drop_keep4(seed, (uint64_t)row * (uint64_t)N + (uint64_t)(col0 + 4 * h), thresh16, keep);
 #pragma unroll
-    for (int j = j4; j < j4 + 4; ++j) {
-      const float g = to_f32(a.e[j]) * act_grad<FAST>(to_f32(b.e[j]), act);
-      o.e[j] = from_f32<TO>(keep[j - j4] ? g * keep_scale : 0.f);
+      for (int w = 0; w < 2; ++w) {
+        const uint32_t aw = a[2 * h + w], bw = b[2 * h + w];
+        const float g0 = __builtin_bit_cast(float, aw << 16) * act_grad<FAST>(__builtin_bit_cast(float, bw << 16), act);
+        const float g1 = __builtin_bit_cast(float, aw & 0xffff0000u) * act_grad<FAST>(__builtin_bit_cast(float, bw & 0xffff0000u), act);
+        const TO r0 = from_f32<TO>(keep[2 * w] ? g0 * keep_scale : 0.f), r1 = from_f32<TO>(keep[2 * w + 1] ? g1 * keep_scale : 0.f);
+        o[2 * h + w] = (uint32_t)__builtin_bit_cast(uint16_t, r0) | ((uint32_t)__builtin_bit_cast(uint16_t, r1) << 16);
+      }
     }
+    return make_uint4(o[0], o[1], o[2], o[3]);
+  } else {
+    constexpr int NE = 16 / sizeof(TO);
+    union { uint4 u; TO e[NE]; } a, b, o;
+    a.u = dhc; b.u = prec;
+    bool keep[4] = {true, true, true, true};
+    if (drop_p > 0.f) drop_keep4(seed, (uint64_t)row * (uint64_t)N + (uint64_t)col0, thresh16, keep);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+      const float g = to_f32(a.e[j]) * act_grad<FAST>(to_f32(b.e[j]), act);
+      o.e[j] = from_f32<TO>(keep[j] ? g * keep_scale : 0.f);
+    }
+    return o.u;
   }
-  return o.u;
 }
 
 // one 1-KiB LDS-DMA piece: 8 tile rows x 128 B.  The LDS image is lane-linear (wave-uniform base +
@@ -572,6 +606,11 @@ __device__ __forceinline__ void lds_dma16_global(const void *src, uint32_t lds_a
 // stages them through ring buffer 1 in two 128-row halves.
 // ------------------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Work-group barrier for LDS traffic only.  __syncthreads() is a release/acquire fence as well: hipcc puts
+// `s_waitcnt vmcnt(0)` in front of it, i.e. every output store of the wave has to reach memory before the
+// barrier - exactly the latency the kernels below hide.  Here only this wave's LDS operations are drained
+// (LDS-DMA arrivals are waited for explicitly with wait_vmcnt where a barrier publishes them).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 struct PTile { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
 
@@ -823,18 +862,6 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
                                          uint64_t seed, float keep_scale, uint32_t thresh16, int tid, int wm, int wn,
                                          int frow, int fg) {
   static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
-  // dgrad fusion (MULPRE): the saved pre-activation chunks this thread will need are fetched first, under the
-  // conversions; the tile is staged as plain dh and turned into dpre chunk by chunk on the way out
-  uint4 pc[MULPRE ? 16 : 1];
-  if (MULPRE) {
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const int c4 = it * NT3 + tid;
-      const int row = c4 >> 4, c = c4 & 15;
-      pc[it] = (row < rows_valid && c * 8 < cols_valid) ? *reinterpret_cast<const uint4 *>(mul_pre + (row0 + row) * N + n0 + c * 8)
-                                                          : make_uint4(0, 0, 0, 0);
-    }
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -857,18 +884,52 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
       *reinterpret_cast<uint2 *>(stg + m * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8) =
           make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
-  __syncthreads();
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const int c4 = it * NT3 + tid;
-    const int row = c4 >> 4, c = c4 & 15;
-    if (row < rows_valid && c * 8 < cols_valid) {
-      uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
-      if (MULPRE) v = actbwd_chunk<TO, true>(v, pc[it], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16);
-      *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) = v;
+  lds_barrier();
+  if constexpr (!MULPRE) {
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int c4 = it * NT3 + tid;
+      const int row = c4 >> 4, c = c4 & 15;
+      if (row < rows_valid && c * 8 < cols_valid)
+        *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
+            *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
     }
+  } else {
+    // dgrad fusion: the tile was staged as plain dh; each 16-byte chunk becomes dpre on the way out with the
+    // matching chunk of the saved pre-activation.  Four chunks per batch, the next batch's pre-activations in
+    // flight under the arithmetic of the current one (a fully interleaved loop spills)
+    auto fetch = [&](uint4 (&pc)[4], int b) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c4 = (b * 4 + u) * NT3 + tid;
+        const int row = c4 >> 4, c = c4 & 15;
+        pc[u] = (row < rows_valid && c * 8 < cols_valid) ? *reinterpret_cast<const uint4 *>(mul_pre + (row0 + row) * N + n0 + c * 8)
+                                                         : make_uint4(0, 0, 0, 0);
+      }
+    };
+    auto emit = [&](const uint4 (&pc)[4], int b) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c4 = (b * 4 + u) * NT3 + tid;
+        const int row = c4 >> 4, c = c4 & 15;
+        if (row < rows_valid && c * 8 < cols_valid) {
+          const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
+          *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
+              actbwd_chunk<TO, true, ACT, DROP>(v, pc[u], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16);
+        }
+      }
+    };
+    uint4 pa[4], pb[4];
+    fetch(pa, 0);
+    fetch(pb, 1); __builtin_amdgcn_sched_barrier(0);
+    emit(pa, 0);  __builtin_amdgcn_sched_barrier(0);
+    fetch(pa, 2); __builtin_amdgcn_sched_barrier(0);
+    emit(pb, 1);  __builtin_amdgcn_sched_barrier(0);
+    fetch(pb, 3); __builtin_amdgcn_sched_barrier(0);
+    emit(pa, 2);  __builtin_amdgcn_sched_barrier(0);
+    emit(pb, 3);
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 template <typename TO>
@@ -954,7 +1015,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #undef SGB
   };
   wait_vmcnt<12>();   // stage 0 (vmcnt retires in order)
-  __syncthreads();
+  lds_barrier();
   load_w(wf[0], 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const frag *>(xbase + j * 16 * ROWB3);
@@ -967,7 +1028,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       const int nxt = cur + SLOT3 == RING3 ? 0 : cur + SLOT3;                                            \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
       if ((S) + 2 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();                                           \
-      __syncthreads();                                                                                   \
+      lds_barrier();                                                                                   \
       if ((S) + 3 < nk) issue((uint32_t)cur, (S) + 3);                                                   \
       __builtin_amdgcn_s_setprio(1);                                                                     \
       sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
@@ -983,7 +1044,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #undef SUB
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __syncthreads();   // every wave is done with the ring: it becomes the output staging area
+  lds_barrier();   // every wave is done with the ring: it becomes the output staging area
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
@@ -998,8 +1059,11 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #define OUT(RAW, A, D, DST, ...) \
   nt2x_out<TO, RAW, A, D, ##__VA_ARGS__>(acc, bv, DST, mul_pre, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
   if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);
-  if (mul_pre) OUT(false, -1, false, C, true);
-  else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
+  if (mul_pre) {
+    if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C, true);
+    else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C, true);
+    else OUT(false, -1, false, C, true);
+  } else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
   else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C);
   else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C);
   else OUT(false, -1, false, C);

@@ -70,14 +70,18 @@ def gemm():
             lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, None, rows, N, K, wc.shape[-1], E, 0, 0.0, 0, 1, 1, S())
         def nt_epi():
             lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), P(pre), None, rows, N, K, wc.shape[-1], E, 1, 0.1, 7, 1, 1, S())
+        def nt_actbwd():
+            lib.apertis_grouped_gemm_nt(P(x), P(wc), None, P(offs), P(out), None, P(pre), rows, N, K, wc.shape[-1], E, 1, 0.1, 7, 1, 1, S())
         dw = torch.empty(E, N, K, device=dev)
         ws = torch.empty(max(16, _lib.load().apertis_grouped_gemm_tn_workspace_bytes(E, 1)), device=dev, dtype=torch.uint8)
         def tn():
             lib.apertis_grouped_gemm_tn(P(out), P(x), P(offs), P(dw), None, rows, N, K, E, P(ws), ws.numel(), 1, S())
         fl = 2.0 * rows * N * K
         t1, t2, t3 = timeit(nt), timeit(nt_epi), timeit(tn)
+        pre.normal_()
+        t4 = timeit(nt_actbwd)
         print(f"gemm rows={rows} N={N} K={K} E={E}: NT {t1*1e3:7.1f} us {fl/t1/1e9:6.0f} TF  NT+gelu+drop+pre {t2*1e3:7.1f} us "
-              f"{fl/t2/1e9:6.0f} TF  TN {t3*1e3:7.1f} us {fl/t3/1e9:6.0f} TF")
+              f"{fl/t2/1e9:6.0f} TF  NT*act'(pre)*mask {t4*1e3:7.1f} us {fl/t4/1e9:6.0f} TF  TN {t3*1e3:7.1f} us {fl/t3/1e9:6.0f} TF")
 
 
 def rows():
