@@ -51,8 +51,13 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, int64_t row, int64_t co
 __device__ __forceinline__ uint32_t drop_hash_pair(uint64_t seed, uint64_t pair) {
   uint32_t h = (uint32_t)pair ^ (uint32_t)seed;
   h += (uint32_t)(seed >> 32);
-  const uint32_t hi = (uint32_t)(pair >> 32);
-  if (hi) h += hi * 0x9E3779B9u;   // (zero below 2^33 elements: skips a quarter-rate multiply)
+  // the high word is zero below 2^33 elements: a wave-uniform branch (hipcc if-converts a per-lane one and keeps
+  // the quarter-rate multiply) skips its term
+  uint32_t hi = (uint32_t)(pair >> 32);
+  if (__builtin_amdgcn_ballot_w64(hi != 0u)) {
+    asm volatile("" : "+v"(hi));
+    h += hi * 0x9E3779B9u;
+  }
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return h;
 }

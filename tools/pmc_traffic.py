@@ -12,6 +12,7 @@ import sys
 out = sys.argv[1]
 ENTRY = {  # kernel-name fragment -> C-ABI entry point
     "grouped_gemm_nt256p_k": "apertis_grouped_gemm_nt", "grouped_gemm_nt256_k": "apertis_grouped_gemm_nt",
+    "grouped_gemm_nt2x_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_tn3_k": "apertis_grouped_gemm_tn", "tn3_fold_k": "apertis_grouped_gemm_tn",
     "grouped_gemm_tn2_k": "apertis_grouped_gemm_tn",
     "scan_fwd_state": "apertis_selective_scan_fwd", "scan_fwd_replay": "apertis_selective_scan_fwd",
@@ -53,7 +54,10 @@ for tag, v in entry.items():
             ks = [k for k in agg if frag in k and "FETCH_SIZE" in agg[k]]
             if ks:
                 n = sum(len(agg[k]["FETCH_SIZE"]) for k in ks)
-                n_calls = n if n_calls is None else min(n_calls, n)
+                if tag == "apertis_grouped_gemm_nt":   # each call launches exactly ONE of the NT kernels
+                    n_calls = n + (n_calls or 0)
+                else:
+                    n_calls = n if n_calls is None else min(n_calls, n)
     if not n_calls:
         continue
     res[tag] = {"calls": n_calls, "fetch_bytes_per_call": 2 * v["fetch_kib"] * 1024 / n_calls,
