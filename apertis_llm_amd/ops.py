@@ -1119,8 +1119,9 @@ class _ExpertMLP(torch.autograd.Function):
                     (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, w2t.shape[-1], E, act_code,
                      drop_p, seed, code, code, stream_ptr()), work)
         else:
-            # measured on MI355X: with one 256x256 work-group per CU nothing overlaps the epilogue, so the
-            # fused form costs more than this separate bandwidth-bound pass (in place on dpre)
+            # APERTIS_NO_FUSE_ACT_BWD=1 (A/B switch): plain data gradient, then the separate bandwidth-bound pass in
+            # place on dpre.  On the 256x256 persistent kernel the fused form was slower (nothing overlaps its
+            # epilogue); on the two-per-CU kernel it is +3 % of the whole step
             _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
                     (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, None, max_rows, I, H, w2t.shape[-1], E, _lib.ACT_NONE,
                      0.0, 0, code, code, stream_ptr()), work)
