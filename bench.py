@@ -98,12 +98,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not os.environ.get("APERTIS_BENCH_NO_PRETOUCH"):
+        # set-up, not a step: map the caching allocator's (expandable) segment once, so that no step - timed or
+        # warm-up - pays for hipMemMap calls while its activations grow to their peak
+        free_b, _total = torch.cuda.mem_get_info(dev)
+        pre = torch.empty(int(free_b * 0.90), dtype=torch.uint8, device=dev)
+        del pre
+        torch.cuda.reset_peak_memory_stats(dev)
     log(f"model on device ({n_params / 1e6:.0f}M params); warmup")
     for i in range(args.warmup):
+        tw = time.perf_counter()
         loss = step(**batch())
-        if i == 0:
-            torch.cuda.synchronize()
-            log(f"first step done, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+        torch.cuda.synchronize()
+        log(f"warm-up step {i}: {1e3 * (time.perf_counter() - tw):.0f} ms, peak mem "
+            f"{torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     timer = None
     if not args.no_kernel_timers:
         timer = ops.KernelTimer(["apertis_grouped_gemm_nt", "apertis_grouped_gemm_tn", "apertis_selective_scan_fwd",
