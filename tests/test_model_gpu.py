@@ -229,3 +229,56 @@ def test_shifted_cross_entropy_all_ignored_is_nan_like_torch(dev):
     logits = torch.randn(1, 4, 16, device=dev)
     labels = torch.full((1, 4), -100, device=dev)
     assert torch.isnan(ops.shifted_cross_entropy(logits, labels))
+
+
+def test_trainer_whole_run_matches_reference(dev, tmp_path):
+    """§8(f) N2: a complete run of the reference's ApertisTrainer (captured on the CPU in fp32, dropout and routing noise
+    off, DataLoader order fixed: tools/gen_golden.py gen_trainer_run) against this trainer on the GPU from the same initial
+    weights and files: loss of every optimizer step, learning rates, validation losses, checkpoint directory layout,
+    config.json key set and the final weights."""
+    import numpy as np
+    import apertis_llm_amd as A
+    from apertis_llm_amd import data as D
+    from apertis_llm_amd.trainer import ApertisTrainer
+    g = load_golden("trainer_run")
+    meta = json.loads(bytes(g["meta"].numpy().astype(np.uint8)).decode())
+    init = {k[6:]: v for k, v in g.items() if isinstance(k, str) and k.startswith("init::")}
+    final = {k[7:]: v for k, v in g.items() if isinstance(k, str) and k.startswith("final::")}
+    vpath = tmp_path / "vocab.json"
+    vpath.write_text(json.dumps(meta["vocab"]))
+    (tmp_path / "train.jsonl").write_text("\n".join(meta["train_lines"]) + "\n")
+    (tmp_path / "val.jsonl").write_text("\n".join(meta["val_lines"]) + "\n")
+    vocab, n = D.load_vocabulary(str(vpath))
+    tk = meta["trainer"]
+    tr = D.ApertisPretrainDataset(str(tmp_path / "train.jsonl"), vocab, n, max_length=tk["max_length"])
+    va = D.ApertisPretrainDataset(str(tmp_path / "val.jsonl"), vocab, n, max_length=tk["max_length"])
+    model = A.ApertisForCausalLM(A.ApertisConfig(**meta["cfg"]))
+    model.load_state_dict(init)
+    out = str(tmp_path / "out")
+    t = ApertisTrainer(model, tr, va, output_dir=out, batch_size=tk["batch_size"], learning_rate=tk["learning_rate"],
+                       num_epochs=tk["num_epochs"], gradient_accumulation_steps=tk["gradient_accumulation_steps"], fp16=False,
+                       device=str(dev), checkpoint_steps=tk["checkpoint_steps"],
+                       iteration_checkpoint_steps=tk["iteration_checkpoint_steps"], use_gradient_checkpointing=False,
+                       original_manual_vocab_path_for_ft=str(vpath), shuffle=False, num_workers=0)
+    t.train()
+    assert np.allclose(t.history["lr"], meta["lrs"], rtol=1e-9)
+    assert len(t.history["loss"]) == len(meta["losses_4dp"])
+    for a, b in zip(t.history["loss"], meta["losses_4dp"]):     # the reference keeps 4 decimals (its progress bar)
+        assert abs(a - b) <= 6e-4, (t.history["loss"], meta["losses_4dp"])
+    for a, b in zip(t.history["val_loss"], meta["val_losses"]):
+        assert abs(a - b) <= 2e-4 * abs(b), (t.history["val_loss"], meta["val_losses"])
+    import os
+    listing = {name: sorted(os.listdir(os.path.join(out, name))) for name in sorted(os.listdir(out))}
+    assert listing == meta["listing"]
+    assert sorted(json.load(open(os.path.join(out, "final", "config.json")))) == meta["config_keys"]
+    sd = torch.load(os.path.join(out, "final", "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    assert sorted(sd) == sorted(final)
+    # Adam normalises every element's update to ~lr, so an element whose gradient is rounding noise moves by +-lr on
+    # either side: compare the tensors' updates in the l2 sense, not element by element
+    worst = 0.0
+    for k, v in final.items():
+        moved = (v.double() - init[k].double()).norm().item()
+        err = (sd[k].double() - v.double()).norm().item()
+        assert err <= 0.01 * moved + 1e-6, (k, err, moved)
+        worst = max(worst, err / max(moved, 1e-12))
+    print("worst relative l2 error of a tensor's update:", worst)

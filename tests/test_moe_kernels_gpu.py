@@ -84,7 +84,8 @@ def test_plan_eval_no_capacity(dev, S, E, K):
     assert _plan_case(dev, S, E, K, None, seed=S) == S * K
 
 
-@pytest.mark.parametrize("S,E,K,skew", [(4096, 8, 2, 0.0), (4096, 8, 2, 2.0), (1000, 4, 2, 1.0), (777, 8, 3, 3.0), (8192, 8, 2, 0.5)])
+@pytest.mark.parametrize("S,E,K,skew", [(4096, 8, 2, 0.0), (4096, 8, 2, 2.0), (1000, 4, 2, 1.0), (777, 8, 3, 3.0), (8192, 8, 2, 0.5),
+                                        (24, 4, 2, 0.0), (24, 4, 2, 1.5), (30, 4, 2, 3.0), (7, 2, 2, 1.0), (100, 4, 2, 2.0)])
 def test_plan_train_capacity_overflow(dev, S, E, K, skew):
     from oracle import ref_cpu
     cap = ref_cpu.expert_capacity(S, E, 1.25)

@@ -266,6 +266,174 @@ def gen_dims(core):
     print("  wrote config_and_dims.json")
 
 
+# ------------------------------------------------------------------------------------------------------------
+# §8(f) N3 / N2: on-disk formats and the trainer.  The input files are authored here (they are data, written into the
+# fixture verbatim); the expected outputs come from the reference's own dataset / trainer classes.
+VOCAB_FLAT = {"<pad>": 0, "<bos>": 1, "<eos>": 2, "<unk>": 3, "the": 4, "cat": 5, "sat": 6, "on": 7, "mat": 8, "User:": 9,
+              "Assistant:": 10, "what": 11, "is": 12, "a": 13, "dog": 14, "it": 15, "barks": 16, "Q:": 17, "A:": 18,
+              "big": 40, "huge": 41}
+VOCAB_LIST = {"tokens": ["<pad>", "<bos>", "<eos>", "<unk>", "alpha", "beta", "gamma", "beta"]}
+PRETRAIN_LINES = [
+    '{"text": "the cat sat on the mat"}',
+    '{"text": "the dog barks   and the cat sat"}',
+    'this line is not json',
+    '{"no_text_here": 1}',
+    '{"text": ["the", 5, "zebra", 41, 6]}',
+    '{"text": "big huge cat on a mat the cat sat on the mat the cat"}',
+    '{"text": ""}',
+    '   {"text": "a"}   ',
+    '{"text": 17}',
+]
+FINETUNE_LINES = [
+    '{"instruction": "what is a cat", "output": "it sat on the mat"}',
+    '{"instruction": "what is a dog", "output": ""}',
+    '{"instruction": "only instruction"}',
+    'garbage',
+    '{"instruction": "what is the big cat on the mat the cat sat on", "output": "it barks it barks it barks"}',
+    '{"instruction": "", "output": "the cat"}',
+]
+
+
+def _items(ds):
+    out = []
+    for i in range(len(ds)):
+        it = ds[i]
+        out.append({k: np.asarray(v).tolist() for k, v in it.items()})
+    return out
+
+
+def gen_data_formats(pipe):
+    import tempfile
+    cases = {}
+    with tempfile.TemporaryDirectory() as d:
+        def write(name, text):
+            path = os.path.join(d, name)
+            with open(path, "w", encoding="utf-8") as f:
+                f.write(text)
+            return path
+        vf, vl = write("vocab_flat.json", json.dumps(VOCAB_FLAT)), write("vocab_list.json", json.dumps(VOCAB_LIST))
+        pre, ft = write("pre.jsonl", "\n".join(PRETRAIN_LINES) + "\n"), write("ft.jsonl", "\n".join(FINETUNE_LINES) + "\n")
+        vocab_cases = {}
+        for name, text in [("flat", json.dumps(VOCAB_FLAT)), ("list", json.dumps(VOCAB_LIST)), ("empty_dict", "{}"),
+                           ("empty_list", '{"tokens": []}'), ("dup_id", '{"a": 1, "b": 1}'), ("neg_id", '{"a": 0, "b": -2}'),
+                           ("dup_then_bad", '{"a": 1, "b": 1, "c": "x"}'), ("bad_then_dup", '{"a": 1.5, "b": 2, "c": 2}'),
+                           ("json_list", '["a", "b"]'), ("tokens_not_list", '{"tokens": 5, "x": 6}')]:
+            path = write("v_" + name + ".json", text)
+            try:
+                v, n = pipe._load_vocabulary_and_get_size(path)
+                vocab_cases[name] = {"text": text, "vocab": v, "size": n}
+            except Exception as e:
+                vocab_cases[name] = {"text": text, "error": type(e).__name__, "message_head": str(e).split(" in /")[0][:60]}
+        cases["vocab"] = vocab_cases
+        flat, n_flat = pipe._load_vocabulary_and_get_size(vf)
+        pre_cases = []
+        for kw in [dict(model_config_vocab_size=n_flat, max_length=8), dict(model_config_vocab_size=20, max_length=5),
+                   dict(model_config_vocab_size=n_flat, max_length=16, pad_token_id_from_config=2, unk_token_id_from_config=1)]:
+            ds = pipe.ApertisPretrainDataset(pre, flat, **kw)
+            pre_cases.append({"kwargs": kw, "items": _items(ds)})
+        cases["pretrain"] = {"lines": PRETRAIN_LINES, "vocab": VOCAB_FLAT, "cases": pre_cases}
+        ft_cases = []
+        for kw in [dict(max_length=16), dict(max_length=8), dict(max_length=12, prompt_template="Q: {instruction} A: {output}"),
+                   dict(max_length=12, prompt_template="no placeholders"),
+                   dict(max_length=10, model_config_pad_token_id=2)]:
+            full = dict(model_config_vocab_size=n_flat, model_config_eos_token_id=2, model_config_pad_token_id=0,
+                        model_config_unk_token_id=3, model_config_bos_token_id=1)
+            full.update(kw)
+            ds = pipe.ApertisFineTuneDataset(ft, flat, is_hf_tokenizer=False, **full)
+            ft_cases.append({"kwargs": full, "items": _items(ds)})
+        cases["finetune"] = {"lines": FINETUNE_LINES, "vocab": VOCAB_FLAT, "cases": ft_cases}
+    with open(os.path.join(OUT, "data_formats.json"), "w") as f:
+        json.dump(cases, f, indent=0, sort_keys=True)
+    print(f"  wrote data_formats.json ({os.path.getsize(os.path.join(OUT, 'data_formats.json')) / 1024:.1f} KB)")
+
+
+def gen_trainer_run(core, pipe):
+    """A whole reference training run on CPU (fp32, dropout / routing noise off so that it is deterministic): the loss
+    of every optimizer step, the learning rates, validation losses, checkpoint directory listing and the saved
+    config.json key set.  DataLoader shuffling is switched off for the capture (the trainer under test gets
+    shuffle=False) - the order of a shuffled epoch depends on how much RNG the model construction consumed."""
+    import tempfile
+    import torch.utils.data as tud
+    rng = np.random.RandomState(7)
+    words = [w for w in VOCAB_FLAT if not w.startswith("<")]
+    # every text fills max_length: a padded position is the all-zero embedding row (padding_idx), and LayerNorm with the
+    # model's eps = 1e-12 turns such a row's aux-loss gradient into 1e13..1e16 (in the reference as well) - the clipped
+    # update is then rounding noise, which no two implementations share
+    train_lines = [json.dumps({"text": " ".join(rng.choice(words, size=rng.randint(12, 17)))}) for _ in range(10)]
+    val_lines = [json.dumps({"text": " ".join(rng.choice(words, size=rng.randint(12, 17)))}) for _ in range(3)]
+    cfg_kw = dict(vocab_size=max(VOCAB_FLAT.values()) + 1, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                  intermediate_size=64, attention_type="selective_ssm", use_expert_system=True, num_experts=4,
+                  experts_per_token=2, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                  use_noisy_top_k_routing=False, use_expert_dropout=False, max_position_embeddings=64,
+                  # no capacity overflow in this run: identical token rows (same word, same causal history) tie exactly in
+                  # the overflow top-n, and torch.topk's pick among equals is not a defined order (the kernels keep the
+                  # lowest token index: DESIGN.md section 7); overflow itself is pinned by the moe_train_overflow fixture
+                  expert_capacity_factor=4.0)
+    real_loader = tud.DataLoader
+
+    class NoShuffle(real_loader):
+        def __init__(self, *a, **k):
+            k["shuffle"] = False
+            k["num_workers"] = 0
+            k["pin_memory"] = False
+            super().__init__(*a, **k)
+    with tempfile.TemporaryDirectory() as d:
+        vpath = os.path.join(d, "vocab.json")
+        json.dump(VOCAB_FLAT, open(vpath, "w"))
+        for name, lines in (("train.jsonl", train_lines), ("val.jsonl", val_lines)):
+            open(os.path.join(d, name), "w").write("\n".join(lines) + "\n")
+        torch.manual_seed(11)
+        model = core.ApertisForCausalLM(core.ApertisConfig(**cfg_kw))
+        init_sd = {k: v.clone() for k, v in model.state_dict().items()}
+        vocab, n = pipe._load_vocabulary_and_get_size(vpath)
+        tr = pipe.ApertisPretrainDataset(os.path.join(d, "train.jsonl"), vocab, n, max_length=12)
+        va = pipe.ApertisPretrainDataset(os.path.join(d, "val.jsonl"), vocab, n, max_length=12)
+        losses, lrs = [], []
+        pipe.DataLoader = NoShuffle
+        try:
+            trainer = pipe.ApertisTrainer(model, tr, va, output_dir=os.path.join(d, "out"), batch_size=2, learning_rate=1e-3,
+                                          num_epochs=2, gradient_accumulation_steps=2, fp16=False, device="cpu",
+                                          checkpoint_steps=2, iteration_checkpoint_steps=4, use_gradient_checkpointing=False,
+                                          original_manual_vocab_path_for_ft=vpath)
+            sched_step = trainer.scheduler.step
+
+            def spy():
+                sched_step()
+                lrs.append(trainer.scheduler.get_last_lr()[0])
+            trainer.scheduler.step = spy
+            real_set_postfix = pipe.tqdm.set_postfix if hasattr(pipe.tqdm, "set_postfix") else None
+
+            class Bar:
+                def __init__(self, *a, **k): pass
+                def set_postfix(self, dct): losses.append(float(dct["loss"]))
+                def update(self, n=1): pass
+                def close(self): pass
+            pipe.tqdm = Bar
+            val_losses = []
+            real_eval = trainer.evaluate
+
+            def eval_spy():
+                v = real_eval()
+                val_losses.append(v)
+                return v
+            trainer.evaluate = eval_spy
+            trainer.train()
+        finally:
+            pipe.DataLoader = real_loader
+        out = os.path.join(d, "out")
+        listing = {name: sorted(os.listdir(os.path.join(out, name))) for name in sorted(os.listdir(out))}
+        cfg_keys = sorted(json.load(open(os.path.join(out, "final", "config.json"))).keys())
+        final_sd = torch.load(os.path.join(out, "final", "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    meta = dict(cfg=cfg_kw, train_lines=train_lines, val_lines=val_lines, vocab=VOCAB_FLAT, losses_4dp=losses, lrs=lrs,
+                val_losses=val_losses, listing=listing, config_keys=cfg_keys,
+                trainer=dict(batch_size=2, learning_rate=1e-3, num_epochs=2, gradient_accumulation_steps=2, fp16=False,
+                             checkpoint_steps=2, iteration_checkpoint_steps=4, max_length=12))
+    arrs = sd_arrays(init_sd, "init::")
+    arrs.update(sd_arrays(final_sd, "final::"))
+    npz("trainer_run", meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrs)
+    print("    optimizer steps:", len(lrs), "losses:", losses, "val:", val_losses, "dirs:", list(listing))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
@@ -277,3 +445,6 @@ if __name__ == "__main__":
     gen_vision(core)
     gen_models(core)
     gen_dims(core)
+    import src.training.pipeline as pipe
+    gen_data_formats(pipe)
+    gen_trainer_run(core, pipe)
