@@ -148,3 +148,44 @@ def test_trainer_schedule_checkpoints_and_stop(tmp_path):
     t2.train()
     assert len(t2.history["loss"]) == 2 and not os.path.exists(os.path.join(out2, "final"))
     assert t2.evaluate() == float("inf")
+
+
+def test_build_from_config_pretrain_and_finetune_resize(tmp_path):
+    """The reference's training-config schema (pipeline.py:708-980): the tokenizer decides vocab size and special ids; a
+    fine-tune from a checkpoint with a different vocabulary keeps the overlapping embedding rows.  (Construction only:
+    running the model needs the GPU.)"""
+    from apertis_llm_amd.trainer import build_from_config
+    vocab = {"<pad>": 0, "<bos>": 5, "<eos>": 6, "<unk>": 7, "a": 8, "b": 9, "c": 10}
+    vpath = _write(tmp_path, "vocab.json", json.dumps(vocab))
+    train = _write(tmp_path, "train.jsonl", "\n".join(json.dumps({"text": "a b c a"}) for _ in range(4)))
+    cfg = {"data_config": {"train_data_path": train, "val_data_path": train, "tokenizer_path": vpath, "max_length": 6},
+           "model_config": {"target_param_count": "1M", "attention_type": "selective_ssm", "use_expert_system": True,
+                            "num_experts": 4, "experts_per_token": 2},
+           "training_config": {"output_dir": str(tmp_path / "out"), "batch_size": 2, "num_epochs": 1, "device": "cpu",
+                               "gradient_accumulation_steps": 1, "fp16": False}}
+    t = build_from_config(cfg, num_workers=0)
+    c = t.model.config
+    assert (c.vocab_size, c.pad_token_id, c.bos_token_id, c.eos_token_id, c.unk_token_id) == (11, 0, 5, 6, 7)
+    assert c.attention_type == "selective_ssm" and c.use_expert_system and c.num_experts == 4
+    assert isinstance(t.train_dataset, D.ApertisPretrainDataset) and len(t.val_dataset) == 4
+    assert t.original_manual_vocab_path_for_ft == vpath and not t.is_fine_tuning
+    assert t.train_dataset[0]["input_ids"].tolist() == [8, 9, 10, 8, 0, 0]
+    t.save_checkpoint("base")
+    base = os.path.join(str(tmp_path / "out"), "base")
+    assert sorted(os.listdir(base)) == ["config.json", "pytorch_model.bin", "vocab.json"]
+
+    big = dict(vocab, d=11, e=12, f=13)
+    vpath2 = _write(tmp_path, "vocab2.json", json.dumps(big))
+    ft = _write(tmp_path, "ft.jsonl", json.dumps({"instruction": "a b", "output": "c d"}) + "\n")
+    cfg2 = {"data_config": {"train_data_path": ft, "tokenizer_path": vpath2, "max_length": 8},
+            "model_config": {},
+            "training_config": {"task_type": "finetune", "pretrained_model_path_for_finetune": base, "device": "cpu",
+                                "output_dir": str(tmp_path / "out2"), "fp16": False}}
+    t2 = build_from_config(cfg2, num_workers=0)
+    assert t2.is_fine_tuning and t2.model.config.vocab_size == 14 and isinstance(t2.train_dataset, D.ApertisFineTuneDataset)
+    old, new = t.model.state_dict(), t2.model.state_dict()
+    assert torch.equal(new["model.token_embeddings.weight"][:11], old["model.token_embeddings.weight"])
+    k = "model.layers.0.attention.attention_mechanism_impl.A_log"
+    assert torch.equal(new[k], old[k])
+    item = t2.train_dataset[0]
+    assert item["labels"].tolist()[:4] == [-100] * 4 and item["labels"].tolist()[4:7] == [10, 11, 6]
