@@ -189,3 +189,29 @@ def test_build_from_config_pretrain_and_finetune_resize(tmp_path):
     assert torch.equal(new[k], old[k])
     item = t2.train_dataset[0]
     assert item["labels"].tolist()[:4] == [-100] * 4 and item["labels"].tolist()[4:7] == [10, 11, 6]
+
+
+def _hf_from_spec(vocab, spec):
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    tok = Tokenizer(models.WordLevel(dict(vocab), unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    if spec["bos"]:
+        single = "<bos> $A <eos>" if spec["eos_in_template"] else "<bos> $A"
+        tok.post_processor = processors.TemplateProcessing(single=single, special_tokens=[("<bos>", vocab["<bos>"]),
+                                                                                          ("<eos>", vocab["<eos>"])])
+    kw = dict(bos_token="<bos>", eos_token="<eos>", unk_token="<unk>")
+    if spec["pad"]:
+        kw["pad_token"] = "<pad>"
+    return PreTrainedTokenizerFast(tokenizer_object=tok, **kw)
+
+
+@pytest.mark.parametrize("ci", range(len(GOLD["finetune_hf"]["cases"])))
+def test_finetune_dataset_hf_tokenizer_matches_reference(tmp_path, ci):
+    """The Hugging Face tokenizer branch (prompt-length bookkeeping with BOS / EOS special tokens, truncation, pad falling
+    back to eos) with word-level tokenizers built offline from the fixture's spec."""
+    g = GOLD["finetune_hf"]
+    case = g["cases"][ci]
+    path = _write(tmp_path, "ft.jsonl", "\n".join(g["lines"]) + "\n")
+    hf = _hf_from_spec(g["vocab"], case["spec"])
+    _same_items(D.ApertisFineTuneDataset(path, hf, is_hf_tokenizer=True, **case["kwargs"]), case["items"])

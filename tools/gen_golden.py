@@ -294,6 +294,27 @@ FINETUNE_LINES = [
 ]
 
 
+HF_VOCAB = {"<pad>": 0, "<bos>": 1, "<eos>": 2, "<unk>": 3, "the": 4, "cat": 5, "sat": 6, "on": 7, "mat": 8, "User": 9,
+            "Assistant": 10, "what": 11, "is": 12, "a": 13, "dog": 14, "it": 15, "barks": 16, "Q": 17, "A": 18, ":": 19}
+
+
+def hf_tokenizer_from_spec(vocab, spec):
+    """PreTrainedTokenizerFast over a word-level vocabulary: `bos` = a post-processor that prepends <bos> (and, with
+    `eos_in_template`, appends <eos>) when add_special_tokens=True; `pad` = whether a pad token is defined."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    tok = Tokenizer(models.WordLevel(dict(vocab), unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    if spec["bos"]:
+        single = "<bos> $A <eos>" if spec["eos_in_template"] else "<bos> $A"
+        tok.post_processor = processors.TemplateProcessing(single=single, special_tokens=[("<bos>", vocab["<bos>"]),
+                                                                                          ("<eos>", vocab["<eos>"])])
+    kw = dict(bos_token="<bos>", eos_token="<eos>", unk_token="<unk>")
+    if spec["pad"]:
+        kw["pad_token"] = "<pad>"
+    return PreTrainedTokenizerFast(tokenizer_object=tok, **kw)
+
+
 def _items(ds):
     out = []
     for i in range(len(ds)):
@@ -342,6 +363,16 @@ def gen_data_formats(pipe):
             ds = pipe.ApertisFineTuneDataset(ft, flat, is_hf_tokenizer=False, **full)
             ft_cases.append({"kwargs": full, "items": _items(ds)})
         cases["finetune"] = {"lines": FINETUNE_LINES, "vocab": VOCAB_FLAT, "cases": ft_cases}
+        # the Hugging Face tokenizer branch, with tokenizers built offline from a word-level vocabulary (spec stored in the
+        # fixture; tests rebuild the same object with hf_tokenizer_from_spec)
+        hf_cases = []
+        for spec in [dict(bos=True, pad=True, eos_in_template=False), dict(bos=False, pad=True, eos_in_template=False),
+                     dict(bos=True, pad=False, eos_in_template=False), dict(bos=True, pad=True, eos_in_template=True)]:
+            hf = hf_tokenizer_from_spec(HF_VOCAB, spec)
+            for kw in [dict(max_length=16), dict(max_length=7), dict(max_length=12, prompt_template="Q : {instruction} A : {output}")]:
+                ds = pipe.ApertisFineTuneDataset(ft, hf, is_hf_tokenizer=True, **kw)
+                hf_cases.append({"spec": spec, "kwargs": kw, "items": _items(ds)})
+        cases["finetune_hf"] = {"lines": FINETUNE_LINES, "vocab": HF_VOCAB, "cases": hf_cases}
     with open(os.path.join(OUT, "data_formats.json"), "w") as f:
         json.dump(cases, f, indent=0, sort_keys=True)
     print(f"  wrote data_formats.json ({os.path.getsize(os.path.join(OUT, 'data_formats.json')) / 1024:.1f} KB)")
