@@ -23,6 +23,7 @@ _lock = threading.Lock()
 _lib = None
 
 _vp, _i64, _i32, _f32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint64
+_f64 = ctypes.c_double
 
 # name -> (restype, argtypes).  Order and meaning mirror include/apertis_hip.h exactly.
 SIGNATURES = {
@@ -87,6 +88,10 @@ SIGNATURES = {
     "apertis_cross_entropy_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_colsum_f32": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "apertis_act_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _u64, _i32, _vp]),
+    "apertis_opt_chunk_elems": (_i64, []),
+    "apertis_grad_sumsq": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "apertis_clip_coef": (_i32, [_vp, _i64, _f32, _vp, _vp]),
+    "apertis_adamw_step": (_i32, [_vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _vp, _vp]),
 }
 
 

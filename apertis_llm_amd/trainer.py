@@ -36,7 +36,7 @@ from torch.utils.data.distributed import DistributedSampler
 from .data import ApertisFineTuneDataset, ApertisPretrainDataset, load_vocabulary
 from .model import ApertisConfig, ApertisForCausalLM, create_apertis_model
 from .parallel import BucketedDataParallel
-from .training import build_optimizer
+from .training import build_optimizer, clip_and_step
 
 logger = logging.getLogger(__name__)
 
@@ -129,8 +129,7 @@ class ApertisTrainer:
     def _optimizer_step(self):
         if self.dp is not None:
             self.dp.finish()
-        torch.nn.utils.clip_grad_norm_(self._params, self.max_grad_norm)
-        self.optimizer.step()
+        clip_and_step(self.optimizer, self._params, self.max_grad_norm)
         self.scheduler.step()
         if self.dp is not None:
             self.dp.zero_grad()

@@ -24,9 +24,115 @@ def build_optimizer(model, lr: float = 5e-5, weight_decay: float = 0.01, fused: 
     named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
     groups = [{"params": [p for n, p in named if not any(nd in n for nd in NO_DECAY)], "weight_decay": weight_decay},
               {"params": [p for n, p in named if any(nd in n for nd in NO_DECAY)], "weight_decay": 0.0}]
+    on_gpu = all(p.is_cuda and p.dtype == torch.float32 for _, p in named)
+    if fused is None and on_gpu and not os.environ.get("APERTIS_TORCH_ADAMW"):
+        return ApertisAdamW(groups, lr=lr)             # clip + AdamW on the HIP kernels (csrc/optimizer.hip)
     if fused is None:
         fused = named[0][1].is_cuda
     return torch.optim.AdamW(groups, lr=lr, fused=fused)
+
+
+def clip_and_step(optimizer, params, max_grad_norm):
+    """clip_grad_norm_ + optimizer.step() (pipeline.py:544-546); one fused call on ApertisAdamW."""
+    if isinstance(optimizer, ApertisAdamW):
+        optimizer.step(max_grad_norm=max_grad_norm)
+    else:
+        torch.nn.utils.clip_grad_norm_(params, max_grad_norm, foreach=True if params and params[0].is_cuda else None)
+        optimizer.step()
+
+
+class ApertisAdamW(torch.optim.Optimizer):
+    """AdamW with the gradient-norm clip folded in, on the HIP kernels `apertis_grad_sumsq` / `apertis_clip_coef` /
+    `apertis_adamw_step` (csrc/optimizer.hip): what the reference does as clip_grad_norm_ + optimizer.step
+    (pipeline.py:544-546) in two passes over the gradients.  Same update rule, parameter-group options and state keys
+    (`step`, `exp_avg`, `exp_avg_sq`) as torch.optim.AdamW, so LR schedulers and optimizer state dicts carry over.
+    `step(max_grad_norm=...)` clips by the global norm over ALL groups first; `last_grad_norm` (a device scalar) holds
+    that norm afterwards.  fp32 CUDA parameters only - anything else raises."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = None
+        self.last_grad_norm = None
+
+    def _build_tables(self):
+        from . import _lib
+        import numpy as np
+        lib = _lib.load()
+        chunk = int(lib.apertis_opt_chunk_elems())
+        tables, key, n_total = [], [], 0
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.grad is not None]
+            rec = np.zeros((len(ps), 5), dtype=np.int64)
+            ct, ci = [], []
+            for i, p in enumerate(ps):
+                if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous()
+                        and p.grad.is_contiguous()):
+                    raise _lib.ApertisHipError("ApertisAdamW needs contiguous fp32 CUDA parameters and gradients")
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                nc = -(-p.numel() // chunk)
+                ct.append(np.full(nc, i, dtype=np.int32))
+                ci.append(np.arange(nc, dtype=np.int32))
+                key.append((p.data_ptr(), p.grad.data_ptr()))
+            dev = ps[0].device if ps else None
+            ct = np.concatenate(ct) if ct else np.zeros(0, np.int32)
+            ci = np.concatenate(ci) if ci else np.zeros(0, np.int32)
+            tables.append(dict(params=ps, n=len(ct), first=n_total,
+                               rec=torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev) if ps else None,
+                               ct=torch.from_numpy(ct).to(dev) if ps else None,
+                               ci=torch.from_numpy(ci).to(dev) if ps else None))
+            n_total += len(ct)
+        dev = next((t["params"][0].device for t in tables if t["params"]), None)
+        self._tables = dict(groups=tables, key=key, n_total=n_total,
+                            partials=torch.empty(max(n_total, 1), device=dev, dtype=torch.float32) if dev is not None else None,
+                            norm_coef=torch.zeros(2, device=dev, dtype=torch.float32) if dev is not None else None)
+
+    def _tables_current(self):
+        if self._tables is None:
+            return False
+        key = [(p.data_ptr(), p.grad.data_ptr()) for g in self.param_groups for p in g["params"] if p.grad is not None]
+        return key == self._tables["key"]
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm: Optional[float] = None):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._tables_current():       # gradients were reallocated (zero_grad(set_to_none=True)) or first call
+            self._build_tables()
+        T = self._tables
+        if T["partials"] is None:
+            return loss
+        lib = _lib.load()
+        coef = None
+        if max_grad_norm is not None:
+            for g in T["groups"]:
+                if g["n"]:
+                    check(lib.apertis_grad_sumsq(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"],
+                                                 ptr(T["partials"][g["first"]:]), stream_ptr()), "apertis_grad_sumsq")
+            check(lib.apertis_clip_coef(ptr(T["partials"]), T["n_total"], float(max_grad_norm), ptr(T["norm_coef"]),
+                                        stream_ptr()), "apertis_clip_coef")
+            coef = T["norm_coef"]
+            self.last_grad_norm = coef[0]
+        for group, g in zip(self.param_groups, T["groups"]):
+            if not g["n"]:
+                continue
+            st0 = self.state[g["params"][0]]
+            step = int(st0["step"].item()) + 1
+            for p in g["params"]:
+                self.state[p]["step"] += 1
+            b1, b2 = group["betas"]
+            check(lib.apertis_adamw_step(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"], float(group["lr"]), float(b1),
+                                         float(b2), float(group["eps"]), float(group["weight_decay"]), step, ptr(coef),
+                                         stream_ptr()), "apertis_adamw_step")
+        return loss
 
 
 class TrainStep:
@@ -64,8 +170,7 @@ class TrainStep:
         if last:
             if self.dp is not None:
                 self.dp.finish()
-            torch.nn.utils.clip_grad_norm_(self._params, self.max_grad_norm, foreach=True)
-            self.optimizer.step()
+            clip_and_step(self.optimizer, self._params, self.max_grad_norm)
             self.scheduler.step()
             if self.dp is not None:
                 self.dp.zero_grad()

@@ -375,6 +375,30 @@ int apertis_cross_entropy_bwd(const void *logits, const int64_t *labels, const f
                               int64_t label_stride, int64_t n_pos, int64_t ignore_index, int dtype,
                               void *stream);
 
+/* ---- optimizer step of the trainer (reference src/training/pipeline.py:469-473 AdamW groups, :544-546
+ * clip_grad_norm_ + optimizer.step).  A parameter group is described by a DEVICE table of apertis_opt_tensor records - fp32
+ * parameter, gradient, first and second moment, element count - and two int32 device arrays that cut the tensors into
+ * chunks of apertis_opt_chunk_elems() consecutive elements: chunk c covers elements [chunk_index[c]*chunk,
+ * +chunk) of tensor chunk_tensor[c].  The caller builds them once (pointers change only when tensors are reallocated). */
+typedef struct apertis_opt_tensor {
+  float *p, *g, *m, *v;
+  int64_t numel;
+} apertis_opt_tensor;
+int64_t apertis_opt_chunk_elems(void);
+/* partials[c] = sum of g^2 over chunk c (fixed summation order). */
+int apertis_grad_sumsq(const void *tensors, const int32_t *chunk_tensor, const int32_t *chunk_index,
+                       int64_t n_chunks, float *partials, void *stream);
+/* norm_coef[0] = sqrt(sum of partials[0..n)) summed in index order, norm_coef[1] = min(1, max_norm/(norm+1e-6)):
+ * torch.nn.utils.clip_grad_norm_'s coefficient, left on the device. */
+int apertis_clip_coef(const float *partials, int64_t n, float max_norm, float *norm_coef, void *stream);
+/* AdamW (torch.optim.AdamW's rule, decoupled decay, bias correction for `step` >= 1) on every chunk, with the gradient
+ * scaled by norm_coef[1] when norm_coef != NULL.  p, m, v are updated in place; g is left as it was.  The hyper-
+ * parameters are doubles: the derived constants (1-beta, 1-lr*wd, lr/bias_correction) are formed in double and rounded
+ * once, as the Python optimizer does. */
+int apertis_adamw_step(const void *tensors, const int32_t *chunk_tensor, const int32_t *chunk_index,
+                       int64_t n_chunks, double lr, double beta1, double beta2, double eps, double weight_decay,
+                       int64_t step, const float *norm_coef, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -282,3 +282,42 @@ def test_trainer_whole_run_matches_reference(dev, tmp_path):
         assert err <= 0.01 * moved + 1e-6, (k, err, moved)
         worst = max(worst, err / max(moved, 1e-12))
     print("worst relative l2 error of a tensor's update:", worst)
+
+
+def test_adamw_kernels_match_torch(dev):
+    """apertis_grad_sumsq / apertis_clip_coef / apertis_adamw_step (ApertisAdamW.step(max_grad_norm)) against
+    torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW over several steps: two parameter groups with different weight
+    decay, tensor sizes that are not multiples of the vector width or of the chunk, a changing learning rate, a step
+    where the clip is active and one where it is not."""
+    from apertis_llm_amd.training import ApertisAdamW
+    torch.manual_seed(3)
+    shapes = [(5,), (1023,), (16384,), (16385,), (3, 7, 11), (70001,), (1,), (256, 130)]
+    mine = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+
+    def groups(ps):
+        return [{"params": ps[:5], "weight_decay": 0.01}, {"params": ps[5:], "weight_decay": 0.0}]
+    o1, o2 = ApertisAdamW(groups(mine), lr=1e-2), torch.optim.AdamW(groups(ref), lr=1e-2)
+    norms = []
+    for it in range(5):
+        scale = 10.0 if it % 2 == 0 else 1e-3           # clip active / inactive
+        for a, b in zip(mine, ref):
+            g = torch.randn_like(a) * scale
+            a.grad, b.grad = g.clone(), g.clone()
+        for o in (o1, o2):
+            for gr in o.param_groups:
+                gr["lr"] = 1e-2 / (it + 1)
+        o1.step(max_grad_norm=1.0)
+        norms.append((float(o1.last_grad_norm), float(torch.nn.utils.clip_grad_norm_(ref, 1.0))))
+        o2.step()
+    for a, b in norms:
+        assert abs(a - b) <= 1e-5 * b, norms
+    for a, b, s in zip(mine, ref, shapes):
+        _close(a.detach(), b.detach(), f"param {s}", rtol=2e-6, atol_scale=1e-6)
+        _close(o1.state[a]["exp_avg"], o2.state[b]["exp_avg"], f"exp_avg {s}", rtol=2e-6, atol_scale=1e-6)
+        _close(o1.state[a]["exp_avg_sq"], o2.state[b]["exp_avg_sq"], f"exp_avg_sq {s}", rtol=2e-6, atol_scale=1e-6)
+        assert float(o1.state[a]["step"]) == 5.0
+    # state dicts are interchangeable with torch.optim.AdamW's
+    o3 = torch.optim.AdamW(groups([p.detach().clone().requires_grad_(True) for p in mine]), lr=1e-2)
+    o3.load_state_dict(o1.state_dict())
+    assert sorted(o3.state_dict()["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
