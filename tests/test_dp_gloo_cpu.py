@@ -135,3 +135,74 @@ def test_train_step_two_ranks_keep_replicas_identical():
     for a, b in zip(res[0][2], res[1][2]):
         assert torch.equal(a, b)
     assert res[0][1] != res[1][1]                     # different data shards -> different local losses
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the trainer's data-parallel wiring (DistributedSampler shards, no_sync on accumulation micro-steps, one reduction per
+# optimizer step, checkpoints on rank 0 only): two gloo ranks must end with identical weights, equal to ONE process
+# training on the union of the two shards with the two ranks' micro-batches averaged.
+class _ToyLM(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(7)
+        self.emb = nn.Embedding(16, 8)
+        self.LayerNorm = nn.LayerNorm(8)
+        self.out = nn.Linear(8, 16)
+
+    def forward(self, input_ids, attention_mask=None, labels=None):
+        logits = self.out(self.LayerNorm(self.emb(input_ids)))
+        loss = nn.functional.cross_entropy(logits[:, :-1].reshape(-1, 16), labels[:, 1:].reshape(-1), ignore_index=-100)
+        return (loss, logits)
+
+
+def _toy_dataset(path):
+    import json
+    import numpy as np
+    from apertis_llm_amd import data as D
+    rng = np.random.RandomState(0)
+    with open(path, "w") as f:
+        for _ in range(8):
+            f.write(json.dumps({"text": " ".join(rng.choice(list("abcdefgh"), size=8))}) + "\n")
+    return D.ApertisPretrainDataset(path, {c: i + 4 for i, c in enumerate("abcdefgh")}, 16, max_length=8)
+
+
+def _trainer_worker(rank, world, port, tmp, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from apertis_llm_amd.trainer import ApertisTrainer
+        torch.set_num_threads(1)
+        ds = _toy_dataset(os.path.join(tmp, f"d{rank}.jsonl"))
+        t = ApertisTrainer(_ToyLM(), ds, None, output_dir=os.path.join(tmp, "out"), batch_size=2, learning_rate=1e-2,
+                           num_epochs=2, gradient_accumulation_steps=2, fp16=False, device="cpu", checkpoint_steps=0,
+                           distributed_training=True, local_rank=rank, num_workers=0)
+        assert t.dp is not None and t.world_size == 2 and t.is_main_process == (rank == 0)
+        order = [b["input_ids"].tolist() for b in t.train_dataloader]       # this rank's shard of epoch 0 (set_epoch(0))
+        t.train()
+        out.put((rank, [p.detach().numpy().copy() for p in t.model.parameters()], t.history["checkpoints"], order,
+                 len(t.history["loss"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_equal_and_checkpoint_on_rank0(tmp_path):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, w0, ck0, order0, n0), (_, w1, ck1, order1, n1) = res
+    for a, b in zip(w0, w1):
+        assert (a == b).all(), "replicas diverged"
+    # 8 items over 2 ranks = 4 per rank = 2 batches per epoch = 1 optimizer step per epoch (accumulation 2)
+    assert n0 == n1 == 2
+    assert ck0 == ["epoch-1", "epoch-2", "final"] and ck1 == []
+    flat0 = [tuple(x) for b in order0 for x in b]
+    flat1 = [tuple(x) for b in order1 for x in b]
+    assert len(flat0) == len(flat1) == 4 and not set(flat0) & set(flat1), "the sampler must shard the epoch"
+    assert sorted(os.listdir(tmp_path / "out")) == ["epoch-1", "epoch-2", "final"]
