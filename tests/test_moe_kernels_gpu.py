@@ -631,3 +631,80 @@ def test_grouped_gemm_nt_two_per_cu_kernel(dev, sizes, N, K):
     frac = float((kept & (act != 0)).sum()) / max(1.0, float((act != 0).sum()))
     assert abs(frac - 0.75) < 0.01, frac
     _close(drop.float()[kept], (act.float() / 0.75)[kept], "kept values rescaled", rtol=8e-3, atol_scale=1e-5)
+
+
+def test_moe_full_size_properties(dev):
+    """BASELINE sizes (1.5B MoE: 32 x 4096 tokens, H=704, I=2816, 8 experts, top-2, capacity 1.25): the kernels the
+    launch heuristics pick at THIS size (two-per-CU and persistent NT, TN v3 pair, radix select, fused activation backward)
+    checked through size-independent properties - the plan is a bijection onto the kept assignments in canonical order
+    under the capacity, and sampled rows / one expert's weight gradient of the expert MLP equal dense fp64 / fp32 math on
+    the same bf16-rounded operands."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(0)
+    S, H, I, E, K = 32 * 4096, 704, 2816, 8, 2
+    logits = torch.randn(S, E, device=dev)
+    logits[:, 0] += 0.7                                    # skew: experts 0 overflows, others vary
+    _, idx, w = ops.moe_gate_topk(logits, K)
+    cap = max(1, int((S / E) * 1.25))
+    plan = ops.moe_plan(idx, w, E, cap, None)
+    offs = plan.offsets.cpu().numpy().astype(np.int64)
+    total = int(offs[-1])
+    counts = np.diff(offs)
+    assert (counts >= 0).all() and (counts <= cap).all() and total <= E * cap
+    want = np.minimum(np.bincount(idx.cpu().numpy().reshape(-1), minlength=E), cap)
+    assert counts.tolist() == want.tolist(), "every expert keeps min(assigned, capacity) rows"
+    rt, rk = plan.row_token.cpu().numpy()[:total].astype(np.int64), plan.row_k.cpu().numpy()[:total].astype(np.int64)
+    slot = plan.slot_of.cpu().numpy()
+    assert len(np.unique(rt * K + rk)) == total, "an assignment is kept at most once"
+    assert (slot[rt, rk] == np.arange(total)).all() and int((slot >= 0).sum()) == total, "slot_of inverts the row lists"
+    idx_c = idx.cpu().numpy()
+    for e in range(E):
+        a, b = offs[e], offs[e + 1]
+        assert (idx_c[rt[a:b], rk[a:b]] == e).all(), "rows of an expert's range were routed to it"
+        key = rk[a:b] * S + rt[a:b]
+        assert (np.diff(key) > 0).all(), "canonical order inside an expert: k, then token"
+    # overflow keeps the largest weights of each (expert, k) slot
+    w_c = w.cpu().numpy()
+    e0k0 = (idx_c[:, 0] == 0)
+    kept0 = np.zeros(S, bool)
+    sel = rt[offs[0]:offs[1]][rk[offs[0]:offs[1]] == 0]
+    kept0[sel] = True
+    if e0k0.sum() > len(sel) > 0:
+        assert w_c[e0k0 & kept0, 0].min() >= w_c[e0k0 & ~kept0, 0].max()
+
+    # expert MLP at the planned row counts
+    rows = int(plan.max_rows)
+    xg = torch.randn(rows, H, device=dev).bfloat16().requires_grad_(True)
+    w1 = (torch.randn(E, I, H, device=dev) * 0.03).requires_grad_(True)
+    b1 = (torch.randn(E, I, device=dev) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(E, H, I, device=dev) * 0.03).requires_grad_(True)
+    b2 = (torch.randn(E, H, device=dev) * 0.1).requires_grad_(True)
+    y = ops.expert_mlp(xg, w1, b1, w2, b2, plan.offsets, rows, act="gelu", drop_p=0.0, seed=0, compute_dtype=torch.bfloat16)
+    dy = torch.randn(rows, H, device=dev).bfloat16()
+    y.backward(dy)
+    sample = torch.from_numpy(np.random.default_rng(1).choice(total, 384, replace=False)).to(dev)
+    exp_of = torch.bucketize(sample, plan.offsets[1:].long(), right=True)
+    w1q, w2q = w1.detach().bfloat16().double(), w2.detach().bfloat16().double()
+    xs = xg.detach()[sample].double().requires_grad_(True)
+    pre = torch.einsum("rh,rih->ri", xs, w1q[exp_of]) + b1.detach().double()[exp_of]
+    hmid = torch.nn.functional.gelu(pre.bfloat16().double())          # the kernel rounds pre and h to bf16 between the GEMMs
+    ref = torch.einsum("ri,rhi->rh", hmid.bfloat16().double(), w2q[exp_of]) + b2.detach().double()[exp_of]
+    _close(y.detach()[sample].double(), ref, "expert MLP rows (sampled)", rtol=2e-2, atol_scale=1e-2)
+    # input gradient of the sampled rows (through both data-gradient GEMMs and the fused act' epilogue)
+    dh = torch.einsum("rh,rhi->ri", dy[sample].double(), w2q[exp_of]).bfloat16().double()
+    gp = torch.autograd.grad(torch.nn.functional.gelu(pre), pre, dh)[0].bfloat16().double()
+    dx_ref = torch.einsum("ri,rih->rh", gp, w1q[exp_of])
+    _close(xg.grad[sample].double(), dx_ref, "dx rows (sampled)", rtol=3e-2, atol_scale=2e-2)
+    # one expert's weight and bias gradients (TN v3 pair) against fp32 dense math on the same rows
+    e = 3
+    a, b = int(offs[e]), int(offs[e + 1])
+    xe = xg.detach()[a:b].float()
+    pre_e = (xe @ w1.detach()[e].bfloat16().float().T + b1.detach()[e]).bfloat16().float()
+    h_e = torch.nn.functional.gelu(pre_e).bfloat16().float()
+    _close(w2.grad[e], dy[a:b].float().T @ h_e, "dW2[e]", rtol=2e-2, atol_scale=1e-2)
+    _close(b2.grad[e], dy[a:b].float().sum(0), "db2[e]", rtol=2e-2, atol_scale=1e-2)
+    dh_e = (dy[a:b].float() @ w2.detach()[e].bfloat16().float()).bfloat16().float()
+    pre_g = pre_e.clone().requires_grad_(True)
+    dpre_e = torch.autograd.grad(torch.nn.functional.gelu(pre_g), pre_g, dh_e)[0].bfloat16().float()
+    _close(w1.grad[e], dpre_e.T @ xe, "dW1[e]", rtol=2e-2, atol_scale=1e-2)
+    _close(b1.grad[e], dpre_e.sum(0), "db1[e]", rtol=2e-2, atol_scale=1e-2)
