@@ -932,7 +932,10 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
   lds_barrier();
 }
 
-template <typename TO>
+// RAGGED: K % 32 != 0 - W's rows are zero-padded to whole sub-steps (row pitch ldw), X's last sub-step over-reads into
+// the next row (finite values against W's zeros) and the K offset moves into the range-checked lane offset so that
+// the tile's last row reads zeros past the buffer instead
+template <typename TO, bool RAGGED = false>
 __global__ void __launch_bounds__(NT3, 2)
 grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
@@ -976,13 +979,14 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const uint32_t lds0 = lds_addr_of(smem);
   auto issue = [&](uint32_t slot_off, int s) {   // sub-step s: this wave's 4 X pieces and 2 W pieces
     const uint32_t kb = (uint32_t)s * ROWB3, base = lds0 + slot_off;
+    const uint32_t kv = RAGGED ? kb : 0u, ks = RAGGED ? 0u : kb;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lds_dma16s(xrs, base + (wave * 4 + j) * 1024, vx0 + (uint32_t)(j * 16 * ldb), kb);
+    for (int j = 0; j < 4; ++j) lds_dma16s(xrs, base + (wave * 4 + j) * 1024, vx0 + (uint32_t)(j * 16 * ldb) + kv, ks);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-      lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + j) * 1024, vw0 + (uint32_t)(j * 16 * ldwb), kb);
+      lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + j) * 1024, vw0 + (uint32_t)(j * 16 * ldwb) + kv, ks);
   };
-  const int nk = K / 32;   // >= 3 (launcher)
+  const int nk = (K + 31) / 32;   // >= 3 (launcher)
   issue(0, 0); issue(SLOT3, 1); issue(2 * SLOT3, 2);
 
   f32x4 acc[4][8];
@@ -1701,12 +1705,17 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // two work-groups per CU pay off when the epilogue is heavy next to the K loop (activation / dropout /
     // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop)
     static const int force2x = getenv("APERTIS_GEMM_NT2X") ? atoi(getenv("APERTIS_GEMM_NT2X")) : -1;
-    const bool use2x = force2x >= 0 ? force2x != 0 : ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512);
-    if (use2x && K % 32 == 0 && K >= 96 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
+    // ... and for the SSM block's dense projections (one group, short K, HBM-bound): 92 vs 114 us at N=352/K=704, 72 vs 89
+    // at N=704/K=176, 56 vs 64 at N=400/K=176; the N=176 data gradients stay on the 256-wide tile (63 vs 60 us)
+    static const int dense2x = getenv("APERTIS_GEMM_DENSE2X") ? atoi(getenv("APERTIS_GEMM_DENSE2X")) : 1;
+    const bool use2x = force2x >= 0 ? force2x != 0 : (((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
+                                                     (dense2x && E == 1 && K <= 1024 && N >= 256));
+    const bool ragged2x = K % 32 != 0;
+    if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);
       const int64_t grid3 = (ceil_div64(max_rows, BM3) + E) * nt3;
       if (grid3 < 0x7fffffffLL) {
-        auto k3 = grouped_gemm_nt2x_k<TO>;
+        auto k3 = ragged2x ? grouped_gemm_nt2x_k<TO, true> : grouped_gemm_nt2x_k<TO, false>;
         hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         hipLaunchKernelGGL(k3, dim3((unsigned)grid3), dim3(NT3), RING3, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act, drop_p, seed);
