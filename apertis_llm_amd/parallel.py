@@ -6,8 +6,11 @@ Replaces torch DistributedDataParallel as the reference uses it (src/training/pi
 DDP(find_unused_parameters=False), gradient MEAN over ranks, default 25 MB buckets).  Choices
 made for point-to-point xGMI (7 links x ~153 GB/s per GPU, ring collectives are per-link bound):
   - large buckets (default 128 MiB) so each all-reduce is bandwidth- not latency-bound;
-  - gradients live INSIDE the flat bucket buffers (param.grad is a view), so a bucket is ready the
-    moment its last gradient is accumulated and nothing is copied before the collective;
+  - gradients end up INSIDE the flat bucket buffers: the post-accumulate hook moves a fresh gradient into its
+    slice (one read + one write) and makes param.grad that view, so the optimizer and further accumulation
+    micro-steps work on the bucket in place and a bucket is ready the moment its last gradient has arrived.
+    Between optimizer steps the gradients are None (zero_grad drops the views instead of zeroing 4 bytes per
+    parameter, and autograd assigns instead of accumulating into zeros: two passes over the gradients fewer);
   - buckets are filled in reverse parameter order = the order backward produces gradients;
   - the collective is issued on a dedicated stream behind an event recorded on the compute
     stream; `finish()` makes the compute stream wait before clipping / the optimizer;
@@ -78,7 +81,7 @@ class BucketedDataParallel(nn.Module):
             offsets, off = [], 0
             for p in g:
                 offsets.append(off)
-                p.grad = flat[off:off + p.numel()].view_as(p)
+                p.grad = None
                 off += -(-p.numel() // 64) * 64
             b = _Bucket(flat, g, offsets)
             bi = len(self.buckets)
@@ -130,7 +133,10 @@ class BucketedDataParallel(nn.Module):
             for b in self.buckets:
                 if b.pending != 0:
                     # some parameter of this bucket received no gradient this step (e.g. the vision tower
-                    # on a text-only batch): its slice of the flat buffer is still zero, reduce it as is
+                    # on a text-only batch): its slice still holds an earlier step's values - reduce zeros instead
+                    for i, p in enumerate(b.params):
+                        if p.grad is None:
+                            b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
                     if b.pending != len(b.params) and not self._warned_partial:
                         self._warned_partial = True
                         import warnings
@@ -148,10 +154,15 @@ class BucketedDataParallel(nn.Module):
         for b in self.buckets:
             b.pending = len(b.params)
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Zero the flat buffers (gradients stay views into them)."""
+    def zero_grad(self, set_to_none: bool = True):
+        """Drop the gradients (the next backward assigns fresh ones, which the hooks move into the buckets).
+        set_to_none=False keeps the views and zeroes the flat buffers instead."""
         for b in self.buckets:
-            b.flat.zero_()
+            if set_to_none:
+                for p in b.params:
+                    p.grad = None
+            else:
+                b.flat.zero_()
 
     @contextlib.contextmanager
     def no_sync(self):
