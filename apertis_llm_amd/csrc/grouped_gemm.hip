@@ -21,6 +21,7 @@
 // Global -> LDS goes through registers (one tile in flight, written to the other buffer after
 // the MFMAs of the current one: one barrier per K step).
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -614,6 +615,13 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 struct PTile { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
 
+// Dynamic tile queue of the persistent kernel (qslot >= 0): after its first (static, XCD-affine) tile a work-group takes
+// tile indices from a device counter, so a work-group that starts late - its CU was held by another kernel, e.g. an RCCL
+// collective on the communication stream - simply finds the queue drained instead of walking a full static share on its
+// own after everybody else has finished.  One counter pair per launch slot; the last work-group to leave resets it.
+__device__ int g_pq_next[256];
+__device__ int g_pq_done[256];
+
 // raw = the pre-activation pass, r = round; ACT >= 0 fixes the activation and DROP the dropout at
 // compile time (a per-value runtime switch costs more than the conversion itself), ACT < 0 = runtime
 template <typename TO, bool raw, int r, int ACT, bool DROP>
@@ -680,7 +688,7 @@ __global__ void __launch_bounds__(NT2)
 grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                       const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
                       const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int total_tiles,
-                      int solo, int act, float drop_p, uint64_t seed) {
+                      int solo, int act, float drop_p, uint64_t seed, int qslot) {
   typedef bf16_t T;
   typedef bf16x8 frag;
   constexpr int BK = 64;
@@ -708,7 +716,8 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
   PTile cur; cur.valid = 0; cur.e = 0; cur.rows_valid = 0; cur.n0 = 0; cur.cols_valid = 0; cur.row0 = 0;
   // one pass of this loop = [find + prefetch tile i] [epilogue of tile i-1] [K loop of tile i]; every
   // piece of code has a single call site
-  for (int t = blockIdx.x;; t += G) {
+  int *s_next = s_off + 1026;   // (E <= 1024: the offsets end at s_off[1024])
+  for (int t = blockIdx.x;;) {
     PTile nxt; nxt.valid = 0;
     if (t < n_valid) {
       const int r = t / G, within = t - r * G, gr = min(G, n_valid - r * G);
@@ -795,6 +804,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     }
     if (!nxt.valid) break;
     cur = nxt;
+    if (qslot >= 0 && tid == 0) *s_next = G + atomicAdd(&g_pq_next[qslot], 1);   // (its latency hides under the K loop)
 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -830,6 +840,11 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
       }
     }
     __syncthreads();   // every wave is done with both ring buffers
+    t = qslot >= 0 ? __builtin_amdgcn_readfirstlane(*s_next) : t + G;
+  }
+  if (qslot >= 0 && tid == 0 && atomicAdd(&g_pq_done[qslot], 1) == G - 1) {   // last one out resets the slot
+    g_pq_next[qslot] = 0;
+    g_pq_done[qslot] = 0;
   }
 }
 
@@ -1730,11 +1745,15 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         const int gp = (int)std::min<int64_t>(grid2, ncu);          // one persistent work-group per CU
         size_t ldsp = 4 * TILE2_BYTES + 4096 + 16;                   // ring + group offsets
         static const int solo = getenv("APERTIS_GEMM_SOLO") ? atoi(getenv("APERTIS_GEMM_SOLO")) : 4;
+        // read per launch: BucketedDataParallel sets it when it wraps a model for world_size > 1
+        const char *dyn_env = getenv("APERTIS_GEMM_DYNAMIC");
+        const bool dynq = dyn_env && atoi(dyn_env) != 0;
+        static std::atomic<unsigned> pq_seq{0};
         auto kp = (K % 64 == 0 && ldw == K) ? grouped_gemm_nt256p_k<TO, false> : grouped_gemm_nt256p_k<TO, true>;
         hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         hipLaunchKernelGGL(kp, dim3((unsigned)gp), dim3(NT2), ldsp, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt2, (int)grid2, solo,
-                           act, drop_p, seed);
+                           act, drop_p, seed, dynq ? (int)(pq_seq.fetch_add(1) & 255u) : -1);
         return apertis_check_launch();
       }
       if (K % 64) return APERTIS_ERR_UNSUPPORTED;   // only reachable with E > 1024 groups
