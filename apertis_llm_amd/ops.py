@@ -1074,6 +1074,17 @@ def layer_norm_pass(x, weight, bias, eps, out_dtype=None):
 FUSE_ACT_BWD = not _os.environ.get("APERTIS_NO_FUSE_ACT_BWD")
 
 
+def grad_destination(param, shape, device):
+    """Where a backward kernel should write the fp32 gradient of `param`: a fresh alias of the slice the data-parallel
+    wrapper reserved for it in its bucket (`param._apertis_grad_view`, parallel.BucketedDataParallel) when the parameter
+    has no gradient yet - autograd then adopts that tensor as param.grad and nothing is copied into the bucket - else a
+    new tensor (accumulation micro-steps add into the bucket in place)."""
+    view = getattr(param, "_apertis_grad_view", None)
+    if view is not None and param.grad is None and view.dtype == torch.float32 and tuple(view.shape) == tuple(shape):
+        return view.view_as(view)
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
 class _ExpertMLP(torch.autograd.Function):
     """yr = (dropout(act(xg @ W1[e].T + b1[e]))) @ W2[e].T + b2[e] per group, as ONE autograd node so the
     backward can fuse act'/dropout into the epilogue of the second layer's data-gradient GEMM."""
@@ -1101,6 +1112,7 @@ class _ExpertMLP(torch.autograd.Function):
                  0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
         ctx.save_for_backward(xg, pre, h, w1t, w2t, offsets)
         ctx.cfg = (E, I, H, max_rows, act_code, float(drop_p), int(seed), w1.dtype, w2.dtype)
+        ctx.wparams = (w1, w2)     # for grad_destination() in the backward
         return yr
 
     @staticmethod
@@ -1135,9 +1147,9 @@ class _ExpertMLP(torch.autograd.Function):
                     (ptr(dpre), ptr(w1t), None, ptr(offsets), ptr(dxg), None, None, max_rows, H, I, w1t.shape[-1], E, _lib.ACT_NONE,
                      0.0, 0, code, code, stream_ptr()), work)
         # both weight gradients in ONE launch: dW2 = dyr^T h, dW1 = dpre^T xg
-        dw2 = torch.empty(E, H, I, device=dev, dtype=torch.float32)
+        dw2 = grad_destination(ctx.wparams[1], (E, H, I), dev)
         db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
-        dw1 = torch.empty(E, I, H, device=dev, dtype=torch.float32)
+        dw1 = grad_destination(ctx.wparams[0], (E, I, H), dev)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
         ws, ws_bytes = _tn_workspace(E, 2, dev)
         _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair,

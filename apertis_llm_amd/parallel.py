@@ -45,6 +45,7 @@ class BucketedDataParallel(nn.Module):
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.reduce_dtype = reduce_dtype
         self._sync = True
+        self.copied_bytes = 0     # gradient bytes the hooks had to move into the buckets (diagnostic)
         self._warned_partial = False
         import os as _os
         self._force = _os.environ.get("APERTIS_FORCE_DP") == "1"
@@ -56,6 +57,8 @@ class BucketedDataParallel(nn.Module):
         self.device = params[0].device
         self._cuda = self.device.type == "cuda"
         self.comm_stream = torch.cuda.Stream(device=self.device) if self._cuda else None
+        self._avg_op = bool(self._cuda and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+                            and not _os.environ.get("APERTIS_DP_NO_AVG"))
         if broadcast_parameters and self.world_size > 1:
             # DDP semantics: every replica starts from rank 0's parameters and buffers
             with torch.no_grad():
@@ -86,6 +89,8 @@ class BucketedDataParallel(nn.Module):
             for p in g:
                 offsets.append(off)
                 p.grad = None
+                # backward kernels that can write their weight gradient anywhere (ops.grad_destination) write it here
+                p._apertis_grad_view = flat[off:off + p.numel()].view_as(p)
                 off += -(-p.numel() // 64) * 64
             b = _Bucket(flat, g, offsets)
             bi = len(self.buckets)
@@ -103,6 +108,7 @@ class BucketedDataParallel(nn.Module):
                 # autograd replaced the gradient tensor: fold it back into the bucket
                 if p.grad is not None:
                     view.copy_(p.grad)
+                    self.copied_bytes += p.numel() * p.element_size()
                 p.grad = view
             b.pending -= 1
             if b.pending == 0 and self._sync and (self.world_size > 1 or self._force):
@@ -116,14 +122,19 @@ class BucketedDataParallel(nn.Module):
             ev.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                # RCCL averages inside the collective (ReduceOp.AVG): no separate 1/world pass over the bucket
+                avg = self._avg_op
                 if self.reduce_dtype is not None and self.reduce_dtype != b.flat.dtype:
                     b.wire = b.flat.to(self.reduce_dtype)
-                    dist.all_reduce(b.wire, op=dist.ReduceOp.SUM, group=self.group)
-                    b.flat.copy_(b.wire).mul_(inv)
+                    dist.all_reduce(b.wire, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group)
+                    b.flat.copy_(b.wire)
+                    if not avg:
+                        b.flat.mul_(inv)
                     b.wire.record_stream(self.comm_stream)
                 else:
-                    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
-                    b.flat.mul_(inv)
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group)
+                    if not avg:
+                        b.flat.mul_(inv)
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

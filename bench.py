@@ -126,6 +126,9 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.set_kernel_timer(None)
     log(f"timed region done: {elapsed:.2f}s for {args.steps} steps")
+    if getattr(step, "dp", None) is not None:
+        log(f"DP wrapper: {step.dp.copied_bytes / 2**30:.2f} GiB of gradients moved into buckets by hooks so far "
+            f"({step.dp.gradient_bytes() / 2**30:.2f} GiB of gradients per step)")
     last_loss = float(loss)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
