@@ -61,39 +61,39 @@ template <int VB> __device__ __forceinline__ typename vec_bytes<VB>::type zero_v
 
 // HBM -> LDS: LT rows of ROWB bytes each (LDS pitch = ROWB), source rows `rsb` bytes apart.
 // Rows >= rows_valid and bytes >= bytes_valid are zero-filled.
-template <int VB, int ROWB, int LT>
+template <int VB, int ROWB, int LT, int NTH = NTHREADS>
 __device__ __forceinline__ void stage_in(char *lds, const char *g, int64_t rsb, int rows_valid,
                                          int bytes_valid, int tid) {
   typedef typename vec_bytes<VB>::type V;
   constexpr int CPR = ROWB / VB;
   constexpr int TOTAL = LT * CPR;
-  constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+  constexpr int ITERS = (TOTAL + NTH - 1) / NTH;
   V regs[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    int idx = tid + it * NTHREADS;
+    int idx = tid + it * NTH;
     int row = idx / CPR, cb = (idx % CPR) * VB;
     bool ok = idx < TOTAL && row < rows_valid && cb < bytes_valid;
     regs[it] = ok ? *reinterpret_cast<const V *>(g + (int64_t)row * rsb + cb) : zero_vec<VB>();
   }
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    int idx = tid + it * NTHREADS;
+    int idx = tid + it * NTH;
     if (idx < TOTAL) *reinterpret_cast<V *>(lds + idx * VB) = regs[it];
   }
 }
 
 // LDS -> HBM, mirror of stage_in.
-template <int VB, int ROWB, int LT>
+template <int VB, int ROWB, int LT, int NTH = NTHREADS>
 __device__ __forceinline__ void stage_out(const char *lds, char *g, int64_t rsb, int rows_valid,
                                           int bytes_valid, int tid) {
   typedef typename vec_bytes<VB>::type V;
   constexpr int CPR = ROWB / VB;
   constexpr int TOTAL = LT * CPR;
-  constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+  constexpr int ITERS = (TOTAL + NTH - 1) / NTH;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    int idx = tid + it * NTHREADS;
+    int idx = tid + it * NTH;
     int row = idx / CPR, cb = (idx % CPR) * VB;
     if (idx < TOTAL && row < rows_valid && cb < bytes_valid)
       *reinterpret_cast<V *>(g + (int64_t)row * rsb + cb) =
@@ -102,10 +102,10 @@ __device__ __forceinline__ void stage_out(const char *lds, char *g, int64_t rsb,
 }
 
 // delta tile: dl[t][hh] for the HT = 64/N heads covered by the channel tile
-template <int LT>
+template <int LT, int NTH = NTHREADS>
 __device__ __forceinline__ void stage_delta(float *dl, const float *dlt, int64_t tok0, int rows_valid,
                                             int head0, int h, int HT, int softplus, int tid) {
-  for (int idx = tid; idx < LT * HT; idx += NTHREADS) {
+  for (int idx = tid; idx < LT * HT; idx += NTH) {
     int t = idx / HT, hh = idx - t * HT;
     float v = 0.f;
     if (t < rows_valid && head0 + hh < h) {
@@ -126,11 +126,12 @@ struct ScanDims {
 // a 4x64 LDS table.  forward: chunks [0, chunk) left-to-right from `init`; reverse: chunks
 // (chunk, nchunks) right-to-left from 0.  Replaces a separate prefix launch (which cost as much as
 // the streaming passes at B*L = 32k tokens).  Contains one __syncthreads().
+template <int NS = NSEG>
 __device__ __forceinline__ float chunk_carry(const float2 *__restrict__ agg, const float *__restrict__ init, int b,
                                              int chunk, int c, bool chan_ok, const ScanDims &d, int seg, int lane,
                                              float2 *lk, bool reverse) {
   const int lo = reverse ? chunk + 1 : 0, hi = reverse ? d.nchunks : chunk;   // [lo, hi)
-  const int n = hi - lo, q = (n + NSEG - 1) / NSEG;
+  const int n = hi - lo, q = (n + NS - 1) / NS;
   // wave `seg` takes the seg-th sub-range in COMPOSITION order
   int s0 = lo + seg * q, s1 = min(s0 + q, hi);
   if (reverse) { s1 = hi - seg * q; s0 = max(s1 - q, lo); }
@@ -146,7 +147,7 @@ __device__ __forceinline__ float chunk_carry(const float2 *__restrict__ agg, con
   __syncthreads();
   float carry = (init && chan_ok) ? init[(int64_t)b * d.Dn + c] : 0.f;
 #pragma unroll
-  for (int s = 0; s < NSEG; ++s) { float2 t = lk[s * TC + lane]; carry = fmaf(t.x, carry, t.y); }
+  for (int s = 0; s < NS; ++s) { float2 t = lk[s * TC + lane]; carry = fmaf(t.x, carry, t.y); }
   return carry;
 }
 
@@ -498,8 +499,10 @@ scan_bwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
 }
 
 // backward pass 3: recompute states in the chunk, run the adjoint right-to-left
-template <typename TIN, typename TY, int VB, int VBY, int LT>
-__global__ void __launch_bounds__(NTHREADS)
+// NS waves per work-group: 8 (segments of 8 tokens) halves the per-thread register arrays, so twice as many waves
+// fit next to the same LDS tiles (the tile of fp32 dy makes LDS, not registers, the limit on work-groups per CU)
+template <typename TIN, typename TY, int VB, int VBY, int LT, int NS>
+__global__ void __launch_bounds__(TC * NS)
 scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
                 const TIN *__restrict__ Bt, int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs,
                 const TY *__restrict__ dy, int64_t dy_rs, const float *__restrict__ h_in,
@@ -508,15 +511,16 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
                 float *__restrict__ dA_part, ScanDims d) {
   constexpr int ROWB = TC * sizeof(TIN);
   constexpr int ROWY = TC * sizeof(TY);
-  constexpr int TS = LT / NSEG;
+  constexpr int TS = LT / NS;
+  constexpr int NTH = TC * NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TIN *bt = reinterpret_cast<TIN *>(smem);
   TIN *cc = reinterpret_cast<TIN *>(smem + LT * ROWB);
   TY *gy = reinterpret_cast<TY *>(smem + 2 * LT * ROWB);
   float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB + LT * ROWY);
   float *ddl = dl + LT * d.HT;
-  float *segs = ddl + LT * d.HT;  // [NSEG][TC][3]
-  float2 *lk = reinterpret_cast<float2 *>(segs + NSEG * TC * 3);
+  float *segs = ddl + LT * d.HT;  // [NS][TC][3]
+  float2 *lk = reinterpret_cast<float2 *>(segs);   // look-back table: aliases segs (barrier below), 40 KiB in all = 4 per CU
 
   const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
   const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
@@ -527,23 +531,24 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   const int64_t tok0 = (int64_t)b * d.L + t0;
   const int head0 = c0 >> d.log2N;
 
-  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt),
+  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(bt),
                          reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
                          bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc),
+  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(cc),
                          reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
                          c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_in<VBY, ROWY, LT>(reinterpret_cast<char *>(gy),
+  stage_in<VBY, ROWY, LT, NTH>(reinterpret_cast<char *>(gy),
                           reinterpret_cast<const char *>(dy + tok0 * dy_rs + c0),
                           dy_rs * sizeof(TY), rows_valid, ch_valid * (int)sizeof(TY), tid);
-  stage_delta<LT>(dl, dlt, tok0, rows_valid, head0, (int)d.h, d.HT, d.softplus, tid);
+  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, head0, (int)d.h, d.HT, d.softplus, tid);
   const bool chan_ok = c < d.Dn;
   const float Ac = chan_ok ? -expf(A_log[c]) : 0.f;
   const float A2 = Ac * LOG2E_F;
   const int64_t cidx = ((int64_t)b * d.nchunks + chunk) * d.Dn + c;
   float hcar = chan_ok ? h_in[cidx] : 0.f;
   // mu entering from the right: composed from the later chunks' reverse aggregates
-  float mcar = chunk_carry(agg, nullptr, b, chunk, c, chan_ok, d, seg, lane, lk, true);
+  float mcar = chunk_carry<NS>(agg, nullptr, b, chunk, c, chan_ok, d, seg, lane, lk, true);
+  __syncthreads();   // every wave has read lk before segs (same LDS) is written
 
   float a[TS], hs[TS];
   float P = 1.f, S = 0.f, M = 0.f;
@@ -567,7 +572,7 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   __syncthreads();
   for (int s = 0; s < seg; ++s)
     hcar = fmaf(segs[(s * TC + lane) * 3 + 0], hcar, segs[(s * TC + lane) * 3 + 1]);
-  for (int s = NSEG - 1; s > seg; --s)
+  for (int s = NS - 1; s > seg; --s)
     mcar = fmaf(segs[(s * TC + lane) * 3 + 0], mcar, segs[(s * TC + lane) * 3 + 2]);
 
   // forward recompute of the states of this segment
@@ -597,13 +602,13 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   }
   __syncthreads();  // dBt/dC/ddl tiles complete; segs free for reuse
   segs[seg * TC + lane] = dA_acc;
-  stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(bt),
+  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(bt),
                           reinterpret_cast<char *>(dBt + tok0 * dbt_rs + c0), dbt_rs * sizeof(TIN),
                           rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(cc),
+  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(cc),
                           reinterpret_cast<char *>(dC + tok0 * dc_rs + c0), dc_rs * sizeof(TIN),
                           rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  for (int idx = tid; idx < LT * d.HT; idx += NTHREADS) {
+  for (int idx = tid; idx < LT * d.HT; idx += NTH) {
     int t = idx / d.HT, hx = idx - t * d.HT;
     if (t < rows_valid && head0 + hx < d.h) {
       float v = ddl[idx];
@@ -613,25 +618,30 @@ scan_bwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   }
   __syncthreads();
   if (seg == 0 && chan_ok) {
-    float s = segs[lane] + segs[TC + lane] + segs[2 * TC + lane] + segs[3 * TC + lane];
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < NS; ++w) s += segs[w * TC + lane];
     dA_part[cidx] = s;
   }
 }
 
-// column sums of a [rows, cols] fp32 matrix in a fixed order: out[c] = sum_r in[r][c]
+// column sums of a [rows, cols] fp32 matrix in a fixed order: block (x, y) sums rows [y*rpg, (y+1)*rpg) of its 64
+// columns into out[y][c].  Two levels (row groups, then the group sums): a single level leaves the whole matrix to
+// cols/64 work-groups - 3 at Dn = 176, 15.6 us for 1.4 MB at the bench shape, a tenth of the backward.
 __global__ void __launch_bounds__(1024)
-colsum_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols) {
+colsum_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t rows, int64_t cols, int64_t rpg) {
   __shared__ float part[16][TC];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int64_t c = (int64_t)blockIdx.x * TC + lane;
+  const int64_t r0 = (int64_t)blockIdx.y * rpg, r1 = min(r0 + rpg, rows);
   float s = 0.f;
   if (c < cols) {
-    int64_t r = seg;
-    for (; r + 48 < rows; r += 64) {
+    int64_t r = r0 + seg;
+    for (; r + 48 < r1; r += 64) {
       float a0 = in[r * cols + c], a1 = in[(r + 16) * cols + c], a2 = in[(r + 32) * cols + c], a3 = in[(r + 48) * cols + c];
       s += (a0 + a1) + (a2 + a3);
     }
-    for (; r < rows; r += 16) s += in[r * cols + c];
+    for (; r < r1; r += 16) s += in[r * cols + c];
   }
   part[seg][lane] = s;
   __syncthreads();
@@ -639,7 +649,7 @@ colsum_kernel(const float *__restrict__ in, float *__restrict__ out, int64_t row
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += part[i][lane];
-    out[c] = t;
+    out[(int64_t)blockIdx.y * cols + c] = t;
   }
 }
 
@@ -728,20 +738,29 @@ int launch_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
                int64_t c_rs, const void *dy, int64_t dy_rs, const float *h_in, void *dBt,
                int64_t dbt_rs, void *dC, int64_t dc_rs, float *d_dlt, float *dA_log, float *agg,
                float *mu_in, float *dA_part, const ScanDims &d, hipStream_t st) {
-  (void)mu_in;  // kept in the ABI; the reverse carry is composed in-kernel since r1
+  // mu_in: [B, nchunks, Dn] fp32 workspace of the ABI (the reverse carry is composed in-kernel since r1); its head holds
+  // the row-group sums of the two-level dA_log fold
   constexpr int LT = LT_DEFAULT;
   dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
   size_t dlb = (size_t)LT * d.HT * 4;
   size_t lds1 = LT * TC * (sizeof(TIN) + sizeof(TY)) + dlb + NSEG * TC * sizeof(float2);
-  size_t lds3 = LT * TC * (2 * sizeof(TIN) + sizeof(TY)) + 2 * dlb + NSEG * TC * 3 * sizeof(float) +
-                NSEG * TC * sizeof(float2);
+  constexpr int NS3 = 8;   // waves per work-group of the replay pass
+  size_t lds3 = LT * TC * (2 * sizeof(TIN) + sizeof(TY)) + 2 * dlb + NS3 * TC * 3 * sizeof(float);
   hipLaunchKernelGGL((scan_bwd_state<TIN, TY, VB, VBY, LT>), grid, block, lds1, st, dlt, A_log,
                      (const TIN *)C, c_rs, (const TY *)dy, dy_rs, (float2 *)agg, d);
-  hipLaunchKernelGGL((scan_bwd_replay<TIN, TY, VB, VBY, LT>), grid, block, lds3, st, dlt, A_log,
+  hipLaunchKernelGGL((scan_bwd_replay<TIN, TY, VB, VBY, LT, NS3>), grid, dim3(TC * NS3), lds3, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const TY *)dy, dy_rs, h_in,
                      (const float2 *)agg, (TIN *)dBt, dbt_rs, (TIN *)dC, dc_rs, d_dlt, dA_part, d);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)ceil_div64(d.Dn, TC)), dim3(1024), 0, st,
-                     dA_part, dA_log, d.B * d.nchunks, d.Dn);
+  const int64_t rows = d.B * d.nchunks;
+  const unsigned ctiles = (unsigned)ceil_div64(d.Dn, TC);
+  if (rows <= 128) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctiles), dim3(1024), 0, st, dA_part, dA_log, rows, d.Dn, rows);
+  } else {
+    const int64_t groups = std::min<int64_t>(64, ceil_div64(rows, 64)), rpg = ceil_div64(rows, groups);
+    const int64_t ng = ceil_div64(rows, rpg);   // <= groups <= rows: fits the head of mu_in
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctiles, (unsigned)ng), dim3(1024), 0, st, dA_part, mu_in, rows, d.Dn, rpg);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctiles), dim3(1024), 0, st, mu_in, dA_log, ng, d.Dn, ng);
+  }
   return apertis_check_launch();
 }
 
