@@ -153,12 +153,13 @@ __device__ __forceinline__ float chunk_carry(const float2 *__restrict__ agg, con
 
 // ---------------------------------------------------------------------------------------
 // pass 1 (forward): per-chunk aggregate (P = prod a, S = state from zero) -> agg[b][j][c]
-template <typename TIN, int VB, int LT>
-__global__ void __launch_bounds__(NTHREADS)
+template <typename TIN, int VB, int LT, int NS>
+__global__ void __launch_bounds__(TC * NS)
 scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
                const TIN *__restrict__ Bt, int64_t bt_rs, float2 *__restrict__ agg, ScanDims d) {
   constexpr int ROWB = TC * sizeof(TIN);
-  constexpr int TS = LT / NSEG;
+  constexpr int TS = LT / NS;
+  constexpr int NTH = TC * NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TIN *bt = reinterpret_cast<TIN *>(smem);
   float *dl = reinterpret_cast<float *>(smem + LT * ROWB);
@@ -172,10 +173,10 @@ scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
   const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
   const int64_t tok0 = (int64_t)b * d.L + t0;
 
-  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt),
+  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(bt),
                          reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
                          bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
+  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
   const float A2 = c < d.Dn ? -expf(A_log[c]) * LOG2E_F : 0.f;
   __syncthreads();
 
@@ -192,7 +193,7 @@ scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
   __syncthreads();
   if (seg == 0 && c < d.Dn) {
 #pragma unroll
-    for (int s = 1; s < NSEG; ++s) {
+    for (int s = 1; s < NS; ++s) {
       float2 q = segs[s * TC + lane];
       S = fmaf(q.x, S, q.y);
       P *= q.x;
@@ -202,20 +203,25 @@ scan_fwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
 }
 
 // pass 2 (forward): compose the carry-in from the other chunks' aggregates, replay the chunk, write y
-template <typename TIN, typename TY, int VB, int LT>
-__global__ void __launch_bounds__(NTHREADS)
+// The forward walks chunks of LT = 128 tokens on NS = 8 waves (a quarter of the look-back reads of 64-token chunks:
+// half as many work-groups, each composing half as many aggregates - at 64 tokens the look-back moved as many bytes
+// through L2 as the tile loads did); the backward keeps 64-token chunks (its fp32 dy tile would halve the work-groups
+// per CU at 128), so the carry-in is saved at 64-token granularity: h_in[b][2*chunk + {0,1}] from waves 0 and NS/2.
+template <typename TIN, typename TY, int VB, int LT, int NS>
+__global__ void __launch_bounds__(TC * NS)
 scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
                 const TIN *__restrict__ Bt, int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs,
                 const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in,
-                float *__restrict__ h_last, TY *__restrict__ y, int64_t y_rs, ScanDims d) {
+                float *__restrict__ h_last, TY *__restrict__ y, int64_t y_rs, ScanDims d, int64_t nch64) {
   constexpr int ROWB = TC * sizeof(TIN);
-  constexpr int TS = LT / NSEG;
+  constexpr int TS = LT / NS;
+  constexpr int NTH = TC * NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TIN *bt = reinterpret_cast<TIN *>(smem);
   TIN *cc = reinterpret_cast<TIN *>(smem + LT * ROWB);
   float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB);
   float2 *segs = reinterpret_cast<float2 *>(smem + 2 * LT * ROWB + LT * d.HT * 4);
-  float2 *lk = segs + NSEG * TC;
+  float2 *lk = segs;   // look-back table: aliases segs (barrier below)
 
   const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
   const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
@@ -225,18 +231,18 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
   const int64_t tok0 = (int64_t)b * d.L + t0;
 
-  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt),
+  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(bt),
                          reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
                          bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc),
+  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(cc),
                          reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
                          c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
+  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
   const bool chan_ok = c < d.Dn;
   const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
   // carry-in from the other chunks' aggregates (its barrier also covers the staged tiles)
-  float hcar = chunk_carry(agg, h0, b, chunk, c, chan_ok, d, seg, lane, lk, false);
-  if (seg == 0 && chan_ok) h_in[((int64_t)b * d.nchunks + chunk) * d.Dn + c] = hcar;   // saved for the backward
+  float hcar = chunk_carry<NS>(agg, h0, b, chunk, c, chan_ok, d, seg, lane, lk, false);
+  __syncthreads();   // every wave has read lk before segs (same LDS) is written
 
   float a[TS];
   float P = 1.f, S = 0.f;
@@ -253,6 +259,11 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
   for (int s = 0; s < seg; ++s) {
     float2 q = segs[s * TC + lane];
     hcar = fmaf(q.x, hcar, q.y);
+  }
+  // state entering each 64-token half of the chunk, saved for the backward
+  if ((seg == 0 || seg == NS / 2) && chan_ok) {
+    const int64_t j64 = (int64_t)chunk * (LT / 64) + (seg ? 1 : 0);
+    if (j64 < nch64) h_in[((int64_t)b * nch64 + j64) * d.Dn + c] = hcar;
   }
   float hst = hcar;
   if constexpr (sizeof(TY) == 4) {
@@ -279,12 +290,12 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
     __syncthreads();
     // y rows are contiguous [.., Dn]; alignment of the y slice may be lower than Bt's: use 2 B
     // granularity unless y_rs and c0 allow wider (decided by the host through VB of y == VB)
-    stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(cc),
+    stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(cc),
                             reinterpret_cast<char *>(y + tok0 * y_rs + c0), y_rs * sizeof(TY),
                             rows_valid, ch_valid * (int)sizeof(TY), tid);
   }
   // final state (padding tokens are identities, so the last segment's state is s_{L-1})
-  if (h_last && chunk == d.nchunks - 1 && seg == NSEG - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
+  if (h_last && chunk == d.nchunks - 1 && seg == NS - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -440,14 +451,15 @@ scan_fwd_fused(const float *__restrict__ dlt, const float *__restrict__ A_log, c
 // ---------------------------------------------------------------------------------------
 // backward pass 1: reverse chunk aggregates (P = prod a, M = mu at chunk start from zero)
 //   u_t = dy_t*C_t,  mu_t = a_t*(u_t + mu_{t+1})
-template <typename TIN, typename TY, int VB, int VBY, int LT>
-__global__ void __launch_bounds__(NTHREADS)
+template <typename TIN, typename TY, int VB, int VBY, int LT, int NS>
+__global__ void __launch_bounds__(TC * NS)
 scan_bwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
                const TIN *__restrict__ C, int64_t c_rs, const TY *__restrict__ dy, int64_t dy_rs,
                float2 *__restrict__ agg, ScanDims d) {
   constexpr int ROWB = TC * sizeof(TIN);
   constexpr int ROWY = TC * sizeof(TY);
-  constexpr int TS = LT / NSEG;
+  constexpr int TS = LT / NS;
+  constexpr int NTH = TC * NS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   TIN *cc = reinterpret_cast<TIN *>(smem);
   TY *gy = reinterpret_cast<TY *>(smem + LT * ROWB);
@@ -462,13 +474,13 @@ scan_bwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
   const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
   const int64_t tok0 = (int64_t)b * d.L + t0;
 
-  stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc),
+  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(cc),
                          reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
                          c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-  stage_in<VBY, ROWY, LT>(reinterpret_cast<char *>(gy),
+  stage_in<VBY, ROWY, LT, NTH>(reinterpret_cast<char *>(gy),
                           reinterpret_cast<const char *>(dy + tok0 * dy_rs + c0),
                           dy_rs * sizeof(TY), rows_valid, ch_valid * (int)sizeof(TY), tid);
-  stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
+  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
   const float A2 = c < d.Dn ? -expf(A_log[c]) * LOG2E_F : 0.f;
   __syncthreads();
 
@@ -486,10 +498,10 @@ scan_bwd_state(const float *__restrict__ dlt, const float *__restrict__ A_log,
   __syncthreads();
   if (seg == 0 && c < d.Dn) {
     // compose right-to-left: start from the last segment
-    float2 q = segs[(NSEG - 1) * TC + lane];
+    float2 q = segs[(NS - 1) * TC + lane];
     float Pt = q.x, Mt = q.y;
 #pragma unroll
-    for (int s = NSEG - 2; s >= 0; --s) {
+    for (int s = NS - 2; s >= 0; --s) {
       float2 r = segs[s * TC + lane];
       Mt = fmaf(r.x, Mt, r.y);
       Pt *= r.x;
@@ -659,7 +671,8 @@ int ilog2_exact(int64_t n) {
   return (1LL << l) == n ? l : -1;
 }
 
-constexpr int LT_DEFAULT = 64;
+constexpr int LT_DEFAULT = 64;   // chunk length of the ABI's workspaces (agg, h_in, dA_part) and of the backward
+constexpr int LT_FWD = 128, NS_FWD = 8;   // the forward's own chunking
 
 int make_dims(ScanDims &d, int64_t B, int64_t L, int64_t h, int64_t N, int softplus) {
   if (B <= 0 || L <= 0 || h <= 0 || N <= 0) return APERTIS_ERR_ARG;
@@ -692,17 +705,22 @@ namespace {
 template <typename TIN, typename TY, int VB>
 int launch_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
                int64_t c_rs, const float *h0, void *y, int64_t y_rs, float *h_last, float *agg,
-               float *h_in, const ScanDims &d, hipStream_t st) {
-  constexpr int LT = LT_DEFAULT;
-  dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
+               float *h_in, const ScanDims &d64, hipStream_t st) {
+  constexpr int LT = LT_FWD, NS = NS_FWD;
+  static_assert(LT == 2 * LT_DEFAULT && (NS / 2) * (LT / NS) == LT_DEFAULT, "h_in is exported at LT_DEFAULT granularity by waves 0 and NS/2");
+  ScanDims d = d64;
+  d.nchunks = (int)ceil_div64(d.L, LT);   // the forward's own chunking (agg needs no more than the ABI's workspace)
+  dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(TC * NS);
   size_t dlb = (size_t)LT * d.HT * 4;
-  size_t lds1 = LT * TC * sizeof(TIN) + dlb + NSEG * TC * sizeof(float2);
-  size_t lds3 = 2 * LT * TC * sizeof(TIN) + dlb + 2 * NSEG * TC * sizeof(float2);
-  hipLaunchKernelGGL((scan_fwd_state<TIN, VB, LT>), grid, block, lds1, st, dlt, A_log,
+  size_t lds1 = LT * TC * sizeof(TIN) + dlb + NS * TC * sizeof(float2);
+  size_t lds3 = 2 * LT * TC * sizeof(TIN) + dlb + NS * TC * sizeof(float2);
+  hipLaunchKernelGGL((scan_fwd_state<TIN, VB, LT, NS>), grid, block, lds1, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (float2 *)agg, d);
-  hipLaunchKernelGGL((scan_fwd_replay<TIN, TY, VB, LT>), grid, block, lds3, st, dlt, A_log,
+  if (lds3 > 64 * 1024)   // fp32 tiles: 70 KiB
+    hipFuncSetAttribute((const void *)scan_fwd_replay<TIN, TY, VB, LT, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+  hipLaunchKernelGGL((scan_fwd_replay<TIN, TY, VB, LT, NS>), grid, block, lds3, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const float2 *)agg, h0, h_in, h_last, (TY *)y,
-                     y_rs, d);
+                     y_rs, d, (int64_t)d64.nchunks);
   return apertis_check_launch();
 }
 
@@ -743,10 +761,10 @@ int launch_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
   constexpr int LT = LT_DEFAULT;
   dim3 grid(d.nchunks, (unsigned)ceil_div64(d.Dn, TC), (unsigned)d.B), block(NTHREADS);
   size_t dlb = (size_t)LT * d.HT * 4;
-  size_t lds1 = LT * TC * (sizeof(TIN) + sizeof(TY)) + dlb + NSEG * TC * sizeof(float2);
-  constexpr int NS3 = 8;   // waves per work-group of the replay pass
+  constexpr int NS3 = 8;   // waves per work-group of both streaming passes
+  size_t lds1 = LT * TC * (sizeof(TIN) + sizeof(TY)) + dlb + NS3 * TC * sizeof(float2);
   size_t lds3 = LT * TC * (2 * sizeof(TIN) + sizeof(TY)) + 2 * dlb + NS3 * TC * 3 * sizeof(float);
-  hipLaunchKernelGGL((scan_bwd_state<TIN, TY, VB, VBY, LT>), grid, block, lds1, st, dlt, A_log,
+  hipLaunchKernelGGL((scan_bwd_state<TIN, TY, VB, VBY, LT, NS3>), grid, dim3(TC * NS3), lds1, st, dlt, A_log,
                      (const TIN *)C, c_rs, (const TY *)dy, dy_rs, (float2 *)agg, d);
   hipLaunchKernelGGL((scan_bwd_replay<TIN, TY, VB, VBY, LT, NS3>), grid, dim3(TC * NS3), lds3, st, dlt, A_log,
                      (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, (const TY *)dy, dy_rs, h_in,
