@@ -1480,7 +1480,6 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
 // (entry q < N*K is dW[q], the next N are db; thread p owns q = p, p + 128, ...), folded in a fixed order.
 // ------------------------------------------------------------------------------------------
 constexpr int TL_MAXK = 64, TL_MAXN = 16, TL_ROWS = 128;
-constexpr int TL_ACC = (TL_MAXN * TL_MAXK + TL_MAXN + TL_ROWS - 1) / TL_ROWS;   // dW/db entries per thread
 
 // a thread's K-element row slice -> floats.  VEC: 16-byte loads (row start 16-byte aligned, the slice rounded
 // up to whole chunks stays inside the row); lanes hold different rows ~ld apart, so every load instruction
@@ -1517,38 +1516,58 @@ __device__ __forceinline__ void tl_load_row(const TX *row, int K, float (&xr)[TL
   }
 }
 
-template <typename TX, bool VEC>
-__global__ void __launch_bounds__(TL_ROWS)
-tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ b,
-                  float *__restrict__ y, int64_t T, int K, int N) {
-  __shared__ float sW[TL_MAXN * TL_MAXK + TL_MAXN];
-  for (int i = threadIdx.x; i < N * K; i += TL_ROWS) sW[i] = W[i];
-  for (int i = threadIdx.x; i < N; i += TL_ROWS) sW[N * K + i] = b ? b[i] : 0.f;
-  __syncthreads();
-  for (int64_t t = (int64_t)blockIdx.x * TL_ROWS + threadIdx.x; t < T; t += (int64_t)gridDim.x * TL_ROWS) {
-    float xr[TL_MAXK];
-    tl_load_row<TX, VEC>(x + t * ldx, K, xr);
-    for (int j = 0; j < N; ++j) {
-      float a = sW[N * K + j];
-#pragma unroll
-      for (int r = 0; r < TL_MAXK; ++r)
-        if (r < K) a = fmaf(xr[r], sW[j * K + r], a);
-      y[t * N + j] = a;
-    }
+// W (and b) in LDS as a zero-padded [TL_MAXN][TL_MAXK] table read four weights at a time (ds_read_b128, all lanes the
+// same address): one LDS instruction per four FMAs instead of one per FMA - the kernels were LDS-issue-bound
+__device__ __forceinline__ void tl_stage_w(float *sW, const float *__restrict__ W, int K, int N) {
+  for (int i = threadIdx.x; i < TL_MAXN * TL_MAXK; i += TL_ROWS) {
+    const int j = i / TL_MAXK, r = i - j * TL_MAXK;
+    sW[i] = (j < N && r < K) ? W[j * K + r] : 0.f;
   }
 }
 
 template <typename TX, bool VEC>
 __global__ void __launch_bounds__(TL_ROWS)
+tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ b,
+                  float *__restrict__ y, int64_t T, int K, int N) {
+  __shared__ __attribute__((aligned(16))) float sW[TL_MAXN * TL_MAXK + TL_MAXN];
+  tl_stage_w(sW, W, K, N);
+  for (int i = threadIdx.x; i < N; i += TL_ROWS) sW[TL_MAXN * TL_MAXK + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  const float4 *sW4 = reinterpret_cast<const float4 *>(sW);
+  for (int64_t t = (int64_t)blockIdx.x * TL_ROWS + threadIdx.x; t < T; t += (int64_t)gridDim.x * TL_ROWS) {
+    float xr[TL_MAXK];
+    tl_load_row<TX, VEC>(x + t * ldx, K, xr);
+    for (int j = 0; j < N; ++j) {
+      float a = sW[TL_MAXN * TL_MAXK + j];
+#pragma unroll
+      for (int r4 = 0; r4 < TL_MAXK / 4; ++r4)
+        if (r4 * 4 < K) {    // the pad entries of the last chunk are zeros on both sides
+          const float4 w = sW4[j * (TL_MAXK / 4) + r4];
+          a = fmaf(xr[4 * r4], w.x, a); a = fmaf(xr[4 * r4 + 1], w.y, a);
+          a = fmaf(xr[4 * r4 + 2], w.z, a); a = fmaf(xr[4 * r4 + 3], w.w, a);
+        }
+      y[t * N + j] = a;
+    }
+  }
+}
+
+// Backward.  dx per row (W four at a time from LDS, as above).  dW/db as per-block partial sums over the row tile
+// staged in LDS: thread p owns the 2 x 4 block dW[2*(p/16) + {0,1}][4*(p%16) + {0..3}] (and db of its two rows when
+// p%16 == 0) and reads one 8-byte dy pair and one 16-byte x chunk per row for eight FMAs; rows are walked in order and
+// the per-block partials folded in a fixed order.
+template <typename TX, bool VEC>
+__global__ void __launch_bounds__(TL_ROWS)
 tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ dy,
                   TX *__restrict__ dx, int64_t lddx, float *__restrict__ part, int64_t T, int K, int N) {
-  __shared__ float sW[TL_MAXN * TL_MAXK];
-  __shared__ float sx[TL_ROWS][TL_MAXK + 1], sdy[TL_ROWS][TL_MAXN + 1];
-  for (int i = threadIdx.x; i < N * K; i += TL_ROWS) sW[i] = W[i];
+  static_assert(TL_ROWS == (TL_MAXN / 2) * (TL_MAXK / 4), "one 2 x 4 block of dW per thread");
+  __shared__ __attribute__((aligned(16))) float sW[TL_MAXN * TL_MAXK];
+  __shared__ __attribute__((aligned(16))) float sx[TL_ROWS][TL_MAXK + 4];
+  __shared__ __attribute__((aligned(16))) float sdy[TL_ROWS][TL_MAXN + 2];
+  tl_stage_w(sW, W, K, N);
+  const float4 *sW4 = reinterpret_cast<const float4 *>(sW);
   const int nq = N * K + N;
-  float acc[TL_ACC];
-#pragma unroll
-  for (int a = 0; a < TL_ACC; ++a) acc[a] = 0.f;
+  const int jb = threadIdx.x >> 4, rb = threadIdx.x & 15;
+  float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accb[2] = {0.f, 0.f};
   for (int64_t t0 = (int64_t)blockIdx.x * TL_ROWS; t0 < T; t0 += (int64_t)gridDim.x * TL_ROWS) {
     const int64_t t = t0 + threadIdx.x;
     const bool live = t < T;
@@ -1557,7 +1576,9 @@ tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
       float xr[TL_MAXK];
       if (live) tl_load_row<TX, VEC>(x + t * ldx, K, xr);
 #pragma unroll
-      for (int r = 0; r < TL_MAXK; ++r) sx[threadIdx.x][r] = live ? xr[r] : 0.f;
+      for (int r4 = 0; r4 < TL_MAXK / 4; ++r4)
+        *reinterpret_cast<float4 *>(&sx[threadIdx.x][4 * r4]) =
+            live ? make_float4(xr[4 * r4], xr[4 * r4 + 1], xr[4 * r4 + 2], xr[4 * r4 + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float dyr[TL_MAXN];
 #pragma unroll
@@ -1571,12 +1592,17 @@ tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
       for (int r0 = 0; r0 < K; r0 += EPC) {
         float a[EPC];
 #pragma unroll
-        for (int u = 0; u < EPC; ++u) {
-          a[u] = 0.f;
+        for (int u = 0; u < EPC; ++u) a[u] = 0.f;
 #pragma unroll
-          for (int j = 0; j < TL_MAXN; ++j)
-            if (j < N && r0 + u < K) a[u] = fmaf(dyr[j], sW[j * K + r0 + u], a[u]);
-        }
+        for (int j = 0; j < TL_MAXN; ++j)
+          if (j < N) {
+#pragma unroll
+            for (int u4 = 0; u4 < EPC / 4; ++u4) {
+              const float4 w = sW4[j * (TL_MAXK / 4) + (r0 >> 2) + u4];   // zeros past K
+              a[4 * u4] = fmaf(dyr[j], w.x, a[4 * u4]); a[4 * u4 + 1] = fmaf(dyr[j], w.y, a[4 * u4 + 1]);
+              a[4 * u4 + 2] = fmaf(dyr[j], w.z, a[4 * u4 + 2]); a[4 * u4 + 3] = fmaf(dyr[j], w.w, a[4 * u4 + 3]);
+            }
+          }
         if (VEC && r0 + EPC <= K) {      // whole 16-byte chunk (the output rows are 16-byte aligned when VEC)
           if constexpr (sizeof(TX) == 2) {
             uint32_t wq[4];
@@ -1596,25 +1622,28 @@ tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
       }
     }
     __syncthreads();
-#pragma unroll
-    for (int a = 0; a < TL_ACC; ++a) {
-      const int q = threadIdx.x + a * TL_ROWS;
-      if (q < N * K) {
-        const int qj = q / K, qr = q - qj * K;
-        float v = acc[a];
-        for (int row = 0; row < TL_ROWS; ++row) v = fmaf(sdy[row][qj], sx[row][qr], v);
-        acc[a] = v;
-      } else if (q < nq) {
-        float v = acc[a];
-        for (int row = 0; row < TL_ROWS; ++row) v += sdy[row][q - N * K];
-        acc[a] = v;
+    if (2 * jb < N && 4 * rb < K) {
+      for (int row = 0; row < TL_ROWS; ++row) {
+        const float2 d = *reinterpret_cast<const float2 *>(&sdy[row][2 * jb]);
+        const float4 xv = *reinterpret_cast<const float4 *>(&sx[row][4 * rb]);
+        acc[0][0] = fmaf(d.x, xv.x, acc[0][0]); acc[0][1] = fmaf(d.x, xv.y, acc[0][1]);
+        acc[0][2] = fmaf(d.x, xv.z, acc[0][2]); acc[0][3] = fmaf(d.x, xv.w, acc[0][3]);
+        acc[1][0] = fmaf(d.y, xv.x, acc[1][0]); acc[1][1] = fmaf(d.y, xv.y, acc[1][1]);
+        acc[1][2] = fmaf(d.y, xv.z, acc[1][2]); acc[1][3] = fmaf(d.y, xv.w, acc[1][3]);
+        if (rb == 0) { accb[0] += d.x; accb[1] += d.y; }
       }
     }
   }
+  float *dst = part + (int64_t)blockIdx.x * nq;
 #pragma unroll
-  for (int a = 0; a < TL_ACC; ++a) {
-    const int q = threadIdx.x + a * TL_ROWS;
-    if (q < nq) part[(int64_t)blockIdx.x * nq + q] = acc[a];
+  for (int jj = 0; jj < 2; ++jj) {
+    const int j = 2 * jb + jj;
+    if (j < N) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (4 * rb + u < K) dst[j * K + 4 * rb + u] = acc[jj][u];
+      if (rb == 0) dst[N * K + j] = accb[jj];
+    }
   }
 }
 

@@ -25,8 +25,9 @@ def timeit(fn, reps=20, warm=3):
     return ts[len(ts) // 2]
 
 
-def scan():
-    for (B, L, h, N, dt) in [(8, 4096, 11, 16, torch.bfloat16), (16, 4096, 11, 16, torch.bfloat16),
+def scan(only_bench_shape=False):
+    shapes = [(32, 4096, 11, 16, torch.bfloat16)] if only_bench_shape else None
+    for (B, L, h, N, dt) in shapes or [(8, 4096, 11, 16, torch.bfloat16), (16, 4096, 11, 16, torch.bfloat16),
                              (32, 4096, 11, 16, torch.bfloat16), (32, 4096, 11, 16, torch.float32),
                              (8, 4096, 4, 16, torch.bfloat16), (32, 2048, 14, 16, torch.bfloat16),
                              (64, 4096, 11, 16, torch.bfloat16)]:
@@ -117,6 +118,8 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("scan", "all"):
         scan()
+    if what == "scan1":          # the bench shape only (for rocprofv3 --kernel-trace --stats)
+        scan(True)
     if what in ("gemm", "all"):
         gemm()
     if what in ("rows", "all"):
