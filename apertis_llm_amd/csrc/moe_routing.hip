@@ -1320,6 +1320,9 @@ router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
   }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Backward, one wave per row (every lane busy, per-row scalar work done once): W in LDS, the dW / dgamma /
 // dbeta accumulators in registers (2 waves per SIMD), the wave's next row prefetched while this one is
 // computed.  (A form with the columns split over the block's waves - small accumulators, more waves - ran
@@ -1381,28 +1384,34 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
     const float mean = lane_val(meta, NN), rstd = lane_val(meta, NN + 1);
     float4 xh[IT], dn[IT];
     float s1 = 0.f, s2 = 0.f;
+    // the row's arithmetic runs on the packed fp32 pipe (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two floats per
+    // lane per instruction, the same IEEE fma per element): the accumulators keep the kernel at one wave per SIMD, where
+    // time follows the instruction count (PMC: VALU busy a third of the time, 494 VALU instructions per row before)
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const bool in = lane + 64 * i < Q;
       const float4 xv = raw_to_f4(xc[i]);
-      xh[i] = in ? make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd)
-                 : make_float4(0, 0, 0, 0);
-      const float4 xn = make_float4(fmaf(xh[i].x, g4[i].x, b4[i].x), fmaf(xh[i].y, g4[i].y, b4[i].y), fmaf(xh[i].z, g4[i].z, b4[i].z),
-                                    fmaf(xh[i].w, g4[i].w, b4[i].w));
-      float4 d = make_float4(0, 0, 0, 0);   // dxn = dlogits @ W
+      const v2f mm = {-mean, -mean}, rs = {rstd, rstd};
+      v2f xh0 = in ? ((v2f){xv.x, xv.y} + mm) * rs : (v2f){0.f, 0.f}, xh1 = in ? ((v2f){xv.z, xv.w} + mm) * rs : (v2f){0.f, 0.f};
+      xh[i] = make_float4(xh0.x, xh0.y, xh1.x, xh1.y);
+      const v2f g0 = {g4[i].x, g4[i].y}, g1 = {g4[i].z, g4[i].w};
+      const v2f xn0 = pk_fma2(xh0, g0, (v2f){b4[i].x, b4[i].y}), xn1 = pk_fma2(xh1, g1, (v2f){b4[i].z, b4[i].w});
+      v2f d0 = {0.f, 0.f}, d1 = {0.f, 0.f};   // dxn = dlogits @ W
 #pragma unroll
       for (int n = 0; n < NN; ++n) {
         const float4 wn = in ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
-        // explicit FMAs: the file is built with -ffp-contract=off (parity kernels), which would make every
-        // accumulation here a multiply and an add - 2x the instructions of a VALU-bound kernel
-        d.x = fmaf(g[n], wn.x, d.x); d.y = fmaf(g[n], wn.y, d.y); d.z = fmaf(g[n], wn.z, d.z); d.w = fmaf(g[n], wn.w, d.w);
-        aw[n][i].x = fmaf(g[n], xn.x, aw[n][i].x); aw[n][i].y = fmaf(g[n], xn.y, aw[n][i].y);
-        aw[n][i].z = fmaf(g[n], xn.z, aw[n][i].z); aw[n][i].w = fmaf(g[n], xn.w, aw[n][i].w);
+        const v2f gn = {g[n], g[n]};
+        d0 = pk_fma2(gn, (v2f){wn.x, wn.y}, d0); d1 = pk_fma2(gn, (v2f){wn.z, wn.w}, d1);
+        v2f a0 = {aw[n][i].x, aw[n][i].y}, a1 = {aw[n][i].z, aw[n][i].w};
+        a0 = pk_fma2(gn, xn0, a0); a1 = pk_fma2(gn, xn1, a1);
+        aw[n][i] = make_float4(a0.x, a0.y, a1.x, a1.y);
       }
-      ag[i].x = fmaf(d.x, xh[i].x, ag[i].x); ag[i].y = fmaf(d.y, xh[i].y, ag[i].y);
-      ag[i].z = fmaf(d.z, xh[i].z, ag[i].z); ag[i].w = fmaf(d.w, xh[i].w, ag[i].w);
-      ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-      dn[i] = make_float4(d.x * g4[i].x, d.y * g4[i].y, d.z * g4[i].z, d.w * g4[i].w);
+      v2f ag0 = pk_fma2(d0, xh0, (v2f){ag[i].x, ag[i].y}), ag1 = pk_fma2(d1, xh1, (v2f){ag[i].z, ag[i].w});
+      ag[i] = make_float4(ag0.x, ag0.y, ag1.x, ag1.y);
+      const v2f ab0 = (v2f){ab[i].x, ab[i].y} + d0, ab1 = (v2f){ab[i].z, ab[i].w} + d1;
+      ab[i] = make_float4(ab0.x, ab0.y, ab1.x, ab1.y);
+      const v2f dn0 = d0 * g0, dn1 = d1 * g1;
+      dn[i] = make_float4(dn0.x, dn0.y, dn1.x, dn1.y);
       s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
       s2 += (dn[i].x * xh[i].x + dn[i].y * xh[i].y) + (dn[i].z * xh[i].z + dn[i].w * xh[i].w);
     }
