@@ -58,7 +58,8 @@ const char *apertis_strerror(int code);
  * core.py:377-385) and batch stride L*row_stride.  y is [B,L,Dn] with row stride y_rs.
  * dtype_bc / dtype_y select fp32 or bf16 storage; state and arithmetic are always fp32.
  *
- * Chunked scan: L is cut into chunks of apertis_scan_chunk_len() tokens.
+ * Chunked scan: the workspaces are laid out in chunks of apertis_scan_chunk_len() tokens (the backward's chunk length;
+ * the forward walks pairs of them and saves the carry-in of each).
  *   agg   : workspace  [B, nchunks, Dn, 2] fp32   (chunk aggregates, scratch)
  *   h_in  : output     [B, nchunks, Dn]    fp32   (state entering each chunk; saved for bwd)
  *   h_last: optional   [B, Dn] fp32 final state (core.py:351 new_ssm_state), may be NULL
@@ -95,7 +96,7 @@ int apertis_selective_scan_fwd_fused(const float *dlt, const float *A_log,
  *   dA_log        : [h*N] fp32 (overwritten)
  *   h_in          : saved by the forward
  *   agg           : workspace [B,nchunks,Dn,2] fp32
- *   mu_in         : reserved (ignored; may be NULL... pass a [B,nchunks,Dn] fp32 buffer for ABI stability)
+ *   mu_in         : workspace [B,nchunks,Dn] fp32, required (its head holds the row-group sums of the two-level dA_log fold)
  *   dA_part       : workspace [B*nchunks, Dn]  fp32
  */
 int apertis_selective_scan_bwd(const float *dlt, const float *A_log,
