@@ -107,7 +107,7 @@ ssm_gate_bwd_k(const TIO *__restrict__ dout, int64_t dout_rs, const TY *__restri
 }
 
 // ---------------------------------------------------------------- depthwise causal conv + SiLU
-constexpr int CONV_TT = 32;  // tokens per thread run
+constexpr int CONV_TT = 16;  // tokens per thread run
 
 template <typename T, int KW>
 __global__ void __launch_bounds__(256)
