@@ -488,7 +488,7 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
 // expert-sorted); at the end the block's four waves are combined in LDS first when they all ended
 // in the same expert, so the common case issues one set of atomics per 32 rows.
 template <typename TX, typename TG, int IT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, IT <= 3 ? 4 : 1)   // narrow rows: <= 128 VGPRs = four waves per SIMD (IT = 3 took 132)
 gather_ln_bwd2_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token, const int32_t *__restrict__ offsets,
                  const float *__restrict__ gamma, const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
                  const TG *__restrict__ dxg, TG *__restrict__ dxr, float *__restrict__ dgamma, float *__restrict__ dbeta,
