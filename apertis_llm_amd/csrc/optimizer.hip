@@ -65,7 +65,10 @@ __global__ void __launch_bounds__(1024) clip_coef_k(const float *__restrict__ pa
   if (threadIdx.x == 0) {
     const float norm = (float)sqrt(sm[0]);
     out[0] = norm;
-    out[1] = fminf(max_norm / (norm + 1e-6f), 1.f);   // clip_grad_norm_: coef clamped to 1
+    // clip_grad_norm_: coef = clamp(max / (norm + 1e-6), max = 1); torch.clamp hands a NaN through (fminf would
+    // turn it into 1 and apply an unclipped step on non-finite gradients)
+    const float c = max_norm / (norm + 1e-6f);
+    out[1] = (c != c) ? c : fminf(c, 1.f);
   }
 }
 

@@ -8,6 +8,7 @@ dispatch and the expert GEMMs run as HIP kernels through libapertis_hip.so (aper
 stock torch (rocBLAS / hipBLASLt) keeps the plain dense projections, LayerNorm, embeddings and
 the loss.  There is no eager fallback for the kernel paths: off-GPU they raise ApertisHipError.
 """
+import functools
 import inspect
 import json
 import logging
@@ -24,6 +25,21 @@ from . import ops
 from .multimodal import UnifiedMultimodalEncoder
 
 logger = logging.getLogger(__name__)
+
+
+def _on_input_device(fn):
+    """Run a module's forward with its first tensor argument's device current.  Stock torch ops guard themselves; the
+    C-ABI kernels launch on the CURRENT HIP device and stream, so a model placed on cuda:1 without
+    torch.cuda.set_device(1) (the reference's trainer never calls it, pipeline.py:447-460) would otherwise launch its
+    kernels on GPU 0's stream.  No-op when the device is already current or the input is not on a GPU."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        t = next((a for a in (*args, *kwargs.values()) if isinstance(a, torch.Tensor)), None)
+        if t is None or not t.is_cuda or t.device.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with ops.device_guard(t):
+            return fn(self, *args, **kwargs)
+    return wrapper
 
 
 # ----------------------------------------------------------------------------------------------
@@ -303,6 +319,7 @@ class SelectiveLinearAttention(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, self.hidden_size, bias=False)
         self.use_cache = False
 
+    @_on_input_device
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions: bool = False, use_cache: bool = False):
         self.use_cache = use_cache
@@ -422,6 +439,7 @@ class AdaptiveExpertSystem(nn.Module):
             self.expert_ln_weight.fill_(1.0)
             self.expert_ln_bias.zero_()
 
+    @_on_input_device
     def forward(self, hidden_states, lazy_combine=False):
         zero = hidden_states.new_zeros(())
         if self.num_experts <= 0 or self.router is None:
@@ -718,6 +736,7 @@ class ApertisModel(nn.Module):
             return None
         return (1.0 - allow.to(inputs_embeds.dtype)) * torch.finfo(inputs_embeds.dtype).min
 
+    @_on_input_device
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, pixel_values=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None):
@@ -838,6 +857,7 @@ class ApertisForCausalLM(nn.Module):
         self.config.vocab_size = self.lm_head.out_features
         return self.lm_head
 
+    @_on_input_device
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, pixel_values=None, labels=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None):

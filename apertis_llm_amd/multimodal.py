@@ -5,12 +5,35 @@ Patch embedding runs as a GEMM on the MFMA tile: stride == kernel, so Conv2d(3, 
 (module.py:35-40,102-103).  The 12-layer ViT body stays stock nn.TransformerEncoderLayer on
 ROCm (not a kernel target, ~98.7 % of the encoder FLOPs).
 """
+import threading
 from typing import List
 
 import torch
 import torch.nn as nn
 
 from . import ops
+
+
+_fp_lock = threading.Lock()
+_fp_depth = 0
+_fp_saved = True
+
+
+def _fastpath_enter():
+    global _fp_depth, _fp_saved
+    with _fp_lock:
+        if _fp_depth == 0:
+            _fp_saved = torch.backends.mha.get_fastpath_enabled()
+            torch.backends.mha.set_fastpath_enabled(False)
+        _fp_depth += 1
+
+
+def _fastpath_exit():
+    global _fp_depth
+    with _fp_lock:
+        _fp_depth -= 1
+        if _fp_depth == 0:
+            torch.backends.mha.set_fastpath_enabled(_fp_saved)
 
 
 class UnifiedMultimodalEncoder(nn.Module):
@@ -54,6 +77,10 @@ class UnifiedMultimodalEncoder(nn.Module):
 
     def embed_patches(self, pixel_values: torch.Tensor) -> torch.Tensor:
         """Patch-embed stage of forward() (module.py:102-103) -> [B, num_patches, Dv]."""
+        with ops.device_guard(pixel_values):
+            return self._embed_patches(pixel_values)
+
+    def _embed_patches(self, pixel_values: torch.Tensor) -> torch.Tensor:
         cols = self.patchify(pixel_values)
         cd = cols.dtype
         if torch.is_autocast_enabled():
@@ -65,16 +92,16 @@ class UnifiedMultimodalEncoder(nn.Module):
         B = pixel_values.shape[0]
         patches = self.embed_patches(pixel_values).to(self.vision_pos_embed.dtype)
         x = torch.cat([self.cls_token.expand(B, -1, -1), patches], dim=1) + self.vision_pos_embed   # module.py:106-110
-        # torch's fused inference "fast path" for TransformerEncoderLayer loses ~1e-4 on ROCm
-        # (measured: 1.4e-4 vs 3e-7 abs error against fp64 for one layer); parity with the
-        # reference's fp32 CPU path needs the regular op-by-op path
-        fast = torch.backends.mha.get_fastpath_enabled()
-        torch.backends.mha.set_fastpath_enabled(False)
+        # torch's fused inference "fast path" for TransformerEncoderLayer loses ~1e-4 on ROCm (measured: 1.4e-4 vs 3e-7
+        # abs error against fp64 for one layer); parity with the reference's fp32 CPU path needs the op-by-op path.
+        # The switch is process-global and the reference runs training in daemon threads (interface.py:1188): it is
+        # flipped under a lock that counts the forwards inside, restored when the last one leaves.
+        _fastpath_enter()
         try:
             for layer in self.vision_layers:                                                          # module.py:113-114
                 x = layer(x)
         finally:
-            torch.backends.mha.set_fastpath_enabled(fast)
+            _fastpath_exit()
         return self.vision_ln(x)                                                                      # module.py:117
 
     # -- PIL helpers (module.py:121-161) without the torchvision dependency ----------------------

@@ -53,10 +53,48 @@ def _launch(name, fn, args, work=0.0):
 
 
 def _require_gpu(*ts):
+    """Every tensor of a call lives on ONE ROCm device and that device is the current one: the library launches on the
+    current HIP device and on torch's current stream of it (`_lib.stream_ptr`), so a tensor elsewhere would be touched
+    by a kernel on another GPU's stream.  The model's forward switches to its tensors' device (`device_guard`); a
+    direct caller of an op on a non-current device gets this error instead of a silent cross-device launch."""
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise ApertisHipError("apertis_llm_amd ops run on a ROCm device only (tensor on %s); "
                                   "there is no CPU fallback" % t.device)
+        if dev is None:
+            dev = t.device.index
+        elif t.device.index != dev:
+            raise ApertisHipError(f"tensors of one call on different devices (cuda:{dev} and {t.device})")
+    if dev is not None and dev != torch.cuda.current_device():
+        raise ApertisHipError(f"tensor on cuda:{dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                              "call torch.cuda.set_device() / run under `with torch.cuda.device(t.device)` "
+                              "(apertis_llm_amd.ops.device_guard)")
+
+
+class device_guard:
+    """`with device_guard(t):` makes t's device the current one for the block (no-op when it already is, or off-GPU)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        self.idx = t.device.index if (t is not None and t.is_cuda) else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+            self.prev = None
+        return False
 
 
 def _rows(t, width):
@@ -1176,7 +1214,10 @@ class _ShiftedCrossEntropy(torch.autograd.Function):
         row_loss = torch.empty(B * L, device=logits.device, dtype=torch.float32)
         check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(labels), ptr(lse), ptr(row_loss), B, L, V, labels.shape[1], n_pos,
                                             ignore_index, dtype_code(logits), stream_ptr()), "apertis_cross_entropy_fwd")
-        count = (labels[:, 1:n_pos + 1] != ignore_index).sum().to(torch.float32)   # 0 targets -> nan, like F.cross_entropy
+        # the same predicate as the kernel (a label outside [0, V) is skipped there): 0 targets -> nan, like
+        # F.cross_entropy; out-of-range labels are rejected by shifted_cross_entropy() unless it was told not to look
+        tgt = labels[:, 1:n_pos + 1]
+        count = ((tgt != ignore_index) & (tgt >= 0) & (tgt < V)).sum().to(torch.float32)
         ctx.save_for_backward(logits, labels, lse, count)
         ctx.cfg = (n_pos, ignore_index)
         return row_loss.sum() / count

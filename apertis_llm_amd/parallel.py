@@ -46,6 +46,7 @@ class BucketedDataParallel(nn.Module):
         self.reduce_dtype = reduce_dtype
         self._sync = True
         self.copied_bytes = 0     # gradient bytes the hooks had to move into the buckets (diagnostic)
+        self.reduced_bytes = 0    # bytes handed to all_reduce so far, in the wire dtype (diagnostic; bench.py reports it)
         self._warned_partial = False
         import os as _os
         self._force = _os.environ.get("APERTIS_FORCE_DP") == "1"
@@ -117,6 +118,8 @@ class BucketedDataParallel(nn.Module):
 
     def _launch(self, b: _Bucket):
         inv = 1.0 / self.world_size
+        wire_dt = self.reduce_dtype if (self._cuda and self.reduce_dtype is not None) else b.flat.dtype
+        self.reduced_bytes += b.flat.numel() * torch.empty((), dtype=wire_dt).element_size()
         if self._cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.device))

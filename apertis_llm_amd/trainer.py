@@ -75,11 +75,6 @@ class ApertisTrainer:
         if distributed_training:
             if self.local_rank == -1:
                 self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
-            if not dist.is_initialized():
-                dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-            self.world_size = dist.get_world_size()
-            self.is_main_process = self.local_rank == 0
-        if distributed_training:
             self.device = torch.device(f"cuda:{self.local_rank}" if torch.cuda.is_available() else "cpu")
         elif gpu_ids and torch.cuda.is_available():
             self.device = torch.device(f"cuda:{gpu_ids[0]}")
@@ -87,6 +82,18 @@ class ApertisTrainer:
             self.device = torch.device(device)
         else:
             self.device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+        if self.device.type == "cuda":
+            # the HIP kernels launch on the CURRENT device and stream (stock torch ops guard themselves, which is why
+            # the reference's trainer gets away without this call, pipeline.py:447-460)
+            torch.cuda.set_device(self.device)
+        if distributed_training:
+            if not dist.is_initialized():
+                if self.device.type == "cuda":
+                    dist.init_process_group(backend="nccl", device_id=self.device)
+                else:
+                    dist.init_process_group(backend="gloo")
+            self.world_size = dist.get_world_size()
+            self.is_main_process = self.local_rank == 0
         if use_gradient_checkpointing and hasattr(model, "gradient_checkpointing_enable"):
             model.gradient_checkpointing_enable()
         model.to(self.device)

@@ -54,17 +54,34 @@ class ApertisAdamW(torch.optim.Optimizer):
         self._tables = None
         self.last_grad_norm = None
 
+    def load_state_dict(self, state_dict):
+        """The loaded moments are new tensors: the cached device tables point at the old ones."""
+        super().load_state_dict(state_dict)
+        self._tables = None
+
+    def _key(self):
+        """Everything the cached device tables depend on: parameter, gradient and both moment addresses, and the
+        per-parameter step (parameters that share a step share a launch)."""
+        key = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state.get(p) or {}
+                m, v, stp = st.get("exp_avg"), st.get("exp_avg_sq"), st.get("step")
+                key.append((p.data_ptr(), p.grad.data_ptr(), None if m is None else m.data_ptr(),
+                            None if v is None else v.data_ptr(), None if stp is None else id(stp)))
+        return key
+
     def _build_tables(self):
         from . import _lib
         import numpy as np
         lib = _lib.load()
         chunk = int(lib.apertis_opt_chunk_elems())
-        tables, key, n_total = [], [], 0
-        for group in self.param_groups:
+        tables, n_total = [], 0
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
-            rec = np.zeros((len(ps), 5), dtype=np.int64)
-            ct, ci = [], []
-            for i, p in enumerate(ps):
+            for p in ps:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous()
                         and p.grad.is_contiguous()):
                     raise _lib.ApertisHipError("ApertisAdamW needs contiguous fp32 CUDA parameters and gradients")
@@ -73,29 +90,36 @@ class ApertisAdamW(torch.optim.Optimizer):
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-                nc = -(-p.numel() // chunk)
-                ct.append(np.full(nc, i, dtype=np.int32))
-                ci.append(np.arange(nc, dtype=np.int32))
-                key.append((p.data_ptr(), p.grad.data_ptr()))
-            dev = ps[0].device if ps else None
-            ct = np.concatenate(ct) if ct else np.zeros(0, np.int32)
-            ci = np.concatenate(ci) if ci else np.zeros(0, np.int32)
-            tables.append(dict(params=ps, n=len(ct), first=n_total,
-                               rec=torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev) if ps else None,
-                               ct=torch.from_numpy(ct).to(dev) if ps else None,
-                               ci=torch.from_numpy(ci).to(dev) if ps else None))
-            n_total += len(ct)
-        dev = next((t["params"][0].device for t in tables if t["params"]), None)
-        self._tables = dict(groups=tables, key=key, n_total=n_total,
+                elif st["step"].is_cuda:         # a state dict saved by torch's fused / capturable AdamW
+                    st["step"] = st["step"].detach().cpu()
+            # torch.optim.AdamW keeps `step` per parameter (bias correction of a parameter that first gets a gradient
+            # late, e.g. the vision tower after text-only steps, starts at 1): one launch per distinct step value
+            by_step = {}
+            for p in ps:
+                by_step.setdefault(int(self.state[p]["step"].item()), []).append(p)
+            for step0, sub in sorted(by_step.items()):
+                rec = np.zeros((len(sub), 5), dtype=np.int64)
+                ct, ci = [], []
+                for i, p in enumerate(sub):
+                    st = self.state[p]
+                    rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                              p.numel())
+                    nc = -(-p.numel() // chunk)
+                    ct.append(np.full(nc, i, dtype=np.int32))
+                    ci.append(np.arange(nc, dtype=np.int32))
+                dev = sub[0].device
+                ct, ci = np.concatenate(ct), np.concatenate(ci)
+                tables.append(dict(group=gi, params=sub, n=len(ct), first=n_total,
+                                   rec=torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev),
+                                   ct=torch.from_numpy(ct).to(dev), ci=torch.from_numpy(ci).to(dev)))
+                n_total += len(ct)
+        dev = next((t["params"][0].device for t in tables), None)
+        self._tables = dict(groups=tables, key=self._key(), n_total=n_total,
                             partials=torch.empty(max(n_total, 1), device=dev, dtype=torch.float32) if dev is not None else None,
                             norm_coef=torch.zeros(2, device=dev, dtype=torch.float32) if dev is not None else None)
 
     def _tables_current(self):
-        if self._tables is None:
-            return False
-        key = [(p.data_ptr(), p.grad.data_ptr()) for g in self.param_groups for p in g["params"] if p.grad is not None]
-        return key == self._tables["key"]
+        return self._tables is not None and self._key() == self._tables["key"]
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm: Optional[float] = None):
@@ -105,33 +129,31 @@ class ApertisAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self._tables_current():       # gradients were reallocated (zero_grad(set_to_none=True)) or first call
+        if not self._tables_current():       # gradients / moments were reallocated, a parameter joined, or first call
             self._build_tables()
         T = self._tables
         if T["partials"] is None:
             return loss
         lib = _lib.load()
         coef = None
-        if max_grad_norm is not None:
-            for g in T["groups"]:
-                if g["n"]:
+        with torch.cuda.device(T["partials"].device):
+            if max_grad_norm is not None:
+                for g in T["groups"]:
                     check(lib.apertis_grad_sumsq(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"],
                                                  ptr(T["partials"][g["first"]:]), stream_ptr()), "apertis_grad_sumsq")
-            check(lib.apertis_clip_coef(ptr(T["partials"]), T["n_total"], float(max_grad_norm), ptr(T["norm_coef"]),
-                                        stream_ptr()), "apertis_clip_coef")
-            coef = T["norm_coef"]
-            self.last_grad_norm = coef[0]
-        for group, g in zip(self.param_groups, T["groups"]):
-            if not g["n"]:
-                continue
-            st0 = self.state[g["params"][0]]
-            step = int(st0["step"].item()) + 1
-            for p in g["params"]:
-                self.state[p]["step"] += 1
-            b1, b2 = group["betas"]
-            check(lib.apertis_adamw_step(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"], float(group["lr"]), float(b1),
-                                         float(b2), float(group["eps"]), float(group["weight_decay"]), step, ptr(coef),
-                                         stream_ptr()), "apertis_adamw_step")
+                check(lib.apertis_clip_coef(ptr(T["partials"]), T["n_total"], float(max_grad_norm), ptr(T["norm_coef"]),
+                                            stream_ptr()), "apertis_clip_coef")
+                coef = T["norm_coef"]
+                self.last_grad_norm = coef[0]
+            for g in T["groups"]:
+                group = self.param_groups[g["group"]]
+                step = int(self.state[g["params"][0]]["step"].item()) + 1
+                for p in g["params"]:
+                    self.state[p]["step"] += 1
+                b1, b2 = group["betas"]
+                check(lib.apertis_adamw_step(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"], float(group["lr"]), float(b1),
+                                             float(b2), float(group["eps"]), float(group["weight_decay"]), step, ptr(coef),
+                                             stream_ptr()), "apertis_adamw_step")
         return loss
 
 

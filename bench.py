@@ -6,8 +6,11 @@
 A "step" is one data-parallel training step (bf16-autocast forward + loss + backward +
 gradient all-reduce + clip + AdamW) of the BASELINE.json model on synthetic random tokens,
 random-init weights, reference-default dropout / noisy routing / expert capacity.
-N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...`,
-one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+N>1: one rank per GPU over RCCL.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N ...`:
+RANK / LOCAL_RANK / WORLD_SIZE in the environment) this file is a rank; invoked plainly as
+`python bench.py --gpus N` it starts the N ranks itself as child processes (before any HIP call is made in
+the parent; nothing is exec'ed from a process that has touched the GPU) and relays rank 0's line.
+`--gpus` must equal the world size.  Rank 0 prints ONE JSON line (the last line of stdout).
 """
 import argparse
 import json
@@ -32,17 +35,122 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 
+def launch_ranks(n, argv):
+    """Parent of a self-launched N-rank run (reference: DDP ranks of pipeline.py:435-447,463,501-505, which the
+    reference leaves to an external launcher).  Starts N children of this file with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, never imports torch, relays rank 0's JSON line as its own last stdout line and returns non-zero if
+    any child failed (the others are then terminated so that nobody waits in a rendezvous for ever)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # rank 0's stdout carries the result line; the other ranks' stdout joins stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    lines = [ln.rstrip("\n") for ln in out0 if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)
+    if rc == 0 and not (lines and lines[-1].lstrip().startswith("{")):
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+def launcher_selftest(args, rank, world):
+    """The rank protocol of main() on CPU over gloo with a stub step (a tiny Linear model through
+    BucketedDataParallel): rendezvous, barrier-bracketed timing, MAX over ranks, one JSON line from rank 0.
+    Used by tests/test_bench_launcher_cpu.py; the line is marked as a self-test, never a measurement."""
+    import torch
+    import torch.distributed as dist
+    from apertis_llm_amd.parallel import BucketedDataParallel
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Linear(32, 32)
+    dp = BucketedDataParallel(model) if world > 1 else None
+    gen = torch.Generator().manual_seed(1000 + rank)
+
+    def step():
+        model(torch.randn(8, 32, generator=gen)).square().mean().backward()
+        if dp is not None:
+            dp.finish()
+            dp.zero_grad()
+        else:
+            model.zero_grad()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    reduced = dp.reduced_bytes // max(args.steps + args.warmup, 1) if dp is not None else 0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+        ranks = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks = 1
+    if rank == 0:
+        print(json.dumps({"metric": "LAUNCHER SELF-TEST (stub step on CPU over gloo; not a measurement)",
+                          "value": 8 * world * args.steps / elapsed, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "selftest": True,
+                          "config": {"workload": "stub", "parallelism": f"dp{world}", "rccl_ranks": ranks,
+                                     "allreduce_bytes_per_step": reduced}}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # SURVEY 8(d): 10 warm-up, >= 50 timed steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="1.5b-moe", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU micro-batch (0 = config default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="CPU/gloo self-test of the rank launcher and the timing protocol (tests/): no GPU work, "
+                         "the line says so and is not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: be the launcher.  Nothing above this line imports torch or touches HIP.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -51,8 +159,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line for a "
+                         "different number of ranks than was asked for")
+    if args.launcher_selftest:
+        raise SystemExit(launcher_selftest(args, rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -146,6 +256,9 @@ def main():
                                f"{n_params / 1e6:.0f}M params, train step fwd+loss+bwd+allreduce+clip+AdamW, "
                                f"reference-default dropout/noise/capacity",
                    "global_batch": B * world, "per_gpu_batch": B, "seq_len": seq, "parallelism": f"dp{world}",
+                   "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                   "allreduce_bytes_per_step": (step.dp.reduced_bytes // max(args.steps + args.warmup, 1)
+                                                if getattr(step, "dp", None) is not None else 0),
                    "final_loss": last_loss},
     }
     if rank == 0 and timer is not None:
@@ -179,13 +292,14 @@ def main():
             result["roofline"] = dict(rl[dom], kernel=dom)
             result["roofline_all"] = rl
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # CPU oracle in a CHILD process (never touches the GPU), bounded sample: one layer at
-        # B=1, L=1024 of the same shape; a hard timeout keeps the default run within minutes
+        # CPU oracle in a CHILD process (never touches the GPU), bounded sample: one layer of the same shape at
+        # B=1 and the benchmark's sequence length, train mode, 1 warm-up + median of 3 (about 20 s of CPU work); a
+        # hard timeout keeps the default run within minutes
         import subprocess
         log("cpu baseline (oracle on host cores, child process)")
         argv = [sys.executable, "-m", "oracle.cpu_baseline"] + [str(int(v)) for v in (
             cfg.hidden_size, cfg.num_attention_heads, cfg.ssm_d_state, cfg.intermediate_size, max(cfg.num_experts, 1),
-            max(cfg.experts_per_token, 1), int(moe), 1024, cfg.vocab_size, cfg.num_hidden_layers)]
+            max(cfg.experts_per_token, 1), int(moe), seq, cfg.vocab_size, cfg.num_hidden_layers)]
         try:
             out = subprocess.run(argv, cwd=ROOT, capture_output=True, text=True, timeout=180)
             result["cpu_baseline"] = json.loads(out.stdout.strip().splitlines()[-1])

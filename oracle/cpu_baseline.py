@@ -45,11 +45,13 @@ def _random_layer_state(H, h, N, I, E, R, moe, gen):
     return sd
 
 
-def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, budget_s=25.0, threads=None):
-    """fwd+bwd of ONE layer of the given shape at B=1, seq L, plus the lm_head+CE, through the
-    oracle with torch autograd; extrapolated to n_layers_total layers.  Returns a dict."""
+def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, reps=3):
+    """fwd+bwd of ONE layer of the given shape at B=1 and the benchmark's sequence length L, in TRAIN mode (expert
+    capacity on, dropout p = 0 for determinism), plus the lm_head + CE, through the oracle with torch autograd:
+    one warm-up repetition, then the median of `reps`; extrapolated to n_layers_total layers.  Returns a dict."""
+    avail = os.cpu_count() or 1
     # the recurrence is a Python loop of tiny ops: more threads than ~32 only adds pool overhead
-    threads = threads or min(os.cpu_count() or 1, 32)
+    threads = threads or min(avail, 32)
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(0)
     R = math.ceil(H / 16)
@@ -58,8 +60,6 @@ def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, budget_s=25.0, t
         v.requires_grad_(True)
     emb = (torch.randn(vocab, H, generator=gen) * 0.02).requires_grad_(True)
     ids = torch.randint(4, vocab, (1, L), generator=gen)
-    cfg = dict(hidden_size=H, layer_norm_eps=1e-12, num_hidden_layers=1, num_attention_heads=h, ssm_d_state=N,
-               ssm_dt_rank=R, use_expert_system=moe, num_experts=E, experts_per_token=K, hidden_act="gelu")
 
     def one_layer():
         x = F.embedding(ids, emb)
@@ -68,30 +68,41 @@ def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, budget_s=25.0, t
         x = x + ref_cpu.ssm_layer(sd, lp + "attention.attention_mechanism_impl.", hh, h, N, R)
         hh = F.layer_norm(x, (H,), sd[lp + "feed_forward.pre_norm.weight"], sd[lp + "feed_forward.pre_norm.bias"], 1e-12)
         if moe:
-            f, _, _, _ = ref_cpu.moe_layer(sd, lp + "feed_forward.ffn.", hh, E, K, "gelu", 1e-12, training=False)
-        else:
-            f = F.linear(F.gelu(F.linear(hh, sd[lp + "feed_forward.ffn.0.weight"], sd[lp + "feed_forward.ffn.0.bias"])),
-                         sd[lp + "feed_forward.ffn.3.weight"], sd[lp + "feed_forward.ffn.3.bias"])
-        return x + f
+            f, lb, rz, _ = ref_cpu.moe_layer(sd, lp + "feed_forward.ffn.", hh, E, K, "gelu", 1e-12, training=True)
+            return x + f, lb + rz
+        f = F.linear(F.gelu(F.linear(hh, sd[lp + "feed_forward.ffn.0.weight"], sd[lp + "feed_forward.ffn.0.bias"])),
+                     sd[lp + "feed_forward.ffn.3.weight"], sd[lp + "feed_forward.ffn.3.bias"])
+        return x + f, x.new_zeros(())
 
-    t0 = time.perf_counter()
-    y = one_layer()
-    t_fwd = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    y.sum().backward()
-    t_bwd = time.perf_counter() - t0
-    # head: final LN + tied lm_head + CE, fwd+bwd
-    xh = y.detach().requires_grad_(True)
-    t0 = time.perf_counter()
-    logits = F.linear(F.layer_norm(xh, (H,)), emb)
-    loss = F.cross_entropy(logits[:, :-1].reshape(-1, vocab), ids[:, 1:].reshape(-1))
-    loss.backward()
-    t_head = time.perf_counter() - t0
+    def one_rep():
+        for v in sd.values():
+            v.grad = None
+        emb.grad = None
+        t0 = time.perf_counter()
+        y, aux = one_layer()
+        t_fwd = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        (y.sum() + aux).backward()
+        t_bwd = time.perf_counter() - t0
+        # head: final LN + tied lm_head + CE, fwd+bwd
+        xh = y.detach().requires_grad_(True)
+        t0 = time.perf_counter()
+        logits = F.linear(F.layer_norm(xh, (H,)), emb)
+        loss = F.cross_entropy(logits[:, :-1].reshape(-1, vocab), ids[:, 1:].reshape(-1))
+        loss.backward()
+        t_head = time.perf_counter() - t0
+        return t_fwd, t_bwd, t_head
+
+    one_rep()                                                   # warm-up: allocator, thread pool, page-in
+    runs = sorted(one_rep() for _ in range(reps))               # by forward time; medians taken per leg below
+    med = lambda i: sorted(r[i] for r in runs)[len(runs) // 2]
+    t_fwd, t_bwd, t_head = med(0), med(1), med(2)
     step_s = n_layers_total * (t_fwd + t_bwd) + t_head
-    return {"value": L / step_s, "unit": "tokens/s", "cores": threads, "kind": "port",
+    return {"value": L / step_s, "unit": "tokens/s", "cores": threads, "cores_available": avail, "kind": "port",
             "sample": f"oracle (torch-CPU restatement, sequential-recurrence scan as the reference trainer executes it) "
-                      f"fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, fp32; layer fwd {t_fwd:.2f}s "
-                      f"bwd {t_bwd:.2f}s head {t_head:.2f}s; step time extrapolated as {n_layers_total}x layer + head"}
+                      f"fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, fp32, train mode (expert "
+                      f"capacity on, dropout p=0), 1 warm-up + median of {reps}: layer fwd {t_fwd:.2f}s bwd {t_bwd:.2f}s "
+                      f"head {t_head:.2f}s; step time extrapolated as {n_layers_total}x layer + head"}
 
 
 if __name__ == "__main__":   # child process of bench.py: prints one JSON object

@@ -14,11 +14,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def pytest_collection_modifyitems(config, items):
-    """`-m gpu` tests must never silently pass without a GPU: they fail loudly instead."""
-    pass
-
-
 def load_golden(name):
     import torch
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)

@@ -250,3 +250,32 @@ def test_product_package_never_imports_the_oracle():
     code = "import sys; import apertis_llm_amd, apertis_llm_amd.ops, apertis_llm_amd.training; " \
            "assert not any(m.startswith('oracle') for m in sys.modules)"
     subprocess.run([sys.executable, "-c", code], cwd=ROOT, check=True)
+
+
+def test_device_guard_and_require_gpu_logic(monkeypatch):
+    """The C-ABI kernels launch on the current HIP device and stream: `_require_gpu` refuses tensors that are on
+    another device (or on two devices), `device_guard` switches to the tensor's device and back.  No GPU here: the
+    torch.cuda calls are stubbed and the tensors are stand-ins."""
+    import types
+    import torch
+    from apertis_llm_amd import ops
+    from apertis_llm_amd._lib import ApertisHipError
+    cur = {"dev": 0, "calls": []}
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: cur["dev"])
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: (cur["calls"].append(d), cur.__setitem__("dev", d)))
+    fake = lambda i: types.SimpleNamespace(is_cuda=True, device=types.SimpleNamespace(index=i, type="cuda"))
+    ops._require_gpu(fake(0), None, fake(0))
+    with pytest.raises(ApertisHipError, match="different devices"):
+        ops._require_gpu(fake(0), fake(1))
+    with pytest.raises(ApertisHipError, match="current device"):
+        ops._require_gpu(fake(1))
+    with ops.device_guard(fake(1)):
+        assert cur["dev"] == 1
+        ops._require_gpu(fake(1))
+    assert cur["dev"] == 0 and cur["calls"] == [1, 0]
+    with ops.device_guard(fake(0)):                 # already current: no switch at all
+        pass
+    assert cur["calls"] == [1, 0]
+    with ops.device_guard(torch.zeros(1)):          # CPU tensor: no-op
+        pass
+    assert cur["calls"] == [1, 0]

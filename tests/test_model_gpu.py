@@ -321,3 +321,65 @@ def test_adamw_kernels_match_torch(dev):
     o3 = torch.optim.AdamW(groups([p.detach().clone().requires_grad_(True) for p in mine]), lr=1e-2)
     o3.load_state_dict(o1.state_dict())
     assert sorted(o3.state_dict()["state"][0]) == ["exp_avg", "exp_avg_sq", "step"]
+
+
+def test_adamw_load_state_dict_late_parameters_and_nan_norm(dev):
+    """(i) load_state_dict() after a step must make the kernels use the LOADED moments (the device tables
+    cache raw pointers); (ii) a parameter that first receives a gradient later gets ITS OWN bias correction (torch keeps
+    `step` per parameter); (iii) a non-finite gradient norm propagates (clip_grad_norm_ hands NaN through), it is not
+    turned into an unclipped step."""
+    from apertis_llm_amd.training import ApertisAdamW
+    torch.manual_seed(5)
+    shapes = [(33,), (4097,), (64, 9)]
+    mine = [torch.randn(s, device=dev).requires_grad_(True) for s in shapes]
+    ref = [p.detach().clone().requires_grad_(True) for p in mine]
+    o1, o2 = ApertisAdamW(mine, lr=1e-2), torch.optim.AdamW(ref, lr=1e-2)
+
+    def both(active, scale=1.0):
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if i in active:
+                g = torch.randn_like(a) * scale
+                a.grad, b.grad = g.clone(), g.clone()
+            else:
+                a.grad = b.grad = None
+        o1.step(max_grad_norm=1.0)
+        torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], 1.0)
+        o2.step()
+
+    both({0, 1})            # parameter 2 gets no gradient for two steps ...
+    both({0, 1})
+    both({0, 1, 2})         # ... then joins: its step must be 1, the others' 3
+    assert [float(o1.state[p]["step"]) for p in mine] == [3.0, 3.0, 1.0]
+    for a, b, s in zip(mine, ref, shapes):
+        _close(a.detach(), b.detach(), f"late-parameter run, param {s}", rtol=2e-6, atol_scale=1e-6)
+    # (i) swap in a state dict with different moments: the next step must start from them
+    sd = o2.state_dict()
+    for st in sd["state"].values():
+        st["exp_avg"] = st["exp_avg"] * 3.0 + 0.5
+        st["exp_avg_sq"] = st["exp_avg_sq"] * 2.0 + 0.25
+    o1.load_state_dict(sd)
+    o2.load_state_dict(sd)
+    both({0, 1, 2})
+    for a, b, s in zip(mine, ref, shapes):
+        _close(a.detach(), b.detach(), f"after load_state_dict, param {s}", rtol=2e-6, atol_scale=1e-6)
+        _close(o1.state[a]["exp_avg"], o2.state[b]["exp_avg"], f"exp_avg {s}", rtol=2e-6, atol_scale=1e-6)
+    # (iii) NaN gradient: torch's clip makes every gradient NaN, so does the kernel's coefficient
+    for a in mine:
+        a.grad = torch.randn_like(a)
+    mine[1].grad[7] = float("nan")
+    o1.step(max_grad_norm=1.0)
+    assert torch.isnan(o1.last_grad_norm)
+    assert all(torch.isnan(p).all() for p in mine)
+
+
+def test_ops_refuse_a_tensor_on_a_non_current_device(dev, monkeypatch):
+    """the library launches on the CURRENT HIP device/stream; an op whose tensors live on another
+    device must raise instead of launching on the wrong GPU.  One card on this box: pretend another device is current."""
+    from apertis_llm_amd import ops
+    from apertis_llm_amd._lib import ApertisHipError
+    x = torch.randn(4, 64, device=dev)
+    w, b = torch.ones(64, device=dev), torch.zeros(64, device=dev)
+    ops.layer_norm(x, w, b, 1e-5)                                  # fine on the current device
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    with pytest.raises(ApertisHipError, match="current device"):
+        ops.layer_norm(x, w, b, 1e-5)
