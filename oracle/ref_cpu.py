@@ -297,9 +297,10 @@ def vision_encoder(sd, pre, pixel_values, patch, n_layers, n_heads):
 # ----------------------------------------------------------------------------------------------
 # G1/G2 — ApertisModel / ApertisForCausalLM forward, eval mode (core.py:1142-1307, 1361-1472)
 # ----------------------------------------------------------------------------------------------
-def model_forward(sd, cfg, input_ids, pixel_values=None, labels=None):
+def model_forward(sd, cfg, input_ids, pixel_values=None, labels=None, aux_out=None):
     """cfg: dict with the ApertisConfig fields.  selective_ssm attention, LayerNorm, dense-FFN or
-    MoE feed-forward; eval mode (no dropout / noise / capacity).  Returns (loss, logits)."""
+    MoE feed-forward; eval mode (no dropout / noise / capacity).  Returns (loss, logits).  aux_out: optional list that
+    receives each MoE layer's routing record (gates, idx, ...), for tests that assert a minimum top-k gap."""
     H = cfg["hidden_size"]
     eps = cfg["layer_norm_eps"]
     x = F.embedding(input_ids, sd["model.token_embeddings.weight"])                     # :1158
@@ -318,8 +319,10 @@ def model_forward(sd, cfg, input_ids, pixel_values=None, labels=None):
                           cfg["ssm_d_state"], cfg["ssm_dt_rank"])                        # :699-704,:836-837
         h = F.layer_norm(x, (H,), sd[lp + "feed_forward.pre_norm.weight"], sd[lp + "feed_forward.pre_norm.bias"], eps)  # :888
         if cfg.get("use_expert_system") and cfg.get("num_experts", 0) > 0:
-            f, lb, rz, _ = moe_layer(sd, lp + "feed_forward.ffn.", h, cfg["num_experts"], cfg["experts_per_token"],
-                                     cfg["hidden_act"], eps, training=False)
+            f, lb, rz, aux = moe_layer(sd, lp + "feed_forward.ffn.", h, cfg["num_experts"], cfg["experts_per_token"],
+                                       cfg["hidden_act"], eps, training=False)
+            if aux_out is not None:
+                aux_out.append(aux)
         else:
             f = F.linear(activation(cfg["hidden_act"])(F.linear(h, sd[lp + "feed_forward.ffn.0.weight"],
                                                                 sd[lp + "feed_forward.ffn.0.bias"])),

@@ -279,3 +279,38 @@ def test_device_guard_and_require_gpu_logic(monkeypatch):
     with ops.device_guard(torch.zeros(1)):          # CPU tensor: no-op
         pass
     assert cur["calls"] == [1, 0]
+
+
+def test_config1_125m_on_cpu_matches_reference_capture():
+    """BASELINE config 1 at its stated size (create-model 125M, vocab 32000, B=2, L=512, forward + loss on CPU).
+    standard_mha - what the CLI literally builds - runs through this package's stock-torch fallback; selective_ssm has no
+    CPU path in the product (by design), so on CPU it is the ORACLE that is held to the reference's numbers here and
+    the HIP path to the same fixture in tests/test_configs_gpu.py.  Weights: oracle/seeded.py on both sides."""
+    import json
+    import torch
+    import apertis_llm_amd as A
+    from conftest import load_golden, rel_error_report
+    from oracle import ref_cpu, seeded
+    g = load_golden("config1_125m")
+    ids = g["input_ids"]
+    model = A.create_apertis_model("125M", vocab_size_override=32000)
+    cfg = model.config
+    assert cfg.attention_type == "standard_mha"
+    assert cfg.to_dict() == json.loads(str(g["standard_mha::config_json"]))
+    assert sum(p.numel() for p in model.parameters()) == int(g["standard_mha::n_params"])
+    model.load_state_dict(seeded.fill_state_dict(model.state_dict()))
+    model.eval()
+    with torch.no_grad():
+        loss, logits = model(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids)[:2]
+    rel_error_report("config1_125m standard_mha (CPU) logits sample", logits[:, ::37, ::251], g["standard_mha::logits_sample"],
+                     rtol=1e-4)
+    assert abs(float(loss) - float(g["standard_mha::loss"])) <= 1e-5 * float(g["standard_mha::loss"])
+    del model, logits
+    scfg = json.loads(str(g["selective_ssm::config_json"]))
+    shapes = A.ApertisForCausalLM(A.ApertisConfig.from_dict(scfg)).state_dict()
+    sd = seeded.fill_state_dict(shapes)
+    with torch.no_grad():
+        o_loss, o_logits = ref_cpu.model_forward(sd, scfg, ids, None, ids)
+    rel_error_report("config1_125m selective_ssm ORACLE (CPU) logits sample", o_logits[:, ::37, ::251],
+                     g["selective_ssm::logits_sample"], rtol=1e-4)      # bit-equal at the capture's thread count (4)
+    assert abs(float(o_loss) - float(g["selective_ssm::loss"])) <= 1e-5 * float(g["selective_ssm::loss"])

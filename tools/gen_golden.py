@@ -465,17 +465,58 @@ def gen_trainer_run(core, pipe):
     print("    optimizer steps:", len(lrs), "losses:", losses, "val:", val_losses, "dirs:", list(listing))
 
 
+def gen_config1(core):
+    """BASELINE config 1 at its stated size: `create-model --target-params 125M` (H896 / 10 layers / 14 heads / I3584,
+    vocab 32000), B=2, L=512, forward + loss in eval mode, for BOTH attention types: standard_mha (what the CLI
+    builds) and selective_ssm (the north-star path).  The 100 M weights are not stored: both sides rebuild them from
+    oracle/seeded.py (one generator per state-dict key).  Stored: the token ids, the loss, and a strided sample of
+    the logits."""
+    from oracle import ref_cpu, seeded
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(4, 32000, (2, 512), generator=g)
+    arrs = dict(input_ids=ids)
+    for att in ("standard_mha", "selective_ssm"):
+        torch.manual_seed(0)
+        m = core.create_apertis_model("125M", vocab_size_override=32000, attention_type_override=att)
+        cfg = m.config
+        assert (cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.intermediate_size) == (896, 10, 14, 3584)
+        sd = seeded.fill_state_dict(m.state_dict())
+        m.load_state_dict(sd)
+        m.eval()
+        with torch.no_grad():
+            out = m(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids)
+        arrs[att + "::loss"] = out[0]
+        arrs[att + "::logits_sample"] = out[1][:, ::37, ::251].contiguous()
+        arrs[att + "::logits_absmax"] = out[1].abs().max()
+        arrs[att + "::config_json"] = json.dumps(cfg.to_dict())
+        arrs[att + "::n_params"] = sum(p.numel() for p in m.parameters())
+        msg = f"  config1 {att}: loss {float(out[0]):.6f}"
+        if att == "selective_ssm":
+            o_loss, o_logits = ref_cpu.model_forward(sd, dict(cfg.to_dict()), ids, None, ids)
+            rel = float(((o_logits - out[1]).abs() / (out[1].abs() + 1e-3)).max())
+            msg += f"; oracle {float(o_loss):.6f}, logits max rel diff {rel:.2e}"
+        print(msg)
+    npz("config1_125m", **arrs)
+
+
+GENERATORS = ["scan", "ssm_layer", "moe", "vision", "models", "dims", "data_formats", "trainer_run", "config1"]
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
+    only = [a for a in sys.argv[1:] if not a.startswith("-")] or GENERATORS     # e.g. `gen_golden.py config1`
+    unknown = [a for a in only if a not in GENERATORS]
+    if unknown:
+        raise SystemExit(f"unknown fixture group(s) {unknown}; choose from {GENERATORS}")
     core = import_reference()
     print("reference imported from /root/reference")
-    gen_scan(core)
-    gen_ssm_layer(core)
-    gen_moe(core)
-    gen_vision(core)
-    gen_models(core)
-    gen_dims(core)
     import src.training.pipeline as pipe
-    gen_data_formats(pipe)
-    gen_trainer_run(core, pipe)
+    for name in only:
+        fn = globals()["gen_" + name]
+        if name == "data_formats":
+            fn(pipe)
+        elif name == "trainer_run":
+            fn(core, pipe)
+        else:
+            fn(core)
