@@ -43,6 +43,15 @@ SIGNATURES = {
     "apertis_ssm_gate_bwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64,
                                     _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "apertis_ssm_gate_bwd_blocks": (_i64, [_i64, _i64]),
+    "apertis_scan_gate_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "apertis_scan_gate_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
+                                     _vp, ctypes.c_uint32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apertis_scan_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+                                     _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _i64, _i64,
+                                     _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apertis_ssm_decode_conv": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_ssm_decode_state": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
+                                        _i32, _vp]),
     "apertis_dropout_add_fwd": (_i32, [_vp, _vp, _vp, _i64, _f32, _u64, _i32, _i32, _vp]),
     "apertis_dropout_bwd": (_i32, [_vp, _vp, _i64, _f32, _u64, _i32, _i32, _vp]),
     "apertis_dwconv_silu_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),

@@ -319,6 +319,18 @@ class SelectiveLinearAttention(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, self.hidden_size, bias=False)
         self.use_cache = False
 
+    def _padded_param_weight(self):
+        """x_param_proj.weight with its output columns re-ordered and zero-padded so that, in the GEMM output p, the Bt
+        and C column blocks each start on a 128-byte boundary and every row does too (core.py:376-381 reads them as
+        [dt | Bt | C]; the scan reads whole 128-byte row segments): rows [Bt | 0 | C | 0 | dt | 0], block widths
+        (Wb, Wb, Wr) multiples of 64 columns.  The GEMM tiles are 128 columns wide either way, so the pad costs no MFMA
+        work.  Returns (weight [2*Wb + Wr, Dn], Wb, Wr)."""
+        w, Dn, R = self.x_param_proj.weight, self.d_inner, self.dt_rank
+        Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
+        zb = w.new_zeros(Wb - Dn, Dn)
+        zr = w.new_zeros(Wr - R, Dn)
+        return torch.cat([w[R:R + Dn], zb, w[R + Dn:], zb, w[:R], zr], dim=0), Wb, Wr
+
     @_on_input_device
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions: bool = False, use_cache: bool = False):
@@ -328,36 +340,55 @@ class SelectiveLinearAttention(nn.Module):
         conv_prev = ssm_prev = None
         if past_key_value is not None:
             conv_prev, ssm_prev = past_key_value
+        have_window = (conv_prev is not None and use_cache and conv_prev.shape[1] == Dn and conv_prev.shape[2] == kw - 1)
         # in_proj_x and in_proj_z share their input: one GEMM with the stacked weight, outputs are
         # column views (core.py:366-367)
         xz = _mfma_linear(hidden_states, torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
+        wp, Wb, Wr = self._padded_param_weight()
+        if (L == 1 and have_window and ssm_prev is not None and not output_attentions and not torch.is_grad_enabled()
+                and hidden_states.is_cuda and kw > 1):
+            # single-token decode step (generate(), core.py:1578-1603): two small kernels around the projections
+            # instead of the chunk machinery
+            xz2 = xz.reshape(B, 2 * Dn)
+            xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias)
+            p = _mfma_linear(xc, wp)                                                   # [B, 2*Wb + Wr]
+            dt_in = p[:, 2 * Wb:2 * Wb + R]
+            if ops.tiny_linear_supported(dt_in, R, self.num_heads):
+                dt_logits = ops.tiny_linear(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias)
+            else:
+                dt_logits = self.dt_proj_head(dt_in).float()
+            state = ssm_prev.reshape(B, Dn).float().clone()
+            gated = ops.ssm_decode_state(dt_logits, self.A_log, p[:, :Dn], p[:, Wb:Wb + Dn], xc, xz2[:, Dn:], self.D, state)
+            out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight)
+            return out, None, (conv_state, state.reshape(B, self.num_heads, self.d_state))
         xp, z = ops.split_cols(xz, (Dn, Dn))
         conv_in = xp
-        if conv_prev is not None and use_cache and conv_prev.shape[1] == Dn and conv_prev.shape[2] == kw - 1:
+        if have_window:
             # the reference prepends the cached window and keeps the FIRST L conv outputs
             # (core.py:369-373); reproduced as is so cached decode matches `apertis chat`
             conv_in = torch.cat([conv_prev.transpose(1, 2).to(xp.dtype), xp], dim=1)
         conv_state = conv_in[:, -(kw - 1):].transpose(1, 2).detach() if use_cache else None
         xc = ops.dwconv_silu(conv_in, self.conv1d.weight, self.conv1d.bias)[:, :L]      # core.py:373-375
-        # x_param_proj (core.py:376); output rows padded to a multiple of 8 columns so every row of
-        # p starts 16-byte aligned (the pad columns are zero weights and are never read)
-        wp = self.x_param_proj.weight
-        pad = (-wp.shape[0]) % 8
-        if pad:
-            wp = torch.cat([wp, wp.new_zeros(pad, wp.shape[1])], dim=0)
-        p = _mfma_linear(xc, wp)                                             # [B,L,R+2Dn(+pad)]
-        # dt / Bt / C are column slices of p taken in place (core.py:382-385)
-        dt_in, Bt, Cm = ops.split_cols(p, (R, Dn, Dn, pad))[:3]
+        p = _mfma_linear(xc, wp)                                             # x_param_proj (core.py:376), padded layout
+        # Bt / C / dt are column slices of p taken in place (core.py:382-385); the Bt and C slices keep their zero pad
+        Btp, Cp, dt_in = ops.split_cols(p, (Wb, Wb, R, Wr - R))[:3]
         if ops.tiny_linear_supported(dt_in, R, self.num_heads):
             dt_logits = ops.tiny_linear(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias)   # [B,L,h] fp32
         else:
             dt_logits = self.dt_proj_head(dt_in).float()
         h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None
         # softplus (core.py:383) is applied inside the scan kernel
-        res = ops.selective_scan(dt_logits, self.A_log, Bt, Cm, h0=h0,
-                                 delta_softplus=True, y_dtype=torch.float32, return_last=use_cache)
-        y, h_last = res if use_cache else (res, None)
-        gated = ops.ssm_gate(y, xc, z, self.D)                               # core.py:395-396
+        if output_attentions or not hidden_states.is_cuda:
+            # the caller wants y_ssm itself (core.py:401): scan and gate as two ops, y in fp32
+            res = ops.selective_scan(dt_logits, self.A_log, Btp[..., :Dn], Cp[..., :Dn], h0=h0,
+                                     delta_softplus=True, y_dtype=torch.float32, return_last=use_cache)
+            y, h_last = res if use_cache else (res, None)
+            gated = ops.ssm_gate(y, xc, z, self.D)                           # core.py:395-396
+        else:
+            # recurrence + skip + gate in one kernel per direction; y is never written (core.py:388-396)
+            res = ops.scan_gate(dt_logits, self.A_log, Btp, Cp, xc, z, self.D, h0=h0, delta_softplus=True,
+                                return_last=use_cache)
+            (gated, h_last), y = (res if use_cache else (res, None)), None
         out = _mfma_linear(gated, self.out_proj.weight)                     # core.py:397
         cache = (conv_state, h_last.reshape(B, self.num_heads, self.d_state)) if use_cache else None
         return out, (y if output_attentions else None), cache

@@ -237,6 +237,164 @@ def selective_scan(dlt, A_log, Bt, C, h0=None, delta_softplus=False, y_dtype=tor
 
 
 # ----------------------------------------------------------------------------------------------
+# scan with the skip + gate fused in (no fp32 y / dy in HBM), single launch per direction
+# ----------------------------------------------------------------------------------------------
+# APERTIS_SCAN_SINGLE_PASS=0 selects the two-launch form of the same kernels (state pass + replay; same bits)
+SCAN_SINGLE_PASS = _os.environ.get("APERTIS_SCAN_SINGLE_PASS", "1") != "0"
+_gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
+
+
+def _scan_gate_ws(lib, B, L, Dn, device):
+    """Look-back workspace of the single-pass kernels: one per (device, stream), zero-filled once, and the epoch of the
+    next launch on it (incremented by exactly one per launch: the two ticket counters in its head alternate)."""
+    need = int(lib.apertis_scan_gate_workspace_bytes(B, L, Dn))
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ent = _gate_ws.get(key)
+    if ent is None or ent[0].numel() < need or ent[1] >= 0xFFFFFFF0:
+        ent = _gate_ws[key] = [torch.zeros(need, device=device, dtype=torch.uint8), 0]
+    ent[1] += 1
+    return ent[0], ent[1]
+
+
+def scan_gate_error(device=None):
+    """Non-zero if a single-pass scan launch hit its bounded-wait timeout on any workspace of `device` (host sync)."""
+    bad = 0
+    for (dev, _), ent in _gate_ws.items():
+        if device is None or torch.device(dev) == torch.device(device):
+            torch.cuda.synchronize(dev)
+            bad |= int(ent[0][8:12].view(torch.int32).item())
+    return bad
+
+
+class _ScanGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last):
+        _require_gpu(dlt, A_log, Bt, C, xc, z, D, h0)
+        lib = _lib.load()
+        B, L, h = dlt.shape
+        N = A_log.shape[1]
+        Dn = h * N
+        wB, wC = Bt.shape[-1], C.shape[-1]          # >= Dn: zero-padded slices of the projection output
+        if (tuple(Bt.shape[:2]) != (B, L) or tuple(C.shape[:2]) != (B, L) or wB < Dn or wC != wB or A_log.shape[0] != h or
+                tuple(xc.shape) != (B, L, Dn) or tuple(z.shape) != (B, L, Dn) or wB > -(-Dn // 64) * 64):
+            raise ApertisHipError(f"scan_gate shapes: dlt {tuple(dlt.shape)} A_log {tuple(A_log.shape)} Bt {tuple(Bt.shape)} "
+                                  f"C {tuple(C.shape)} xc {tuple(xc.shape)} z {tuple(z.shape)}")
+        if not (Bt.dtype == C.dtype == xc.dtype == z.dtype):
+            raise ApertisHipError("Bt, C, xc and z must share a dtype")
+        dlt = dlt.float().contiguous()
+        A_log = A_log.float().contiguous()
+        Df = D.detach().float().contiguous()
+        if h0 is not None:
+            h0 = h0.float().reshape(B, Dn).contiguous()
+        ctx.slots = (_slot_of(Bt), _slot_of(C), _slot_of(z), _slot_of(xc))
+        (Bt, bt_rs), (C, c_rs), (xc, xc_rs), (z, z_rs) = _rows(Bt, wB), _rows(C, wC), _rows(xc, Dn), _rows(z, Dn)
+        nch = lib.apertis_scan_num_chunks(B, L, Dn)
+        dev = dlt.device
+        out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
+        h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
+        h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
+        e = xc.element_size()
+        work = B * L * (5 * Dn * e + 4 * h) + 4 * h * N          # algorithmic bytes, fused variant (SURVEY 8d)
+        if SCAN_SINGLE_PASS:
+            ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
+            agg = None
+        else:
+            ws, epoch = None, 0
+            agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+        _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
+                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out), Dn,
+                 ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(delta_softplus),
+                 int(SCAN_SINGLE_PASS), stream_ptr()), work)
+        ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in)
+        ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
+        ctx.mark_non_differentiable(*([h_last] if return_last else []))
+        return (out, h_last) if return_last else out
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        lib = _lib.load()
+        dlt, A_log, Bt, C, xc, z, Df, h_in = ctx.saved_tensors
+        B, L, h, N, sp, wB, Ddt = ctx.cfg
+        Dn = h * N
+        dev = dlt.device
+        dout = dout.to(xc.dtype).contiguous()
+        nch = h_in.shape[1]
+        dBt, dbt_rs = _grad_out(ctx.slots[0], (B, L), wB, Bt.dtype, dev)
+        dC, dc_rs = _grad_out(ctx.slots[1], (B, L), wB, C.dtype, dev)
+        dz, dz_rs = _grad_out(ctx.slots[2], (B, L), Dn, z.dtype, dev)
+        dxc, dxc_rs = _grad_out(ctx.slots[3], (B, L), Dn, xc.dtype, dev)
+        d_dlt = torch.empty(B, L, h, device=dev, dtype=torch.float32)
+        dA_dD = torch.empty(2, Dn, device=dev, dtype=torch.float32)
+        part = torch.empty(B * nch, 2 * Dn, device=dev, dtype=torch.float32)
+        fold = torch.empty(64, 2 * Dn, device=dev, dtype=torch.float32)
+        e = xc.element_size()
+        work = B * L * (9 * Dn * e + 8 * h) + 8 * h * N          # algorithmic bytes, fused variant
+        if SCAN_SINGLE_PASS:
+            ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
+            agg = None
+        else:
+            ws, epoch = None, 0
+            agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+        _launch("apertis_scan_gate_bwd", lib.apertis_scan_gate_bwd,
+                (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
+                 ptr(Df), ptr(dout), Dn, ptr(h_in), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
+                 ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(sp),
+                 int(SCAN_SINGLE_PASS), stream_ptr()), work)
+        return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt), None, None, None
+
+
+def scan_gate(dlt, A_log, Bt, C, xc, z, D, h0=None, delta_softplus=False, return_last=False):
+    """(C*s + D*xc) * silu(z) with s_t = exp(delta_t*A)*s_{t-1} + Bt_t: the recurrence (reference core.py:337-353) and
+    the skip + gate (core.py:395-396) in ONE kernel per direction; y is never written (the backward recomputes it).
+
+    dlt [B,L,h] fp32 (pre-softplus logits when delta_softplus), A_log [h,N], xc / z [B,L,h*N], D [h*N];
+    Bt / C [B,L,w] with h*N <= w <= ceil(h*N/64)*64: the (possibly zero-padded) column slices of the projection output,
+    of which the first h*N columns are used; their gradients come back [B,L,w] with zeros in the pad.
+    Returns out [B,L,h*N] in the activations' dtype (and the final state [B,h*N] fp32 when return_last)."""
+    return _ScanGate.apply(dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
+
+
+def ssm_decode_step(xp, conv_state, conv_w, conv_b):
+    """First half of the single-token SSM step (reference core.py:368-375 with a cached window): returns
+    (xc [B,Dn], new conv_state [B,Dn,k-1]).  xp [B,Dn] (a row-strided view is fine), conv_state [B,Dn,k-1]."""
+    _require_gpu(xp, conv_state, conv_w, conv_b)
+    lib = _lib.load()
+    B, Dn = xp.shape
+    k = conv_w.shape[-1]
+    if xp.stride(-1) != 1:
+        xp = xp.contiguous()
+    cs = conv_state.to(xp.dtype).contiguous()
+    w2 = conv_w.detach().float().reshape(Dn, k).contiguous()
+    b2 = conv_b.detach().float().contiguous()
+    xc = torch.empty(B, Dn, device=xp.device, dtype=xp.dtype)
+    cs_out = torch.empty_like(cs)
+    check(lib.apertis_ssm_decode_conv(ptr(xp), xp.stride(0), ptr(cs), ptr(cs_out), ptr(w2), ptr(b2), ptr(xc), B, Dn, k,
+                                      dtype_code(xp), stream_ptr()), "apertis_ssm_decode_conv")
+    return xc, cs_out
+
+
+def ssm_decode_state(dt_logits, A_log, Bt, C, xc, z, D, state, delta_softplus=True):
+    """Second half: state <- exp(delta*A)*state + Bt (in place, fp32 [B,Dn]); returns (C*state + D*xc)*silu(z) [B,Dn]
+    (reference core.py:347-349 for one token, then :395-396).  Bt / C / z may be row-strided views."""
+    _require_gpu(dt_logits, A_log, Bt, C, xc, z, D, state)
+    lib = _lib.load()
+    B, h = dt_logits.shape
+    N = A_log.shape[1]
+    Dn = h * N
+    fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
+    Bt, C, z = fix(Bt), fix(C), fix(z)
+    xc = xc.contiguous()
+    if not (Bt.dtype == C.dtype == xc.dtype == z.dtype) or state.dtype != torch.float32 or not state.is_contiguous():
+        raise ApertisHipError("ssm_decode_state: Bt, C, xc, z share a dtype; state is contiguous fp32")
+    out = torch.empty(B, Dn, device=xc.device, dtype=xc.dtype)
+    check(lib.apertis_ssm_decode_state(ptr(dt_logits.float().contiguous()), ptr(A_log.detach().float().contiguous()), ptr(Bt),
+                                       Bt.stride(0), ptr(C), C.stride(0), ptr(xc), ptr(z), z.stride(0),
+                                       ptr(D.detach().float().contiguous()), ptr(state), ptr(out), B, h, N, dtype_code(xc),
+                                       int(delta_softplus), stream_ptr()), "apertis_ssm_decode_state")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # SSM companions: depthwise causal conv + SiLU, post-scan gate
 # ----------------------------------------------------------------------------------------------
 class _DwConvSilu(torch.autograd.Function):

@@ -225,8 +225,8 @@ def main():
     timer = None
     if not args.no_kernel_timers:
         timer = ops.KernelTimer(["apertis_grouped_gemm_nt", "apertis_grouped_gemm_tn", "apertis_selective_scan_fwd",
-                                 "apertis_selective_scan_bwd", "apertis_grouped_gemm_nt[dense]",
-                                 "apertis_grouped_gemm_tn[dense]"])
+                                 "apertis_selective_scan_bwd", "apertis_scan_gate_fwd", "apertis_scan_gate_bwd",
+                                 "apertis_grouped_gemm_nt[dense]", "apertis_grouped_gemm_tn[dense]"])
     sync()
     ops.set_kernel_timer(timer)
     t0 = time.perf_counter()

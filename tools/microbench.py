@@ -51,6 +51,44 @@ def scan(only_bench_shape=False):
               f"bwd(+autograd overhead) {t_b*1e3:7.1f} us {bb/t_b/1e6:7.0f} GB/s ({bb/t_b/8e9*100:4.1f}%)  [{fb/1e6:.0f}/{bb/1e6:.0f} MB]")
 
 
+def scan_gate(only_bench_shape=False):
+    """The fused scan + gate op (what the model runs), both forms, on the model's padded layout; GB/s on the fused
+    variant's own byte count (5*Dn*e + 4h forward, 9*Dn*e + 8h backward)."""
+    shapes = [(32, 4096, 11, 16, torch.bfloat16)] if only_bench_shape else [
+        (8, 4096, 11, 16, torch.bfloat16), (32, 4096, 11, 16, torch.bfloat16), (16, 4096, 4, 16, torch.bfloat16),
+        (32, 2048, 14, 16, torch.bfloat16), (16, 2245, 11, 16, torch.bfloat16), (8, 4096, 11, 16, torch.float32)]
+    for (B, L, h, N, dt) in shapes:
+        Dn, R = h * N, math.ceil(h * 64 / 16)
+        Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
+        p = torch.randn(B, L, 2 * Wb + Wr, device=dev).to(dt).requires_grad_(True)
+        xz = torch.randn(B, L, 2 * Dn, device=dev).to(dt).requires_grad_(True)
+        xc = torch.randn(B, L, Dn, device=dev).to(dt).requires_grad_(True)
+        dl = (torch.randn(B, L, h, device=dev) - 4).requires_grad_(True)
+        A = torch.empty(h, N, device=dev).uniform_(math.log(.5), math.log(.99)).requires_grad_(True)
+        D = torch.ones(Dn, device=dev, requires_grad=True)
+        dout = torch.randn(B, L, Dn, device=dev).to(dt)
+        e, T = p.element_size(), B * L
+        fb, bb = T * (5 * Dn * e + 4 * h), T * (9 * Dn * e + 8 * h)
+        for sp in (False, True):
+            ops.SCAN_SINGLE_PASS = sp
+
+            def mk():
+                Btp, Cp, _ = ops.split_cols(p, (Wb, Wb, Wr))
+                _, z = ops.split_cols(xz, (Dn, Dn))
+                return ops.scan_gate(dl, A, Btp, Cp, xc, z, D, delta_softplus=True)
+            with torch.no_grad():
+                t_f = timeit(mk)
+            out = mk()
+
+            def b():
+                torch.autograd.grad(out, (dl, A, p, xz, xc, D), dout, retain_graph=True)
+            t_b = timeit(b)
+            print(f"scan_gate {'1-launch' if sp else '2-launch'} B={B} L={L} Dn={Dn} {str(dt)[6:]}: fwd {t_f*1e3:7.1f} us "
+                  f"{fb/t_f/1e6:7.0f} GB/s ({fb/t_f/8e9*100:4.1f}%)  bwd(+autograd/split overhead) {t_b*1e3:7.1f} us "
+                  f"{bb/t_b/1e6:7.0f} GB/s ({bb/t_b/8e9*100:4.1f}%)  [{fb/1e6:.0f}/{bb/1e6:.0f} MB]  err={ops.scan_gate_error()}")
+        ops.SCAN_SINGLE_PASS = True
+
+
 def gemm():
     import numpy as np
     for (rows, N, K, E) in [(163840, 2816, 704, 8), (163840, 704, 2816, 8), (40960, 2816, 704, 8), (40960, 704, 2816, 8), (81920, 2816, 704, 8), (81920, 704, 2816, 8),
@@ -118,6 +156,10 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("scan", "all"):
         scan()
+    if what in ("scan_gate", "all"):
+        scan_gate()
+    if what == "scan_gate1":
+        scan_gate(True)
     if what == "scan1":          # the bench shape only (for rocprofv3 --kernel-trace --stats)
         scan(True)
     if what in ("gemm", "all"):
