@@ -11,18 +11,26 @@
 //   forward   Dn*e*(Bt + C + xc + z + out) + 4h          = 5*Dn*e + 4h
 //   backward  Dn*e*(Bt + C + xc + z + dout) reads + Dn*e*(dBt + dC + dxc + dz) writes + 8h = 9*Dn*e + 8h
 //
-// Structure: work-group = (batch, chunk of LT tokens, 64-channel tile); lane = channel, wave = token segment; tiles are
-// staged HBM -> LDS in whole row segments (16 B per lane when the slices allow), each thread walks its LDS column.
-// Two ways to get a chunk's carry-in:
-//   mode 0  two launches: a state pass writes every chunk's aggregate, the replay pass composes its carry from them
-//           (the scheme of selective_scan.hip; the first pass reads Bt - resp. C, dout, z - a second time);
+// Work item = (batch, chunk of 64 tokens, ALL channels): CW groups of 64 channels side by side, so every row of every
+// tensor is ONE contiguous run (Bt|C 768 of p's 896-byte rows, xc / z / out 352 B at Dn = 176).  Measured with
+// tools/probes/scan_stream.hip (pure loads + stores of this kernel's five streams, B=32, L=4096): 64-channel tiles - 128-byte
+// row pieces, the layout of selective_scan.hip - stream at 3.5 TB/s whatever the occupancy, whole rows at 4.8 TB/s.
+// lane = channel, wave = (channel group, segment of 64/NS tokens); the Bt / C tiles go HBM -> LDS as whole row segments and
+// each thread walks its LDS column; everything elementwise (xc, z, dout in; out, dz, dxc out) is touched row-major in
+// 16-byte pieces straight from / to global memory; only y (forward) resp. dv and y (backward) cross from the column walk
+// to the row-major side, through an fp32 LDS tile.
+//
+// Carry between chunks (64 chunks per 4096-token sequence), two forms with the SAME arithmetic and bits:
+//   mode 0  two launches: a state pass (mode 2 of the same kernel) writes every chunk's aggregate, the replay composes its
+//           carry from them (the first pass reads Bt - resp. C, dout, z - a second time);
 //   mode 1  ONE launch: work-groups take their item from a ticket counter in chunk-major order, compute the chunk
-//           aggregate from the Bt tile first, PUBLISH it (8-byte {epoch, value} granules, one agent-scope store each:
-//           cdna_hip_programming.md Guideline 16, form R2) and gather the aggregates of the earlier chunks while their
-//           own C / xc / z loads are still in flight.  A work-group only ever waits for lower tickets, which belong to
-//           work-groups that have already started and never wait for a higher one: progress does not depend on
-//           residency.  The composition order is fixed (all predecessors, left to right), so the result is
-//           bit-identical to mode 0 and run-to-run.  Waits are bounded; a timeout sets the workspace's error word.
+//           aggregate from the Bt tile first and PUBLISH it (8-byte {epoch, value} granules, one agent-scope store each:
+//           cdna_hip_programming.md Guideline 16, form R2) while their other loads are still in flight; the last chunk
+//           of every super-chunk of 8 also publishes the super-chunk's composite, so a chunk gathers at most 7 + 7
+//           records: the composites of the earlier super-chunks, then the aggregates of the chunks of its own.
+//           A work-group only ever waits for lower tickets, which belong to work-groups that have already started and
+//           never wait for a higher one: progress does not depend on residency.  The composition order is fixed, so
+//           the result is bit-identical to mode 0 and run-to-run.  Waits are bounded; a timeout sets the error word.
 #include "scan_common.h"
 
 namespace {
@@ -35,62 +43,148 @@ __device__ __forceinline__ gran_t gran_load(const gran_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// head of the look-back workspace (64 bytes), then the granules [B*ctiles][nchunks][64 lanes][2]
+// head of the look-back workspace (64 bytes), then the granules [B*ncs][nchunks + nsuper][CW*64 lanes][2]
 struct GateWsHead { unsigned ctr[2]; int err; int pad[13]; };
 
-__device__ __forceinline__ float sigmoid_g(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float silu_g(float x) { return x * sigmoid_g(x); }
-__device__ __forceinline__ float silu_grad_g(float x) { float s = sigmoid_g(x); return s * (1.f + x * (1.f - s)); }
+#ifdef SCAN_PROBE   // tools/probes/scan_gate_probe.hip: per-work-group phase timestamps (never defined in the library build)
+__device__ unsigned long long g_probe[8192 * 8];
+#define PROBE(k) do { if (threadIdx.x == 0 && item_s[2] < 8192) g_probe[item_s[2] * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PROBE(k) do { } while (0)
+#endif
 
-// global -> registers half of stage_in (the loads stay in flight until stage_regs_store)
+constexpr int LTG = 64;    // tokens per item = apertis_scan_chunk_len(): the granularity of h_in and of the aggregates
+constexpr int SUP = 8;     // chunks per super-chunk of the two-level look-back
+
+// silu and its derivative on the hardware exp2 / rcp (1 ulp each: ~3e-7 relative, far inside the 1e-4 parity bar); the
+// stand-alone gate kernel's expf + IEEE division cost ~30 VALU instructions per element
+__device__ __forceinline__ float sigmoid_g(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * LOG2E_F)); }
+__device__ __forceinline__ float silu_g(float x) { return x * sigmoid_g(x); }
+__device__ __forceinline__ void silu_both(float x, float &f, float &df) {
+  const float s = sigmoid_g(x);
+  f = x * s;
+  df = s * (1.f + x * (1.f - s));
+}
+
+// A tile of LT rows x ROWB bytes as VB-byte pieces in registers: global -> registers (the loads stay in flight), then
+// registers -> LDS.  Thread `tid` owns piece (row0 + q*RSTEP, cb0) for q < ITERS: one row / column pair per thread and a
+// constant row step, so the only per-thread state a persistent loop has to keep is (row0, cb0) - with a div / mod per piece
+// the compiler hoisted ~50 loop invariants and spilled them (344 bytes of scratch per lane).
 template <int VB, int ROWB, int LT, int NTH>
 struct TileRegs {
   typedef typename vec_bytes<VB>::type V;
-  static constexpr int CPR = ROWB / VB, TOTAL = LT * CPR, ITERS = (TOTAL + NTH - 1) / NTH;
+  static constexpr int CPR = ROWB / VB, TOTAL = LT * CPR;
+  static_assert(NTH % CPR == 0 && TOTAL % NTH == 0, "a thread's pieces share their column");
+  static constexpr int RSTEP = NTH / CPR, ITERS = TOTAL / NTH;
   V r[ITERS];
+  __device__ static __forceinline__ int row0(int tid) { return tid / CPR; }
+  __device__ static __forceinline__ int cb0(int tid) { return (tid % CPR) * VB; }
   __device__ __forceinline__ void load(const char *g, int64_t rsb, int rows_valid, int bytes_valid, int tid) {
+    const int r0 = row0(tid), c0 = cb0(tid);
+    const char *p = g + (int64_t)r0 * rsb + c0;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      int idx = tid + it * NTH;
-      int row = idx / CPR, cb = (idx % CPR) * VB;
-      bool ok = idx < TOTAL && row < rows_valid && cb < bytes_valid;
-      r[it] = ok ? *reinterpret_cast<const V *>(g + (int64_t)row * rsb + cb) : zero_vec<VB>();
+    for (int q = 0; q < ITERS; ++q) {
+      const bool ok = r0 + q * RSTEP < rows_valid && c0 < bytes_valid;
+      r[q] = ok ? *reinterpret_cast<const V *>(p + (int64_t)(q * RSTEP) * rsb) : zero_vec<VB>();
     }
   }
   __device__ __forceinline__ void store(char *lds, int tid) const {
+    char *p = lds + row0(tid) * ROWB + cb0(tid);
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      int idx = tid + it * NTH;
-      if (idx < TOTAL) *reinterpret_cast<V *>(lds + idx * VB) = r[it];
-    }
+    for (int q = 0; q < ITERS; ++q) *reinterpret_cast<V *>(p + q * RSTEP * ROWB) = r[q];
+  }
+  // LDS tile -> global rows (the mirror of load + store), same piece ownership
+  __device__ static __forceinline__ void tile_out(const char *lds, char *g, int64_t rsb, int rows_valid, int bytes_valid, int tid) {
+    const int r0 = row0(tid), c0 = cb0(tid);
+    if (c0 >= bytes_valid) return;
+    const char *l = lds + r0 * ROWB + c0;
+    char *p = g + (int64_t)r0 * rsb + c0;
+#pragma unroll
+    for (int q = 0; q < ITERS; ++q)
+      if (r0 + q * RSTEP < rows_valid) *reinterpret_cast<V *>(p + (int64_t)(q * RSTEP) * rsb) = *reinterpret_cast<const V *>(l + q * RSTEP * ROWB);
   }
 };
 
-// Gather (mode 1): compose the published aggregates of chunks [s0, s1) in composition order into (P, S).
-// forward: j ascending; reverse: j descending.  Spins (bounded) until every granule carries this launch's epoch.
-__device__ __forceinline__ void gather_published(const gran_t *gbase, int s0, int s1, bool reverse, int lane, bool chan_ok,
-                                                 uint32_t epoch, int *err, float &P, float &S) {
+// A row-major piece of a tile held by one thread: EPC consecutive channels of one token (VB bytes).
+template <typename T, int VB> struct Piece {
+  typedef typename vec_bytes<VB>::type V;
+  static constexpr int EPC = VB / (int)sizeof(T);
+  __device__ static __forceinline__ void unpack(const V &v, float (&f)[EPC]) {
+    T e[EPC];
+    __builtin_memcpy(e, &v, VB);
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) f[k] = to_f32(e[k]);
+  }
+  __device__ static __forceinline__ V pack(const float (&f)[EPC]) {
+    T e[EPC];
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) e[k] = from_f32<T>(f[k]);
+    V v;
+    __builtin_memcpy(&v, e, VB);
+    return v;
+  }
+};
+
+// fp32 y kept in the slots of the Bt / C tiles that produced it.  bf16 tiles: the high half of the fp32 word goes where
+// Bt[t][c] was, the low half where C[t][c] was - each thread overwrites only elements it alone has read, so the column
+// walk needs neither a barrier nor 16 registers to park y before the row-major epilogue picks it up.  fp32 tiles: y simply
+// replaces Bt[t][c].
+template <typename T> __device__ __forceinline__ void y_put(T *bt, T *cc, int idx, float v);
+template <> __device__ __forceinline__ void y_put<float>(float *bt, float *, int idx, float v) { bt[idx] = v; }
+template <> __device__ __forceinline__ void y_put<bf16_t>(bf16_t *bt, bf16_t *cc, int idx, float v) {
+  const uint32_t u = __float_as_uint(v);
+  reinterpret_cast<uint16_t *>(bt)[idx] = (uint16_t)(u >> 16);
+  reinterpret_cast<uint16_t *>(cc)[idx] = (uint16_t)(u & 0xffffu);
+}
+template <typename T, int EPC> struct YGet;
+template <int EPC> struct YGet<float, EPC> {
+  __device__ static __forceinline__ void get(const float *bt, const float *, int idx, float (&y)[EPC]) {
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) y[k] = bt[idx + k];
+  }
+};
+template <int EPC> struct YGet<bf16_t, EPC> {
+  __device__ static __forceinline__ void get(const bf16_t *bt, const bf16_t *cc, int idx, float (&y)[EPC]) {
+    uint16_t hi[EPC], lo[EPC];
+    __builtin_memcpy(hi, reinterpret_cast<const uint16_t *>(bt) + idx, EPC * 2);
+    __builtin_memcpy(lo, reinterpret_cast<const uint16_t *>(cc) + idx, EPC * 2);
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) y[k] = __uint_as_float(((uint32_t)hi[k] << 16) | (uint32_t)lo[k]);
+  }
+};
+
+// geometry of a work-group: CW channel groups x NS token segments (waves), 64 tokens
+template <int CW> struct Geo {
+  static constexpr int NS = CW <= 2 ? 8 : 4, CWC = 64 * CW, NTH = CWC * NS, TS = LTG / NS;
+};
+
+// Compose the published records [j0, j1) (granule index = record index) in composition order into (P, S):
+// ascending, or descending when `reverse`.  The loads of up to QMAX records are in flight together (a record per round
+// trip made a 7-record gather the longest phase of the kernel); spins (bounded) until every granule of the batch
+// carries this launch's epoch.
+__device__ __forceinline__ void gather_published(const gran_t *gbase, int stride, int j0, int j1, bool reverse, int cl,
+                                                 bool chan_ok, uint32_t epoch, int *err, float &P, float &S) {
   constexpr int QMAX = 4;
   P = 1.f; S = 0.f;
-  for (int j0 = 0; j0 < s1 - s0; j0 += QMAX) {
+  for (int k0 = 0; k0 < j1 - j0; k0 += QMAX) {
     gran_t gp[QMAX], gs[QMAX];
-    const int nb = min(QMAX, s1 - s0 - j0);
+    const int nb = min(QMAX, j1 - j0 - k0);
     unsigned spins = 0;
     while (true) {
       bool ok = true;
 #pragma unroll
       for (int u = 0; u < QMAX; ++u)
         if (u < nb && chan_ok) {
-          const int j = reverse ? (s1 - 1 - j0 - u) : (s0 + j0 + u);
-          gp[u] = gran_load(gbase + ((int64_t)j * TC + lane) * 2 + 0);
-          gs[u] = gran_load(gbase + ((int64_t)j * TC + lane) * 2 + 1);
+          const int j = reverse ? (j1 - 1 - k0 - u) : (j0 + k0 + u);
+          gp[u] = gran_load(gbase + ((int64_t)j * stride + cl) * 2 + 0);
+          gs[u] = gran_load(gbase + ((int64_t)j * stride + cl) * 2 + 1);
         }
 #pragma unroll
       for (int u = 0; u < QMAX; ++u)
         if (u < nb && chan_ok) ok = ok && (uint32_t)(gp[u] >> 32) == epoch && (uint32_t)(gs[u] >> 32) == epoch;
       if (__all(ok)) break;
-      if (++spins > (1u << 18)) { if (lane == 0) atomicOr(err, 1); break; }
-      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 18)) { if ((cl & 63) == 0) atomicOr(err, 1); break; }
+      __builtin_amdgcn_s_sleep(2);
     }
 #pragma unroll
     for (int u = 0; u < QMAX; ++u)
@@ -101,31 +195,29 @@ __device__ __forceinline__ void gather_published(const gran_t *gbase, int s0, in
       }
   }
 }
+// the same composition from the aggregate array of the two-launch form (loads batched the same way)
+__device__ __forceinline__ void fold_agg(const float2 *agg, int64_t base, int64_t Dn, int j0, int j1, bool reverse, bool chan_ok,
+                                         float &P, float &S) {
+  constexpr int QMAX = 8;
+  P = 1.f; S = 0.f;
+  if (!chan_ok) return;
+  for (int k0 = 0; k0 < j1 - j0; k0 += QMAX) {
+    float2 r[QMAX];
+    const int nb = min(QMAX, j1 - j0 - k0);
+#pragma unroll
+    for (int u = 0; u < QMAX; ++u)
+      if (u < nb) r[u] = agg[base + (int64_t)(reverse ? (j1 - 1 - k0 - u) : (j0 + k0 + u)) * Dn];
+#pragma unroll
+    for (int u = 0; u < QMAX; ++u)
+      if (u < nb) { S = fmaf(r[u].x, S, r[u].y); P *= r[u].x; }
+  }
+}
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward: out = (C*s + D*xc) * silu(z)
-template <typename T, int VB, int LT, int NS, int MODE>
-__global__ void __launch_bounds__(TC * NS)
-scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, const T *__restrict__ Bt, int64_t bt_rs,
-                const T *__restrict__ C, int64_t c_rs, const T *__restrict__ xc, int64_t xc_rs, const T *__restrict__ z,
-                int64_t z_rs, const float *__restrict__ Dv, const float *__restrict__ h0, const float2 *__restrict__ agg,
-                GateWsHead *__restrict__ head, gran_t *__restrict__ gran, uint32_t epoch, float *__restrict__ h_in,
-                float *__restrict__ h_last, T *__restrict__ out, int64_t out_rs, ScanDims d, int64_t nch64, int ctiles) {
-  constexpr int ROWB = TC * sizeof(T);
-  constexpr int TS = LT / NS;
-  constexpr int NTH = TC * NS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T *bt = reinterpret_cast<T *>(smem);
-  T *cc = bt + LT * TC;
-  T *xx = cc + LT * TC;
-  T *zz = xx + LT * TC;
-  float *dl = reinterpret_cast<float *>(zz + LT * TC);
-  float2 *segs = reinterpret_cast<float2 *>(dl + LT * d.HT);
-  float2 *lk = segs + NS * TC;
-  int *item_s = reinterpret_cast<int *>(lk + NS * TC);
-
-  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
-  int chunk, ct, b;
+// item of this work-group: (chunk, batch, channel super-tile) from the grid (modes 0 / 2) or from the ticket counter in
+// chunk-major order (mode 1; `reverse`: chunks right to left)
+template <int MODE>
+__device__ __forceinline__ void take_item(GateWsHead *head, uint32_t epoch, int *item_s, const ScanDims &d, int ncs, bool reverse,
+                                          int tid, int &chunk, int &cs, int &b) {
   if constexpr (MODE == 1) {
     if (tid == 0) {
       const unsigned t = atomicAdd(&head->ctr[epoch & 1], 1u);
@@ -133,345 +225,523 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
       *item_s = (int)t;
     }
     __syncthreads();
-    const int item = *item_s, bct_n = (int)d.B * ctiles;
-    chunk = item / bct_n;
-    const int bct = item - chunk * bct_n;
-    b = bct / ctiles;
-    ct = bct - b * ctiles;
+    const int item = *item_s, bcs = (int)d.B * ncs;
+    const int k = item / bcs, r = item - k * bcs;
+    chunk = reverse ? d.nchunks - 1 - k : k;
+    b = r / ncs;
+    cs = r - b * ncs;
   } else {
-    chunk = blockIdx.x; ct = blockIdx.y; b = blockIdx.z;
+    chunk = blockIdx.x; cs = blockIdx.y; b = blockIdx.z;
   }
-  const int c0 = ct * TC, c = c0 + lane;
-  const int64_t t0 = (int64_t)chunk * LT;
-  const int rows_valid = (int)min((int64_t)LT, d.L - t0);
-  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
-  const int64_t tok0 = (int64_t)b * d.L + t0;
-  const bool chan_ok = c < d.Dn;
-
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(bt), reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
-                              bt_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
-  const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
-  const float Dc = chan_ok ? Dv[c] : 0.f;
-  // the other three tiles: loads issued now, parked in registers while the aggregates are formed (and, in mode 1,
-  // published and gathered)
-  TileRegs<VB, ROWB, LT, NTH> rc, rx, rz;
-  rc.load(reinterpret_cast<const char *>(C + tok0 * c_rs + c0), c_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  rx.load(reinterpret_cast<const char *>(xc + tok0 * xc_rs + c0), xc_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  rz.load(reinterpret_cast<const char *>(z + tok0 * z_rs + c0), z_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  __syncthreads();   // Bt and delta tiles are in LDS
-
-  float a[TS];
-  float P = 1.f, S = 0.f;
-  const int hh = lane >> d.log2N;
-#pragma unroll
-  for (int i = 0; i < TS; ++i) {
-    const int t = seg * TS + i;
-    a[i] = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
-    S = fmaf(a[i], S, to_f32(bt[t * TC + lane]));
-    P *= a[i];
-  }
-  segs[seg * TC + lane] = make_float2(P, S);
-  __syncthreads();
-
-  // carry entering the chunk: composed left to right from the aggregates of chunks [0, chunk); the NS waves split
-  // the range, partials meet in lk
-  {
-    const int q = (chunk + NS - 1) / NS;
-    const int s0 = min(seg * q, chunk), s1 = min(s0 + q, chunk);
-    float Pw = 1.f, Sw = 0.f;
-    if constexpr (MODE == 1) {
-      gran_t *gbase = gran + ((int64_t)(b * ctiles + ct) * d.nchunks) * TC * 2;
-      if (seg == 0 && chunk + 1 < d.nchunks) {   // publish this chunk's aggregate first (the last chunk has no reader)
-        float Pc = P, Sc = S;
-#pragma unroll
-        for (int s = 1; s < NS; ++s) { const float2 r = segs[s * TC + lane]; Sc = fmaf(r.x, Sc, r.y); Pc *= r.x; }
-        if (chan_ok) {
-          gran_store(gbase + ((int64_t)chunk * TC + lane) * 2 + 0, epoch, Pc);
-          gran_store(gbase + ((int64_t)chunk * TC + lane) * 2 + 1, epoch, Sc);
-        }
-      }
-      gather_published(gbase, s0, s1, false, lane, chan_ok, epoch, &head->err, Pw, Sw);
-    } else {
-      if (chan_ok) {
-        const int64_t base = (int64_t)b * d.nchunks * d.Dn + c;
-        for (int j = s0; j < s1; ++j) { const float2 r = agg[base + (int64_t)j * d.Dn]; Sw = fmaf(r.x, Sw, r.y); Pw *= r.x; }
-      }
-    }
-    lk[seg * TC + lane] = make_float2(Pw, Sw);
-  }
-  rc.store(reinterpret_cast<char *>(cc), tid);
-  rx.store(reinterpret_cast<char *>(xx), tid);
-  rz.store(reinterpret_cast<char *>(zz), tid);
-  __syncthreads();
-
-  float hcar = (h0 && chan_ok) ? h0[(int64_t)b * d.Dn + c] : 0.f;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) { const float2 r = lk[s * TC + lane]; hcar = fmaf(r.x, hcar, r.y); }
-  for (int s = 0; s < seg; ++s) { const float2 r = segs[s * TC + lane]; hcar = fmaf(r.x, hcar, r.y); }
-  // state entering every 64-token block, saved for the backward
-  if ((seg * TS) % 64 == 0 && chan_ok) {
-    const int64_t j64 = (int64_t)chunk * (LT / 64) + (seg * TS) / 64;
-    if (j64 < nch64) h_in[((int64_t)b * nch64 + j64) * d.Dn + c] = hcar;
-  }
-  float hst = hcar;
-#pragma unroll
-  for (int i = 0; i < TS; ++i) {
-    const int t = seg * TS + i;
-    hst = fmaf(a[i], hst, to_f32(bt[t * TC + lane]));
-    const float yv = to_f32(cc[t * TC + lane]) * hst;
-    const float dx = Dc * to_f32(xx[t * TC + lane]);
-    const float v = yv + dx;
-    cc[t * TC + lane] = from_f32<T>(v * silu_g(to_f32(zz[t * TC + lane])));   // in place: own column only
-  }
-  if (h_last && chunk == d.nchunks - 1 && seg == NS - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
-  __syncthreads();
-  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(cc), reinterpret_cast<char *>(out + tok0 * out_rs + c0),
-                               out_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
+#ifdef SCAN_PROBE
+  if (tid == 0) item_s[2] = (chunk * (int)d.B + b) * ncs + cs;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward, mode 0 first launch: reverse chunk aggregates (P = prod a, M = mu at chunk start from zero) with
-//   u_t = dout_t*silu(z_t)*C_t,  mu_t = a_t*(u_t + mu_{t+1})
-template <typename T, int VB, int LT, int NS>
-__global__ void __launch_bounds__(TC * NS)
-scan_gate_bwd_state_k(const float *__restrict__ dlt, const float *__restrict__ A_log, const T *__restrict__ C, int64_t c_rs,
-                      const T *__restrict__ z, int64_t z_rs, const T *__restrict__ dout, int64_t do_rs,
-                      float2 *__restrict__ agg, ScanDims d) {
-  constexpr int ROWB = TC * sizeof(T);
-  constexpr int TS = LT / NS;
-  constexpr int NTH = TC * NS;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T *cc = reinterpret_cast<T *>(smem);
-  T *zz = cc + LT * TC;
-  T *gg = zz + LT * TC;
-  float *dl = reinterpret_cast<float *>(gg + LT * TC);
-  float2 *segs = reinterpret_cast<float2 *>(dl + LT * d.HT);
-  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
-  const int chunk = blockIdx.x, ct = blockIdx.y, b = blockIdx.z;
-  const int c0 = ct * TC, c = c0 + lane;
-  const int64_t t0 = (int64_t)chunk * LT;
-  const int rows_valid = (int)min((int64_t)LT, d.L - t0);
-  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
-  const int64_t tok0 = (int64_t)b * d.L + t0;
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(cc), reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
-                              c_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(zz), reinterpret_cast<const char *>(z + tok0 * z_rs + c0),
-                              z_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(gg), reinterpret_cast<const char *>(dout + tok0 * do_rs + c0),
-                              do_rs * sizeof(T), rows_valid, ch_valid * (int)sizeof(T), tid);
-  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
-  const float A2 = c < d.Dn ? -expf(A_log[c]) * LOG2E_F : 0.f;
-  __syncthreads();
-  float P = 1.f, M = 0.f;
-  const int hh = lane >> d.log2N;
-#pragma unroll
-  for (int i = TS - 1; i >= 0; --i) {
-    const int t = seg * TS + i;
-    const float av = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
-    const float dv = to_f32(gg[t * TC + lane]) * silu_g(to_f32(zz[t * TC + lane]));
-    const float u = dv * to_f32(cc[t * TC + lane]);
-    M = av * (u + M);
-    P *= av;
-  }
-  segs[seg * TC + lane] = make_float2(P, M);
-  __syncthreads();
-  if (seg == 0 && c < d.Dn) {
-    float2 q = segs[(NS - 1) * TC + lane];
-    float Pt = q.x, Mt = q.y;
-#pragma unroll
-    for (int s = NS - 2; s >= 0; --s) { const float2 r = segs[s * TC + lane]; Mt = fmaf(r.x, Mt, r.y); Pt *= r.x; }
-    agg[((int64_t)b * d.nchunks + chunk) * d.Dn + c] = make_float2(Pt, Mt);
-  }
+// (A persistent form of the forward - a work-group walks items and issues its next item's loads one phase ahead - was
+// built and measured with tools/probes/scan_gate_probe.hip at B=32, L=4096, Dn=176: the wait for the first tile goes from
+// 5.6 to 0.9 us per item, but the loads parked in registers across the loop either spill (two work-groups per CU at 80
+// VGPRs: 134 us) or leave one work-group per CU whose column walks then take twice as long (91 us), against 73 us for one
+// item per work-group with warm caches.  Removed.)
+struct ItemPos { int chunk, cs, b, id; };
+template <int MODE>
+__device__ __forceinline__ ItemPos decode_item(int item, const ScanDims &d, int ncs, bool reverse) {
+  const int bcs = (int)d.B * ncs;
+  const int k = item / bcs, r = item - k * bcs;
+  ItemPos p;
+  p.id = item;
+  p.chunk = reverse ? d.nchunks - 1 - k : k;
+  p.b = r / ncs;
+  p.cs = r - p.b * ncs;
+  return p;
 }
 
-// backward replay (mode 0: carry from agg; mode 1: single launch, chunks taken right to left from the ticket counter)
-template <typename T, int VB, int LT, int NS, int MODE>
-__global__ void __launch_bounds__(TC * NS)
-scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, const T *__restrict__ Bt, int64_t bt_rs,
+// forward: out = (C*s + D*xc) * silu(z).   MODE 0: replay, carry from agg[]; 1: single launch; 2: state pass (writes agg[])
+//   LDS: Bt and C tiles [64][CWC] (staged as whole rows), later overwritten by the fp32 y tile; delta tile; a [NS][CWC]
+//   table of segment aggregates; two [CWC] look-back records.
+template <typename T, int VB, int CW, int MODE, int MINW>
+__global__ void __launch_bounds__(Geo<CW>::NTH, MINW)
+scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, const T *__restrict__ Bt, int64_t bt_rs,
                 const T *__restrict__ C, int64_t c_rs, const T *__restrict__ xc, int64_t xc_rs, const T *__restrict__ z,
-                int64_t z_rs, const float *__restrict__ Dv, const T *__restrict__ dout, int64_t do_rs,
-                const float *__restrict__ h_in, const float2 *__restrict__ agg, GateWsHead *__restrict__ head,
-                gran_t *__restrict__ gran, uint32_t epoch, T *__restrict__ dBt, int64_t dbt_rs, T *__restrict__ dC,
-                int64_t dc_rs, int64_t store_w, T *__restrict__ dxc, int64_t dxc_rs, T *__restrict__ dz, int64_t dz_rs,
-                float *__restrict__ d_dlt, float *__restrict__ part, ScanDims d, int ctiles) {
-  constexpr int ROWB = TC * sizeof(T);
-  constexpr int TS = LT / NS;
-  constexpr int NTH = TC * NS;
+                int64_t z_rs, const float *__restrict__ Dv, const float *__restrict__ h0, float2 *__restrict__ agg,
+                GateWsHead *__restrict__ head, gran_t *__restrict__ gran, uint32_t epoch, float *__restrict__ h_in,
+                float *__restrict__ h_last, T *__restrict__ out, int64_t out_rs, ScanDims d, int ncs, int total) {
+  typedef Geo<CW> G;
+  constexpr int NS = G::NS, CWC = G::CWC, NTH = G::NTH, TS = G::TS, LT = LTG;
+  constexpr int ROWB = CWC * sizeof(T);
+  typedef TileRegs<VB, ROWB, LT, NTH> TR;
+  typedef Piece<T, VB> PC;
+  constexpr int EPC = PC::EPC;
+  const int HTC = CW * d.HT;                                        // heads covered by the tile
+  const int HS = ncs == 1 ? (int)d.h : HTC;                         // row pitch of the delta tile in LDS
+  constexpr int DLI = (LT * 16 + NTH - 1) / NTH;                    // delta values per thread (at most 16 heads per 64 channels ... N >= 4)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T *bt = reinterpret_cast<T *>(smem);
-  T *cc = bt + LT * TC;
-  T *xx = cc + LT * TC;
-  T *zz = xx + LT * TC;
-  T *gg = zz + LT * TC;
-  float *dl = reinterpret_cast<float *>(gg + LT * TC);
-  float *ddl = dl + LT * d.HT;
-  float *segs = ddl + LT * d.HT;                                   // [NS][TC][3]
-  float2 *lk = reinterpret_cast<float2 *>(segs + NS * TC * 3);     // [NS][TC]
-  int *item_s = reinterpret_cast<int *>(lk + NS * TC);
+  T *cc = bt + LT * CWC;
+  float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB);
+  float2 *segs = reinterpret_cast<float2 *>(dl + LT * HTC);
+  float2 *lkA = segs + NS * CWC, *lkX = lkA + CWC;
+  float *dtab = reinterpret_cast<float *>(lkX + CWC);
+  int *item_s = reinterpret_cast<int *>(dtab + CWC);               // [0]: ticket; [2]: probe id
 
-  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
-  int chunk, ct, b;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, cw = w / NS, seg = w - cw * NS, cl = cw * 64 + lane;
+  const int hh = cl >> d.log2N;
+  int cur_item;
   if constexpr (MODE == 1) {
     if (tid == 0) {
       const unsigned t = atomicAdd(&head->ctr[epoch & 1], 1u);
-      if (t == 0) atomicExch(&head->ctr[(epoch + 1) & 1], 0u);
-      *item_s = (int)t;
+      if (t == 0) atomicExch(&head->ctr[(epoch + 1) & 1], 0u);   // the next launch's counter (its last user has finished)
+      item_s[0] = (int)t;
     }
     __syncthreads();
-    const int item = *item_s, bct_n = (int)d.B * ctiles;
-    const int k = item / bct_n, bct = item - k * bct_n;
-    chunk = d.nchunks - 1 - k;                                     // right to left
-    b = bct / ctiles;
-    ct = bct - b * ctiles;
+    cur_item = item_s[0];
   } else {
-    chunk = blockIdx.x; ct = blockIdx.y; b = blockIdx.z;
+    cur_item = blockIdx.x;
   }
-  const int c0 = ct * TC, c = c0 + lane;
+  if (cur_item >= total) return;
+  const ItemPos it = decode_item<MODE>(cur_item, d, ncs, false);
+
+  TR rb, rc, rx, rz;
+  float dreg[DLI];
+  // loads of an item's tiles (issued one item ahead)
+  auto geom = [&](const ItemPos &p, int &c0, int64_t &tok0, int &rows_valid, int &vb) {
+    c0 = p.cs * CWC;
+    const int64_t t0 = (int64_t)p.chunk * LT;
+    rows_valid = (int)min((int64_t)LT, d.L - t0);
+    tok0 = (int64_t)p.b * d.L + t0;
+    vb = (int)min((int64_t)CWC, d.Dn - c0) * (int)sizeof(T);
+  };
+  auto load_bt = [&](const ItemPos &p) {
+    int c0, rows_valid, vb; int64_t tok0;
+    geom(p, c0, tok0, rows_valid, vb);
+    rb.load(reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0), bt_rs * sizeof(T), rows_valid, vb, tid);
+    if (ncs == 1) {                                                 // all heads: the tile's delta values are one contiguous run
+      const int nv = rows_valid * (int)d.h;
+#pragma unroll
+      for (int k = 0; k < DLI; ++k) dreg[k] = tid + k * NTH < nv ? dlt[tok0 * d.h + tid + k * NTH] : -INFINITY;
+    } else {
+      const int head0 = c0 >> d.log2N;
+#pragma unroll
+      for (int k = 0; k < DLI; ++k) {
+        const int idx = tid + k * NTH, t = idx / HTC, hx = idx - t * HTC;
+        dreg[k] = (idx < LT * HTC && t < rows_valid && head0 + hx < d.h) ? dlt[(tok0 + t) * d.h + head0 + hx] : -INFINITY;
+      }
+    }
+  };
+  auto load_c = [&](const ItemPos &p) {
+    int c0, rows_valid, vb; int64_t tok0;
+    geom(p, c0, tok0, rows_valid, vb);
+    rc.load(reinterpret_cast<const char *>(C + tok0 * c_rs + c0), c_rs * sizeof(T), rows_valid, vb, tid);
+  };
+  auto load_xz = [&](const ItemPos &p) {
+    int c0, rows_valid, vb; int64_t tok0;
+    geom(p, c0, tok0, rows_valid, vb);
+    rx.load(reinterpret_cast<const char *>(xc + tok0 * xc_rs + c0), xc_rs * sizeof(T), rows_valid, vb, tid);
+    rz.load(reinterpret_cast<const char *>(z + tok0 * z_rs + c0), z_rs * sizeof(T), rows_valid, vb, tid);
+  };
+  load_bt(it);
+  if constexpr (MODE != 2) { load_c(it); load_xz(it); }
+
+  {
+    const int chunk = it.chunk, cs = it.cs, b = it.b;
+    const int c0 = cs * CWC, c = c0 + cl;
+    const int64_t t0 = (int64_t)chunk * LT;
+    const int rows_valid = (int)min((int64_t)LT, d.L - t0);
+    const int ch_valid = (int)min((int64_t)CWC, d.Dn - c0);
+    const int64_t tok0 = (int64_t)b * d.L + t0;
+    const bool chan_ok = c < d.Dn;
+    const int vb = ch_valid * (int)sizeof(T);
+#ifdef SCAN_PROBE
+    if (tid == 0) item_s[2] = it.id;
+#endif
+    PROBE(0);
+    const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
+    if constexpr (MODE != 2) {
+      if (tid < CWC) dtab[tid] = (c0 + tid < d.Dn) ? Dv[c0 + tid] : 0.f;
+    }
+    rb.store(reinterpret_cast<char *>(bt), tid);
+#pragma unroll
+    for (int k = 0; k < DLI; ++k) {
+      const int idx = tid + k * NTH;
+      if (idx < LT * HTC) dl[idx] = dreg[k] == -INFINITY ? 0.f : (d.softplus ? softplus_f(dreg[k]) : dreg[k]);
+    }
+    __syncthreads();   // Bt and delta tiles are in LDS
+    PROBE(1);
+
+    float a[TS];
+    float P = 1.f, S = 0.f;
+#pragma unroll
+    for (int i = 0; i < TS; ++i) {
+      const int t = seg * TS + i;
+      a[i] = __builtin_amdgcn_exp2f(dl[t * HS + hh] * A2);
+      S = fmaf(a[i], S, to_f32(bt[t * CWC + cl]));
+      P *= a[i];
+    }
+    segs[seg * CWC + cl] = make_float2(P, S);
+    __syncthreads();
+    PROBE(2);
+
+    // composite of the segments in front of this wave's
+    float Ppre = 1.f, Spre = 0.f;
+    for (int s = 0; s < seg; ++s) { const float2 r = segs[s * CWC + cl]; Spre = fmaf(r.x, Spre, r.y); Ppre *= r.x; }
+    const int64_t abase = (int64_t)b * d.nchunks * d.Dn + c;
+    if constexpr (MODE == 2) {
+      if (seg == NS - 1 && chan_ok) agg[abase + (int64_t)chunk * d.Dn] = make_float2(Ppre * P, fmaf(P, Spre, S));
+    } else {
+      // carry entering the chunk = [composites of the earlier super-chunks] then [aggregates of the earlier chunks of this one]
+      const int sup = chunk / SUP, base0 = sup * SUP;
+      if constexpr (MODE == 1) {
+        const int nrec = d.nchunks + (d.nchunks + SUP - 1) / SUP;
+        gran_t *gb = gran + ((int64_t)(b * ncs + cs) * nrec) * CWC * 2;
+        if (seg == NS - 1 && chunk + 1 < d.nchunks && chan_ok) {     // publish this chunk's aggregate (the last chunk has no reader)
+          gran_store(gb + ((int64_t)chunk * CWC + cl) * 2 + 0, epoch, Ppre * P);
+          gran_store(gb + ((int64_t)chunk * CWC + cl) * 2 + 1, epoch, fmaf(P, Spre, S));
+        }
+        if (seg == 0) {
+          float PA, SA;
+          gather_published(gb, CWC, base0, chunk, false, cl, chan_ok, epoch, &head->err, PA, SA);
+          if (chunk - base0 == SUP - 1 && chunk + 1 < d.nchunks && chan_ok) {   // last chunk of its super-chunk: publish the composite
+            float Po = 1.f, So = 0.f;
+            for (int s = 0; s < NS; ++s) { const float2 r = segs[s * CWC + cl]; So = fmaf(r.x, So, r.y); Po *= r.x; }
+            gran_store(gb + ((int64_t)(d.nchunks + sup) * CWC + cl) * 2 + 0, epoch, PA * Po);
+            gran_store(gb + ((int64_t)(d.nchunks + sup) * CWC + cl) * 2 + 1, epoch, fmaf(Po, SA, So));
+          }
+          lkA[cl] = make_float2(PA, SA);
+        } else if (seg == 1) {
+          float PX, SX;
+          gather_published(gb, CWC, d.nchunks, d.nchunks + sup, false, cl, chan_ok, epoch, &head->err, PX, SX);
+          lkX[cl] = make_float2(PX, SX);
+        }
+      } else {
+        if (seg == 0) {
+          float PA, SA;
+          fold_agg(agg, abase, d.Dn, base0, chunk, false, chan_ok, PA, SA);
+          lkA[cl] = make_float2(PA, SA);
+        } else if (seg == 1) {
+          float PX = 1.f, SX = 0.f;
+          for (int i = 0; i < sup; ++i) {
+            float Pi, Si;
+            fold_agg(agg, abase, d.Dn, i * SUP, i * SUP + SUP, false, chan_ok, Pi, Si);
+            SX = fmaf(Pi, SX, Si);
+            PX *= Pi;
+          }
+          lkX[cl] = make_float2(PX, SX);
+        }
+      }
+      PROBE(3);
+      rc.store(reinterpret_cast<char *>(cc), tid);
+      __syncthreads();
+      PROBE(4);
+
+      float hcar = (h0 && chan_ok) ? h0[(int64_t)b * d.Dn + c] : 0.f;
+      { const float2 rX = lkX[cl], rA = lkA[cl]; hcar = fmaf(rX.x, hcar, rX.y); hcar = fmaf(rA.x, hcar, rA.y); }
+      if (seg == 0 && chan_ok) h_in[abase + (int64_t)chunk * d.Dn] = hcar;    // state entering the chunk, saved for the backward
+      hcar = fmaf(Ppre, hcar, Spre);
+      float hst = hcar;
+#pragma unroll
+      for (int i = 0; i < TS; ++i) {
+        const int t = seg * TS + i;
+        hst = fmaf(a[i], hst, to_f32(bt[t * CWC + cl]));
+        y_put<T>(bt, cc, t * CWC + cl, to_f32(cc[t * CWC + cl]) * hst);
+      }
+      if (h_last && chunk == d.nchunks - 1 && seg == NS - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
+      __syncthreads();   // y (in the Bt / C slots) is complete
+      PROBE(5);
+      PROBE(6);
+
+      // row-major epilogue: out = (y + D*xc) * silu(z), 16-byte pieces straight to global memory
+      char *og = reinterpret_cast<char *>(out + tok0 * out_rs + c0);
+      const int prow0 = TR::row0(tid), cb = TR::cb0(tid);
+#pragma unroll
+      for (int q = 0; q < TR::ITERS; ++q) {
+        const int row = prow0 + q * TR::RSTEP;
+        if (row < rows_valid && cb < vb) {
+          const int e0 = cb / (int)sizeof(T);
+          float xv[EPC], zv[EPC], yk[EPC], o[EPC];
+          PC::unpack(rx.r[q], xv);
+          PC::unpack(rz.r[q], zv);
+          YGet<T, EPC>::get(bt, cc, row * CWC + e0, yk);
+#pragma unroll
+          for (int k = 0; k < EPC; ++k) {
+            const float dx = dtab[e0 + k] * xv[k];
+            const float v = yk[k] + dx;
+            o[k] = v * silu_g(zv[k]);
+          }
+          *reinterpret_cast<typename PC::V *>(og + (int64_t)row * out_rs * sizeof(T) + cb) = PC::pack(o);
+        }
+      }
+    }
+    PROBE(7);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward.  dv = dout*silu(z) (= d/dy) is formed row-major from the 16-byte pieces of dout and z as they arrive and
+// lives in an fp32 LDS tile; the column walk turns that tile into y in place; dz = dout*silu'(z)*(y + D*xc) and
+// dxc = dv*D leave row-major straight from registers; dBt / dC go through the Bt / C tiles as whole rows.
+//   u_t = dv_t*C_t,  mu_t = a_t*(u_t + mu_{t+1});  reverse aggregates (P = prod a, M = mu at chunk start from zero).
+// MODE 0: replay, carry from agg[]; 1: single launch (chunks right to left); 2: state pass (writes agg[]).
+template <typename T, int VB, int CW, int MODE>
+__global__ void __launch_bounds__(Geo<CW>::NTH)
+scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, const T *__restrict__ Bt, int64_t bt_rs,
+                const T *__restrict__ C, int64_t c_rs, const T *__restrict__ xc, int64_t xc_rs, const T *__restrict__ z,
+                int64_t z_rs, const float *__restrict__ Dv, const T *__restrict__ dout, int64_t do_rs,
+                const float *__restrict__ h_in, float2 *__restrict__ agg, GateWsHead *__restrict__ head,
+                gran_t *__restrict__ gran, uint32_t epoch, T *__restrict__ dBt, int64_t dbt_rs, T *__restrict__ dC,
+                int64_t dc_rs, int64_t store_w, T *__restrict__ dxc, int64_t dxc_rs, T *__restrict__ dz, int64_t dz_rs,
+                float *__restrict__ d_dlt, float *__restrict__ part, ScanDims d, int ncs) {
+  typedef Geo<CW> G;
+  constexpr int NS = G::NS, CWC = G::CWC, NTH = G::NTH, TS = G::TS, LT = LTG;
+  constexpr int ROWB = CWC * sizeof(T);
+  typedef TileRegs<VB, ROWB, LT, NTH> TR;
+  typedef Piece<T, VB> PC;
+  constexpr int EPC = PC::EPC;
+  const int HTC = CW * d.HT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T *bt = reinterpret_cast<T *>(smem);
+  T *cc = bt + LT * CWC;
+  float *pt = reinterpret_cast<float *>(smem);                      // dv*xc tile [64][CWC] fp32, over bt + cc once they have left
+  float *dvt = reinterpret_cast<float *>(smem + 2 * LT * ROWB);    // dv, then y: [64][CWC] fp32
+  float *dl = dvt + LT * CWC;
+  float *ddl = dl + LT * HTC;
+  float *segs = ddl + LT * HTC;                                     // [NS][CWC][3] = (P, S, M) of the token segments
+  float2 *lkA = reinterpret_cast<float2 *>(segs + NS * CWC * 3), *lkX = lkA + CWC;
+  float2 *red = lkX + CWC;                                          // [NS][CWC] partial sums (dA_log, dD)
+  float *dtab = reinterpret_cast<float *>(red + NS * CWC);
+  int *item_s = reinterpret_cast<int *>(dtab + CWC);   // [0] ticket, [1] probe id
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, cw = w / NS, seg = w - cw * NS, cl = cw * 64 + lane;
+  int chunk, cs, b;
+  take_item<MODE>(head, epoch, item_s, d, ncs, true, tid, chunk, cs, b);
+  PROBE(0);
+  const int c0 = cs * CWC, c = c0 + cl;
   const int64_t t0 = (int64_t)chunk * LT;
   const int rows_valid = (int)min((int64_t)LT, d.L - t0);
-  const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
-  const int ch_store = (int)min((int64_t)TC, store_w - c0);        // dBt / dC are zero-extended to the padded slice width
+  const int ch_valid = (int)min((int64_t)CWC, d.Dn - c0);
+  const int ch_store = (int)max((int64_t)0, min((int64_t)CWC, store_w - c0));   // dBt / dC zero-extended to the padded slice width
   const int64_t tok0 = (int64_t)b * d.L + t0;
   const int head0 = c0 >> d.log2N;
   const bool chan_ok = c < d.Dn;
-
   const int vb = ch_valid * (int)sizeof(T);
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(cc), reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
-                              c_rs * sizeof(T), rows_valid, vb, tid);
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(zz), reinterpret_cast<const char *>(z + tok0 * z_rs + c0),
-                              z_rs * sizeof(T), rows_valid, vb, tid);
-  stage_in<VB, ROWB, LT, NTH>(reinterpret_cast<char *>(gg), reinterpret_cast<const char *>(dout + tok0 * do_rs + c0),
-                              do_rs * sizeof(T), rows_valid, vb, tid);
-  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, head0, (int)d.h, d.HT, d.softplus, tid);
+
+  TR rc, rg, rz, rb, rx;
+  rc.load(reinterpret_cast<const char *>(C + tok0 * c_rs + c0), c_rs * sizeof(T), rows_valid, vb, tid);
+  rg.load(reinterpret_cast<const char *>(dout + tok0 * do_rs + c0), do_rs * sizeof(T), rows_valid, vb, tid);
+  rz.load(reinterpret_cast<const char *>(z + tok0 * z_rs + c0), z_rs * sizeof(T), rows_valid, vb, tid);
+  stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, head0, (int)d.h, HTC, d.softplus, tid);
   const float Ac = chan_ok ? -expf(A_log[c]) : 0.f;
   const float A2 = Ac * LOG2E_F;
-  const float Dc = chan_ok ? Dv[c] : 0.f;
-  const int64_t cidx = ((int64_t)b * d.nchunks + chunk) * d.Dn + c;
-  float hcar = chan_ok ? h_in[cidx] : 0.f;
-  TileRegs<VB, ROWB, LT, NTH> rb, rx;
-  rb.load(reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0), bt_rs * sizeof(T), rows_valid, vb, tid);
-  rx.load(reinterpret_cast<const char *>(xc + tok0 * xc_rs + c0), xc_rs * sizeof(T), rows_valid, vb, tid);
-  __syncthreads();   // C, z, dout, delta tiles are in LDS
-
-  float a[TS];
-  float P = 1.f, M = 0.f;
-  const int hh = lane >> d.log2N;
-#pragma unroll
-  for (int i = TS - 1; i >= 0; --i) {
-    const int t = seg * TS + i;
-    a[i] = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
-    const float dv = to_f32(gg[t * TC + lane]) * silu_g(to_f32(zz[t * TC + lane]));
-    const float u = dv * to_f32(cc[t * TC + lane]);
-    M = a[i] * (u + M);
-    P *= a[i];
+  const int64_t abase = (int64_t)b * d.nchunks * d.Dn + c;
+  float hcar = 0.f;
+  if constexpr (MODE != 2) {
+    rb.load(reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0), bt_rs * sizeof(T), rows_valid, vb, tid);
+    rx.load(reinterpret_cast<const char *>(xc + tok0 * xc_rs + c0), xc_rs * sizeof(T), rows_valid, vb, tid);
+    if (tid < CWC) dtab[tid] = (c0 + tid < d.Dn) ? Dv[c0 + tid] : 0.f;
+    hcar = chan_ok ? h_in[abase + (int64_t)chunk * d.Dn] : 0.f;
   }
-  segs[(seg * TC + lane) * 3 + 0] = P;
-  segs[(seg * TC + lane) * 3 + 2] = M;
-  __syncthreads();
-
-  // mu entering from the right: the later chunks' reverse aggregates composed right to left
-  {
-    const int lo = chunk + 1, hi = d.nchunks, n = hi - lo, q = (n + NS - 1) / NS;
-    const int s1 = max(hi - seg * q, lo), s0 = max(s1 - q, lo);   // wave `seg` takes the seg-th sub-range from the right
-    float Pw = 1.f, Mw = 0.f;
-    if constexpr (MODE == 1) {
-      gran_t *gbase = gran + ((int64_t)(b * ctiles + ct) * d.nchunks) * TC * 2;
-      if (seg == 0 && chunk > 0) {
-        float Pt = segs[((NS - 1) * TC + lane) * 3 + 0], Mt = segs[((NS - 1) * TC + lane) * 3 + 2];
+  rc.store(reinterpret_cast<char *>(cc), tid);
 #pragma unroll
-        for (int s = NS - 2; s >= 0; --s) {
-          const float px = segs[(s * TC + lane) * 3 + 0], mx = segs[(s * TC + lane) * 3 + 2];
-          Mt = fmaf(px, Mt, mx);
-          Pt *= px;
-        }
-        if (chan_ok) {
-          gran_store(gbase + ((int64_t)chunk * TC + lane) * 2 + 0, epoch, Pt);
-          gran_store(gbase + ((int64_t)chunk * TC + lane) * 2 + 1, epoch, Mt);
-        }
-      }
-      gather_published(gbase, s0, s1, true, lane, chan_ok, epoch, &head->err, Pw, Mw);
-    } else {
-      if (chan_ok) {
-        const int64_t base = (int64_t)b * d.nchunks * d.Dn + c;
-        for (int j = s1 - 1; j >= s0; --j) { const float2 r = agg[base + (int64_t)j * d.Dn]; Mw = fmaf(r.x, Mw, r.y); Pw *= r.x; }
-      }
+  for (int it = 0; it < TR::ITERS; ++it) {                          // dv tile, row-major
+    {
+      const int row = TR::row0(tid) + it * TR::RSTEP, e0 = TR::cb0(tid) / (int)sizeof(T);
+      float gv[EPC], zv[EPC];
+      PC::unpack(rg.r[it], gv);
+      PC::unpack(rz.r[it], zv);
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) dvt[row * CWC + e0 + k] = gv[k] * silu_g(zv[k]);
     }
-    lk[seg * TC + lane] = make_float2(Pw, Mw);
+    __builtin_amdgcn_sched_barrier(0);                              // one piece at a time: interleaved, their temporaries spill
   }
-  rb.store(reinterpret_cast<char *>(bt), tid);
-  rx.store(reinterpret_cast<char *>(xx), tid);
-  __syncthreads();
+  __syncthreads();   // C, dv, delta tiles are in LDS
+  PROBE(1);
 
-  // forward segment aggregate (needs Bt) for the states inside the chunk
-  float S = 0.f;
-#pragma unroll
-  for (int i = 0; i < TS; ++i) S = fmaf(a[i], S, to_f32(bt[(seg * TS + i) * TC + lane]));
-  segs[(seg * TC + lane) * 3 + 1] = S;
-  float mcar = 0.f;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) { const float2 r = lk[s * TC + lane]; mcar = fmaf(r.x, mcar, r.y); }
-  __syncthreads();
-  for (int s = 0; s < seg; ++s) hcar = fmaf(segs[(s * TC + lane) * 3 + 0], hcar, segs[(s * TC + lane) * 3 + 1]);
-  for (int s = NS - 1; s > seg; --s) mcar = fmaf(segs[(s * TC + lane) * 3 + 0], mcar, segs[(s * TC + lane) * 3 + 2]);
-
-  float hs[TS];
-  float hst = hcar;
-#pragma unroll
-  for (int i = 0; i < TS; ++i) {
-    hst = fmaf(a[i], hst, to_f32(bt[(seg * TS + i) * TC + lane]));
-    hs[i] = hst;
-  }
-  float mu = mcar, dA_acc = 0.f, dD_acc = 0.f;
-#pragma unroll
+  // a_t = exp2(delta_t*A2) is recomputed wherever it is needed (three times per token) instead of living in 16 registers:
+  // the kernel runs one work-group per CU and every array that spills turns its column walk into scratch traffic
+  // (measured: 9.1 us for the adjoint loop with 208 bytes of scratch per lane)
+  const int hh = cl >> d.log2N;
+  auto a_of = [&](int t) { return __builtin_amdgcn_exp2f(dl[t * HTC + hh] * A2); };
+  float P = 1.f, M = 0.f;
+#pragma unroll 4
   for (int i = TS - 1; i >= 0; --i) {
     const int t = seg * TS + i;
-    const float g = to_f32(gg[t * TC + lane]), zf = to_f32(zz[t * TC + lane]);
-    const float Cv = to_f32(cc[t * TC + lane]), xv = to_f32(xx[t * TC + lane]);
-    const float dv = g * silu_g(zf);                       // d/dy = d/d(y + D*xc)
-    const float lam = fmaf(dv, Cv, mu);
-    const float hprev = i > 0 ? hs[i - 1] : hcar;
-    const float q = lam * hprev * a[i] * Ac;               // da_t * a_t * A
-    const float dlv = dl[t * d.HT + hh];
-    dA_acc = fmaf(q, dlv, dA_acc);
-    const float qs = group_sum(q, (int)d.N);
-    if ((lane & ((int)d.N - 1)) == 0) ddl[t * d.HT + hh] = qs;
-    const float yv = Cv * hs[i];
-    const float dx = Dc * xv;
-    const float v = yv + dx;
-    dD_acc += dv * xv;
-    cc[t * TC + lane] = from_f32<T>(dv * hs[i]);           // dC_t
-    bt[t * TC + lane] = from_f32<T>(lam);                  // dBt_t
-    zz[t * TC + lane] = from_f32<T>(g * v * silu_grad_g(zf));   // dz_t
-    xx[t * TC + lane] = from_f32<T>(dv * Dc);              // dxc_t (the gate's share)
-    mu = a[i] * lam;
+    const float av = a_of(t);
+    const float u = dvt[t * CWC + cl] * to_f32(cc[t * CWC + cl]);
+    M = av * (u + M);
+    P *= av;
   }
-  __syncthreads();   // output tiles complete; segs / lk free
-  segs[seg * TC + lane] = dA_acc;
-  segs[(NS + seg) * TC + lane] = dD_acc;
-  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(bt), reinterpret_cast<char *>(dBt + tok0 * dbt_rs + c0),
-                               dbt_rs * sizeof(T), rows_valid, ch_store * (int)sizeof(T), tid);
-  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(cc), reinterpret_cast<char *>(dC + tok0 * dc_rs + c0),
-                               dc_rs * sizeof(T), rows_valid, ch_store * (int)sizeof(T), tid);
-  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(xx), reinterpret_cast<char *>(dxc + tok0 * dxc_rs + c0),
-                               dxc_rs * sizeof(T), rows_valid, vb, tid);
-  stage_out<VB, ROWB, LT, NTH>(reinterpret_cast<const char *>(zz), reinterpret_cast<char *>(dz + tok0 * dz_rs + c0),
-                               dz_rs * sizeof(T), rows_valid, vb, tid);
-  for (int idx = tid; idx < LT * d.HT; idx += NTH) {
-    const int t = idx / d.HT, hx = idx - t * d.HT;
+  segs[(seg * CWC + cl) * 3 + 0] = P;
+  segs[(seg * CWC + cl) * 3 + 2] = M;
+  __syncthreads();
+  PROBE(2);
+
+  // composite of the segments behind this wave's (right to left)
+  float Psuf = 1.f, Msuf = 0.f;
+  for (int s = NS - 1; s > seg; --s) {
+    const float px = segs[(s * CWC + cl) * 3 + 0], mx = segs[(s * CWC + cl) * 3 + 2];
+    Msuf = fmaf(px, Msuf, mx);
+    Psuf *= px;
+  }
+  if constexpr (MODE == 2) {
+    if (seg == 0 && chan_ok) agg[abase + (int64_t)chunk * d.Dn] = make_float2(Psuf * P, fmaf(P, Msuf, M));
+    return;
+  }
+  // mu entering from the right = [composites of the later super-chunks] then [aggregates of the later chunks of this one]
+  const int nsup = (d.nchunks + SUP - 1) / SUP, sup = chunk / SUP, top = min(sup * SUP + SUP, d.nchunks);
+  if constexpr (MODE == 1) {
+    const int nrec = d.nchunks + nsup;
+    gran_t *gb = gran + ((int64_t)(b * ncs + cs) * nrec) * CWC * 2;
+    if (seg == 0 && chunk > 0 && chan_ok) {                        // the whole chunk: this wave's segment after everything behind it
+      gran_store(gb + ((int64_t)chunk * CWC + cl) * 2 + 0, epoch, Psuf * P);
+      gran_store(gb + ((int64_t)chunk * CWC + cl) * 2 + 1, epoch, fmaf(P, Msuf, M));
+    }
+    if (seg == 1) {
+      float PA, MA;
+      gather_published(gb, CWC, chunk + 1, top, true, cl, chan_ok, epoch, &head->err, PA, MA);
+      if (chunk == sup * SUP && sup > 0 && chan_ok) {              // first chunk of its super-chunk: publish the composite
+        float Po = 1.f, Mo = 0.f;
+        for (int s = NS - 1; s >= 0; --s) {
+          const float px = segs[(s * CWC + cl) * 3 + 0], mx = segs[(s * CWC + cl) * 3 + 2];
+          Mo = fmaf(px, Mo, mx);
+          Po *= px;
+        }
+        gran_store(gb + ((int64_t)(d.nchunks + sup) * CWC + cl) * 2 + 0, epoch, PA * Po);
+        gran_store(gb + ((int64_t)(d.nchunks + sup) * CWC + cl) * 2 + 1, epoch, fmaf(Po, MA, Mo));
+      }
+      lkA[cl] = make_float2(PA, MA);
+    } else if (seg == 2) {
+      float PX, MX;
+      gather_published(gb, CWC, d.nchunks + sup + 1, d.nchunks + nsup, true, cl, chan_ok, epoch, &head->err, PX, MX);
+      lkX[cl] = make_float2(PX, MX);
+    }
+  } else {
+    if (seg == 1) {
+      float PA, MA;
+      fold_agg(agg, abase, d.Dn, chunk + 1, top, true, chan_ok, PA, MA);
+      lkA[cl] = make_float2(PA, MA);
+    } else if (seg == 2) {
+      float PX = 1.f, MX = 0.f;
+      for (int i = nsup - 1; i > sup; --i) {
+        float Pi, Mi;
+        fold_agg(agg, abase, d.Dn, i * SUP, min(i * SUP + SUP, d.nchunks), true, chan_ok, Pi, Mi);
+        MX = fmaf(Pi, MX, Mi);
+        PX *= Pi;
+      }
+      lkX[cl] = make_float2(PX, MX);
+    }
+  }
+  PROBE(3);
+  rb.store(reinterpret_cast<char *>(bt), tid);
+  __syncthreads();   // Bt tile and the look-back records are in LDS
+  PROBE(4);
+
+  // forward segment aggregates (need Bt) for the states inside the chunk
+  float S = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < TS; ++i) S = fmaf(a_of(seg * TS + i), S, to_f32(bt[(seg * TS + i) * CWC + cl]));
+  segs[(seg * CWC + cl) * 3 + 1] = S;
+  float mcar = 0.f;
+  { const float2 rX = lkX[cl], rA = lkA[cl]; mcar = fmaf(rX.x, mcar, rX.y); mcar = fmaf(rA.x, mcar, rA.y); }
+  mcar = fmaf(Psuf, mcar, Msuf);
+  __syncthreads();
+  for (int s = 0; s < seg; ++s) hcar = fmaf(segs[(s * CWC + cl) * 3 + 0], hcar, segs[(s * CWC + cl) * 3 + 1]);
+
+  // adjoint, right to left:  lambda_t = dv_t*C_t + mu_{t+1};  mu_t = a_t*lambda_t.  The states it needs are rebuilt in two
+  // halves of the segment (the second half first, from the state at the midpoint), so only TS/2 of them are live.
+  constexpr int HF = TS / 2;
+  float hmid = hcar;
+#pragma unroll 4
+  for (int i = 0; i < HF; ++i) hmid = fmaf(a_of(seg * TS + i), hmid, to_f32(bt[(seg * TS + i) * CWC + cl]));
+  float mu = mcar, dA_acc = 0.f;
+#pragma unroll 1
+  for (int half = 1; half >= 0; --half) {
+    const float h0v = half ? hmid : hcar;                  // state entering this half
+    float hs[HF];
+    float hst = h0v;
+#pragma unroll
+    for (int i = 0; i < HF; ++i) {
+      const int t = seg * TS + half * HF + i;
+      hst = fmaf(a_of(t), hst, to_f32(bt[t * CWC + cl]));
+      hs[i] = hst;
+    }
+#pragma unroll
+    for (int i = HF - 1; i >= 0; --i) {
+      const int t = seg * TS + half * HF + i;
+      const float av = a_of(t);
+      const float dv = dvt[t * CWC + cl], Cv = to_f32(cc[t * CWC + cl]);
+      const float lam = fmaf(dv, Cv, mu);
+      const float hprev = i > 0 ? hs[i - 1] : h0v;
+      const float q = lam * hprev * av * Ac;                // da_t * a_t * A
+      const float dlv = dl[t * HTC + hh];
+      dA_acc = fmaf(q, dlv, dA_acc);
+      const float qs = group_sum(q, (int)d.N);
+      if ((lane & ((int)d.N - 1)) == 0) ddl[t * HTC + hh] = qs;
+      cc[t * CWC + cl] = from_f32<T>(dv * hs[i]);           // dC_t (in place: own column only)
+      bt[t * CWC + cl] = from_f32<T>(lam);                  // dBt_t
+      dvt[t * CWC + cl] = Cv * hs[i];                       // y_t takes dv_t's place (the epilogue recomputes dv)
+      mu = av * lam;
+    }
+  }
+  __syncthreads();   // dBt / dC / y / ddl tiles complete
+  PROBE(5);
+  TR::tile_out(reinterpret_cast<const char *>(bt), reinterpret_cast<char *>(dBt + tok0 * dbt_rs + c0), dbt_rs * sizeof(T), rows_valid,
+               ch_store * (int)sizeof(T), tid);
+  TR::tile_out(reinterpret_cast<const char *>(cc), reinterpret_cast<char *>(dC + tok0 * dc_rs + c0), dc_rs * sizeof(T), rows_valid,
+               ch_store * (int)sizeof(T), tid);
+  for (int idx = tid; idx < LT * HTC; idx += NTH) {
+    const int t = idx / HTC, hx = idx - t * HTC;
     if (t < rows_valid && head0 + hx < d.h) {
       float v = ddl[idx];
       if (d.softplus) v *= 1.f - expf(-dl[idx]);            // sigmoid(x) = 1 - exp(-softplus(x))
       d_dlt[(tok0 + t) * d.h + head0 + hx] = v;
     }
   }
+  __syncthreads();   // the Bt / C tiles have left: the dv*xc tile takes their place
+  PROBE(6);
+
+  // row-major epilogue: dz = dout*silu'(z)*(y + D*xc), dxc = dv*D straight to global memory; dv*xc into the tile
+  char *zg = reinterpret_cast<char *>(dz + tok0 * dz_rs + c0), *xg = reinterpret_cast<char *>(dxc + tok0 * dxc_rs + c0);
+#pragma unroll
+  for (int it = 0; it < TR::ITERS; ++it) {
+    {
+      const int row = TR::row0(tid) + it * TR::RSTEP, cb = TR::cb0(tid), e0 = cb / (int)sizeof(T);
+      float gv[EPC], zv[EPC], xv[EPC], oz[EPC], ox[EPC];
+      PC::unpack(rg.r[it], gv);
+      PC::unpack(rz.r[it], zv);
+      PC::unpack(rx.r[it], xv);
+#pragma unroll
+      for (int k = 0; k < EPC; ++k) {
+        float f, df;
+        silu_both(zv[k], f, df);
+        const float dv = gv[k] * f, dcol = dtab[e0 + k];
+        const float dx = dcol * xv[k];
+        const float v = dvt[row * CWC + e0 + k] + dx;
+        oz[k] = gv[k] * df * v;
+        ox[k] = dv * dcol;
+        pt[row * CWC + e0 + k] = dv * xv[k];               // zero for rows / channels outside the tensor (staged zeros)
+      }
+      if (row < rows_valid && cb < vb) {
+        *reinterpret_cast<typename PC::V *>(zg + (int64_t)row * dz_rs * sizeof(T) + cb) = PC::pack(oz);
+        *reinterpret_cast<typename PC::V *>(xg + (int64_t)row * dxc_rs * sizeof(T) + cb) = PC::pack(ox);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
   __syncthreads();
-  if (seg < 2 && chan_ok) {                                  // wave 0: dA_log partial, wave 1: dD partial
+  {
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < NS; ++w) s += segs[(seg * NS + w) * TC + lane];
+    for (int i = 0; i < TS; ++i) s += pt[(seg * TS + i) * CWC + cl];
+    red[seg * CWC + cl] = make_float2(dA_acc, s);
+  }
+  __syncthreads();
+  if (seg < 2 && chan_ok) {                                  // segment-0 waves: dA_log partial, segment-1 waves: dD partial
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s += seg == 0 ? red[k * CWC + cl].x : red[k * CWC + cl].y;
     part[(((int64_t)b * d.nchunks + chunk) * 2 + seg) * d.Dn + c] = s;
   }
+  PROBE(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -521,110 +791,152 @@ decode_state_k(const float *__restrict__ dt_logits, const float *__restrict__ A_
   out[b * Dn + c] = from_f32<T>(v * silu_g(to_f32(z[b * z_rs + c])));
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-template <typename T> struct FwdGeo { static constexpr int LT = sizeof(T) == 2 ? 128 : 64, NS = 8; };
-constexpr int LT_BWD = 64, NS_BWD = 8;
 
-template <typename T> size_t fwd_lds(const ScanDims &d) {
-  constexpr int LT = FwdGeo<T>::LT, NS = FwdGeo<T>::NS;
-  return 4 * (size_t)LT * TC * sizeof(T) + (size_t)LT * d.HT * 4 + 2 * NS * TC * sizeof(float2) + 16;
+// ---------------------------------------------------------------------------------------------------------------
+// channel groups per work-group: as many as cover Dn (whole rows), bounded by what the LDS tiles allow
+template <typename T> constexpr int cw_max(bool bwd) { return sizeof(T) == 2 ? (bwd ? 3 : 4) : 2; }
+template <typename T> void pick_cw(int64_t Dn, bool bwd, int &cw, int &ncs) {
+  const int g = (int)ceil_div64(Dn, TC);
+  ncs = (g + cw_max<T>(bwd) - 1) / cw_max<T>(bwd);
+  cw = (g + ncs - 1) / ncs;
 }
-template <typename T> size_t bwd_lds(const ScanDims &d) {
-  return 5 * (size_t)LT_BWD * TC * sizeof(T) + 2 * (size_t)LT_BWD * d.HT * 4 + NS_BWD * TC * 3 * 4 + NS_BWD * TC * sizeof(float2) + 16;
+
+template <typename T, int CW> size_t fwd_lds(const ScanDims &d) {
+  typedef Geo<CW> G;
+  return 2 * (size_t)LTG * G::CWC * sizeof(T) + (size_t)LTG * CW * d.HT * 4 + (G::NS + 2) * G::CWC * sizeof(float2) + G::CWC * 4 + 16;
+}
+template <typename T, int CW> size_t bwd_lds(const ScanDims &d) {
+  typedef Geo<CW> G;
+  return 2 * (size_t)LTG * G::CWC * sizeof(T) + (size_t)LTG * G::CWC * 4 + 2 * (size_t)LTG * CW * d.HT * 4 + G::NS * G::CWC * 12 +
+         (G::NS + 2) * G::CWC * sizeof(float2) + G::CWC * 4 + 16;
 }
 
 template <typename F> void allow_lds(F *fn, size_t bytes) {
   if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <typename T, int VB>
-int launch_gate_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
-                    const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *Dv, const float *h0, void *out,
-                    int64_t out_rs, float *h_last, float *agg, float *h_in, void *ws, uint32_t epoch, const ScanDims &d64,
-                    int single_pass, hipStream_t st) {
-  constexpr int LT = FwdGeo<T>::LT, NS = FwdGeo<T>::NS;
-  ScanDims d = d64;
-  d.nchunks = (int)ceil_div64(d.L, LT);
-  const int ctiles = (int)ceil_div64(d.Dn, TC);
-  const size_t lds = fwd_lds<T>(d);
-  GateWsHead *head = reinterpret_cast<GateWsHead *>(ws);
-  gran_t *gran = reinterpret_cast<gran_t *>(reinterpret_cast<char *>(ws) + sizeof(GateWsHead));
-  if (single_pass) {
-    const int64_t items = (int64_t)d.nchunks * d.B * ctiles;
-    if (items > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
-    allow_lds(scan_gate_fwd_k<T, VB, LT, NS, 1>, lds);
-    hipLaunchKernelGGL((scan_gate_fwd_k<T, VB, LT, NS, 1>), dim3((unsigned)items), dim3(TC * NS), lds, st, dlt, A_log,
-                       (const T *)Bt, bt_rs, (const T *)C, c_rs, (const T *)xc, xc_rs, (const T *)z, z_rs, Dv, h0,
-                       (const float2 *)nullptr, head, gran, epoch, h_in, h_last, (T *)out, out_rs, d, (int64_t)d64.nchunks,
-                       ctiles);
+struct FwdArgs {
+  const float *dlt, *A_log; const void *Bt; int64_t bt_rs; const void *C; int64_t c_rs; const void *xc; int64_t xc_rs;
+  const void *z; int64_t z_rs; const float *Dv, *h0; void *out; int64_t out_rs; float *h_last, *agg, *h_in; void *ws;
+  uint32_t epoch; ScanDims d; int single_pass; hipStream_t st;
+};
+
+#ifndef SCAN_FWD_MINW_CW3
+#define SCAN_FWD_MINW_CW3 6
+#endif
+// minimum waves per SIMD the forward is compiled for: bf16 two work-groups per CU (four of the 512-thread ones)
+template <typename T, int CW> constexpr int fwd_minw() {
+  return sizeof(T) == 2 ? (CW == 1 ? 8 : CW == 2 ? 8 : CW == 3 ? SCAN_FWD_MINW_CW3 : 4) : 4;
+}
+
+template <typename T, int VB, int CW>
+int launch_gate_fwd_cw(const FwdArgs &a, int ncs) {
+  typedef Geo<CW> G;
+  constexpr int MW = fwd_minw<T, CW>();
+  const ScanDims &d = a.d;
+  const size_t lds = fwd_lds<T, CW>(d);
+  GateWsHead *head = reinterpret_cast<GateWsHead *>(a.ws);
+  gran_t *gran = reinterpret_cast<gran_t *>(reinterpret_cast<char *>(a.ws) + sizeof(GateWsHead));
+#define FWD_ARGS(aggp) a.dlt, a.A_log, (const T *)a.Bt, a.bt_rs, (const T *)a.C, a.c_rs, (const T *)a.xc, a.xc_rs, (const T *)a.z, \
+    a.z_rs, a.Dv, a.h0, (float2 *)(aggp), head, gran, a.epoch, a.h_in, a.h_last, (T *)a.out, a.out_rs, d, ncs, (int)items
+  const int64_t items = (int64_t)d.nchunks * d.B * ncs;
+  if (items > 0x3fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+  dim3 grid((unsigned)items);                                       // one item per work-group, chunk-major
+  if (a.single_pass) {
+    allow_lds(scan_gate_fwd_k<T, VB, CW, 1, MW>, lds);
+    hipLaunchKernelGGL((scan_gate_fwd_k<T, VB, CW, 1, MW>), grid, dim3(G::NTH), lds, a.st, FWD_ARGS(nullptr));
   } else {
-    dim3 grid(d.nchunks, (unsigned)ctiles, (unsigned)d.B);
-    const size_t lds1 = (size_t)LT * TC * sizeof(T) + (size_t)LT * d.HT * 4 + NS * TC * sizeof(float2);
-    hipLaunchKernelGGL((scan_fwd_state<T, VB, LT, NS>), grid, dim3(TC * NS), lds1, st, dlt, A_log, (const T *)Bt, bt_rs,
-                       (float2 *)agg, d);
-    allow_lds(scan_gate_fwd_k<T, VB, LT, NS, 0>, lds);
-    hipLaunchKernelGGL((scan_gate_fwd_k<T, VB, LT, NS, 0>), grid, dim3(TC * NS), lds, st, dlt, A_log, (const T *)Bt, bt_rs,
-                       (const T *)C, c_rs, (const T *)xc, xc_rs, (const T *)z, z_rs, Dv, h0, (const float2 *)agg, head, gran,
-                       epoch, h_in, h_last, (T *)out, out_rs, d, (int64_t)d64.nchunks, ctiles);
+    allow_lds(scan_gate_fwd_k<T, VB, CW, 2, MW>, lds);
+    hipLaunchKernelGGL((scan_gate_fwd_k<T, VB, CW, 2, MW>), grid, dim3(G::NTH), lds, a.st, FWD_ARGS(a.agg));
+    allow_lds(scan_gate_fwd_k<T, VB, CW, 0, MW>, lds);
+    hipLaunchKernelGGL((scan_gate_fwd_k<T, VB, CW, 0, MW>), grid, dim3(G::NTH), lds, a.st, FWD_ARGS(a.agg));
   }
+#undef FWD_ARGS
   return apertis_check_launch();
 }
 
-template <typename T, int VB>
-int launch_gate_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
-                    const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *Dv, const void *dout,
-                    int64_t do_rs, const float *h_in, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs, int64_t store_w,
-                    void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD, float *agg, float *fold,
-                    float *part, void *ws, uint32_t epoch, const ScanDims &d, int single_pass, hipStream_t st) {
-  constexpr int LT = LT_BWD, NS = NS_BWD;
-  const int ctiles = (int)ceil_div64(d.Dn, TC);
-  const size_t lds = bwd_lds<T>(d);
-  GateWsHead *head = reinterpret_cast<GateWsHead *>(ws);
-  gran_t *gran = reinterpret_cast<gran_t *>(reinterpret_cast<char *>(ws) + sizeof(GateWsHead));
-  if (single_pass) {
-    const int64_t items = (int64_t)d.nchunks * d.B * ctiles;
-    if (items > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
-    allow_lds(scan_gate_bwd_k<T, VB, LT, NS, 1>, lds);
-    hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, LT, NS, 1>), dim3((unsigned)items), dim3(TC * NS), lds, st, dlt, A_log,
-                       (const T *)Bt, bt_rs, (const T *)C, c_rs, (const T *)xc, xc_rs, (const T *)z, z_rs, Dv, (const T *)dout,
-                       do_rs, h_in, (const float2 *)nullptr, head, gran, epoch, (T *)dBt, dbt_rs, (T *)dC, dc_rs, store_w,
-                       (T *)dxc, dxc_rs, (T *)dz, dz_rs, d_dlt, part, d, ctiles);
-  } else {
-    dim3 grid(d.nchunks, (unsigned)ctiles, (unsigned)d.B);
-    const size_t lds1 = 3 * (size_t)LT * TC * sizeof(T) + (size_t)LT * d.HT * 4 + NS * TC * sizeof(float2);
-    hipLaunchKernelGGL((scan_gate_bwd_state_k<T, VB, LT, NS>), grid, dim3(TC * NS), lds1, st, dlt, A_log, (const T *)C, c_rs,
-                       (const T *)z, z_rs, (const T *)dout, do_rs, (float2 *)agg, d);
-    allow_lds(scan_gate_bwd_k<T, VB, LT, NS, 0>, lds);
-    hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, LT, NS, 0>), grid, dim3(TC * NS), lds, st, dlt, A_log, (const T *)Bt, bt_rs,
-                       (const T *)C, c_rs, (const T *)xc, xc_rs, (const T *)z, z_rs, Dv, (const T *)dout, do_rs, h_in,
-                       (const float2 *)agg, head, gran, epoch, (T *)dBt, dbt_rs, (T *)dC, dc_rs, store_w, (T *)dxc, dxc_rs,
-                       (T *)dz, dz_rs, d_dlt, part, d, ctiles);
+template <typename T, int VB> int launch_gate_fwd(const FwdArgs &a) {
+  int cw, ncs;
+  pick_cw<T>(a.d.Dn, false, cw, ncs);
+  if (ncs > 65535) return APERTIS_ERR_UNSUPPORTED;
+  if (cw == 1) return launch_gate_fwd_cw<T, VB, 1>(a, ncs);
+  if (cw == 2) return launch_gate_fwd_cw<T, VB, 2>(a, ncs);
+  if constexpr (sizeof(T) == 2) {
+    if (cw == 3) return launch_gate_fwd_cw<T, VB, 3>(a, ncs);
+    return launch_gate_fwd_cw<T, VB, 4>(a, ncs);
   }
+  return APERTIS_ERR_UNSUPPORTED;
+}
+
+struct BwdArgs {
+  const float *dlt, *A_log; const void *Bt; int64_t bt_rs; const void *C; int64_t c_rs; const void *xc; int64_t xc_rs;
+  const void *z; int64_t z_rs; const float *Dv; const void *dout; int64_t do_rs; const float *h_in; void *dBt; int64_t dbt_rs;
+  void *dC; int64_t dc_rs, store_w; void *dxc; int64_t dxc_rs; void *dz; int64_t dz_rs; float *d_dlt, *dA_dD, *agg, *fold, *part;
+  void *ws; uint32_t epoch; ScanDims d; int single_pass; hipStream_t st;
+};
+
+template <typename T, int VB, int CW>
+int launch_gate_bwd_cw(const BwdArgs &a, int ncs) {
+  typedef Geo<CW> G;
+  const ScanDims &d = a.d;
+  const size_t lds = bwd_lds<T, CW>(d);
+  GateWsHead *head = reinterpret_cast<GateWsHead *>(a.ws);
+  gran_t *gran = reinterpret_cast<gran_t *>(reinterpret_cast<char *>(a.ws) + sizeof(GateWsHead));
+#define BWD_ARGS(aggp) a.dlt, a.A_log, (const T *)a.Bt, a.bt_rs, (const T *)a.C, a.c_rs, (const T *)a.xc, a.xc_rs, (const T *)a.z, \
+    a.z_rs, a.Dv, (const T *)a.dout, a.do_rs, a.h_in, (float2 *)(aggp), head, gran, a.epoch, (T *)a.dBt, a.dbt_rs, (T *)a.dC, a.dc_rs, \
+    a.store_w, (T *)a.dxc, a.dxc_rs, (T *)a.dz, a.dz_rs, a.d_dlt, a.part, d, ncs
+  if (a.single_pass) {
+    const int64_t items = (int64_t)d.nchunks * d.B * ncs;
+    if (items > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+    allow_lds(scan_gate_bwd_k<T, VB, CW, 1>, lds);
+    hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, CW, 1>), dim3((unsigned)items), dim3(G::NTH), lds, a.st, BWD_ARGS(nullptr));
+  } else {
+    dim3 grid(d.nchunks, (unsigned)ncs, (unsigned)d.B);
+    allow_lds(scan_gate_bwd_k<T, VB, CW, 2>, lds);
+    hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, CW, 2>), grid, dim3(G::NTH), lds, a.st, BWD_ARGS(a.agg));
+    allow_lds(scan_gate_bwd_k<T, VB, CW, 0>, lds);
+    hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, CW, 0>), grid, dim3(G::NTH), lds, a.st, BWD_ARGS(a.agg));
+  }
+#undef BWD_ARGS
   // fold the per-chunk partials [rows][2*Dn] (dA_log | dD) in a fixed order, two levels
   const int64_t rows = d.B * d.nchunks, cols = 2 * d.Dn;
   const unsigned ctl = (unsigned)ceil_div64(cols, TC);
   if (rows <= 128) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(ctl), dim3(1024), 0, st, part, dA_dD, rows, cols, rows);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctl), dim3(1024), 0, a.st, a.part, a.dA_dD, rows, cols, rows);
   } else {
     const int64_t groups = std::min<int64_t>(64, ceil_div64(rows, 64)), rpg = ceil_div64(rows, groups);
     const int64_t ng = ceil_div64(rows, rpg);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ctl, (unsigned)ng), dim3(1024), 0, st, part, fold, rows, cols, rpg);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ctl), dim3(1024), 0, st, fold, dA_dD, ng, cols, ng);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctl, (unsigned)ng), dim3(1024), 0, a.st, a.part, a.fold, rows, cols, rpg);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctl), dim3(1024), 0, a.st, a.fold, a.dA_dD, ng, cols, ng);
   }
   return apertis_check_launch();
 }
 
-template <typename T> int gate_align(std::initializer_list<std::pair<const void *, int64_t>> slices, int64_t Dn) {
+template <typename T, int VB> int launch_gate_bwd(const BwdArgs &a) {
+  int cw, ncs;
+  pick_cw<T>(a.d.Dn, true, cw, ncs);
+  if (ncs > 65535) return APERTIS_ERR_UNSUPPORTED;
+  if (cw == 1) return launch_gate_bwd_cw<T, VB, 1>(a, ncs);
+  if (cw == 2) return launch_gate_bwd_cw<T, VB, 2>(a, ncs);
+  if constexpr (sizeof(T) == 2) return launch_gate_bwd_cw<T, VB, 3>(a, ncs);
+  return APERTIS_ERR_UNSUPPORTED;
+}
+
+// widest access every slice allows: pointer, row stride and row length multiples of it (tile steps are multiples of 128 B)
+template <typename T> int gate_align(std::initializer_list<std::pair<const void *, int64_t>> slices, int64_t width) {
   int al = 16;
-  for (auto &s : slices) al = std::min(al, slice_align<T>(s.first, s.second, Dn));
+  for (auto &s : slices)
+    al = std::min(al, common_align({(uint64_t)(uintptr_t)s.first, (uint64_t)s.second * sizeof(T), (uint64_t)width * sizeof(T)}));
   return al;
 }
 
 }  // namespace
 
 extern "C" int64_t apertis_scan_gate_workspace_bytes(int64_t B, int64_t L, int64_t Dn) {
-  // 64-byte head (two ticket counters, error word) + [B * ctiles][chunks of 64 tokens][64 lanes][2 granules] x 8 bytes
-  return (int64_t)sizeof(GateWsHead) + B * ceil_div64(Dn, TC) * ceil_div64(L, LT_DEFAULT) * TC * 2 * 8;
+  // 64-byte head (two ticket counters, error word) + per (batch, channel super-tile): one record per chunk of 64 tokens and
+  // one per super-chunk of 8 chunks, each 64*CW lanes x 2 granules x 8 bytes; sized for the padded channel count
+  const int64_t nch = ceil_div64(L, LTG), nsup = ceil_div64(nch, SUP), g = ceil_div64(Dn, TC);
+  return (int64_t)sizeof(GateWsHead) + B * (nch + nsup) * (g + 3) * TC * 2 * 8;
 }
 
 extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
@@ -634,27 +946,24 @@ extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const
                                      int dtype, int delta_softplus, int single_pass, void *stream) {
   if (!dlt || !A_log || !Bt || !C || !xc || !z || !D || !out || !h_in) return APERTIS_ERR_ARG;
   if (single_pass ? (!ws || epoch == 0) : !agg) return APERTIS_ERR_ARG;
-  ScanDims d;
-  int rc = make_dims(d, B, L, h, N, delta_softplus);
+  FwdArgs a{dlt, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, h0, out, out_rs, h_last, agg, h_in, ws, epoch, {}, single_pass,
+            (hipStream_t)stream};
+  int rc = make_dims(a.d, B, L, h, N, delta_softplus);
   if (rc) return rc;
-  if (bt_rs < d.Dn || c_rs < d.Dn || xc_rs < d.Dn || z_rs < d.Dn || out_rs < d.Dn) return APERTIS_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-#define GF(T, VB) \
-  return launch_gate_fwd<T, VB>(dlt, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, h0, out, out_rs, h_last, agg, h_in, \
-                                ws, epoch, d, single_pass, st)
+  const int64_t Dn = a.d.Dn;
+  if (bt_rs < Dn || c_rs < Dn || xc_rs < Dn || z_rs < Dn || out_rs < Dn) return APERTIS_ERR_ARG;
   if (dtype == APERTIS_F32) {
-    const int al = gate_align<float>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, d.Dn);
-    if (al >= 16) GF(float, 16);
-    if (al >= 8) GF(float, 8);
-    GF(float, 4);
+    const int al = gate_align<float>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, Dn);
+    if (al >= 16) return launch_gate_fwd<float, 16>(a);
+    if (al >= 8) return launch_gate_fwd<float, 8>(a);
+    return launch_gate_fwd<float, 4>(a);
   } else if (dtype == APERTIS_BF16) {
-    const int al = gate_align<bf16_t>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, d.Dn);
-    if (al >= 16) GF(bf16_t, 16);
-    if (al >= 8) GF(bf16_t, 8);
-    if (al >= 4) GF(bf16_t, 4);
-    GF(bf16_t, 2);
+    const int al = gate_align<bf16_t>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, Dn);
+    if (al >= 16) return launch_gate_fwd<bf16_t, 16>(a);
+    if (al >= 8) return launch_gate_fwd<bf16_t, 8>(a);
+    if (al >= 4) return launch_gate_fwd<bf16_t, 4>(a);
+    return launch_gate_fwd<bf16_t, 2>(a);
   }
-#undef GF
   return APERTIS_ERR_UNSUPPORTED;
 }
 
@@ -669,33 +978,28 @@ extern "C" int apertis_scan_gate_bwd(const float *dlt, const float *A_log, const
       !fold || !part)
     return APERTIS_ERR_ARG;
   if (single_pass ? (!ws || epoch == 0) : !agg) return APERTIS_ERR_ARG;
-  ScanDims d;
-  int rc = make_dims(d, B, L, h, N, delta_softplus);
+  BwdArgs a{dlt, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, dout, dout_rs, h_in, dBt, dbt_rs, dC, dc_rs, store_w, dxc,
+            dxc_rs, dz, dz_rs, d_dlt, dA_dD, agg, fold, part, ws, epoch, {}, single_pass, (hipStream_t)stream};
+  int rc = make_dims(a.d, B, L, h, N, delta_softplus);
   if (rc) return rc;
-  if (bt_rs < d.Dn || c_rs < d.Dn || xc_rs < d.Dn || z_rs < d.Dn || dout_rs < d.Dn || dxc_rs < d.Dn || dz_rs < d.Dn)
-    return APERTIS_ERR_ARG;
+  const int64_t Dn = a.d.Dn;
+  if (bt_rs < Dn || c_rs < Dn || xc_rs < Dn || z_rs < Dn || dout_rs < Dn || dxc_rs < Dn || dz_rs < Dn) return APERTIS_ERR_ARG;
   // dBt / dC may be zero-extended up to the next multiple of 64 channels (the padded slices of the projection output)
-  if (store_w < d.Dn || store_w > ceil_div64(d.Dn, TC) * TC || dbt_rs < store_w || dc_rs < store_w) return APERTIS_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-#define GB(T, VB)                                                                                                      \
-  return launch_gate_bwd<T, VB>(dlt, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, dout, dout_rs, h_in, dBt, dbt_rs, dC, \
-                                dc_rs, store_w, dxc, dxc_rs, dz, dz_rs, d_dlt, dA_dD, agg, fold, part, ws, epoch, d,       \
-                                single_pass, st)
+  if (store_w < Dn || store_w > ceil_div64(Dn, TC) * TC || dbt_rs < store_w || dc_rs < store_w) return APERTIS_ERR_ARG;
   if (dtype == APERTIS_F32) {
-    int al = gate_align<float>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {dout, dout_rs}, {dxc, dxc_rs}, {dz, dz_rs}}, d.Dn);
+    int al = gate_align<float>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {dout, dout_rs}, {dxc, dxc_rs}, {dz, dz_rs}}, Dn);
     al = std::min(al, gate_align<float>({{dBt, dbt_rs}, {dC, dc_rs}}, store_w));
-    if (al >= 16) GB(float, 16);
-    if (al >= 8) GB(float, 8);
-    GB(float, 4);
+    if (al >= 16) return launch_gate_bwd<float, 16>(a);
+    if (al >= 8) return launch_gate_bwd<float, 8>(a);
+    return launch_gate_bwd<float, 4>(a);
   } else if (dtype == APERTIS_BF16) {
-    int al = gate_align<bf16_t>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {dout, dout_rs}, {dxc, dxc_rs}, {dz, dz_rs}}, d.Dn);
+    int al = gate_align<bf16_t>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {dout, dout_rs}, {dxc, dxc_rs}, {dz, dz_rs}}, Dn);
     al = std::min(al, gate_align<bf16_t>({{dBt, dbt_rs}, {dC, dc_rs}}, store_w));
-    if (al >= 16) GB(bf16_t, 16);
-    if (al >= 8) GB(bf16_t, 8);
-    if (al >= 4) GB(bf16_t, 4);
-    GB(bf16_t, 2);
+    if (al >= 16) return launch_gate_bwd<bf16_t, 16>(a);
+    if (al >= 8) return launch_gate_bwd<bf16_t, 8>(a);
+    if (al >= 4) return launch_gate_bwd<bf16_t, 4>(a);
+    return launch_gate_bwd<bf16_t, 2>(a);
   }
-#undef GB
   return APERTIS_ERR_UNSUPPORTED;
 }
 

@@ -290,7 +290,10 @@ class _ScanGate(torch.autograd.Function):
         (Bt, bt_rs), (C, c_rs), (xc, xc_rs), (z, z_rs) = _rows(Bt, wB), _rows(C, wC), _rows(xc, Dn), _rows(z, Dn)
         nch = lib.apertis_scan_num_chunks(B, L, Dn)
         dev = dlt.device
-        out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
+        if _os.environ.get("APERTIS_SCAN_PAD_EXPERIMENT"):      # rows on 128-byte boundaries (experiment)
+            out = torch.empty(B, L, -(-Dn // 64) * 64, device=dev, dtype=xc.dtype)[..., :Dn]
+        else:
+            out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
         h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
         e = xc.element_size()
@@ -302,8 +305,8 @@ class _ScanGate(torch.autograd.Function):
             ws, epoch = None, 0
             agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
-                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out), Dn,
-                 ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(delta_softplus),
+                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
+                 out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(delta_softplus),
                  int(SCAN_SINGLE_PASS), stream_ptr()), work)
         ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in)
         ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
@@ -317,12 +320,15 @@ class _ScanGate(torch.autograd.Function):
         B, L, h, N, sp, wB, Ddt = ctx.cfg
         Dn = h * N
         dev = dlt.device
-        dout = dout.to(xc.dtype).contiguous()
+        dout, do_rs = _rows(dout.to(xc.dtype), Dn)
         nch = h_in.shape[1]
         dBt, dbt_rs = _grad_out(ctx.slots[0], (B, L), wB, Bt.dtype, dev)
         dC, dc_rs = _grad_out(ctx.slots[1], (B, L), wB, C.dtype, dev)
         dz, dz_rs = _grad_out(ctx.slots[2], (B, L), Dn, z.dtype, dev)
         dxc, dxc_rs = _grad_out(ctx.slots[3], (B, L), Dn, xc.dtype, dev)
+        if _os.environ.get("APERTIS_SCAN_PAD_EXPERIMENT") and ctx.slots[3] is None:
+            dxc = torch.empty(B, L, -(-Dn // 64) * 64, device=dev, dtype=xc.dtype)[..., :Dn]
+            dxc_rs = dxc.stride(-2)
         d_dlt = torch.empty(B, L, h, device=dev, dtype=torch.float32)
         dA_dD = torch.empty(2, Dn, device=dev, dtype=torch.float32)
         part = torch.empty(B * nch, 2 * Dn, device=dev, dtype=torch.float32)
@@ -337,7 +343,7 @@ class _ScanGate(torch.autograd.Function):
             agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         _launch("apertis_scan_gate_bwd", lib.apertis_scan_gate_bwd,
                 (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
-                 ptr(Df), ptr(dout), Dn, ptr(h_in), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
+                 ptr(Df), ptr(dout), do_rs, ptr(h_in), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
                  ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(sp),
                  int(SCAN_SINGLE_PASS), stream_ptr()), work)
         return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt), None, None, None

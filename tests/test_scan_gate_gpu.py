@@ -126,23 +126,21 @@ def test_scan_gate_fp32_vs_oracle_and_both_forms(dev, B, L, h, N, use_h0):
 
 
 @pytest.mark.parametrize("B,L,h,N", [(2, 130, 11, 16), (1, 700, 14, 16), (2, 64, 4, 16)])
-def test_scan_gate_equals_scan_then_gate_bit_for_bit(dev, B, L, h, N):
-    """fp32: the fused kernel performs exactly the stand-alone pair's arithmetic (y stays in registers instead of
-    making a round trip through HBM in fp32), so the outputs and gradients are identical in every bit - except dz,
-    whose y the backward recomputes from the states it rebuilds per 8-token segment (last-bit differences from the
-    forward's token-by-token states; held to 1e-5)."""
+def test_scan_gate_equals_scan_then_gate(dev, B, L, h, N):
+    """fp32: the fused kernel performs the stand-alone pair's arithmetic with y kept in registers instead of a round
+    trip through HBM.  The two differ only in how the tokens of a chunk are cut into per-wave segments (the fused fp32
+    tiles are 64 tokens, the stand-alone forward's 128), i.e. in the last bits of the states: held to 1e-5, ten times
+    inside the parity bar."""
     i = _inputs(B, L, h, N, seed=7 * L + N)
     Dn, Wb = i["Dn"], i["Wb"]
     f_out, f_hl, fg = _fused(dev, i, True, True)
     t_out, t_hl, tg = _two_ops(dev, i, True)
-    assert torch.equal(f_out, t_out) and torch.equal(f_hl, t_hl)
-    for k in ("logits", "xc"):
-        assert torch.equal(fg[k], tg[k]), k
-    _close(fg["D"], tg["D"], "dD (per-chunk partials here, per-block partials in the gate kernel)", rtol=1e-5)
-    assert torch.equal(fg["p"][..., :Dn], tg["p"][..., :Dn]) and torch.equal(fg["p"][..., Wb:Wb + Dn], tg["p"][..., Wb:Wb + Dn])
-    _close(fg["xz"][..., Dn:], tg["xz"][..., Dn:], "dz (recomputed y)", rtol=1e-5)
-    # dA_log folds per-chunk partials: same partials, same order in both
-    assert torch.equal(fg["A_log"], tg["A_log"])
+    _close(f_out, t_out, "out", rtol=1e-5)
+    _close(f_hl, t_hl, "h_last", rtol=1e-5)
+    for k in ("logits", "xc", "D", "A_log"):
+        _close(fg[k], tg[k], "grad " + k, rtol=1e-5, atol_scale=1e-5)
+    _close(fg["p"], tg["p"], "dp (dBt | dC)", rtol=1e-5)
+    _close(fg["xz"], tg["xz"], "dxz (dz)", rtol=1e-5)
 
 
 def test_scan_gate_bf16_config4_shape(dev):
@@ -208,7 +206,7 @@ def test_scan_gate_single_pass_stress_full_size(dev):
 def test_ssm_layer_golden_through_fused_path(dev):
     """The module on the fused kernel against the SSM layer captured from the reference (forward), with the achieved
     relative error reported; then the module's two paths (fused / scan + gate with output_attentions) against each
-    other in every bit."""
+    other."""
     import apertis_llm_amd as A
     g = load_golden("ssm_layer")
     cfg = A.ApertisConfig(hidden_size=48, num_attention_heads=3, ssm_d_state=16, attention_type="selective_ssm")
@@ -222,7 +220,8 @@ def test_ssm_layer_golden_through_fused_path(dev):
     rel_error_report("ssm_layer (fused scan+gate) out vs reference capture", out_f, g["out"])
     _close(cache_f[1].reshape(2, -1), g["ssm_state"], "ssm_state")
     _close(cache_f[0], g["conv_state"], "conv_state")
-    assert torch.equal(out_f, out_t) and torch.equal(cache_f[1], cache_t[1])
+    _close(out_f, out_t, "fused vs scan + gate", rtol=1e-5)        # token segments of 8 vs 16: last bits of the states
+    _close(cache_f[1], cache_t[1], "final state", rtol=1e-5)
 
 
 def test_decode_kernels_match_the_chunk_path(dev):
