@@ -1,0 +1,54 @@
+// Probe: the expert-MLP grouped GEMMs of the bench's layer shape (8 experts, rows = 8 * 1.25 * B*4096/8, H=704, I=2816) through
+// the C ABI, cold caches (1 GiB read between launches), hipEvent timing.  The library source is compiled in, so -D
+// switches of grouped_gemm.hip can be A/B'd as separate binaries inside one gpurun call.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-D...] tools/probes/gemm_probe.hip -o tools/probes/gemm_probe.bin
+#include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+__global__ void flush_read_k(const uint4 *p, size_t n, unsigned *sink) {
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { uint4 v = p[i]; acc.x ^= v.x ^ v.y ^ v.z ^ v.w; }
+  if (acc.x == 0x12345678u) *sink = acc.x;
+}
+__global__ void fill_k(bf16_t *p, size_t n, float scale, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (bf16_t)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
+  }
+}
+int main(int argc, char **argv) {
+  const int B = argc > 1 ? atoi(argv[1]) : 32;
+  const int64_t E = 8, H = 704, I = 2816, rows = E * (int64_t)((B * 4096 / E) * 1.25);
+  bf16_t *x, *w1, *w2t, *h, *pre, *y, *dpre; float *b1; int32_t *offs; char *flush; unsigned *sink;
+  hipMalloc(&x, rows * H * 2); hipMalloc(&w1, E * I * H * 2); hipMalloc(&w2t, E * I * H * 2); hipMalloc(&h, rows * I * 2);
+  hipMalloc(&pre, rows * I * 2); hipMalloc(&y, rows * H * 2); hipMalloc(&dpre, rows * I * 2); hipMalloc(&b1, E * I * 4);
+  hipMalloc(&offs, (E + 1) * 4); hipMalloc(&flush, (size_t)1 << 30); hipMalloc(&sink, 64);
+  hipMemset(flush, 1, (size_t)1 << 30); hipMemset(b1, 0, E * I * 4);
+  fill_k<<<2048, 256>>>(x, rows * H, 1.f, 1); fill_k<<<2048, 256>>>(w1, E * I * H, 0.05f, 2); fill_k<<<2048, 256>>>(w2t, E * I * H, 0.05f, 3);
+  fill_k<<<2048, 256>>>(y, rows * H, 1.f, 4);
+  std::vector<int32_t> ho(E + 1); for (int e = 0; e <= E; ++e) ho[e] = (int32_t)(rows * e / E);
+  hipMemcpy(offs, ho.data(), (E + 1) * 4, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto timeit = [&](const char *name, double flops, auto fn) {
+    float best = 1e9, sum = 0; int n = 0;
+    for (int rep = 0; rep < 6; ++rep) {
+      flush_read_k<<<4096, 256>>>((const uint4 *)flush, ((size_t)1 << 30) / 16, sink);
+      hipEventRecord(e0); int rc = fn(); hipEventRecord(e1); hipEventSynchronize(e1);
+      if (rc) { printf("%s rc=%d\n", name, rc); return; }
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (rep) { best = std::min(best, ms); sum += ms; ++n; }
+    }
+    printf("%-46s best %7.1f us  avg %7.1f us  %6.0f TF (best)\n", name, best * 1e3, sum / n * 1e3, flops / best / 1e9);
+  };
+  const double fl = 2.0 * rows * H * I;
+  timeit("fc1 fwd: GELU + dropout + pre-activation out", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc1 fwd shape, plain (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc1 shape: + pre-activation out only", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc1 shape: GELU only (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc1 shape: GELU + dropout (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc1 shape: GELU + pre out (no dropout)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc2 dgrad * act'(pre) * mask", fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc2 fwd (N=704, K=2816), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  return 0;
+}
