@@ -860,12 +860,6 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
 // at chunk position c ^ F[(r >> 2) & 3], F = {0,3,2,1}, which makes both the 1 KiB DMA pieces (16 rows)
 // and the ds_read_b128 fragment reads (lane groups of MI355X_MICROARCH.md's LDS table) conflict-free.
 // ------------------------------------------------------------------------------------------
-#ifndef NT2X_KPRIO
-#define NT2X_KPRIO 1
-#endif
-#ifndef NT2X_EPRIO
-#define NT2X_EPRIO 0
-#endif
 constexpr int NT3 = 256, BM3 = 256, BN3 = 128, ROWB3 = 64;
 constexpr int SLOT3 = (BM3 + BN3) * ROWB3;   // 24 KiB: X rows, then W rows
 constexpr int RING3 = 3 * SLOT3;
@@ -953,96 +947,6 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
   lds_barrier();
 }
 
-// Epilogue of the 256 x 128 tile straight from the accumulators (see the W-row permutation in the kernel): lane (m = frow, fg)
-// holds, for every m-subtile j, the 16 consecutive columns n0 + wn*64 + 16*fg + [0, 16) of row wm*128 + 16*j + frow as
-// acc[i][j][r] with column offset 4*i + r.  Two 16-byte stores per output and row; with `mul_pre` the saved pre-activation
-// comes in as two 16-byte loads of the same 32 bytes.  ACT / DROP fixed at compile time where it matters (see nt2x_out).
-template <typename TO, int ACT, bool DROP, bool PRE, bool MULPRE>
-__device__ __forceinline__ void nt2x_direct_rows(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ C,
-                                                 TO *__restrict__ pre_act, const TO *__restrict__ mul_pre, int64_t row0,
-                                                 int rows_valid, int n0, int cols_valid, int N, int act, float drop_p,
-                                                 uint64_t seed, float keep_scale, uint32_t thresh16, int wm, int wn, int frow,
-                                                 int fg) {
-  static_assert(sizeof(TO) == 2, "2-byte outputs");
-  const int ncol = wn * 64 + fg * 16;                       // first of this lane's 16 columns inside the tile
-  if (ncol >= cols_valid) return;                           // (N % 8 == 0: a lane's 16 columns are valid in halves of 8)
-  const bool hi_ok = ncol + 8 < cols_valid;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int m = wm * 128 + j * 16 + frow;
-    const int64_t g = (row0 + m) * N + n0 + ncol;
-    const bool row_ok = m < rows_valid;
-    uint4 pc[2];
-    if constexpr (MULPRE) {
-      pc[0] = row_ok ? *reinterpret_cast<const uint4 *>(mul_pre + g) : make_uint4(0, 0, 0, 0);
-      pc[1] = (row_ok && hi_ok) ? *reinterpret_cast<const uint4 *>(mul_pre + g + 8) : make_uint4(0, 0, 0, 0);
-    }
-    uint32_t praw[8], pout[8];                              // 16 bf16 each, packed in pairs
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bool keep[4] = {true, true, true, true};
-      if (!MULPRE && (ACT >= 0 ? DROP : drop_p > 0.f))
-        drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + ncol + 4 * i), thresh16, keep);
-      uint32_t oraw[4], o[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = acc[i][j][q] + bv[i][q];
-        const TO vr = from_f32<TO>(v);
-        oraw[q] = __builtin_bit_cast(uint16_t, vr);
-        if constexpr (!MULPRE) {
-          if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(vr), ACT >= 0 ? ACT : act);
-          v = keep[q] ? v * keep_scale : 0.f;              // keep_scale is 1 without dropout
-          o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(v));
-        }
-      }
-      praw[2 * i] = oraw[0] | (oraw[1] << 16); praw[2 * i + 1] = oraw[2] | (oraw[3] << 16);
-      if constexpr (!MULPRE) { pout[2 * i] = o[0] | (o[1] << 16); pout[2 * i + 1] = o[2] | (o[3] << 16); }
-    }
-    if (!row_ok) continue;
-    if constexpr (PRE) {
-      *reinterpret_cast<uint4 *>(pre_act + g) = make_uint4(praw[0], praw[1], praw[2], praw[3]);
-      if (hi_ok) *reinterpret_cast<uint4 *>(pre_act + g + 8) = make_uint4(praw[4], praw[5], praw[6], praw[7]);
-    }
-    if constexpr (MULPRE) {
-      // dgrad fusion: the plain product (rounded to the output type, as the staged form did) times act'(pre) * mask / (1-p)
-      *reinterpret_cast<uint4 *>(C + g) = actbwd_chunk<TO, true, ACT, DROP>(make_uint4(praw[0], praw[1], praw[2], praw[3]), pc[0], row0 + m,
-                                                                            n0 + ncol, N, act, drop_p, seed, keep_scale, thresh16);
-      if (hi_ok)
-        *reinterpret_cast<uint4 *>(C + g + 8) = actbwd_chunk<TO, true, ACT, DROP>(make_uint4(praw[4], praw[5], praw[6], praw[7]), pc[1],
-                                                                                row0 + m, n0 + ncol + 8, N, act, drop_p, seed,
-                                                                                keep_scale, thresh16);
-    } else {
-      *reinterpret_cast<uint4 *>(C + g) = make_uint4(pout[0], pout[1], pout[2], pout[3]);
-      if (hi_ok) *reinterpret_cast<uint4 *>(C + g + 8) = make_uint4(pout[4], pout[5], pout[6], pout[7]);
-    }
-  }
-}
-
-template <typename TO>
-__device__ __forceinline__ void nt2x_out_direct(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ C,
-                                                TO *__restrict__ pre_act, const TO *__restrict__ mul_pre, int64_t row0,
-                                                int rows_valid, int n0, int cols_valid, int N, int act, float drop_p, uint64_t seed,
-                                                float keep_scale, uint32_t thresh16, int wm, int wn, int frow, int fg) {
-#define DR(A, D, P, M) nt2x_direct_rows<TO, A, D, P, M>(acc, bv, C, pre_act, mul_pre, row0, rows_valid, n0, cols_valid, N, act, drop_p, \
-                                                        seed, keep_scale, thresh16, wm, wn, frow, fg)
-  if (mul_pre) {
-    if (act == APERTIS_ACT_GELU && drop_p > 0.f) DR(APERTIS_ACT_GELU, true, false, true);
-    else if (act == APERTIS_ACT_GELU) DR(APERTIS_ACT_GELU, false, false, true);
-    else DR(-1, false, false, true);
-  } else if (pre_act) {
-    if (act == APERTIS_ACT_GELU && drop_p > 0.f) DR(APERTIS_ACT_GELU, true, true, false);
-    else if (act == APERTIS_ACT_GELU) DR(APERTIS_ACT_GELU, false, true, false);
-    else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) DR(APERTIS_ACT_NONE, false, true, false);
-    else DR(-1, false, true, false);
-  } else {
-    if (act == APERTIS_ACT_NONE && drop_p <= 0.f) DR(APERTIS_ACT_NONE, false, false, false);
-    else if (act == APERTIS_ACT_GELU && drop_p > 0.f) DR(APERTIS_ACT_GELU, true, false, false);
-    else if (act == APERTIS_ACT_GELU) DR(APERTIS_ACT_GELU, false, false, false);
-    else DR(-1, false, false, false);
-  }
-#undef DR
-}
-
 // RAGGED: K % 32 != 0 - W's rows are zero-padded to whole sub-steps (row pitch ldw), X's last sub-step over-reads into
 // the next row (finite values against W's zeros) and the K offset moves into the range-checked lane offset so that
 // the tile's last row reads zeros past the buffer instead
@@ -1086,21 +990,16 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const v4i wrs = raw_buffer_rsrc(W + ((int64_t)e * N + n0) * ldw, (uint32_t)cols_valid * (uint32_t)ldwb);
   const int fsw = (4 - ((lane >> 4) & 3)) & 3;                       // F[(row >> 2) & 3] for row = lane >> 2
   const uint32_t vx0 = (uint32_t)((wave * 64 + (lane >> 2)) * ldb + (((lane & 3) ^ fsw) << 4));
-  // W rows enter LDS PERMUTED inside each block of 64: LDS row 16*i + a holds W row 16*(a >> 2) + 4*i + (a & 3).  The MFMA
-  // of n-subtile i then leaves, in the four accumulator registers of lane (m, fg), columns 16*fg + 4*i + {0..3}: over
-  // i = 0..3 a lane owns 16 CONSECUTIVE output columns of its row (32 bytes), the four lanes of a row one whole 128-byte
-  // line - the epilogue stores straight from registers, no LDS staging pass and no barrier (NT2X_DIRECT)
-  auto wrow_of = [](int p) { const int a = p & 15, i = (p >> 4) & 3; return (p & ~63) + 16 * (a >> 2) + 4 * i + (a & 3); };
-  const uint32_t vw0 = (uint32_t)(wrow_of(wave * 32 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
-  const uint32_t vw1 = (uint32_t)(wrow_of(wave * 32 + 16 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
+  const uint32_t vw0 = (uint32_t)((wave * 32 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
   const uint32_t lds0 = lds_addr_of(smem);
   auto issue = [&](uint32_t slot_off, int s) {   // sub-step s: this wave's 4 X pieces and 2 W pieces
     const uint32_t kb = (uint32_t)s * ROWB3, base = lds0 + slot_off;
     const uint32_t kv = RAGGED ? kb : 0u, ks = RAGGED ? 0u : kb;
 #pragma unroll
     for (int j = 0; j < 4; ++j) lds_dma16s(xrs, base + (wave * 4 + j) * 1024, vx0 + (uint32_t)(j * 16 * ldb) + kv, ks);
-    lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + 0) * 1024, vw0 + kv, ks);
-    lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + 1) * 1024, vw1 + kv, ks);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + j) * 1024, vw0 + (uint32_t)(j * 16 * ldwb) + kv, ks);
   };
   const int nk = (K + 31) / 32;   // >= 3 (launcher)
   issue(0, 0); issue(SLOT3, 1); issue(2 * SLOT3, 2);
@@ -1150,7 +1049,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       if ((S) + 2 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();                                           \
       lds_barrier();                                                                                   \
       if ((S) + 3 < nk) issue((uint32_t)cur, (S) + 3);                                                   \
-      __builtin_amdgcn_s_setprio(NT2X_KPRIO);                                                            \
+      __builtin_amdgcn_s_setprio(1);                                                                     \
       sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
       __builtin_amdgcn_s_setprio(0);                                                                     \
       cur = nxt;                                                                                         \
@@ -1165,7 +1064,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lds_barrier();   // every wave is done with the ring: it becomes the output staging area
-  __builtin_amdgcn_s_setprio(NT2X_EPRIO);
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
@@ -1174,12 +1072,9 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + fg * 16 + i * 4 + r;
+      const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
       bv[i][r] = (bias && n < N) ? bias[(int64_t)e * N + n] : 0.f;
     }
-  nt2x_out_direct<TO>(acc, bv, C, pre_act, mul_pre, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16,
-                      wm, wn, frow, fg);
-  return;
 #define OUT(RAW, A, D, DST, ...) \
   nt2x_out<TO, RAW, A, D, ##__VA_ARGS__>(acc, bv, DST, mul_pre, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
   if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);

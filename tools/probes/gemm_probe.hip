@@ -2,6 +2,16 @@
 // the C ABI, cold caches (1 GiB read between launches), hipEvent timing.  The library source is compiled in, so -D
 // switches of grouped_gemm.hip can be A/B'd as separate binaries inside one gpurun call.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-D...] tools/probes/gemm_probe.hip -o tools/probes/gemm_probe.bin
+//
+// Measured with it in round 2 (B=32, cold caches, same box per comparison; fc1 forward = [163840, 704] x 8 x [2816, 704]):
+//   plain 806 us | + pre-activation output 942 | GELU only 890 | GELU + dropout 966 | GELU + pre 1000 | all three 1254;
+//   fc2 data gradient with act'(pre)*mask 1073-1154; fc2 forward (N=704, K=2816, persistent 256^2 kernel) 617-654.
+//   (a) wave priorities of the two-per-CU kernel (s_setprio 1 around the MFMA run on / off, epilogue at priority 0 / 1 / 2):
+//       no difference (1234-1258 us): the epilogue is not losing an arbitration against the partner's K loop.
+//   (b) epilogue straight from the accumulators - W rows permuted on their way into LDS so that a lane owns 16 consecutive
+//       output columns (two 16-byte stores per row and output, no LDS staging pass, no barrier; commit 1a0d5e9 holds it):
+//       correct (all GEMM tests green) and the same speed (1244 vs 1254; plain 811 vs 806): the staging pass is not what
+//       the epilogue costs either.  Reverted.
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
 #include <vector>
