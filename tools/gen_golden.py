@@ -499,7 +499,44 @@ def gen_config1(core):
     npz("config1_125m", **arrs)
 
 
-GENERATORS = ["scan", "ssm_layer", "moe", "vision", "models", "dims", "data_formats", "trainer_run", "config1"]
+def gen_generate(core):
+    """N1: the reference's generate() (core.py:1520-1644) on toy selective-SSM models, greedy, use_cache=True - the path
+    `apertis chat` takes (prefill, then one token per step through the (conv window, SSM state) cache, with the
+    reference's front-slice of the cached conv window, core.py:369-373).  Stored: the prompt, the generated token
+    sequence, and the last-position logits of every step (captured by wrapping forward)."""
+    specs = {"generate_ssm_dense": dict(use_expert_system=False),
+             "generate_ssm_moe": dict(use_expert_system=True, num_experts=4, experts_per_token=2)}
+    for name, extra in specs.items():
+        torch.manual_seed(zlib.crc32(name.encode()) % 1000)
+        cfg = core.ApertisConfig(vocab_size=96, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                 intermediate_size=64, attention_type="selective_ssm", **extra)
+        model = core.ApertisForCausalLM(cfg).eval()
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if p.dim() > 1 and "token_embeddings" not in n_:
+                    p.mul_(8.0)
+        prompt = torch.randint(4, 96, (2, 9))
+        steps = []
+        fwd = model.forward
+
+        def spy(*a, **k):
+            out = fwd(*a, **k)
+            steps.append(out[1][:, -1, :].detach().clone())
+            return out
+        model.forward = spy
+        with torch.no_grad():
+            toks = model.generate(input_ids=prompt, max_new_tokens=16, do_sample=False, use_cache=True, eos_token_id=95)
+        model.forward = fwd
+        logits = torch.stack(steps, dim=1)                       # [B, steps, V]
+        top2 = torch.topk(logits, 2, dim=-1).values
+        gap = float((top2[..., 0] - top2[..., 1]).min())
+        print(f"  {name}: {toks.shape[1] - prompt.shape[1]} new tokens, {len(steps)} forward calls, min top-2 logit gap {gap:.3e}")
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        npz(name, prompt=prompt, tokens=toks, step_logits=logits, min_gap=gap, config_json=json.dumps(cfg.to_dict()),
+            **sd_arrays(sd))
+
+
+GENERATORS = ["scan", "ssm_layer", "moe", "vision", "models", "dims", "data_formats", "trainer_run", "config1", "generate"]
 
 
 if __name__ == "__main__":
