@@ -34,9 +34,6 @@ SIGNATURES = {
     "apertis_scan_num_chunks": (_i64, [_i64, _i64, _i64]),
     "apertis_selective_scan_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
                                           _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
-    "apertis_scan_fused_workspace_bytes": (_i64, [_i64, _i64, _i64]),
-    "apertis_selective_scan_fwd_fused": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, ctypes.c_uint32,
-                                                _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_selective_scan_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
                                           _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_ssm_gate_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp]),
@@ -79,6 +76,8 @@ SIGNATURES = {
                                        _i32, _i32, _vp]),
     "apertis_grouped_gemm_nt": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
                                        _i32, _i32, _vp]),
+    "apertis_grouped_gemm_nt_q": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
+                                         _i32, _i32, _vp, _vp]),
     "apertis_grouped_gemm_tn_workspace_bytes": (_i64, [_i64, _i32]),
     "apertis_grouped_gemm_tn_pair": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                             _vp, _i64, _i32, _vp]),

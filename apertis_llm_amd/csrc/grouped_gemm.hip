@@ -21,8 +21,7 @@
 // Global -> LDS goes through registers (one tile in flight, written to the other buffer after
 // the MFMAs of the current one: one barrier per K step).
 #include "common.h"
-#include <atomic>
-#include <cstdlib>
+#include <algorithm>
 #include <type_traits>
 
 namespace {
@@ -220,23 +219,7 @@ __device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row
   }
 }
 
-// one 1-KiB LDS-DMA piece: 8 tile rows x 128 B.  The LDS image is lane-linear (wave-uniform base +
-// lane*16), so the XOR swizzle is applied to the per-lane SOURCE address (chunk ^ (row & 7)) and
-// again on the fragment read.  Rows past the group's end are clamped to its last row (their
-// outputs are never stored).
-template <typename T>
-__device__ __forceinline__ void glds_piece(char *lds_piece, const T *base, int64_t ld, int row0, int rows_valid,
-                                           int k0, int lane) {
-  constexpr int KPC = 16 / sizeof(T);
-  int r = row0 + (lane >> 3);
-  int c = (lane & 7) ^ (r & 7);
-  r = min(r, rows_valid - 1);
-  const T *src = base + (int64_t)r * ld + k0 + c * KPC;
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                   (__attribute__((address_space(3))) void *)lds_piece, 16, 0, 0);
-}
-
-template <typename T, typename TO, bool GLDS>
+template <typename T, typename TO>
 __global__ void __launch_bounds__(NT)
 grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float *__restrict__ bias,
                   const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
@@ -287,23 +270,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
         for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
     }
   };
-  if constexpr (GLDS) {
-    // direct-to-LDS loads, ONE 32 KiB operand buffer, two barriers per K step; latency is hidden
-    // by the other resident work-groups (4 per CU at 35 KiB LDS / <=128 VGPRs).  Needs K % BK == 0.
-    char *xs = smem, *ws = smem + TILE_BYTES;
-    for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int piece = wave * 4 + j;   // 16 pieces of 8 rows per operand tile
-        glds_piece<T>(xs + piece * 1024, xbase, K, piece * 8, rows_valid, kt * BK, lane);
-        glds_piece<T>(ws + piece * 1024, wbase, ldw, piece * 8, cols_valid, kt * BK, lane);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      compute_tile(xs, ws);
-      __syncthreads();
-    }
-  } else {
+  {
     uint4 xr[4], wr[4];
     load_tile_regs<T>(xr, xbase, K, rows_valid, 0, K, tid);
     load_tile_regs<T>(wr, wbase, ldw, cols_valid, 0, K, tid);
@@ -393,161 +360,12 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
 // = 8 x 4 MFMA tiles of 16x16.  A 128^2 tile needs ~64 flop per L2 byte, i.e. ~39 TB/s from L2 at
 // the MFMA peak - more than the chip's L2 can deliver; 256^2 halves that.  Operands arrive by
 // LDS-DMA (global_load_lds, 16 B/lane) into a double-buffered 2 x 64 KiB ring, one barrier per K
-// step (the next tile's DMA is in flight during the MFMAs of the current one).  Same swizzle,
-// operand roles and epilogue as the 128^2 kernel.  One work-group per CU (128 KiB LDS).
+// step (the next tile's DMA is in flight during the MFMAs of the current one).  Same swizzle and
+// operand roles as the 128^2 kernel.  One work-group per CU (128 KiB LDS); the kernel itself is the persistent
+// grouped_gemm_nt256p_k below (a one-tile-per-work-group form came first and was removed).
 // ------------------------------------------------------------------------------------------
 constexpr int BM2 = 256, BN2 = 256, NT2 = 512;
 constexpr int TILE2_BYTES = BM2 * ROWB;  // 32 KiB per operand tile
-
-__device__ __forceinline__ TileCoord find_tile256(const int32_t *offsets, int E, int mt, int32_t *s_off, int tid) {
-  for (int i = tid; i <= E; i += NT2) s_off[i] = offsets[i];
-  __syncthreads();
-  TileCoord t; t.valid = false;
-  int acc = 0;
-  for (int e = 0; e < E; ++e) {
-    int r0 = s_off[e], r1 = s_off[e + 1];
-    int nt = (r1 - r0 + BM2 - 1) / BM2;
-    if (mt < acc + nt) {
-      t.e = e; t.m0 = (mt - acc) * BM2; t.row0 = (int64_t)r0 + t.m0; t.rows_left = r1 - r0 - t.m0; t.valid = true;
-      return t;
-    }
-    acc += nt;
-  }
-  return t;
-}
-
-template <typename TO>
-__global__ void __launch_bounds__(NT2)
-grouped_gemm_nt256_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
-                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                     const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act, float drop_p,
-                     uint64_t seed) {
-  typedef bf16_t T;
-  typedef bf16x8 frag;
-  constexpr int BK = 64;
-  constexpr int CPITCH = BN2 * sizeof(TO) + 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;   // wave tile: rows [wm*128,+128), cols [wn*64,+64)
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
-  const TileCoord tc = find_tile256(offsets, E, mt, reinterpret_cast<int32_t *>(smem), tid);
-  if (!tc.valid) return;
-  __syncthreads();
-  const int n0 = ntile * BN2;
-  const int rows_valid = min(BM2, tc.rows_left);
-  const int cols_valid = min(BN2, N - n0);
-  const T *xbase = X + tc.row0 * K;
-  const T *wbase = W + ((int64_t)tc.e * N + n0) * ldw;
-
-  f32x4 acc[4][8];  // [n-subtile][m-subtile]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nk = K / BK;
-  const int frow = lane & 15, fg = lane >> 4;
-  auto stage = [&](int buf, int kt) {
-    char *xs = smem + buf * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int piece = wave * 4 + j;  // 32 pieces of 8 rows per operand tile
-      glds_piece<T>(xs + piece * 1024, xbase, K, piece * 8, rows_valid, kt * BK, lane);
-      glds_piece<T>(ws + piece * 1024, wbase, ldw, piece * 8, cols_valid, kt * BK, lane);
-    }
-  };
-  stage(0, 0);
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt has landed for every wave; buffer (kt+1)&1 is free again
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char *xs = smem + (kt & 1) * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      frag wf[4], xf[8];
-      const int chunk = kk * 4 + fg;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int wrow = wn * 64 + i * 16 + frow;
-        wf[i] = *reinterpret_cast<const frag *>(ws + wrow * ROWB + ((chunk ^ (wrow & 7)) << 4));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int xrow = wm * 128 + j * 16 + frow;
-        xf[j] = *reinterpret_cast<const frag *>(xs + xrow * ROWB + ((chunk ^ (xrow & 7)) << 4));
-      }
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mma(acc[i][j], wf[i], xf[j]);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  }
-
-  // epilogue (same contract as the 128^2 kernel)
-  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
-  float bv[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
-      bv[i][r] = (bias && n < N) ? bias[(int64_t)tc.e * N + n] : 0.f;
-    }
-  constexpr int CPR = BN2 * sizeof(TO) / 16;
-  auto flush_tile = [&](TO *dst, const TO *mulp) {
-    __syncthreads();
-    for (int q = tid; q < BM2 * CPR; q += NT2) {
-      int row = q / CPR, c = q % CPR;
-      int ncol = c * (16 / (int)sizeof(TO));
-      if (row < rows_valid && ncol < cols_valid) {
-        const int64_t g = (tc.row0 + row) * N + n0 + ncol;
-        uint4 v = *reinterpret_cast<const uint4 *>(smem + row * CPITCH + c * 16);
-        if (mulp)
-          v = actbwd_chunk<TO, true>(v, *reinterpret_cast<const uint4 *>(mulp + g), tc.row0 + row, n0 + ncol, N, act,
-                                     drop_p, seed, keep_scale, thresh16);
-        *reinterpret_cast<uint4 *>(dst + g) = v;
-      }
-    }
-    __syncthreads();
-  };
-  __syncthreads();  // every wave is done reading the operand ring before it becomes the C tile
-  if (pre_act) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int m = wm * 128 + j * 16 + frow, n = wn * 64 + i * 16 + fg * 4;
-        TO *p = reinterpret_cast<TO *>(smem + m * CPITCH) + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = from_f32<TO>(acc[i][j][r] + bv[i][r]);
-      }
-    flush_tile(pre_act, nullptr);
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int m = wm * 128 + j * 16 + frow, n = wn * 64 + i * 16 + fg * 4;
-      TO *p = reinterpret_cast<TO *>(smem + m * CPITCH) + n;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv[i][r];
-        if (!mul_pre) {
-          v = to_f32(from_f32<TO>(v));
-          v = act_fwd<true>(v, act);
-          if (drop_p > 0.f)
-            v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
-        }
-        p[r] = from_f32<TO>(v);
-      }
-    }
-  flush_tile(C, mul_pre);
-}
 
 // LDS-DMA through inline asm.  hipcc tracks an LDS-DMA builtin as a store to LDS and puts
 // `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint - every
@@ -564,27 +382,12 @@ __device__ __forceinline__ v4i raw_buffer_rsrc(const void *base, uint32_t bytes)
   r[3] = 0x00020000;
   return r;
 }
-// the same buffer seen from `off` bytes in (scalar arithmetic only; keeps the zero-fill past the end)
-__device__ __forceinline__ v4i rsrc_advance(const v4i &r, uint32_t off) {
-  const uint64_t base = (((uint64_t)(uint32_t)r[1] << 32) | (uint32_t)r[0]) + off;
-  v4i o;
-  o[0] = (int)(uint32_t)base;
-  o[1] = (int)(uint32_t)(base >> 32);
-  o[2] = (uint32_t)r[2] > off ? (int)((uint32_t)r[2] - off) : 0;
-  o[3] = r[3];
-  return o;
-}
 __device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
   return (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)p;
 }
 // 64 lanes x 16 B from buffer offset voff (per lane) to LDS lds_addr + 16 * lane (lds_addr wave-uniform)
 __device__ __forceinline__ void lds_dma16(const v4i &rs, uint32_t lds_addr, uint32_t voff) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs) : "memory", "m0");
-}
-// 64 lanes x 4 B
-__device__ __forceinline__ void lds_dma4(const v4i &rs, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
                :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs) : "memory", "m0");
 }
 // same, from a per-lane global address
@@ -594,7 +397,7 @@ __device__ __forceinline__ void lds_dma16_global(const void *src, uint32_t lds_a
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent 256 x 256 NT kernel.  grouped_gemm_nt256_k spends 39 us per K=704 tile, ~24 in the K
+// Persistent 256 x 256 NT kernel.  With one tile per work-group a K=704 tile took 39 us, ~24 in the K
 // loop: every CU ends its K loop at the same time, so a round's epilogue is one chip-wide burst of
 // output stores with the matrix pipes idle, and the K loops run with HBM idle.  Here one work-group
 // per CU walks its tiles and the output stores drain under the next tile's MFMAs.  vmcnt retires in
@@ -615,13 +418,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 struct PTile { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
 
-// Dynamic tile queue of the persistent kernel (qslot >= 0): after its first (static, XCD-affine) tile a work-group takes
-// tile indices from a device counter, so a work-group that starts late - its CU was held by another kernel, e.g. an RCCL
-// collective on the communication stream - simply finds the queue drained instead of walking a full static share on its
-// own after everybody else has finished.  One counter pair per launch slot; the last work-group to leave resets it.
-__device__ int g_pq_next[256];
-__device__ int g_pq_done[256];
-
+// Dynamic tile queue of the persistent kernel (queue != NULL): after its first (static, XCD-affine) tile a work-group
+// takes tile indices from a device counter, so a work-group that starts late - its CU was held by another kernel, e.g. an
+// RCCL collective on the communication stream - simply finds the queue drained instead of walking a full static share on
+// its own after everybody else has finished.  The counter is ONE int32 owned by the caller (stream-owned workspace); the
+// entry point zeroes it on the launch stream in front of the kernel, so nothing survives a launch - no process-global
+// state, and an aborted launch cannot leave a dirty slot behind.
 // raw = the pre-activation pass, r = round; ACT >= 0 fixes the activation and DROP the dropout at
 // compile time (a per-value runtime switch costs more than the conversion itself), ACT < 0 = runtime
 template <typename TO, bool raw, int r, int ACT, bool DROP>
@@ -688,7 +490,7 @@ __global__ void __launch_bounds__(NT2)
 grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                       const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
                       const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int total_tiles,
-                      int solo, int act, float drop_p, uint64_t seed, int qslot) {
+                      int solo, int act, float drop_p, uint64_t seed, int *__restrict__ queue) {
   typedef bf16_t T;
   typedef bf16x8 frag;
   constexpr int BK = 64;
@@ -804,7 +606,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     }
     if (!nxt.valid) break;
     cur = nxt;
-    if (qslot >= 0 && tid == 0) *s_next = G + atomicAdd(&g_pq_next[qslot], 1);   // (its latency hides under the K loop)
+    if (queue && tid == 0) *s_next = G + atomicAdd(queue, 1);   // (its latency hides under the K loop)
 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -840,11 +642,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
       }
     }
     __syncthreads();   // every wave is done with both ring buffers
-    t = qslot >= 0 ? __builtin_amdgcn_readfirstlane(*s_next) : t + G;
-  }
-  if (qslot >= 0 && tid == 0 && atomicAdd(&g_pq_done[qslot], 1) == G - 1) {   // last one out resets the slot
-    g_pq_next[qslot] = 0;
-    g_pq_done[qslot] = 0;
+    t = queue ? __builtin_amdgcn_readfirstlane(*s_next) : t + G;
   }
 }
 
@@ -1672,8 +1470,8 @@ int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t ma
   const int64_t groups = nprob * E;
   const int ncu = device_cu_count();
   if (!ws || groups > ncu) return APERTIS_ERR_UNSUPPORTED;
-  // short groups: a 256-row-deep slice per CU does not amortise the tile prologue/epilogue and the fold
-  if (max_rows / E < 2048 && !getenv("APERTIS_GEMM_TN_V3")) return APERTIS_ERR_UNSUPPORTED;
+  // (short groups - under ~2048 rows each - do not amortise a 256-row-deep slice per CU plus the fold: callers leave
+  // `ws` NULL for those and get the 128 x 128 kernel; the choice is the caller's, the library has no hidden switch)
   const int cpg = (int)(ncu / groups);
   const int grid = (int)(groups * cpg);
   if (ws_bytes < (int64_t)grid * TN3_SLOT * (int64_t)sizeof(float) || (((uintptr_t)ws) & 15)) return APERTIS_ERR_UNSUPPORTED;
@@ -1703,7 +1501,7 @@ template <typename T> bool aligned16(const void *p, int64_t ld) {
 template <typename T, typename TO>
 int launch_nt(const void *A, const void *W, const float *bias, const int32_t *offsets, void *C, void *pre_act,
               const void *mul_pre, int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E, int act, float drop_p,
-              uint64_t seed, hipStream_t st) {
+              uint64_t seed, int32_t *tile_queue, hipStream_t st) {
   if (!aligned16<T>(A, K) || !aligned16<T>(W, ldw) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)) ||
       (mul_pre && !aligned16<TO>(mul_pre, N)))
     return APERTIS_ERR_UNSUPPORTED;
@@ -1711,20 +1509,17 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
   const int64_t m_tiles = ceil_div64(max_rows, BM) + E;  // each group adds at most one partial tile
   const int64_t grid = m_tiles * n_tiles;
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
-  constexpr int BK = ROWB / sizeof(T);
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
-    // the 256x256 kernels step K in 64s: K itself may be ragged when W's rows are zero-padded to the step.
-    // One group (dense projection) takes them at any width: narrow outputs are HBM-bound and the
+    // the 256x256 kernel steps K in 64s: K itself may be ragged when W's rows are zero-padded to the step.
+    // One group (dense projection) takes it at any width: narrow outputs are HBM-bound and the
     // persistent kernel's cross-tile prefetch matters more than the MFMA work a partial n-tile wastes
     const bool kpad_ok = K % 64 == 0 || ldw >= ceil_div64(K, 64) * 64;
     // two work-groups per CU pay off when the epilogue is heavy next to the K loop (activation / dropout /
-    // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop)
-    static const int force2x = getenv("APERTIS_GEMM_NT2X") ? atoi(getenv("APERTIS_GEMM_NT2X")) : -1;
+    // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop).
     // ... and for the SSM block's dense projections (one group, short K, HBM-bound): 92 vs 114 us at N=352/K=704, 72 vs 89
     // at N=704/K=176, 56 vs 64 at N=400/K=176; the N=176 data gradients stay on the 256-wide tile (63 vs 60 us)
-    static const int dense2x = getenv("APERTIS_GEMM_DENSE2X") ? atoi(getenv("APERTIS_GEMM_DENSE2X")) : 1;
-    const bool use2x = force2x >= 0 ? force2x != 0 : (((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
-                                                     (dense2x && E == 1 && K <= 1024 && N >= 256));
+    const bool use2x = ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
+                       (E == 1 && K <= 1024 && N >= 256);
     const bool ragged2x = K % 32 != 0;
     if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);
@@ -1737,57 +1532,39 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         return apertis_check_launch();
       }
     }
-    if (kpad_ok && (N >= 512 || (E == 1 && N >= 128)) && max_rows >= 4096 && !getenv("APERTIS_GEMM_TILE128")) {
+    if (kpad_ok && (N >= 512 || (E == 1 && N >= 128)) && max_rows >= 4096 && E <= 1024) {
       const int nt2 = (int)ceil_div64(N, BN2);
       const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;
-      if ((K % 64 || !getenv("APERTIS_GEMM_NT256_V1")) && E <= 1024 && grid2 < 0x7fffffffLL) {
+      if (grid2 < 0x7fffffffLL) {
         const int ncu = device_cu_count();
         const int gp = (int)std::min<int64_t>(grid2, ncu);          // one persistent work-group per CU
         size_t ldsp = 4 * TILE2_BYTES + 4096 + 16;                   // ring + group offsets
-        static const int solo = getenv("APERTIS_GEMM_SOLO") ? atoi(getenv("APERTIS_GEMM_SOLO")) : 4;
-        // read per launch: BucketedDataParallel sets it when it wraps a model for world_size > 1
-        const char *dyn_env = getenv("APERTIS_GEMM_DYNAMIC");
-        const bool dynq = dyn_env && atoi(dyn_env) != 0;
-        static std::atomic<unsigned> pq_seq{0};
+        constexpr int solo = 4;   // K steps of a tile whose DMA the non-store waves issue alone (measured best of 2..6)
+        if (tile_queue && hipMemsetAsync(tile_queue, 0, sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
         auto kp = (K % 64 == 0 && ldw == K) ? grouped_gemm_nt256p_k<TO, false> : grouped_gemm_nt256p_k<TO, true>;
         hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         hipLaunchKernelGGL(kp, dim3((unsigned)gp), dim3(NT2), ldsp, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt2, (int)grid2, solo,
-                           act, drop_p, seed, dynq ? (int)(pq_seq.fetch_add(1) & 255u) : -1);
+                           act, drop_p, seed, (int *)tile_queue);
         return apertis_check_launch();
       }
-      if (K % 64) return APERTIS_ERR_UNSUPPORTED;   // only reachable with E > 1024 groups
-      size_t lds2 = std::max<size_t>(4 * TILE2_BYTES, (size_t)BM2 * (BN2 * sizeof(TO) + 16));
-      auto k2 = grouped_gemm_nt256_k<TO>;
-      hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-      hipLaunchKernelGGL(k2, dim3((unsigned)grid2), dim3(NT2), lds2, st, (const bf16_t *)A, (const bf16_t *)W, bias,
-                         offsets, (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt2, act, drop_p, seed);
-      return apertis_check_launch();
     }
   }
   const size_t cstage = (size_t)BM * (BN * sizeof(TO) + 16);
-  if (K % BK == 0 && sizeof(T) == 2 && getenv("APERTIS_GEMM_GLDS128")) {
-    size_t lds = std::max<size_t>(2 * TILE_BYTES, cstage);
-    auto kern = grouped_gemm_nt_k<T, TO, true>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, n_tiles, act, drop_p, seed);
-  } else {
-    size_t lds = std::max<size_t>(4 * TILE_BYTES, cstage);
-    auto kern = grouped_gemm_nt_k<T, TO, false>;
-    if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
-                       (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, n_tiles, act, drop_p, seed);
-  }
+  size_t lds = std::max<size_t>(4 * TILE_BYTES, cstage);
+  auto kern = grouped_gemm_nt_k<T, TO>;
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), lds, st, (const T *)A, (const T *)W, bias, offsets, (TO *)C,
+                     (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, n_tiles, act, drop_p, seed);
   return apertis_check_launch();
 }
 
 }  // namespace
 
-extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias, const int32_t *offsets,
-                                       void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K,
-                                       int64_t ldw, int64_t E, int act, float drop_p, uint64_t seed, int dtype, int dtype_out,
-                                       void *stream) {
+extern "C" int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias, const int32_t *offsets,
+                                         void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K,
+                                         int64_t ldw, int64_t E, int act, float drop_p, uint64_t seed, int dtype, int dtype_out,
+                                         int32_t *tile_queue, void *stream) {
   if (!A || !W || !offsets || !C || max_rows < 0 || N <= 0 || K <= 0 || E <= 0 || (ldw != 0 && ldw < K)) return APERTIS_ERR_ARG;
   if (ldw == 0) ldw = K;
   if (drop_p < 0.f || drop_p >= 1.f || (act_bwd_pre && (pre_act || bias))) return APERTIS_ERR_ARG;
@@ -1796,17 +1573,25 @@ extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float
   hipStream_t st = (hipStream_t)stream;
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_BF16) {
     if (K % 8 || N % 8) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, st);
+    return launch_nt<bf16_t, bf16_t>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, tile_queue, st);
   }
   if (dtype == APERTIS_BF16 && dtype_out == APERTIS_F32) {
     if (K % 8 || N % 4) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, st);
+    return launch_nt<bf16_t, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, tile_queue, st);
   }
   if (dtype == APERTIS_F32 && dtype_out == APERTIS_F32) {
     if (K % 4 || N % 4) return APERTIS_ERR_UNSUPPORTED;
-    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, st);
+    return launch_nt<float, float>(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, tile_queue, st);
   }
   return APERTIS_ERR_UNSUPPORTED;
+}
+
+extern "C" int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias, const int32_t *offsets,
+                                       void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K,
+                                       int64_t ldw, int64_t E, int act, float drop_p, uint64_t seed, int dtype, int dtype_out,
+                                       void *stream) {
+  return apertis_grouped_gemm_nt_q(A, W, bias, offsets, C, pre_act, act_bwd_pre, max_rows, N, K, ldw, E, act, drop_p, seed, dtype,
+                                   dtype_out, nullptr, stream);
 }
 
 extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems) {
@@ -1828,20 +1613,15 @@ extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int3
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   if (dtype == APERTIS_BF16) {
     if (M % 8 || N % 8 || !aligned16<bf16_t>(A, M) || !aligned16<bf16_t>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
-    if (ws && !getenv("APERTIS_GEMM_TN_V2") && !getenv("APERTIS_GEMM_TN_V1")) {
+    if (ws) {
       Tn3Problem q{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, (int)ceil_div64(M, 256),
                    (int)ceil_div64(N, 256)};
       const int rc = launch_tn3(q, nullptr, E, max_rows, offsets, (float *)ws, ws_bytes, st);
       if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
     }
-    if (!getenv("APERTIS_GEMM_TN_V1")) {
-      TnProblem q0{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, m_tiles, n_tiles, (int)grid};
-      TnProblem q1{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
-      return launch_tn2(q0, q1, offsets, st);
-    }
-    size_t lds = 2 * 32 * (BM * 2 + 16);
-    hipLaunchKernelGGL(grouped_gemm_tn_k<bf16_t>, dim3((unsigned)grid), dim3(NT), lds, st, (const bf16_t *)A,
-                       (const bf16_t *)Bm, offsets, dW, dbias, (int)M, (int)N, m_tiles, n_tiles);
+    TnProblem q0{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, m_tiles, n_tiles, (int)grid};
+    TnProblem q1{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0};
+    return launch_tn2(q0, q1, offsets, st);
   } else if (dtype == APERTIS_F32) {
     if (M % 4 || N % 4 || !aligned16<float>(A, M) || !aligned16<float>(Bm, N)) return APERTIS_ERR_UNSUPPORTED;
     size_t lds = 2 * 32 * (BM * 4 + 16);
@@ -1886,7 +1666,7 @@ extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, floa
   if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || (M0 | N0 | M1 | N1) % 8) return APERTIS_ERR_UNSUPPORTED;
   if (!aligned16<bf16_t>(A0, M0) || !aligned16<bf16_t>(B0, N0) || !aligned16<bf16_t>(A1, M1) || !aligned16<bf16_t>(B1, N1))
     return APERTIS_ERR_UNSUPPORTED;
-  if (ws && !getenv("APERTIS_GEMM_TN_V2") && max_rows <= 0x7fffffffLL && std::max(std::max(M0, N0), std::max(M1, N1)) < 0x3fffffff) {
+  if (ws && max_rows <= 0x7fffffffLL && std::max(std::max(M0, N0), std::max(M1, N1)) < 0x3fffffff) {
     Tn3Problem p0{(const bf16_t *)A0, (const bf16_t *)B0, dW0, dbias0, (int)M0, (int)N0, (int)ceil_div64(M0, 256),
                   (int)ceil_div64(N0, 256)};
     Tn3Problem p1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, (int)ceil_div64(M1, 256),

@@ -119,156 +119,6 @@ scan_fwd_replay(const float *__restrict__ dlt, const float *__restrict__ A_log,
 }
 
 // ---------------------------------------------------------------------------------------
-// Single-pass forward (one launch, Bt read once).  Persistent work-groups walk (chunk, batch,
-// channel-tile) items in chunk-major order; per item: stage tiles -> local aggregates -> PUBLISH
-// the chunk aggregate -> gather the earlier chunks' aggregates -> replay from LDS -> store y.
-// Cross-work-group hand-off (cdna_hip_programming.md Guideline 16, form R2): every published word
-// is an 8-byte {epoch tag, fp32 value} granule written with ONE agent-scope relaxed atomic store
-// (write-through) and read with agent-scope relaxed atomic loads (bypass L1); no flag, no fence.
-// The caller zeroes the granule workspace once and passes a strictly increasing epoch, so stale
-// granules of earlier launches can never match.  Progress: an item only waits for items with a
-// LOWER index; the grid is at most 4 work-groups per CU (all co-resident), each walking its items in
-// increasing order, so the lowest unfinished item never waits on an unpublished one.  Spins are
-// bounded; a timeout sets *err and the launch completes (with wrong data) instead of hanging.
-// ---------------------------------------------------------------------------------------
-typedef unsigned long long gran_t;
-__device__ __forceinline__ void gran_store(gran_t *p, uint32_t epoch, float v) {
-  __hip_atomic_store(p, ((gran_t)epoch << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ gran_t gran_load(const gran_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-template <typename TIN, typename TY, int VB, int LT>
-__global__ void __launch_bounds__(NTHREADS, 4)   // <= 128 VGPRs: four work-groups per CU must be co-resident
-scan_fwd_fused(const float *__restrict__ dlt, const float *__restrict__ A_log, const TIN *__restrict__ Bt,
-               int64_t bt_rs, const TIN *__restrict__ C, int64_t c_rs, const float *__restrict__ h0,
-               float *__restrict__ h_in, float *__restrict__ h_last, TY *__restrict__ y, int64_t y_rs,
-               gran_t *__restrict__ gran, uint32_t epoch, int *__restrict__ err, ScanDims d, int ctiles) {
-  constexpr int ROWB = TC * sizeof(TIN);
-  constexpr int TS = LT / NSEG;
-  constexpr int QMAX = 4;   // predecessors gathered per wave per batch (kept small: register budget)
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  TIN *bt = reinterpret_cast<TIN *>(smem);
-  TIN *cc = reinterpret_cast<TIN *>(smem + LT * ROWB);
-  float *dl = reinterpret_cast<float *>(smem + 2 * LT * ROWB);
-  float2 *segs = reinterpret_cast<float2 *>(smem + 2 * LT * ROWB + LT * d.HT * 4);
-  float2 *lk = segs + NSEG * TC;
-
-  const int tid = threadIdx.x, lane = tid & 63, seg = tid >> 6;
-  const int hh = lane >> d.log2N;
-  const int bct_n = (int)d.B * ctiles;
-  const int64_t total = (int64_t)d.nchunks * bct_n;
-  for (int64_t item = blockIdx.x; item < total; item += gridDim.x) {
-    const int chunk = (int)(item / bct_n), bct = (int)(item - (int64_t)chunk * bct_n);
-    const int b = bct / ctiles, ct = bct - b * ctiles;
-    const int c0 = ct * TC, c = c0 + lane;
-    const int64_t t0 = (int64_t)chunk * LT;
-    const int rows_valid = (int)min((int64_t)LT, d.L - t0);
-    const int ch_valid = (int)min((int64_t)TC, d.Dn - c0);
-    const int64_t tok0 = (int64_t)b * d.L + t0;
-    const bool chan_ok = c < d.Dn;
-
-    stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(bt), reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0),
-                           bt_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-    stage_in<VB, ROWB, LT>(reinterpret_cast<char *>(cc), reinterpret_cast<const char *>(C + tok0 * c_rs + c0),
-                           c_rs * sizeof(TIN), rows_valid, ch_valid * (int)sizeof(TIN), tid);
-    stage_delta<LT>(dl, dlt, tok0, rows_valid, c0 >> d.log2N, (int)d.h, d.HT, d.softplus, tid);
-    const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
-    __syncthreads();
-
-    float P = 1.f, S = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < TS; ++i) {
-      int t = seg * TS + i;
-      const float av = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
-      S = fmaf(av, S, to_f32(bt[t * TC + lane]));
-      P *= av;
-    }
-    segs[seg * TC + lane] = make_float2(P, S);
-    __syncthreads();
-    gran_t *gbase = gran + ((int64_t)bct * d.nchunks) * TC * 2;
-    if (seg == 0 && chan_ok) {   // publish this chunk's aggregate (skipped for the last chunk: nobody reads it)
-      float Pc = P, Sc = S;
-#pragma unroll
-      for (int sgm = 1; sgm < NSEG; ++sgm) { float2 q = segs[sgm * TC + lane]; Sc = fmaf(q.x, Sc, q.y); Pc *= q.x; }
-      if (chunk + 1 < d.nchunks) {
-        gran_store(gbase + ((int64_t)chunk * TC + lane) * 2 + 0, epoch, Pc);
-        gran_store(gbase + ((int64_t)chunk * TC + lane) * 2 + 1, epoch, Sc);
-      }
-    }
-    // gather the aggregates of chunks [0, chunk): wave `seg` takes the seg-th quarter in order
-    float Pw = 1.f, Sw = 0.f;
-    {
-      const int q = (chunk + NSEG - 1) / NSEG;
-      const int s0 = seg * q, s1 = min(s0 + q, chunk);
-      for (int j0 = s0; j0 < s1; j0 += QMAX) {
-        gran_t gp[QMAX], gs[QMAX];
-        const int nb = min(QMAX, s1 - j0);
-        unsigned spins = 0;
-        bool ok = false;
-        while (true) {
-          ok = true;
-#pragma unroll
-          for (int u = 0; u < QMAX; ++u)
-            if (u < nb && chan_ok) {
-              gp[u] = gran_load(gbase + ((int64_t)(j0 + u) * TC + lane) * 2 + 0);
-              gs[u] = gran_load(gbase + ((int64_t)(j0 + u) * TC + lane) * 2 + 1);
-            }
-#pragma unroll
-          for (int u = 0; u < QMAX; ++u)
-            if (u < nb && chan_ok) ok = ok && (uint32_t)(gp[u] >> 32) == epoch && (uint32_t)(gs[u] >> 32) == epoch;
-          if (__all(ok)) break;
-          if (++spins > (1u << 21)) { if (lane == 0) atomicOr(err, 1); break; }
-          __builtin_amdgcn_s_sleep(8);
-        }
-#pragma unroll
-        for (int u = 0; u < QMAX; ++u)
-          if (u < nb && chan_ok) {
-            float pj = __uint_as_float((uint32_t)gp[u]), sj = __uint_as_float((uint32_t)gs[u]);
-            Sw = fmaf(pj, Sw, sj);
-            Pw *= pj;
-          }
-      }
-    }
-    lk[seg * TC + lane] = make_float2(Pw, Sw);
-    __syncthreads();
-    float hcar = (h0 && chan_ok) ? h0[(int64_t)b * d.Dn + c] : 0.f;
-#pragma unroll
-    for (int sgm = 0; sgm < NSEG; ++sgm) { float2 t = lk[sgm * TC + lane]; hcar = fmaf(t.x, hcar, t.y); }
-    if (seg == 0 && chan_ok && h_in) h_in[((int64_t)b * d.nchunks + chunk) * d.Dn + c] = hcar;
-    for (int sgm = 0; sgm < seg; ++sgm) { float2 q = segs[sgm * TC + lane]; hcar = fmaf(q.x, hcar, q.y); }
-    float hst = hcar;
-    if constexpr (sizeof(TY) == 4) {
-      TY *yp = y + (tok0 + seg * TS) * y_rs + c;
-#pragma unroll 4
-      for (int i = 0; i < TS; ++i) {
-        int t = seg * TS + i;
-        const float av = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);   // recomputed: cheaper than 16 live registers
-        hst = fmaf(av, hst, to_f32(bt[t * TC + lane]));
-        float yv = to_f32(cc[t * TC + lane]) * hst;
-        if (chan_ok && t < rows_valid) yp[(int64_t)i * y_rs] = from_f32<TY>(yv);
-      }
-    } else {
-      static_assert(sizeof(TY) == sizeof(TIN), "bf16 y requires bf16 Bt/C");
-#pragma unroll 4
-      for (int i = 0; i < TS; ++i) {
-        int t = seg * TS + i;
-        const float av = __builtin_amdgcn_exp2f(dl[t * d.HT + hh] * A2);
-        hst = fmaf(av, hst, to_f32(bt[t * TC + lane]));
-        float yv = to_f32(cc[t * TC + lane]) * hst;
-        reinterpret_cast<TY *>(cc)[t * TC + lane] = from_f32<TY>(yv);
-      }
-      __syncthreads();
-      stage_out<VB, ROWB, LT>(reinterpret_cast<const char *>(cc), reinterpret_cast<char *>(y + tok0 * y_rs + c0),
-                              y_rs * sizeof(TY), rows_valid, ch_valid * (int)sizeof(TY), tid);
-    }
-    if (h_last && chunk == d.nchunks - 1 && seg == NSEG - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
-    __syncthreads();   // LDS tiles are reused by the next item
-  }
-}
-
-// ---------------------------------------------------------------------------------------
 // backward pass 1: reverse chunk aggregates (P = prod a, M = mu at chunk start from zero)
 //   u_t = dy_t*C_t,  mu_t = a_t*(u_t + mu_{t+1})
 template <typename TIN, typename TY, int VB, int VBY, int LT, int NS>
@@ -488,33 +338,6 @@ int launch_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_
   return apertis_check_launch();
 }
 
-template <typename TIN, typename TY, int VB>
-int launch_fwd_fused(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
-                     const float *h0, void *y, int64_t y_rs, float *h_last, float *h_in, void *gran, uint32_t epoch,
-                     int *err, const ScanDims &d, hipStream_t st) {
-  constexpr int LT = LT_DEFAULT;
-  const int ctiles = (int)ceil_div64(d.Dn, TC);
-  const int64_t total = (int64_t)d.nchunks * d.B * ctiles;
-  size_t lds = 2 * LT * TC * sizeof(TIN) + (size_t)LT * d.HT * 4 + 2 * NSEG * TC * sizeof(float2);
-  // every work-group of the grid must be resident at once (they wait on each other): size the grid
-  // from the occupancy query minus one block per CU of margin (the API over-reports by one for
-  // SGPR-heavy 256-thread kernels on ROCm 7.2), capped at 4 per CU
-  int occ = 0, ncu = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_fwd_fused<TIN, TY, VB, LT>, NTHREADS, lds) != hipSuccess)
-    return APERTIS_ERR_LAUNCH;
-  hipDeviceProp_t prop;
-  int dev_id = 0;
-  if (hipGetDevice(&dev_id) == hipSuccess && hipGetDeviceProperties(&prop, dev_id) == hipSuccess)
-    ncu = prop.multiProcessorCount;
-  const int per_cu = std::min(4, occ - 1);
-  if (per_cu < 1) return APERTIS_ERR_UNSUPPORTED;
-  const int64_t grid = std::min<int64_t>(total, (int64_t)ncu * per_cu);
-  hipLaunchKernelGGL((scan_fwd_fused<TIN, TY, VB, LT>), dim3((unsigned)grid), dim3(NTHREADS), lds, st, dlt, A_log,
-                     (const TIN *)Bt, bt_rs, (const TIN *)C, c_rs, h0, h_in, h_last, (TY *)y, y_rs, (gran_t *)gran, epoch,
-                     err, d, ctiles);
-  return apertis_check_launch();
-}
-
 template <typename TIN, typename TY, int VB, int VBY>
 int launch_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
                int64_t c_rs, const void *dy, int64_t dy_rs, const float *h_in, void *dBt,
@@ -632,44 +455,5 @@ extern "C" int apertis_selective_scan_bwd(const float *dlt, const float *A_log, 
     }
   }
 #undef BWD
-  return APERTIS_ERR_UNSUPPORTED;
-}
-
-extern "C" int64_t apertis_scan_fused_workspace_bytes(int64_t B, int64_t L, int64_t Dn) {
-  // [B * ctiles][nchunks][64 channels][2 granules] x 8 bytes, plus one int32 error word (padded)
-  return B * ceil_div64(Dn, TC) * ceil_div64(L, LT_DEFAULT) * TC * 2 * 8 + 64;
-}
-
-extern "C" int apertis_selective_scan_fwd_fused(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs,
-                                                const void *C, int64_t c_rs, const float *h0, void *y, int64_t y_rs,
-                                                float *h_last, float *h_in, void *ws, uint32_t epoch, int64_t B,
-                                                int64_t L, int64_t h, int64_t N, int dtype_bc, int dtype_y,
-                                                int delta_softplus, void *stream) {
-  if (!dlt || !A_log || !Bt || !C || !y || !ws || epoch == 0) return APERTIS_ERR_ARG;
-  ScanDims d;
-  int rc = make_dims(d, B, L, h, N, delta_softplus);
-  if (rc) return rc;
-  if (bt_rs < d.Dn || c_rs < d.Dn || y_rs < d.Dn) return APERTIS_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  int *err = reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + apertis_scan_fused_workspace_bytes(B, L, d.Dn) - 64);
-#define FUS(TIN, TY, VB) \
-  return launch_fwd_fused<TIN, TY, VB>(dlt, A_log, Bt, bt_rs, C, c_rs, h0, y, y_rs, h_last, h_in, ws, epoch, err, d, st)
-  if (dtype_bc == APERTIS_F32 && dtype_y == APERTIS_F32) {
-    int al = std::min(slice_align<float>(Bt, bt_rs, d.Dn), slice_align<float>(C, c_rs, d.Dn));
-    if (al >= 16) FUS(float, float, 16);
-    if (al >= 8) FUS(float, float, 8);
-  } else if (dtype_bc == APERTIS_BF16 && dtype_y == APERTIS_F32) {
-    int al = std::min(slice_align<bf16_t>(Bt, bt_rs, d.Dn), slice_align<bf16_t>(C, c_rs, d.Dn));
-    if (al >= 16) FUS(bf16_t, float, 16);
-    if (al >= 8) FUS(bf16_t, float, 8);
-  } else if (dtype_bc == APERTIS_BF16 && dtype_y == APERTIS_BF16) {
-    int al = std::min({slice_align<bf16_t>(Bt, bt_rs, d.Dn), slice_align<bf16_t>(C, c_rs, d.Dn),
-                       slice_align<bf16_t>(y, y_rs, d.Dn)});
-    if (al >= 16) FUS(bf16_t, bf16_t, 16);
-    if (al >= 8) FUS(bf16_t, bf16_t, 8);
-  }
-  // narrower slice alignments would need more staging registers than four co-resident work-groups
-  // per CU allow: the caller uses the two-launch apertis_selective_scan_fwd for those
-#undef FUS
   return APERTIS_ERR_UNSUPPORTED;
 }

@@ -113,40 +113,6 @@ def _rows(t, width):
 # ----------------------------------------------------------------------------------------------
 import os as _os
 
-# Single-launch forward (persistent work-groups + granule hand-off).  Correct and stress-tested, but
-# measured SLOWER than the two-launch form on MI355X at these sizes (30.1 vs 26.2 us per call in
-# the 1.5B step; 2.29 vs 2.46 TB/s at 381 MB): the serial publish -> gather round trip per item with
-# 4 work-groups per CU costs more than the second launch.  Off unless APERTIS_SCAN_FUSED=1.
-SCAN_FUSED = _os.environ.get("APERTIS_SCAN_FUSED", "0") == "1"
-_scan_ws = {}      # device -> [workspace tensor (zeroed once), next epoch]
-
-
-def _fused_scan_ws(lib, B, L, Dn, device):
-    need = lib.apertis_scan_fused_workspace_bytes(B, L, Dn)
-    ent = _scan_ws.get(str(device))
-    if ent is None or ent[0].numel() < need:
-        epoch = ent[1] if ent else 1
-        ent = [torch.zeros(need, device=device, dtype=torch.uint8), epoch]
-        _scan_ws[str(device)] = ent
-    ent[1] += 1
-    if ent[1] >= 0xFFFFFFF0:        # epoch wrap: start over on a clean workspace
-        ent[0].zero_()
-        ent[1] = 2
-    # the error word sits in the last 64 bytes of the size the LIBRARY computes for this shape
-    return ent[0], ent[1] - 1, need
-
-
-def scan_fused_error(device):
-    """Non-zero if any fused-scan launch on this device hit its bounded-spin timeout (host sync)."""
-    ent = _scan_ws.get(str(device))
-    if ent is None:
-        return 0
-    torch.cuda.synchronize(device)
-    flat = ent[0]
-    # an error word lives at (need - 64) for every shape used; scan the whole tail conservatively
-    return int(flat.view(torch.int32)[-16:].abs().sum().item()) if flat.numel() % 4 == 0 else 0
-
-
 class _SelectiveScan(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dlt, A_log, Bt, C, h0, delta_softplus, y_dtype, return_last):
@@ -173,29 +139,9 @@ class _SelectiveScan(torch.autograd.Function):
         h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
         work = B * L * (Dn * (2 * Bt.element_size() + y.element_size()) + 4 * h) + 4 * h * N   # algorithmic bytes
-        done = False
-        if SCAN_FUSED:
-            ws, epoch, _ = _fused_scan_ws(lib, B, L, Dn, dev)
-            args = (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(h_in),
-                    ptr(ws), epoch, B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr())
-            t = _TIMER
-            if t is not None and "apertis_selective_scan_fwd" in t.names:
-                s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s_.record()
-                rc = lib.apertis_selective_scan_fwd_fused(*args)
-                e_.record()
-                if rc == 0:
-                    t.records.append(("apertis_selective_scan_fwd", s_, e_, work))
-            else:
-                rc = lib.apertis_selective_scan_fwd_fused(*args)
-            if rc == 0:
-                done = True
-            elif rc != -2:            # -2 = shape/alignment the single-launch kernel is not built for
-                check(rc, "apertis_selective_scan_fwd_fused")
-        if not done:
-            _launch("apertis_selective_scan_fwd", lib.apertis_selective_scan_fwd,
-                    (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(agg),
-                     ptr(h_in), B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr()), work)
+        _launch("apertis_selective_scan_fwd", lib.apertis_selective_scan_fwd,
+                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(h0), ptr(y), Dn, ptr(h_last), ptr(agg),
+                 ptr(h_in), B, L, h, N, dtype_code(Bt), dtype_code(y), int(delta_softplus), stream_ptr()), work)
         ctx.save_for_backward(dlt, A_log, Bt, C, h_in)
         ctx.cfg = (B, L, h, N, bool(delta_softplus))
         ctx.mark_non_differentiable(*([h_last] if return_last else []))
@@ -1011,6 +957,30 @@ class _RowsWork:
         return float(self.offsets[self.E].item()) * self.per_row
 
 
+# Set by parallel.BucketedDataParallel when it wraps a model for world_size > 1: the persistent NT GEMM then takes its
+# tiles from a per-launch counter (apertis_grouped_gemm_nt_q), so that a work-group whose CU an RCCL kernel holds does
+# not walk a full static share alone at the end.  Off on one GPU (657.7 vs 636 us on the N=704/K=2816 GEMM).
+GEMM_DYNAMIC_QUEUE = False
+_NT_QUEUE = {}
+
+
+def _nt_queue(device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    q = _NT_QUEUE.get(key)
+    if q is None:
+        q = _NT_QUEUE[key] = torch.zeros(16, device=device, dtype=torch.int32)
+    return q
+
+
+def _launch_nt(name, lib, args, work, device):
+    """apertis_grouped_gemm_nt, or its _q form with the stream's tile-queue counter when GEMM_DYNAMIC_QUEUE is on.
+    `args` ends with the stream pointer."""
+    if GEMM_DYNAMIC_QUEUE:
+        _launch(name, lib.apertis_grouped_gemm_nt_q, args[:-1] + (ptr(_nt_queue(device)), args[-1]), work)
+    else:
+        _launch(name, lib.apertis_grouped_gemm_nt, args, work)
+
+
 _ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "relu": _lib.ACT_RELU,
          "silu": _lib.ACT_SILU, "swish": _lib.ACT_SILU}
 
@@ -1018,9 +988,13 @@ _ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "rel
 _TN_WS = {}
 
 
-def _tn_workspace(E, n_problems, device):
+def _tn_workspace(E, n_problems, device, max_rows=None):
     """Scratch for the split tiles of the weight-gradient GEMM: one buffer per (device, stream),
-    sized by the library, contents don't care (apertis_hip.h: TN workspace)."""
+    sized by the library, contents don't care (apertis_hip.h: TN workspace).  Passing it selects the 256 x 256-tile
+    kernel; short groups (under 2048 rows each on average: a 256-row-deep slice per CU does not amortise the tile
+    prologue / epilogue and the fold) get none and run on the 128 x 128 kernel."""
+    if max_rows is not None and max_rows // max(E, 1) < 2048:
+        return None, 0
     nbytes = _lib.load().apertis_grouped_gemm_tn_workspace_bytes(E, n_problems)
     if nbytes <= 0:
         return None, 0
@@ -1053,9 +1027,9 @@ class _GroupedLinear(torch.autograd.Function):
         act_code = _ACTS[act]
         out = torch.empty(x.shape[0], N, device=x.device, dtype=compute_dtype)
         pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
-        _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
+        _launch_nt("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib,
                 (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), None, max_rows, N, K, wc.shape[-1], E, act_code,
-                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
+                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), x.device)
         ctx.save_for_backward(x, wt, pre, offsets)
         ctx.cfg = (E, N, K, max_rows, act_code, float(drop_p), int(seed), bias is not None, weight.dtype)
         return out
@@ -1076,9 +1050,9 @@ class _GroupedLinear(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _launch("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib.apertis_grouped_gemm_nt,
+            _launch_nt("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib,
                     (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, None, max_rows, K, N, wt.shape[-1], E, _lib.ACT_NONE,
-                     0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
+                     0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), dpre.device)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
                 # dense layer: the K dimension of the weight gradient is ALL rows; cut it into
@@ -1102,7 +1076,7 @@ class _GroupedLinear(torch.autograd.Function):
             else:
                 dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
                 db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
-                ws, ws_bytes = _tn_workspace(E, 1, x.device)
+                ws, ws_bytes = _tn_workspace(E, 1, x.device, max_rows)
                 _launch("apertis_grouped_gemm_tn" if E > 1 else "apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
                         (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, ptr(ws), ws_bytes, code,
                          stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
@@ -1305,13 +1279,13 @@ class _ExpertMLP(torch.autograd.Function):
         R = xg.shape[0]
         h = torch.empty(R, I, device=xg.device, dtype=cd)
         pre = torch.empty_like(h) if need else None
-        _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+        _launch_nt("apertis_grouped_gemm_nt", lib,
                 (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, w1c.shape[-1], E, act_code,
-                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
+                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H), xg.device)
         yr = torch.empty(R, H, device=xg.device, dtype=cd)
-        _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+        _launch_nt("apertis_grouped_gemm_nt", lib,
                 (ptr(h), ptr(w2c), ptr(b2f), ptr(offsets), ptr(yr), None, None, max_rows, H, I, w2c.shape[-1], E, _lib.ACT_NONE,
-                 0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H))
+                 0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H), h.device)
         ctx.save_for_backward(xg, pre, h, w1t, w2t, offsets)
         ctx.cfg = (E, I, H, max_rows, act_code, float(drop_p), int(seed), w1.dtype, w2.dtype)
         ctx.wparams = (w1, w2)     # for grad_destination() in the backward
@@ -1329,31 +1303,31 @@ class _ExpertMLP(torch.autograd.Function):
         dpre = torch.empty_like(h)
         if FUSE_ACT_BWD:
             # dpre = (dyr @ W2) * keep/(1-p) * act'(pre): layer 1's activation backward in the dgrad epilogue
-            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+            _launch_nt("apertis_grouped_gemm_nt", lib,
                     (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, w2t.shape[-1], E, act_code,
-                     drop_p, seed, code, code, stream_ptr()), work)
+                     drop_p, seed, code, code, stream_ptr()), work, dyr.device)
         else:
             # APERTIS_NO_FUSE_ACT_BWD=1 (A/B switch): plain data gradient, then the separate bandwidth-bound pass in
             # place on dpre.  On the 256x256 persistent kernel the fused form was slower (nothing overlaps its
             # epilogue); on the two-per-CU kernel it is +3 % of the whole step
-            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+            _launch_nt("apertis_grouped_gemm_nt", lib,
                     (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, None, max_rows, I, H, w2t.shape[-1], E, _lib.ACT_NONE,
-                     0.0, 0, code, code, stream_ptr()), work)
+                     0.0, 0, code, code, stream_ptr()), work, dyr.device)
             if act_code != _lib.ACT_NONE or drop_p > 0:
                 check(lib.apertis_act_dropout_bwd(ptr(dpre), ptr(pre), ptr(dpre), ptr(offsets), max_rows, I, E, act_code,
                                                   drop_p, seed, code, stream_ptr()), "apertis_act_dropout_bwd")
         dxg = None
         if ctx.needs_input_grad[0]:
             dxg = torch.empty_like(xg)
-            _launch("apertis_grouped_gemm_nt", lib.apertis_grouped_gemm_nt,
+            _launch_nt("apertis_grouped_gemm_nt", lib,
                     (ptr(dpre), ptr(w1t), None, ptr(offsets), ptr(dxg), None, None, max_rows, H, I, w1t.shape[-1], E, _lib.ACT_NONE,
-                     0.0, 0, code, code, stream_ptr()), work)
+                     0.0, 0, code, code, stream_ptr()), work, dpre.device)
         # both weight gradients in ONE launch: dW2 = dyr^T h, dW1 = dpre^T xg
         dw2 = grad_destination(ctx.wparams[1], (E, H, I), dev)
         db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
         dw1 = grad_destination(ctx.wparams[0], (E, I, H), dev)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
-        ws, ws_bytes = _tn_workspace(E, 2, dev)
+        ws, ws_bytes = _tn_workspace(E, 2, dev, max_rows)
         _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair,
                 (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
                  max_rows, E, ptr(ws), ws_bytes, code, stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))

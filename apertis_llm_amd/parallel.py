@@ -53,7 +53,8 @@ class BucketedDataParallel(nn.Module):
         if self.world_size > 1:
             # collectives will share the GPU with the persistent GEMM kernels: let those take their tiles from a queue,
             # so a work-group whose CU an RCCL kernel holds does not walk a full static share alone at the end
-            _os.environ.setdefault("APERTIS_GEMM_DYNAMIC", "1")
+            from . import ops as _ops
+            _ops.GEMM_DYNAMIC_QUEUE = True
         params = [p for p in module.parameters() if p.requires_grad]
         self.device = params[0].device
         self._cuda = self.device.type == "cuda"

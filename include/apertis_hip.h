@@ -12,7 +12,9 @@
  *   - the caller owns every buffer (inputs, outputs, workspaces); kernels never allocate;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it, no sync;
  *   - returns 0 (APERTIS_OK) or a negative error code; never throws across the ABI;
- *   - re-entrant, no process-global state, safe to dlopen lazily after fork().
+ *   - re-entrant, safe to dlopen lazily after fork().  No mutable process-global state: kernels keep nothing between
+ *     launches (cross-work-group counters live in caller-owned workspaces); the only cached value is a device attribute
+ *     (the CU count, read once).
  */
 #ifndef APERTIS_HIP_H
 #define APERTIS_HIP_H
@@ -73,21 +75,6 @@ int apertis_selective_scan_fwd(const float *dlt, const float *A_log,
                                float *agg, float *h_in,
                                int64_t B, int64_t L, int64_t h, int64_t N,
                                int dtype_bc, int dtype_y, int delta_softplus, void *stream);
-
-/* Single-launch forward (same math and outputs as apertis_selective_scan_fwd): persistent
- * work-groups publish chunk aggregates to each other through 8-byte {epoch, value} granules
- * (agent-scope relaxed atomics), so Bt is read once and there is one launch instead of two.
- *   ws    : apertis_scan_fused_workspace_bytes() bytes, zero-filled ONCE by the caller and then
- *           reused; its last 64 bytes hold an int32 error word (non-zero = a bounded spin timed out)
- *   epoch : non-zero, strictly increasing over the launches that share `ws`
- * One launch at a time may use a given `ws`. */
-int64_t apertis_scan_fused_workspace_bytes(int64_t B, int64_t L, int64_t Dn);
-int apertis_selective_scan_fwd_fused(const float *dlt, const float *A_log,
-                                     const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
-                                     const float *h0, void *y, int64_t y_rs, float *h_last,
-                                     float *h_in, void *ws, uint32_t epoch,
-                                     int64_t B, int64_t L, int64_t h, int64_t N,
-                                     int dtype_bc, int dtype_y, int delta_softplus, void *stream);
 
 /* Backward of the scan (no reference code: autograd through core.py:347-349).
  *   dy            : [B,L,Dn] (row stride dy_rs, dtype_y)
@@ -374,11 +361,24 @@ int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
                             int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E,
                             int act, float drop_p, uint64_t seed,
                             int dtype, int dtype_out, void *stream);
+/* The same with a dynamic tile queue for the persistent 256 x 256 kernel: tile_queue = ONE caller-owned int32 (per
+ * stream; the entry point zeroes it on `stream` in front of the launch).  After its first tile a work-group then takes
+ * its tiles from that counter instead of a static stride, so a work-group whose CU was held by a concurrent kernel (an
+ * RCCL collective on the communication stream of the data-parallel step) does not finish a full share alone.
+ * tile_queue == NULL: static schedule (what apertis_grouped_gemm_nt does). */
+int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias,
+                              const int32_t *offsets, void *C, void *pre_act,
+                              const void *act_bwd_pre,
+                              int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E,
+                              int act, float drop_p, uint64_t seed,
+                              int dtype, int dtype_out, int32_t *tile_queue, void *stream);
 /* TN workspace (bf16 only): the 256x256-tile kernel deals the CUs out to the (problem, group)
  * pairs and splits the tiles left after the full rounds along the rows; the partial tiles live
  * in a caller-owned scratch buffer `ws` (16-byte aligned, apertis_grouped_gemm_tn_workspace_bytes
  * bytes, contents don't care) and are summed in a fixed order.  ws == NULL, a too-small buffer
- * or E * n_problems > #CUs select the 128x128-tile kernel, which needs none. */
+ * or E * n_problems > #CUs select the 128x128-tile kernel, which needs none.  The choice is the caller's: the 256x256
+ * kernel pays off from about 2048 rows per group (below that a 256-row-deep slice per CU does not amortise the tile
+ * prologue / epilogue and the fold); the library applies no threshold of its own and reads no environment variable. */
 int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,

@@ -56,7 +56,8 @@ def _worker(rank, world, port, out):
         # (2) the same backward under the wrapper: buckets, hooks, grad_destination, side stream
         m1 = fresh()
         dp = BucketedDataParallel(m1, bucket_bytes=256 << 10)
-        assert os.environ.get("APERTIS_GEMM_DYNAMIC") == "1"
+        from apertis_llm_amd import ops as _ops
+        assert _ops.GEMM_DYNAMIC_QUEUE is True      # the persistent NT GEMM takes its tiles from the per-stream queue counter
         dp(**batch)[0].backward()
         dp.finish()
         torch.cuda.synchronize()

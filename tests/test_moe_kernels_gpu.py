@@ -401,13 +401,9 @@ def _tn_call(dev, A, Bm, offsets, E, with_bias, ws_mode, R=None):
     db = torch.full((E, M), float("nan"), device=dev) if with_bias else None
     nbytes = lib.apertis_grouped_gemm_tn_workspace_bytes(E, 1)
     ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8) if ws_mode else None
-    import os
-    os.environ["APERTIS_GEMM_TN_V3"] = "1"      # the 256x256-tile kernel also for groups the library would call too short for it
-    try:
-        rc = lib.apertis_grouped_gemm_tn(_lib.ptr(A), _lib.ptr(Bm), _lib.ptr(offsets), _lib.ptr(dW), _lib.ptr(db), R, M, N, E,
-                                         _lib.ptr(ws), nbytes if ws_mode else 0, _lib.BF16, _lib.stream_ptr())
-    finally:
-        del os.environ["APERTIS_GEMM_TN_V3"]
+    # a workspace selects the 256x256-tile kernel, also for groups a caller would normally call too short for it
+    rc = lib.apertis_grouped_gemm_tn(_lib.ptr(A), _lib.ptr(Bm), _lib.ptr(offsets), _lib.ptr(dW), _lib.ptr(db), R, M, N, E,
+                                     _lib.ptr(ws), nbytes if ws_mode else 0, _lib.BF16, _lib.stream_ptr())
     assert rc == 0, _lib.load().apertis_strerror(rc)
     torch.cuda.synchronize()
     return dW, db

@@ -173,32 +173,6 @@ def test_scan_rejects_bad_input(dev):
         ops.selective_scan(d.cpu(), A.cpu(), x.cpu(), x.cpu())
 
 
-def test_scan_fused_single_launch_stress(dev):
-    """The single-launch forward (granule hand-off between persistent work-groups): many launches
-    of changing shapes share one workspace with increasing epochs; results must equal the
-    two-launch kernel bit for bit... (same arithmetic order) and no spin may time out."""
-    from apertis_llm_amd import ops
-    torch.manual_seed(1)
-    shapes = [(8, 4096, 11, 16), (1, 64, 1, 16), (3, 1000, 4, 16), (16, 2048, 14, 16), (2, 4096, 11, 16), (5, 130, 2, 8)]
-    for rep in range(3):
-        for (B, L, h, N) in shapes:
-            Dn = h * N
-            R = 8 * ((h * 4 + 7) // 8)
-            p = torch.randn(B, L, R + 2 * Dn, device=dev).bfloat16()
-            dl = torch.randn(B, L, h, device=dev) - 4
-            A = torch.empty(h, N, device=dev).uniform_(math.log(.5), math.log(.99))
-            h0 = torch.randn(B, Dn, device=dev)
-            ops.SCAN_FUSED = True
-            y1, l1 = ops.selective_scan(dl, A, p[..., R:R + Dn], p[..., R + Dn:R + 2 * Dn], h0=h0, delta_softplus=True,
-                                        return_last=True)
-            ops.SCAN_FUSED = False
-            y2, l2 = ops.selective_scan(dl, A, p[..., R:R + Dn], p[..., R + Dn:R + 2 * Dn], h0=h0, delta_softplus=True,
-                                        return_last=True)
-            _close(y1, y2.cpu(), f"fused vs two-launch y {B,L,h,N}", rtol=2e-5, atol_scale=2e-6)
-            _close(l1, l2.cpu(), "final state", rtol=2e-5, atol_scale=2e-6)
-    assert ops.scan_fused_error(dev) == 0
-
-
 # ------------------------------------------------------------------ dt_proj_head / column split
 @pytest.mark.parametrize("dt,B,L,K,N,ld", [(torch.float32, 2, 300, 22, 11, 64), (torch.bfloat16, 3, 257, 22, 11, 368),
                                             (torch.float32, 1, 5, 1, 1, 1), (torch.bfloat16, 2, 1000, 32, 7, 32),
