@@ -850,6 +850,9 @@ class ApertisForCausalLM(nn.Module):
             self.lm_head.weight = self.model.token_embeddings.weight
         else:
             self.lm_head.weight.data.normal_(0.0, config.initializer_range)
+        # training-loop opt-in: loss straight from the hidden states, logits never materialised (forward returns
+        # None in their slot).  Off by default: the reference's callers may read outputs[1].
+        self.fused_lm_head_loss = False
 
     def load_state_dict(self, state_dict, strict=True):
         return super().load_state_dict(state_dict, strict=strict)
@@ -903,6 +906,16 @@ class ApertisForCausalLM(nn.Module):
             start = hs.shape[1] - input_ids.shape[1]                     # text positions are last, core.py:1399-1406
             if start >= 0:
                 hs = hs[:, start:]
+        if (labels is not None and self.fused_lm_head_loss and self.training and
+                ops.linear_cross_entropy_supported(hs, self.lm_head.weight, labels)):
+            # LM head + shifted cross entropy one sequence at a time (core.py:1412-1450): no [B, L, V] logits tensor, the
+            # tuple's logits slot is None.  Opt-in (TrainStep / ApertisTrainer set it: they only read the loss).
+            loss = ops.linear_cross_entropy(hs, self.lm_head.weight, labels, ignore_index=-100, compute_dtype=_compute_dtype(hs))
+            if outs[4] is not None:
+                loss = loss + outs[4]
+            if outs[5] is not None:
+                loss = loss + outs[5]
+            return (loss, None) + outs[1:]
         logits = self.lm_head(hs)
         loss = None
         if labels is not None:

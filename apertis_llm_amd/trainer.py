@@ -97,6 +97,8 @@ class ApertisTrainer:
         if use_gradient_checkpointing and hasattr(model, "gradient_checkpointing_enable"):
             model.gradient_checkpointing_enable()
         model.to(self.device)
+        if hasattr(model, "fused_lm_head_loss"):
+            model.fused_lm_head_loss = True      # this loop reads only outputs[0]: LM head + CE without the [B, L, V] logits
         self.dp = BucketedDataParallel(model) if (distributed_training and self.world_size > 1) else None
 
         self._create_dataloaders()

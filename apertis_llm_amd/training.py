@@ -161,12 +161,14 @@ class TrainStep:
     """loss = model(**batch)[0]; backward; (all-reduce); clip; AdamW; OneCycleLR."""
 
     def __init__(self, model, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0, total_steps=1000, bf16=True,
-                 gradient_accumulation_steps=1, bucket_bytes=128 << 20, reduce_dtype=None):
+                 gradient_accumulation_steps=1, bucket_bytes=128 << 20, reduce_dtype=None, fused_lm_head_loss=True):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         force = os.environ.get("APERTIS_FORCE_DP") == "1" and dist.is_initialized()   # exercise the DP path at world 1
         self.dp = (BucketedDataParallel(model, bucket_bytes=bucket_bytes, reduce_dtype=reduce_dtype)
                    if (self.world > 1 or force) else None)
         self.model = model
+        if hasattr(model, "fused_lm_head_loss"):
+            model.fused_lm_head_loss = bool(fused_lm_head_loss)   # the step reads only the loss: LM head + CE without the logits tensor
         self.optimizer = build_optimizer(model, lr, weight_decay)
         total_steps = max(int(total_steps), 2)
         if abs(0.1 * total_steps - 1.0) < 1e-9:      # OneCycleLR divides by (pct_start*total - 1): avoid the 0/0 case

@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--logits-path", action="store_true", help="A/B: materialise the [B, L, V] logits (LM head, then the loss)")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU/gloo self-test of the rank launcher and the timing protocol (tests/): no GPU work, "
                          "the line says so and is not a measurement")
@@ -193,7 +194,8 @@ def main():
     model = model.to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     step = TrainStep(model, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0, total_steps=args.steps + args.warmup + 1,
-                     bf16=True, reduce_dtype=torch.bfloat16 if args.reduce_dtype == "bf16" else None)
+                     bf16=True, reduce_dtype=torch.bfloat16 if args.reduce_dtype == "bf16" else None,
+                     fused_lm_head_loss=not args.logits_path)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
 
     def batch():

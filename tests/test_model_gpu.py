@@ -227,6 +227,61 @@ def test_shifted_cross_entropy_matches_reference_formula(dev, dt, B, L, V, Ll):
     assert float(x.grad[:, n:].abs().max()) == 0.0     # positions without a target get an exact zero gradient
 
 
+@pytest.mark.parametrize("dt,B,L,H,V,Ll", [(torch.float32, 3, 33, 64, 32000, 33), (torch.bfloat16, 2, 257, 128, 32000, 257),
+                                            (torch.float32, 2, 9, 32, 100, 12), (torch.bfloat16, 1, 2, 64, 512, 2)])
+def test_linear_cross_entropy_matches_lm_head_then_loss(dev, dt, B, L, H, V, Ll):
+    """N4: ops.linear_cross_entropy (LM head + shifted CE one sequence at a time, no [B, L, V] logits tensor, core.py:1412-1450)
+    against F.linear -> shift -> CrossEntropyLoss(ignore_index=-100) on the same (dtype-rounded) operands, at the
+    reference's vocabulary size: loss 1e-5 (fp32) / 2e-3 (bf16 logits), d hidden and d W to the compute dtype's rounding."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(B * 100 + L + H)
+    h = (torch.randn(B, L, H) * 0.7).to(dt)
+    W = torch.randn(V, H) * 0.1
+    labels = torch.randint(0, V, (B, Ll))
+    if Ll > 4:
+        labels[0, 3] = -100
+    n = min(L, Ll) - 1
+    hr, Wr = h.double().clone().requires_grad_(True), W.to(dt).double().clone().requires_grad_(True)
+    ref = F.cross_entropy(F.linear(hr, Wr)[:, :n].reshape(-1, V), labels[:, 1:n + 1].reshape(-1), ignore_index=-100)
+    (ref * 1.3).backward()
+    hd, Wd = h.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+    assert ops.linear_cross_entropy_supported(hd, Wd, labels.to(dev))
+    loss = ops.linear_cross_entropy(hd, Wd, labels.to(dev), compute_dtype=dt)
+    (loss * 1.3).backward()
+    ltol = 1e-5 if dt == torch.float32 else 2e-3
+    assert abs(float(loss) - float(ref)) <= ltol * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    rtol, asc = (1e-4, 1e-5) if dt == torch.float32 else (3e-2, 2e-2)       # bf16: logits, dlogits and the outputs are rounded
+    _close(hd.grad, hr.grad, "d hidden", rtol=rtol, atol_scale=asc)
+    _close(Wd.grad, Wr.grad, "d W", rtol=rtol, atol_scale=asc)
+    assert hd.grad.dtype == dt and Wd.grad.dtype == torch.float32
+    assert float(hd.grad[:, n:].abs().max()) == 0.0     # positions without a target get an exact zero gradient
+
+
+def test_fused_lm_head_loss_equals_the_logits_path(dev):
+    """The model with fused_lm_head_loss (what TrainStep / ApertisTrainer switch on) against its own logits path: same loss,
+    same parameter gradients (fp32, 1e-5), and the logits slot of the 7-tuple is None."""
+    import apertis_llm_amd as A
+    torch.manual_seed(0)
+    cfg = A.ApertisConfig(vocab_size=512, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                          attention_type="selective_ssm", use_expert_system=True, num_experts=4, hidden_dropout_prob=0.0,
+                          attention_probs_dropout_prob=0.0, use_noisy_top_k_routing=False, use_expert_dropout=False)
+    model = A.ApertisForCausalLM(cfg).to(dev).train()
+    ids = torch.randint(4, 512, (3, 40), device=dev)
+    labels = ids.clone()
+    labels[1, :5] = -100
+    out_a = model(input_ids=ids, labels=labels)
+    out_a[0].backward()
+    ga = {n: p.grad.clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    model.fused_lm_head_loss = True
+    out_b = model(input_ids=ids, labels=labels)
+    assert out_b[1] is None and len(out_b) == 7
+    out_b[0].backward()
+    assert abs(float(out_a[0]) - float(out_b[0])) <= 1e-6 * abs(float(out_a[0]))
+    for n, p in model.named_parameters():
+        _close(p.grad, ga[n], "grad " + n, rtol=1e-4, atol_scale=1e-5)
+
+
 def test_shifted_cross_entropy_all_ignored_is_nan_like_torch(dev):
     from apertis_llm_amd import ops
     logits = torch.randn(1, 4, 16, device=dev)
