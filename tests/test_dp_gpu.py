@@ -112,3 +112,57 @@ def test_two_ranks_on_hip_kernels_reduce_to_mean_and_stay_identical(dev):
     assert all(np.isfinite(loss0)) and all(np.isfinite(loss1)) and loss0 != loss1
     for i, (a, b) in enumerate(zip(p0, p1)):
         assert np.array_equal(a, b), f"parameter {i}: replicas diverged after three steps"
+
+
+def _nccl_worker(port, out):
+    """One rank on the RCCL backend (`nccl` on ROCm) with the wrapper forced on: the collective itself is
+    ReduceOp.AVG on the side stream - what every rank of the multi-GPU run executes per bucket."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", APERTIS_FORCE_DP="1",
+                      RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import apertis_llm_amd as A
+        from apertis_llm_amd.parallel import BucketedDataParallel
+        torch.manual_seed(0)
+        init = A.ApertisForCausalLM(A.ApertisConfig(**CFG)).state_dict()
+        batch = _batch(0, dev)
+
+        def fresh():
+            m = A.ApertisForCausalLM(A.ApertisConfig(**CFG))
+            m.load_state_dict(init)
+            return m.to(dev).train()
+        m0 = fresh()
+        m0(**batch)[0].backward()
+        local = [p.grad.detach().float().cpu() for p in m0.parameters()]
+        m1 = fresh()
+        dp = BucketedDataParallel(m1, bucket_bytes=256 << 10)
+        assert dp._avg_op and dp._force and dist.get_backend() == "nccl"
+        dp(**batch)[0].backward()
+        dp.finish()
+        torch.cuda.synchronize()
+        red = [p.grad.detach().float().cpu() for p in m1.parameters()]
+        ok = all(torch.allclose(a, b, rtol=1e-4, atol=1e-5 * float(a.abs().max()) + 1e-30) for a, b in zip(local, red))
+        out.put((ok, dp.reduced_bytes, dp.gradient_bytes(), len(dp.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_avg_all_reduce_on_the_side_stream(dev):
+    """ReduceOp.AVG on the RCCL backend through BucketedDataParallel (world 1, wrapper forced: the one-card box cannot host
+    two RCCL ranks): every bucket goes through dist.all_reduce(op=AVG) on the communication stream and the gradients that
+    come back equal the plain backward's (mean over one rank)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    try:
+        ok, reduced, total, nb = q.get(timeout=600)
+    finally:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+    assert p.exitcode == 0
+    assert ok, "gradients after the RCCL AVG all-reduce differ from the plain backward"
+    assert nb > 1 and reduced == total, (reduced, total)       # every bucket was handed to all_reduce exactly once
