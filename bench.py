@@ -27,8 +27,9 @@ CONFIGS = {
     # name: (target params, moe, multimodal, seq, default per-GPU batch)   BASELINE.json configs[1..4]
     "125m": ("125M", False, False, 2048, 32),
     "350m-moe": ("350M", True, False, 4096, 16),
-    # per-GPU batch 32 x 4096 tokens: 181 GiB of the 288 GB HBM3E (measured); B=24 gives 244k tok/s, 32: 249k
-    "1.5b-moe": ("1.5B", True, False, 4096, 32),
+    # per-GPU batch 40 x 4096 tokens: 214 GiB of the 288 GB HBM3E (measured, r2: the LM head + loss no longer hold the
+    # [B, L, 32000] logits); 32: 300.0k tokens/s at 175 GiB, 40: 305.3k, 48: 306.4k at 252 GiB (same box)
+    "1.5b-moe": ("1.5B", True, False, 4096, 40),
     "1.5b-moe-mm": ("1.5B", True, True, 2048, 16),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -267,10 +268,11 @@ def main():
         summ = timer.summary()
         rl = {}
         # HBM traffic per call from the committed rocprofv3 --pmc passes of the same launches
-        # (tools/run_pmc.sh benchmix -> profiles/r1_pmc_traffic_*.json); only valid for the workload
+        # (tools/run_pmc.sh benchmix -> profiles/r2_pmc_traffic_*.json); only valid for the workload
         # those passes were taken on, else null
         traffic = {}
-        tf = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_{args.config}_b{B}.json")
+        tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic_{args.config}_b{B}.json") for r in (2, 1))
+                   if os.path.exists(f)), "")
         if os.path.exists(tf):
             with open(tf) as fh:
                 traffic = {k: v.get("traffic_bytes_per_call") for k, v in json.load(fh).items()}

@@ -11,16 +11,17 @@ import sys
 
 out = sys.argv[1]
 ENTRY = {  # kernel-name fragment -> C-ABI entry point
-    "grouped_gemm_nt256p_k": "apertis_grouped_gemm_nt", "grouped_gemm_nt256_k": "apertis_grouped_gemm_nt",
+    "grouped_gemm_nt256p_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_nt2x_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_tn3_k": "apertis_grouped_gemm_tn", "tn3_fold_k": "apertis_grouped_gemm_tn",
     "grouped_gemm_tn2_k": "apertis_grouped_gemm_tn",
     "scan_fwd_state": "apertis_selective_scan_fwd", "scan_fwd_replay": "apertis_selective_scan_fwd",
     "scan_bwd_state": "apertis_selective_scan_bwd", "scan_bwd_replay": "apertis_selective_scan_bwd",
-    "colsum_kernel": "apertis_selective_scan_bwd",
+    "scan_gate_fwd_k": "apertis_scan_gate_fwd", "scan_gate_bwd_k": "apertis_scan_gate_bwd",
+    "colsum_kernel": "apertis_scan_gate_bwd",
 }
 CALLS_PER_REP = {"apertis_grouped_gemm_nt": 4, "apertis_grouped_gemm_tn": 1, "apertis_selective_scan_fwd": 1,
-                 "apertis_selective_scan_bwd": 1}
+                 "apertis_selective_scan_bwd": 1, "apertis_scan_gate_fwd": 1, "apertis_scan_gate_bwd": 1}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):

@@ -19,12 +19,16 @@ if what == "benchmix":
     # exactly the per-layer hot-kernel launches of bench.py's default workload (1.5b-moe, per-GPU batch 32)
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
     L, h, N, H, I, E = 4096, 11, 16, 704, 2816, 8
-    Dn, R = h * N, 48      # dt_rank 44 + pad to a 16-byte row
+    Dn, R = h * N, 44
+    Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64                 # the model's padded x_param_proj layout [Bt | 0 | C | 0 | dt | 0]
     rows = E * int((B * L / E) * 1.25)      # capacity-limited rows of the train step
-    p = torch.randn(B, L, R + 2 * Dn, device=dev).bfloat16().requires_grad_(True)
+    p = torch.randn(B, L, 2 * Wb + Wr, device=dev).bfloat16().requires_grad_(True)
+    xz = torch.randn(B, L, 2 * Dn, device=dev).bfloat16().requires_grad_(True)
+    xc = torch.randn(B, L, Dn, device=dev).bfloat16().requires_grad_(True)
     dl = (torch.randn(B, L, h, device=dev) - 4).requires_grad_(True)
     A = torch.empty(h, N, device=dev).uniform_(math.log(.5), math.log(.99)).requires_grad_(True)
-    dy = torch.randn(B, L, Dn, device=dev)
+    Dsk = torch.ones(Dn, device=dev, requires_grad=True)
+    dy = torch.randn(B, L, Dn, device=dev).bfloat16()
     xg = torch.randn(rows, H, device=dev).bfloat16().requires_grad_(True)
     w1 = (torch.randn(E, I, H, device=dev) * 0.02).requires_grad_(True)
     b1 = torch.zeros(E, I, device=dev, requires_grad=True)
@@ -33,7 +37,9 @@ if what == "benchmix":
     offs = torch.tensor(np.linspace(0, rows, E + 1).astype(np.int32), device=dev)
     dyr = torch.randn(rows, H, device=dev).bfloat16()
     for _ in range(reps):
-        y = ops.selective_scan(dl, A, p[..., R:R + Dn], p[..., R + Dn:R + 2 * Dn], delta_softplus=True)
+        Btp, Cp, _dt = ops.split_cols(p, (Wb, Wb, Wr))
+        _xp, z = ops.split_cols(xz, (Dn, Dn))
+        y = ops.scan_gate(dl, A, Btp, Cp, xc, z, Dsk, delta_softplus=True)
         y.backward(dy)
         yr = ops.expert_mlp(xg, w1, b1, w2, b2, offs, rows, act="gelu", drop_p=0.1, seed=5, compute_dtype=torch.bfloat16)
         yr.backward(dyr)
