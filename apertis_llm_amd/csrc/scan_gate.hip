@@ -821,12 +821,9 @@ struct FwdArgs {
   uint32_t epoch; ScanDims d; int single_pass; hipStream_t st;
 };
 
-#ifndef SCAN_FWD_MINW_CW3
-#define SCAN_FWD_MINW_CW3 6
-#endif
 // minimum waves per SIMD the forward is compiled for: bf16 two work-groups per CU (four of the 512-thread ones)
 template <typename T, int CW> constexpr int fwd_minw() {
-  return sizeof(T) == 2 ? (CW == 1 ? 8 : CW == 2 ? 8 : CW == 3 ? SCAN_FWD_MINW_CW3 : 4) : 4;
+  return sizeof(T) == 2 ? (CW == 1 ? 8 : CW == 2 ? 8 : CW == 3 ? 6 : 4) : 4;
 }
 
 template <typename T, int VB, int CW>

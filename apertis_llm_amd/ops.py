@@ -236,10 +236,7 @@ class _ScanGate(torch.autograd.Function):
         (Bt, bt_rs), (C, c_rs), (xc, xc_rs), (z, z_rs) = _rows(Bt, wB), _rows(C, wC), _rows(xc, Dn), _rows(z, Dn)
         nch = lib.apertis_scan_num_chunks(B, L, Dn)
         dev = dlt.device
-        if _os.environ.get("APERTIS_SCAN_PAD_EXPERIMENT"):      # rows on 128-byte boundaries (experiment)
-            out = torch.empty(B, L, -(-Dn // 64) * 64, device=dev, dtype=xc.dtype)[..., :Dn]
-        else:
-            out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
+        out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
         h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
         e = xc.element_size()
@@ -272,9 +269,6 @@ class _ScanGate(torch.autograd.Function):
         dC, dc_rs = _grad_out(ctx.slots[1], (B, L), wB, C.dtype, dev)
         dz, dz_rs = _grad_out(ctx.slots[2], (B, L), Dn, z.dtype, dev)
         dxc, dxc_rs = _grad_out(ctx.slots[3], (B, L), Dn, xc.dtype, dev)
-        if _os.environ.get("APERTIS_SCAN_PAD_EXPERIMENT") and ctx.slots[3] is None:
-            dxc = torch.empty(B, L, -(-Dn // 64) * 64, device=dev, dtype=xc.dtype)[..., :Dn]
-            dxc_rs = dxc.stride(-2)
         d_dlt = torch.empty(B, L, h, device=dev, dtype=torch.float32)
         dA_dD = torch.empty(2, Dn, device=dev, dtype=torch.float32)
         part = torch.empty(B * nch, 2 * Dn, device=dev, dtype=torch.float32)
