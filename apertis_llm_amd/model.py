@@ -318,6 +318,7 @@ class SelectiveLinearAttention(nn.Module):
         self.D = nn.Parameter(torch.ones(self.d_inner))
         self.out_proj = nn.Linear(self.d_inner, self.hidden_size, bias=False)
         self.use_cache = False
+        self._pad_idx = None
 
     def _padded_param_weight(self):
         """x_param_proj.weight with its output columns re-ordered and zero-padded so that, in the GEMM output p, the Bt
@@ -327,6 +328,14 @@ class SelectiveLinearAttention(nn.Module):
         work.  Returns (weight [2*Wb + Wr, Dn], Wb, Wr)."""
         w, Dn, R = self.x_param_proj.weight, self.d_inner, self.dt_rank
         Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
+        if w.is_cuda:
+            idx = self._pad_idx
+            if idx is None or idx.device != w.device:
+                # source row i of [dt | Bt | C] lands at: dt -> 2*Wb + i, Bt -> i - R, C -> Wb + i - R - Dn
+                i = torch.arange(R + 2 * Dn)
+                dst = torch.where(i < R, 2 * Wb + i, torch.where(i < R + Dn, i - R, Wb + i - R - Dn))
+                idx = self._pad_idx = dst.to(w.device)
+            return ops.scatter_rows(w, idx, 2 * Wb + Wr), Wb, Wr
         zb = w.new_zeros(Wb - Dn, Dn)
         zr = w.new_zeros(Wr - R, Dn)
         return torch.cat([w[R:R + Dn], zb, w[R + Dn:], zb, w[:R], zr], dim=0), Wb, Wr
@@ -397,6 +406,18 @@ class SelectiveLinearAttention(nn.Module):
 # ----------------------------------------------------------------------------------------------
 # AdaptiveExpertSystem  (reference core.py:403-607) on HIP kernels
 # ----------------------------------------------------------------------------------------------
+_ZERO_SCALARS = {}
+
+
+def _zero_scalar(device, dtype):
+    """A shared 0-dim zero (never written in place): the auxiliary-loss slots of layers without an expert system."""
+    key = (device, dtype)
+    z = _ZERO_SCALARS.get(key)
+    if z is None:
+        z = _ZERO_SCALARS[key] = torch.zeros((), device=device, dtype=dtype)
+    return z
+
+
 class AdaptiveExpertSystem(nn.Module):
     """Top-K routed mixture of `LayerNorm -> Linear -> act -> Dropout -> Linear` experts.
 
@@ -471,9 +492,13 @@ class AdaptiveExpertSystem(nn.Module):
             self.expert_ln_bias.zero_()
 
     @_on_input_device
-    def forward(self, hidden_states, lazy_combine=False):
-        zero = hidden_states.new_zeros(())
+    def forward(self, hidden_states, lazy_combine=False, aux_dtype=None):
+        """`aux_dtype`: dtype of the two auxiliary losses (core.py:607 casts them to hidden_states.dtype; the layer passes
+        the residual stream's dtype, which is what hidden_states has in the reference under autocast - here the
+        pre-norm kernels hand over the bf16 activation, and bf16 losses would also cost two mixed-dtype adds per layer)."""
+        aux_dtype = aux_dtype or hidden_states.dtype
         if self.num_experts <= 0 or self.router is None:
+            zero = _zero_scalar(hidden_states.device, aux_dtype)
             return hidden_states, zero, zero
         B, L, H = hidden_states.shape
         S, E, K = B * L, self.num_experts, self.experts_per_token
@@ -490,14 +515,14 @@ class AdaptiveExpertSystem(nn.Module):
                 logits = self.router(xn).float()
         if self.use_noisy_top_k_routing and self.training:                                # core.py:485-488
             logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
-        lb_loss, rz_loss = zero, zero
+        lb_loss = rz_loss = None
         lb_coef = self.load_balancing_loss_coef if (self.use_load_balancing_loss and self.training) else 0.0
         rz_coef = self.router_z_loss_coef if (self.use_router_z_loss and self.training) else 0.0
         if logits.is_cuda and S > 0 and (lb_coef > 0 or rz_coef > 0):
             # gate + both auxiliary losses in one pass (core.py:491-505, 524-529)
             idx, w, lb, rz = ops.moe_gate_topk_aux(logits, K, lb_coef, rz_coef)
-            lb_loss = lb if lb_coef > 0 else zero
-            rz_loss = rz if rz_coef > 0 else zero
+            lb_loss = lb if lb_coef > 0 else None
+            rz_loss = rz if rz_coef > 0 else None
         else:
             gates, idx, w = ops.moe_gate_topk(logits, K)                                  # core.py:491-492,529
             if lb_coef > 0:                                                               # core.py:499-505
@@ -528,7 +553,11 @@ class AdaptiveExpertSystem(nn.Module):
         out = _LazyCombine(yr, w, plan, (B, L, H), xf.dtype)                              # core.py:594,605
         if not lazy_combine:
             out = out.materialise()
-        return out, lb_loss.to(hidden_states.dtype), rz_loss.to(hidden_states.dtype)
+        if lb_loss is None or rz_loss is None:
+            zero = _zero_scalar(hidden_states.device, aux_dtype)
+            lb_loss = zero if lb_loss is None else lb_loss
+            rz_loss = zero if rz_loss is None else rz_loss
+        return out, lb_loss.to(aux_dtype), rz_loss.to(aux_dtype)
 
 
 class StateTrackingRecurrentCell(nn.Module):
@@ -652,11 +681,12 @@ class ApertisFeedForward(nn.Module):
 
     def forward(self, hidden_s, defer=False):
         x, hidden_s = _enter_block(self.pre_norm, hidden_s)
-        lb = rz = hidden_s.new_zeros(())
         if self.is_expert_system:
-            out, lb, rz = self.ffn(x, lazy_combine=defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"))
+            out, lb, rz = self.ffn(x, lazy_combine=defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"),
+                                   aux_dtype=hidden_s.dtype)
         else:
             out = self.ffn(x)
+            lb = rz = _zero_scalar(hidden_s.device, hidden_s.dtype)
         if defer:
             return _Pending(out, hidden_s, self.output_dropout), lb, rz
         return _dropout_add(self.output_dropout, out, hidden_s), lb, rz
@@ -808,7 +838,7 @@ class ApertisModel(nn.Module):
         mask = None if ssm else self._prepare_decoder_attention_mask(attention_mask, (B, x.shape[1]), x, past_len)
 
         all_hs, all_att, all_cache = [], [], []
-        lb_tot, rz_tot = x.new_zeros(()), x.new_zeros(())
+        lbs, rzs = [], []
         for i, layer in enumerate(self.layers):
             if out_hs:
                 all_hs.append(x)
@@ -824,10 +854,15 @@ class ApertisModel(nn.Module):
             if use_c:
                 all_cache.append(cache)
             if cfg.use_expert_system:
-                lb_tot, rz_tot = lb_tot + lb, rz_tot + rz
+                lbs.append(lb)
+                rzs.append(rz)
         x, _ = _enter_block(self.final_post_norm, x)
         if out_hs:
             all_hs.append(x)
+        if cfg.use_expert_system:
+            # one reduction over the layers instead of two scalar adds per layer (core.py:1283-1287 sums as it goes)
+            lb_tot = torch.stack(lbs).sum() if lbs else _zero_scalar(x.device, x.dtype)
+            rz_tot = torch.stack(rzs).sum() if rzs else _zero_scalar(x.device, x.dtype)
         return (x, tuple(all_hs) if out_hs and all_hs else None, tuple(all_att) if out_att and all_att else None,
                 tuple(all_cache) if use_c and all_cache else None,
                 lb_tot if cfg.use_expert_system else None, rz_tot if cfg.use_expert_system else None)

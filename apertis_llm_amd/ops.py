@@ -836,8 +836,8 @@ class _GatherLN(torch.autograd.Function):
         dev = x.device
         dxg = dxg.contiguous()
         dxr = torch.empty_like(dxg)
-        dgamma = torch.zeros(plan.E, H, device=dev, dtype=torch.float32)
-        dbeta = torch.zeros(plan.E, H, device=dev, dtype=torch.float32)
+        dgb = torch.zeros(2, plan.E, H, device=dev, dtype=torch.float32)      # one fill for both accumulators
+        dgamma, dbeta = dgb[0], dgb[1]
         nblk = lib.apertis_moe_gather_ln_bwd_blocks(plan.max_rows)
         part = torch.empty(nblk, 2 * H, device=dev, dtype=torch.float32)
         blk_e = torch.empty(nblk, device=dev, dtype=torch.int32)
@@ -1459,6 +1459,27 @@ def linear_cross_entropy(hidden, weight, labels, ignore_index=-100, compute_dtyp
     the shifted cross entropy (core.py:1417-1450) as one op that never holds more than one sequence of logits.
     hidden [B, L, H], weight [V, H] (the tied embedding), labels [B, >= L] int64."""
     return _LinearCrossEntropy.apply(hidden, weight, labels, ignore_index, compute_dtype or hidden.dtype)
+
+
+class _ScatterRows(torch.autograd.Function):
+    """out[dst_idx[i]] = w[i], every other row zero; the backward gathers the same rows back.  (As slices + zeros + cat
+    the backward was eight fill / copy / add kernels per call.)"""
+    @staticmethod
+    def forward(ctx, w, dst_idx, rows_out):
+        out = w.new_zeros(rows_out, *w.shape[1:])
+        out.index_copy_(0, dst_idx, w.detach())
+        ctx.save_for_backward(dst_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dst_idx,) = ctx.saved_tensors
+        return g.index_select(0, dst_idx), None, None
+
+
+def scatter_rows(w, dst_idx, rows_out):
+    """Rows of `w` placed at `dst_idx` (int64 device tensor, a permutation into `rows_out` >= len(w) rows), the rest zero."""
+    return _ScatterRows.apply(w, dst_idx, rows_out)
 
 
 def linear_mfma(x, weight, bias=None, act=None, compute_dtype=None):
