@@ -243,7 +243,14 @@ __device__ __forceinline__ void take_item(GateWsHead *head, uint32_t epoch, int 
 // built and measured with tools/probes/scan_gate_probe.hip at B=32, L=4096, Dn=176: the wait for the first tile goes from
 // 5.6 to 0.9 us per item, but the loads parked in registers across the loop either spill (two work-groups per CU at 80
 // VGPRs: 134 us) or leave one work-group per CU whose column walks then take twice as long (91 us), against 73 us for one
-// item per work-group with warm caches.  Removed.)
+// item per work-group with warm caches.  Removed.
+//  Two more forms measured later in round 2 (same probe, cold caches, B=32; this kernel: 84.0 us, 11.5 us per item, 321
+//  work-groups in flight): (i) work-groups that keep taking tickets (the next one drawn late in the item, nothing
+//  prefetched, the thread index laundered per trip so nothing per-thread is hoisted): 365 in flight but 14.7 us per item -
+//  every phase, the pure-compute replay included, runs slower with two work-groups truly co-resident all the time - 90.2 us;
+//  (ii) the same with ONE walk per item (y from a zero state to the tile, C*prod(a) kept in registers, y += q*H after the
+//  look-back): the read-modify-write of the split 2-byte y slots costs 1.9 us and the late xc / z loads 0.8 us - 87.6 us.
+//  The kernel is bound by per-CU instruction issue (walks, silu, bf16 packing) and latency together, not by slots.)
 struct ItemPos { int chunk, cs, b, id; };
 template <int MODE>
 __device__ __forceinline__ ItemPos decode_item(int item, const ScanDims &d, int ncs, bool reverse) {
