@@ -12,6 +12,12 @@
 //       output columns (two 16-byte stores per row and output, no LDS staging pass, no barrier; commit 1a0d5e9 holds it):
 //       correct (all GEMM tests green) and the same speed (1244 vs 1254; plain 811 vs 806): the staging pass is not what
 //       the epilogue costs either.  Reverted.
+//   (c) persistent 256^2 kernel, the LDS addresses of its DMA pieces: the solo path keeps eight of them in VGPRs and two spill
+//       (44 B of scratch; each reload puts an `s_waitcnt vmcnt(1)` between two DMA instructions).  Built from a scalar base
+//       the reloads leave the DMA path (20 B of scratch, all in the epilogue): 636-642 vs 626 us on fc2 forward, 800 vs 799
+//       on the plain fc1 shape - not what bounds it.  The same DMA as inline asm with a memory clobber (the form of the
+//       two-per-CU and TN kernels): 829 vs 613 us - the clobber pins the LDS reads and MFMAs around 64 DMA instructions per
+//       step.  Both reverted.
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
 #include <vector>
