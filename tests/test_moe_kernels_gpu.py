@@ -198,7 +198,9 @@ def test_grouped_linear_fp32_exact_path(dev, sizes, N, K, act):
 
 
 @pytest.mark.parametrize("sizes,N,K", [([700, 100, 0, 513], 256, 128), ([640] * 8, 1024, 256), ([300, 5], 704, 2816),
-                                        ([3000, 0, 1500, 257, 1, 600], 704, 128), ([4100, 90], 512, 704)])
+                                        ([3000, 0, 1500, 257, 1, 600], 704, 128), ([4100, 90], 512, 704),
+                                        # config 3 (H=256, I=1024) at its bench batch: fc1 and fc2 of the expert MLP
+                                        ([10240] * 8, 1024, 256), ([10240] * 8, 256, 1024), ([640] * 8, 256, 1024)])
 def test_grouped_linear_bf16_mfma(dev, sizes, N, K):
     """bf16 operands / fp32 accumulate: compare with fp64 math on the SAME bf16-rounded operands;
     only the output rounding (bf16, 2^-8) and fp32 accumulation order differ."""

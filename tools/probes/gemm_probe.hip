@@ -2,6 +2,7 @@
 // the C ABI, cold caches (1 GiB read between launches), hipEvent timing.  The library source is compiled in, so -D
 // switches of grouped_gemm.hip can be A/B'd as separate binaries inside one gpurun call.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-D...] tools/probes/gemm_probe.hip -o tools/probes/gemm_probe.bin
+// run:   gemm_probe.bin [B=32] [H=704] [I=2816]     (config 3: 16 256 1024)
 //
 // Measured with it in round 2 (B=32, cold caches, same box per comparison; fc1 forward = [163840, 704] x 8 x [2816, 704]):
 //   plain 806 us | + pre-activation output 942 | GELU only 890 | GELU + dropout 966 | GELU + pre 1000 | all three 1254;
@@ -35,7 +36,7 @@ __global__ void fill_k(bf16_t *p, size_t n, float scale, unsigned seed) {
 }
 int main(int argc, char **argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 32;
-  const int64_t E = 8, H = 704, I = 2816, rows = E * (int64_t)((B * 4096 / E) * 1.25);
+  const int64_t E = 8, H = argc > 2 ? atoi(argv[2]) : 704, I = argc > 3 ? atoi(argv[3]) : 2816, rows = E * (int64_t)((B * 4096 / E) * 1.25);
   bf16_t *x, *w1, *w2t, *h, *pre, *y, *dpre; float *b1; int32_t *offs; char *flush; unsigned *sink;
   hipMalloc(&x, rows * H * 2); hipMalloc(&w1, E * I * H * 2); hipMalloc(&w2t, E * I * H * 2); hipMalloc(&h, rows * I * 2);
   hipMalloc(&pre, rows * I * 2); hipMalloc(&y, rows * H * 2); hipMalloc(&dpre, rows * I * 2); hipMalloc(&b1, E * I * 4);
@@ -65,6 +66,6 @@ int main(int argc, char **argv) {
   timeit("fc1 shape: GELU + dropout (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc1 shape: GELU + pre out (no dropout)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc2 dgrad * act'(pre) * mask", fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
-  timeit("fc2 fwd (N=704, K=2816), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc2 fwd (N=H, K=I), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   return 0;
 }
