@@ -1518,11 +1518,16 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop).
     // ... and for the SSM block's dense projections (one group, short K, HBM-bound): 92 vs 114 us at N=352/K=704, 72 vs 89
     // at N=704/K=176, 56 vs 64 at N=400/K=176; the N=176 data gradients stay on the 256-wide tile (63 vs 60 us)
+#ifdef NT_PROBE_FORCE   // tools/probes only: 1 = two-per-CU kernel wherever it applies, 2 = never
+    const bool use2x = NT_PROBE_FORCE == 1;
+    (void)act; (void)drop_p;
+#else
     const bool use2x = ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
                        (E == 1 && K <= 1024 && N >= 256) ||
                        // narrow expert outputs (the H = 256 family's fc2 forward / fc1 data gradient, N = 256, K = 1024):
                        // 67 us here, 77 on the 256 x 256 tile, 90 on the 128 x 128 kernel they used to fall to
                        (K <= 1024 && N >= 256 && N < 512);
+#endif
     const bool ragged2x = K % 32 != 0;
     if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);

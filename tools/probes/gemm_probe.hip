@@ -19,6 +19,13 @@
 //       on the plain fc1 shape - not what bounds it.  The same DMA as inline asm with a memory clobber (the form of the
 //       two-per-CU and TN kernels): 829 vs 613 us - the clobber pins the LDS reads and MFMAs around 64 DMA instructions per
 //       step.  Both reverted.
+//   (d) the SSM block's dense projections (`gemm_probe.bin 40 704 2816 dense`, one group, T = 163840 rows, cold caches), two-per-CU
+//       kernel / persistent 256^2 kernel (-DNT_PROBE_FORCE=1 / 2) against the 5 TB/s streaming floor of operand + output bytes:
+//       in_proj fwd (N=352, K=704) 119 / 133 us, floor 69 | x_param fwd (448, 176) 81 / 86, floor 41 | out_proj fwd (704, 176)
+//       114 / 131, floor 58 | in_proj dgrad (704, 352) 150 / 177, floor 69 | x_param dgrad (176, 448) 60 / 67, floor 41 |
+//       out_proj dgrad (176, 704) 85 / 87, floor 58: 54 % of the floor on the better kernel; L2 -> LDS fill (X re-read once per
+//       128-wide n-tile) and the per-tile prologue / epilogue latency with two work-groups per CU, not HBM, bound them.
+//   (e) config 3 (`gemm_probe.bin 16 256 1024`): DESIGN.md "Config 3".
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
 #include <vector>
@@ -58,6 +65,20 @@ int main(int argc, char **argv) {
     }
     printf("%-46s best %7.1f us  avg %7.1f us  %6.0f TF (best)\n", name, best * 1e3, sum / n * 1e3, flops / best / 1e9);
   };
+  if (argc > 4) {   // dense projections of the SSM block (one group): gemm_probe.bin B 704 2816 dense
+    const int64_t T = (int64_t)B * 4096;
+    const int32_t o1[2] = {0, (int32_t)T};
+    hipMemcpy(offs, o1, 8, hipMemcpyHostToDevice);
+    const int shapes[6][2] = {{352, 704}, {448, 176}, {704, 176}, {704, 352}, {176, 448}, {176, 704}};   // (N, K)
+    const char *names[6] = {"in_proj fwd   N=352 K=704", "x_param fwd   N=448 K=176", "out_proj fwd  N=704 K=176",
+                            "in_proj dgrad N=704 K=352", "x_param dgrad N=176 K=448", "out_proj dgrad N=176 K=704"};
+    for (int i = 0; i < 6; ++i) {
+      const int64_t N = shapes[i][0], K = shapes[i][1], ldw = (K + 63) / 64 * 64;
+      char nm[128]; snprintf(nm, sizeof nm, "%s  floor %5.1f us @5TB/s", names[i], T * (N + K) * 2 / 5e6);
+      timeit(nm, 2.0 * T * N * K, [&] { return apertis_grouped_gemm_nt(h, w1, nullptr, offs, pre, nullptr, nullptr, T, N, K, ldw, 1, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+    }
+    return 0;
+  }
   const double fl = 2.0 * rows * H * I;
   timeit("fc1 fwd: GELU + dropout + pre-activation out", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc1 fwd shape, plain (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
