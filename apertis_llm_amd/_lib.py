@@ -81,6 +81,9 @@ SIGNATURES = {
     "apertis_grouped_gemm_tn_workspace_bytes": (_i64, [_i64, _i32]),
     "apertis_grouped_gemm_tn_pair": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                             _vp, _i64, _i32, _vp]),
+    "apertis_grouped_gemm_tn_pair_q": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
+                                              _vp, _i64, _i32, _i32, _vp]),
+    "apertis_grouped_gemm_tn_q": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp]),
     "apertis_cast_transpose": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _vp]),
     "apertis_moe_gate_topk_aux_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp]),

@@ -1252,8 +1252,12 @@ struct Tn3Args {
   Tn3Problem p0, p1;
   int nprob, E, cpg;   // cpg = CUs (work-groups) per (problem, expert) group
   float *ws;           // [grid][TN3_SLOT] partial tiles (+ 256 partial bias sums each)
+  int *ctr;            // [groups] item counters of the launch (zeroed in front of it), behind the partial tiles in `ws`
 };
 constexpr int TN3_SLOT = 256 * 256 + 256;
+constexpr int TN3_CTR_STRIDE = 64;                      // ints between two groups' counters: a 256-byte line each - on one line the
+                                                        // device-scope atomics of all XCDs queue up behind each other
+constexpr int TN3_CTR_BYTES = 1024 * TN3_CTR_STRIDE * 4;   // item counters of the groups (groups <= #CUs <= 1024), behind the partial tiles
 
 // the part of the schedule the GEMM and the fold kernel must agree on
 struct Tn3Sched { int T, full, rem, s; };
@@ -1310,20 +1314,31 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
   for (int q = 0; q < 8; ++q) ones[q] = (bf16_t)1.0f;
   const int wn_u = __builtin_amdgcn_readfirstlane(wn);
 
-  for (int it = 0; it <= sc.full; ++it) {
-    int tile, s0 = 0, s1 = nsteps;
+  // A group's items in order: the full tiles round by round, then the row slices of the remainder tiles.
+  //  static walk (a.ctr == NULL): work-group j takes items j, j + cpg, ... and the slice j.
+  //  item queue (a.ctr): after its first item a work-group takes the next from the group's counter - one whose CU was held by
+  //  another kernel when the grid started (an RCCL collective on the communication stream) then finds the group's items
+  //  taken instead of walking a full static share alone.  tools/probes/hog_probe.hip, 32 of 256 CUs held for the whole
+  //  launch: static 2400 us against 1460 alone, queue 1900 us; alone the queue costs 3 % (1510 us), which is why it is the
+  //  caller's choice.  Which work-group computes an item changes neither its arithmetic nor where it lands: bit-identical.
+  int *s_next = reinterpret_cast<int *>(smem + 4 * OPB);
+  const int n_full = sc.full * a.cpg, n_items = n_full + (sc.rem ? sc.rem * sc.s : 0);
+  int item = j;   // first item: the work-group's own index
+  for (int par = 1; item < n_items; par ^= 1) {
+    int nxt = 0;
+    if (a.ctr && tid == 0) nxt = a.cpg + atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);   // returns under the K loop
+    int tile, s0 = 0, s1 = nsteps, slot = 0;
     bool partial = false;
-    if (it < sc.full) {
-      tile = it * a.cpg + j;
+    if (item < n_full) {
+      tile = item;
     } else {
-      if (!sc.rem) break;
-      const int ri = j / sc.s;
-      if (ri >= sc.rem) break;
-      const int sl = j - ri * sc.s, per = (nsteps + sc.s - 1) / sc.s;
-      tile = sc.full * a.cpg + ri;
+      const int r = item - n_full, ri = r / sc.s;
+      const int sl = r - ri * sc.s, per = (nsteps + sc.s - 1) / sc.s;
+      tile = n_full + ri;
       s0 = min(sl * per, nsteps);
       s1 = min(s0 + per, nsteps);
       partial = sc.s > 1;
+      slot = g * a.cpg + r;
     }
     int mt, nt;
     tn3_tile_coord(tile, m_tiles, n_tiles, mt, nt);
@@ -1394,13 +1409,21 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
         __builtin_amdgcn_s_setprio(0);
       }
     }
+    // the next ticket rides on the barrier that ends the K loop; two slots in turn, so the slot written now was last read
+    // two barriers ago (no barrier of its own: one behind the epilogue would have every wave wait for the slowest one's
+    // store issue before the next item's first DMA)
+    if (a.ctr && tid == 0) s_next[par] = nxt;
     __syncthreads();   // the ring is free again before the next item's first DMA
+    int item_next;
+    if (a.ctr) item_next = __builtin_amdgcn_readfirstlane(s_next[par]);   // wave-uniform: keeps the item's tile arithmetic scalar
+    else if (item + a.cpg < n_full) item_next = item + a.cpg;
+    else item_next = (item < n_full && j < n_items - n_full) ? n_full + j : n_items;
 
     // D rows = n (fg*4 + r within subtile jn), D cols = m (frow within subtile im)
     float *out;
     int64_t ldo;
     bool bounded;
-    if (partial) { out = a.ws + (int64_t)id * TN3_SLOT; ldo = 256; bounded = false; }
+    if (partial) { out = a.ws + (int64_t)slot * TN3_SLOT; ldo = 256; bounded = false; }
     else { out = dW + (int64_t)e * M * N + (int64_t)m0 * N + n0; ldo = N; bounded = true; }
 #pragma unroll
     for (int jn = 0; jn < 4; ++jn)
@@ -1413,10 +1436,11 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int m = wm * 128 + (2 * wn + ii) * 16 + frow;
-        if (partial) a.ws[(int64_t)id * TN3_SLOT + 256 * 256 + m] = accb[ii][0];
+        if (partial) a.ws[(int64_t)slot * TN3_SLOT + 256 * 256 + m] = accb[ii][0];
         else if (m0 + m < M) dbias[(int64_t)e * M + m0 + m] = accb[ii][0];
       }
     }
+    item = item_next;
   }
 }
 
@@ -1465,7 +1489,7 @@ int device_cu_count() {
 
 // returns APERTIS_ERR_UNSUPPORTED when the shape does not fit v3's assumptions (the caller falls back to v2)
 int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t max_rows, const int32_t *offsets, float *ws,
-               int64_t ws_bytes, hipStream_t st) {
+               int64_t ws_bytes, bool item_queue, hipStream_t st) {
   const int nprob = q1 ? 2 : 1;
   const int64_t groups = nprob * E;
   const int ncu = device_cu_count();
@@ -1474,14 +1498,17 @@ int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t ma
   // `ws` NULL for those and get the 128 x 128 kernel; the choice is the caller's, the library has no hidden switch)
   const int cpg = (int)(ncu / groups);
   const int grid = (int)(groups * cpg);
-  if (ws_bytes < (int64_t)grid * TN3_SLOT * (int64_t)sizeof(float) || (((uintptr_t)ws) & 15)) return APERTIS_ERR_UNSUPPORTED;
+  const int64_t slots_bytes = (int64_t)grid * TN3_SLOT * (int64_t)sizeof(float);
+  if (ws_bytes < slots_bytes + TN3_CTR_BYTES || (((uintptr_t)ws) & 15)) return APERTIS_ERR_UNSUPPORTED;
   const int64_t ldmax = std::max<int64_t>(std::max(q0.M, q0.N), q1 ? std::max(q1->M, q1->N) : 0) * 2;
   if ((max_rows + 256) * ldmax >= 0xffffffffLL) return APERTIS_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   Tn3Args a;
   a.p0 = q0;
   a.p1 = q1 ? *q1 : Tn3Problem{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   a.nprob = nprob; a.E = (int)E; a.cpg = cpg; a.ws = ws;
-  const size_t lds = 4 * 64 * 512;
+  a.ctr = item_queue ? reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + slots_bytes) : nullptr;
+  if (a.ctr && hipMemsetAsync(a.ctr, 0, (size_t)groups * TN3_CTR_STRIDE * sizeof(int), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
+  const size_t lds = 4 * 64 * 512 + 16;
   hipFuncSetAttribute((const void *)grouped_gemm_tn3_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(grouped_gemm_tn3_k, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
   bool split = false;
@@ -1607,12 +1634,12 @@ extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_prob
   const int ncu = device_cu_count();
   const int64_t groups = E * n_problems;
   if (groups > ncu) return 0;   // v3 does not apply; no workspace needed
-  return (ncu / groups) * groups * (int64_t)TN3_SLOT * (int64_t)sizeof(float);
+  return (ncu / groups) * groups * (int64_t)TN3_SLOT * (int64_t)sizeof(float) + TN3_CTR_BYTES;
 }
 
-extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets, float *dW,
-                                       float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, void *ws,
-                                       int64_t ws_bytes, int dtype, void *stream) {
+extern "C" int apertis_grouped_gemm_tn_q(const void *A, const void *Bm, const int32_t *offsets, float *dW,
+                                         float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, void *ws,
+                                         int64_t ws_bytes, int dtype, int item_queue, void *stream) {
   if (!A || !Bm || !offsets || !dW || max_rows < 0 || M <= 0 || N <= 0 || E <= 0) return APERTIS_ERR_ARG;
   if (M > 0x3fffffff || N > 0x3fffffff || max_rows > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -1624,7 +1651,7 @@ extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int3
     if (ws) {
       Tn3Problem q{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, (int)ceil_div64(M, 256),
                    (int)ceil_div64(N, 256)};
-      const int rc = launch_tn3(q, nullptr, E, max_rows, offsets, (float *)ws, ws_bytes, st);
+      const int rc = launch_tn3(q, nullptr, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, st);
       if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
     }
     TnProblem q0{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, m_tiles, n_tiles, (int)grid};
@@ -1662,10 +1689,16 @@ extern "C" int apertis_act_dropout_bwd(const void *dh, const void *pre_act, void
   return apertis_check_launch();
 }
 
-extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, float *dbias0, int64_t M0,
-                                            int64_t N0, const void *A1, const void *B1, float *dW1, float *dbias1,
-                                            int64_t M1, int64_t N1, const int32_t *offsets, int64_t max_rows, int64_t E,
-                                            void *ws, int64_t ws_bytes, int dtype, void *stream) {
+extern "C" int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets, float *dW,
+                                       float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, void *ws,
+                                       int64_t ws_bytes, int dtype, void *stream) {
+  return apertis_grouped_gemm_tn_q(A, Bm, offsets, dW, dbias, max_rows, M, N, E, ws, ws_bytes, dtype, 0, stream);
+}
+
+extern "C" int apertis_grouped_gemm_tn_pair_q(const void *A0, const void *B0, float *dW0, float *dbias0, int64_t M0,
+                                              int64_t N0, const void *A1, const void *B1, float *dW1, float *dbias1,
+                                              int64_t M1, int64_t N1, const int32_t *offsets, int64_t max_rows, int64_t E,
+                                              void *ws, int64_t ws_bytes, int dtype, int item_queue, void *stream) {
   if (!A0 || !B0 || !dW0 || !A1 || !B1 || !dW1 || !offsets || max_rows < 0 || E <= 0) return APERTIS_ERR_ARG;
   if (dtype != APERTIS_BF16) {   // fp32 parity path: two ordinary launches
     int rc = apertis_grouped_gemm_tn(A0, B0, offsets, dW0, dbias0, max_rows, M0, N0, E, nullptr, 0, dtype, stream);
@@ -1679,7 +1712,7 @@ extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, floa
                   (int)ceil_div64(N0, 256)};
     Tn3Problem p1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, (int)ceil_div64(M1, 256),
                   (int)ceil_div64(N1, 256)};
-    const int rc = launch_tn3(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, (hipStream_t)stream);
+    const int rc = launch_tn3(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);
     if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
   }
   const int mt0 = (int)ceil_div64(M0, BM), nt0 = (int)ceil_div64(N0, BN), mt1 = (int)ceil_div64(M1, BM),
@@ -1689,4 +1722,12 @@ extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, floa
   TnProblem q0{(const bf16_t *)A0, (const bf16_t *)B0, dW0, dbias0, (int)M0, (int)N0, mt0, nt0, (int)g0};
   TnProblem q1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, mt1, nt1, (int)g1};
   return launch_tn2(q0, q1, offsets, (hipStream_t)stream);
+}
+
+extern "C" int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, float *dbias0, int64_t M0,
+                                            int64_t N0, const void *A1, const void *B1, float *dW1, float *dbias1,
+                                            int64_t M1, int64_t N1, const int32_t *offsets, int64_t max_rows, int64_t E,
+                                            void *ws, int64_t ws_bytes, int dtype, void *stream) {
+  return apertis_grouped_gemm_tn_pair_q(A0, B0, dW0, dbias0, M0, N0, A1, B1, dW1, dbias1, M1, N1, offsets, max_rows, E, ws,
+                                        ws_bytes, dtype, 0, stream);
 }

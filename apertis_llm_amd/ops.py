@@ -951,9 +951,11 @@ class _RowsWork:
         return float(self.offsets[self.E].item()) * self.per_row
 
 
-# Set by parallel.BucketedDataParallel when it wraps a model for world_size > 1: the persistent NT GEMM then takes its
-# tiles from a per-launch counter (apertis_grouped_gemm_nt_q), so that a work-group whose CU an RCCL kernel holds does
-# not walk a full static share alone at the end.  Off on one GPU (657.7 vs 636 us on the N=704/K=2816 GEMM).
+# Set by parallel.BucketedDataParallel when it wraps a model for world_size > 1: the persistent NT GEMM and the 256x256
+# weight-gradient kernel then take their tiles from per-launch counters (apertis_grouped_gemm_nt_q / _tn_q / _tn_pair_q), so
+# that a work-group whose CU an RCCL kernel holds does not walk a full static share alone at the end (measured with
+# tools/probes/hog_probe.hip: 32 of 256 CUs held -> NT 1109 us static / 762 queue / 702 alone, TN 2400 / 1900 / 1460).
+# Off on one GPU: the queues cost 3 % there.
 GEMM_DYNAMIC_QUEUE = False
 _NT_QUEUE = {}
 
@@ -1071,9 +1073,9 @@ class _GroupedLinear(torch.autograd.Function):
                 dw = torch.empty(E, N, K, device=x.device, dtype=torch.float32)
                 db = torch.empty(E, N, device=x.device, dtype=torch.float32) if has_bias else None
                 ws, ws_bytes = _tn_workspace(E, 1, x.device, max_rows)
-                _launch("apertis_grouped_gemm_tn" if E > 1 else "apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
+                _launch("apertis_grouped_gemm_tn" if E > 1 else "apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn_q,
                         (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, ptr(ws), ws_bytes, code,
-                         stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
+                         int(GEMM_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
             dw = dw.to(wdtype)
         return dx, dw, db, None, None, None, None, None, None
 
@@ -1322,9 +1324,10 @@ class _ExpertMLP(torch.autograd.Function):
         dw1 = grad_destination(ctx.wparams[0], (E, I, H), dev)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
         ws, ws_bytes = _tn_workspace(E, 2, dev, max_rows)
-        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair,
+        # (item queue of the 256x256 kernel: on when the step overlaps RCCL kernels, see GEMM_DYNAMIC_QUEUE)
+        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair_q,
                 (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
-                 max_rows, E, ptr(ws), ws_bytes, code, stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
+                 max_rows, E, ptr(ws), ws_bytes, code, int(GEMM_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
         return dxg, dw1.to(w1dt), db1, dw2.to(w2dt), db2, None, None, None, None, None, None
 
 

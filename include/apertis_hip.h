@@ -375,7 +375,8 @@ int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias,
 /* TN workspace (bf16 only): the 256x256-tile kernel deals the CUs out to the (problem, group)
  * pairs and splits the tiles left after the full rounds along the rows; the partial tiles live
  * in a caller-owned scratch buffer `ws` (16-byte aligned, apertis_grouped_gemm_tn_workspace_bytes
- * bytes, contents don't care) and are summed in a fixed order.  ws == NULL, a too-small buffer
+ * bytes, contents don't care) and are summed in a fixed order.  (The last 256 KiB of `ws` are the
+ * item counters of the _q entry points below.)  ws == NULL, a too-small buffer
  * or E * n_problems > #CUs select the 128x128-tile kernel, which needs none.  The choice is the caller's: the 256x256
  * kernel pays off from about 2048 rows per group (below that a 256-row-deep slice per CU does not amortise the tile
  * prologue / epilogue and the fold); the library applies no threshold of its own and reads no environment variable. */
@@ -390,6 +391,20 @@ int apertis_grouped_gemm_tn_pair(const void *A0, const void *B0, float *dW0, flo
                                  float *dW1, float *dbias1, int64_t M1, int64_t N1,
                                  const int32_t *offsets, int64_t max_rows, int64_t E,
                                  void *ws, int64_t ws_bytes, int dtype, void *stream);
+/* The same two entry points with the 256x256 kernel's ITEM QUEUE (item_queue != 0; needs `ws`): work-groups take a
+ * group's tiles from per-group counters kept in the last 256 KiB of `ws` (zeroed on `stream` by the entry point)
+ * instead of a static share each, so a work-group that starts late - its CU held by a concurrent kernel such as an
+ * RCCL collective of the data-parallel step - does not leave a full share undone.  Measured with
+ * tools/probes/hog_probe.hip (32 of 256 CUs held): 2400 us static, 1900 us queue, 1460 us alone; alone the queue
+ * costs 3 %, hence the switch.  The result is bit-identical either way. */
+int apertis_grouped_gemm_tn_q(const void *A, const void *Bm, const int32_t *offsets,
+                              float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
+                              int64_t E, void *ws, int64_t ws_bytes, int dtype, int item_queue, void *stream);
+int apertis_grouped_gemm_tn_pair_q(const void *A0, const void *B0, float *dW0, float *dbias0,
+                                   int64_t M0, int64_t N0, const void *A1, const void *B1,
+                                   float *dW1, float *dbias1, int64_t M1, int64_t N1,
+                                   const int32_t *offsets, int64_t max_rows, int64_t E,
+                                   void *ws, int64_t ws_bytes, int dtype, int item_queue, void *stream);
 /* Compute copies of fp32 master weights src [E,R,C]: dst [E,R,ld_dst] and/or dstT [E,C,ld_dstT]
  * in dtype_out (either may be NULL).  Replaces what torch.autocast does per nn.Linear call.
  * ld_dst in [C, C rounded up to 64], ld_dstT in [R, R rounded up to 64] (0 = unpadded); pad columns

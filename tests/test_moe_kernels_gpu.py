@@ -404,8 +404,10 @@ def _tn_call(dev, A, Bm, offsets, E, with_bias, ws_mode, R=None):
     nbytes = lib.apertis_grouped_gemm_tn_workspace_bytes(E, 1)
     ws = torch.empty(max(nbytes, 16), device=dev, dtype=torch.uint8) if ws_mode else None
     # a workspace selects the 256x256-tile kernel, also for groups a caller would normally call too short for it
-    rc = lib.apertis_grouped_gemm_tn(_lib.ptr(A), _lib.ptr(Bm), _lib.ptr(offsets), _lib.ptr(dW), _lib.ptr(db), R, M, N, E,
-                                     _lib.ptr(ws), nbytes if ws_mode else 0, _lib.BF16, _lib.stream_ptr())
+    # ws_mode == "queue": the same kernel taking its tiles from the per-group item counters (what the data-parallel step uses)
+    rc = lib.apertis_grouped_gemm_tn_q(_lib.ptr(A), _lib.ptr(Bm), _lib.ptr(offsets), _lib.ptr(dW), _lib.ptr(db), R, M, N, E,
+                                       _lib.ptr(ws), nbytes if ws_mode else 0, _lib.BF16, int(ws_mode == "queue"),
+                                       _lib.stream_ptr())
     assert rc == 0, _lib.load().apertis_strerror(rc)
     torch.cuda.synchronize()
     return dW, db
@@ -435,9 +437,14 @@ def test_grouped_gemm_tn_bf16(dev, sizes, M, N, with_bias):
         ref_w[e] = Ac[r0:r1].T @ Bc[r0:r1]
         ref_b[e] = Ac[r0:r1].sum(0)
     scale = max(1.0, float(max(sizes)) ** 0.5)
-    for ws_mode in (True, False):
+    static = None
+    for ws_mode in (True, "queue", False):
         dW, db = _tn_call(dev, A, Bm, offs, E, with_bias, ws_mode, R=R)
         assert torch.isfinite(dW).all(), "every output element must be written"
+        if ws_mode is True:
+            static = (dW, db)
+        elif ws_mode == "queue":     # who computes a tile changes nothing: bit-identical to the static walk
+            assert torch.equal(dW, static[0]) and (db is None or torch.equal(db, static[1]))
         err = (dW.double().cpu() - ref_w).abs().max().item()
         assert err <= 2e-5 * scale * 8, f"ws={ws_mode}: max abs err {err:.3e}"   # fp32 accumulation of exact bf16 products
         if with_bias:
@@ -453,8 +460,8 @@ def test_grouped_gemm_tn_is_deterministic(dev):
     A = torch.randn(sum(sizes), 704, device=dev).bfloat16()
     Bm = torch.randn(sum(sizes), 512, device=dev).bfloat16()
     first = _tn_call(dev, A, Bm, offs, 4, True, True)
-    for _ in range(3):
-        again = _tn_call(dev, A, Bm, offs, 4, True, True)
+    for mode in (True, True, "queue", "queue"):
+        again = _tn_call(dev, A, Bm, offs, 4, True, mode)
         assert torch.equal(first[0], again[0]) and torch.equal(first[1], again[1])
 
 
