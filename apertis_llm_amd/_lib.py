@@ -88,6 +88,10 @@ SIGNATURES = {
     "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _vp]),
     "apertis_moe_gate_topk_aux_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp]),
     "apertis_moe_gate_topk_aux_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _i64, _i64, _i64, _vp]),
+    "apertis_moe_gate_topk_noisy_aux_fwd": (_i32, [_vp, _vp, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32,
+                                                   _f32, _vp]),
+    "apertis_moe_gate_topk_noisy_aux_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _f32, _u64, _vp, _vp, _vp,
+                                                   _i64, _i64, _i64, _vp]),
     "apertis_moe_gate_aux_blocks": (_i64, [_i64]),
     "apertis_router_fwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_router_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),

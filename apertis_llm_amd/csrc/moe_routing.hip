@@ -1085,9 +1085,39 @@ fold_rows_k(const float *__restrict__ part, float *__restrict__ out, int64_t nro
 // As stock tensor ops the two losses are ~35 launches forward and ~25 backward per layer, 4-5 us each
 // on [S, 8] tensors, plus a 47 us index_add.  stats out: [lb, rz, frac_0..frac_{E-1}].
 // ------------------------------------------------------------------------------------------
+// Noisy top-k routing (reference core.py:485-488): logits += randn * softplus(w_noise) * alpha.  The standard normals come
+// from a counter hash of (seed, token, expert pair) through Box-Muller, so the backward regenerates them instead of keeping
+// a [S, E] tensor, and the whole noise path is part of the gate kernels (as tensor ops it was ten launches per layer).
+__device__ __forceinline__ void gauss_pair(uint64_t seed, uint64_t pair, float &n0, float &n1) {
+  const uint32_t h0 = drop_hash_pair(seed, 2 * pair), h1 = drop_hash_pair(seed ^ 0x9E3779B97F4A7C15ull, 2 * pair + 1);
+  const float u1 = ((float)(h0 >> 8) + 1.0f) * (1.0f / 16777216.0f);      // (0, 1]
+  const float u2 = (float)(h1 >> 8) * (1.0f / 16777216.0f);               // [0, 1)
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincospif(2.0f * u2, &sn, &cs);
+  n0 = r * cs;
+  n1 = r * sn;
+}
+__device__ __forceinline__ float softplus_gate(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus (beta 1, threshold 20)
+// the row's E standard normals (pairs share one Box-Muller draw; an odd last expert uses the first of its pair)
+template <int CAP>
+__device__ __forceinline__ void row_noise(uint64_t seed, int64_t s, int E, float (&nz)[CAP]) {
+  const int64_t ppr = (E + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < CAP; i += 2) {
+    if (i < E) {
+      float a, b;
+      gauss_pair(seed, (uint64_t)(s * ppr + (i >> 1)), a, b);
+      nz[i] = a;
+      if (i + 1 < CAP) nz[i + 1] = b;
+    }
+  }
+}
+
 template <int EC>
 __global__ void __launch_bounds__(256)
-gate_topk_aux_fwd_k(const float *__restrict__ logits, float *__restrict__ gates, int32_t *__restrict__ idx,
+gate_topk_aux_fwd_k(const float *__restrict__ logits, const float *__restrict__ w_noise, float alpha, uint64_t seed,
+                    float *__restrict__ gates, int32_t *__restrict__ idx,
                     float *__restrict__ w, float *__restrict__ lse, float *__restrict__ part, int64_t S, int E_rt, int K) {
   constexpr int CAP = EC > 0 ? EC : MAXE;
   const int E = EC > 0 ? EC : E_rt;
@@ -1103,7 +1133,17 @@ gate_topk_aux_fwd_k(const float *__restrict__ logits, float *__restrict__ gates,
     float m = -INFINITY;
 #pragma unroll
     for (int i = 0; i < CAP; ++i)
-      if (i < E) { v[i] = row[i]; m = fmaxf(m, v[i]); }
+      if (i < E) v[i] = row[i];
+    if (w_noise) {
+      float nz[CAP];
+      row_noise<CAP>(seed, s, E, nz);
+#pragma unroll
+      for (int i = 0; i < CAP; ++i)
+        if (i < E) v[i] += nz[i] * (softplus_gate(w_noise[i]) * alpha);
+    }
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (i < E) m = fmaxf(m, v[i]);
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < CAP; ++i)
@@ -1182,15 +1222,20 @@ gate_aux_fold_k(const float *__restrict__ part, float *__restrict__ stats, int64
 // backward of gate + losses: dgates[s,e] = dlb * lb_coef * E * frac_e / S (the load-balancing loss through the
 // gate means), dlogits += drz * rz_coef * 2 lse_s / S * gates[s,e] (d lse / d logits = softmax)
 template <int EC>
-__global__ void gate_topk_aux_bwd_k(const float *__restrict__ gates, const int32_t *__restrict__ idx,
-                                    const float *__restrict__ dw, const float *__restrict__ lse,
-                                    const float *__restrict__ stats, const float *__restrict__ dlb,
-                                    const float *__restrict__ drz, float lb_coef, float rz_coef,
-                                    float *__restrict__ dlogits, int64_t S, int E_rt, int K) {
+__global__ void __launch_bounds__(256)
+gate_topk_aux_bwd_k(const float *__restrict__ gates, const int32_t *__restrict__ idx,
+                    const float *__restrict__ dw, const float *__restrict__ lse,
+                    const float *__restrict__ stats, const float *__restrict__ dlb,
+                    const float *__restrict__ drz, float lb_coef, float rz_coef,
+                    float *__restrict__ dlogits, float *__restrict__ npart, uint64_t seed, int64_t S, int E_rt, int K) {
+  // npart != NULL (noisy routing): [gridDim.x][E] block sums of dlogits * n, the gradient of the per-expert noise scale
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
   constexpr int CAP = EC > 0 ? EC : MAXE;
   const int E = EC > 0 ? EC : E_rt;
+  float dsc[CAP];
+#pragma unroll
+  for (int i = 0; i < CAP; ++i) dsc[i] = 0.f;
+  if (s < S) {
   const float glb = dlb ? dlb[0] * lb_coef * (float)E / (float)S : 0.f;
   const float grz = drz ? drz[0] * rz_coef * 2.f * lse[s] / (float)S : 0.f;
   float g[CAP], dg[CAP];
@@ -1222,9 +1267,46 @@ __global__ void gate_topk_aux_bwd_k(const float *__restrict__ gates, const int32
 #pragma unroll
   for (int i = 0; i < CAP; ++i)
     if (i < E) inner += dg[i] * g[i];
+  float nz[CAP];
+  if (npart) row_noise<CAP>(seed, s, E, nz);
 #pragma unroll
   for (int i = 0; i < CAP; ++i)
-    if (i < E) dlogits[s * E + i] = g[i] * (dg[i] - inner) + grz * g[i];
+    if (i < E) {
+      const float dl = g[i] * (dg[i] - inner) + grz * g[i];
+      dlogits[s * E + i] = dl;
+      if (npart) dsc[i] = dl * nz[i];
+    }
+  }
+  if (npart) {
+    __shared__ float red[4][MAXE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < CAP; ++i)
+      if (i < E) {
+        const float a = wave_sum(dsc[i]);
+        if (lane == 0) red[wv][i] = a;
+      }
+    __syncthreads();
+    if (threadIdx.x < E)
+      npart[(int64_t)blockIdx.x * E + threadIdx.x] =
+          (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  }
+}
+
+// d w_noise[e] = (sum over blocks of npart[., e]) * alpha * sigmoid(w_noise[e])  (softplus' = sigmoid), fixed order
+__global__ void __launch_bounds__(1024)
+gate_noise_fold_k(const float *__restrict__ npart, const float *__restrict__ w_noise, float alpha, float *__restrict__ dw_noise,
+                  int64_t nblk, int E) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int e = wv; e < E; e += 16) {
+    float a = 0.f;
+    for (int64_t b = lane; b < nblk; b += 64) a += npart[b * E + e];
+    a = wave_sum(a);
+    if (lane == 0) {
+      const float x = w_noise[e];
+      dw_noise[e] = a * alpha * (x > 20.f ? 1.f : 1.f / (1.f + expf(-x)));
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2006,34 +2088,53 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
 
 extern "C" int64_t apertis_moe_gate_aux_blocks(int64_t S) { return ceil_div64(S > 0 ? S : 1, 256); }
 
-extern "C" int apertis_moe_gate_topk_aux_fwd(const float *logits, float *gates, int32_t *idx, float *w, float *lse,
-                                             float *part, float *stats, int64_t S, int64_t E, int64_t K, float lb_coef,
-                                             float rz_coef, void *stream) {
-  // part: workspace [apertis_moe_gate_aux_blocks(S)][2E+1]; stats: out [2 + E] = [lb, rz, frac_e]
+extern "C" int apertis_moe_gate_topk_noisy_aux_fwd(const float *logits, const float *w_noise, float alpha, uint64_t seed,
+                                                   float *gates, int32_t *idx, float *w, float *lse, float *part, float *stats,
+                                                   int64_t S, int64_t E, int64_t K, float lb_coef, float rz_coef, void *stream) {
+  // part: workspace [apertis_moe_gate_aux_blocks(S)][2E+1]; stats: out [2 + E] = [lb, rz, frac_e]; w_noise NULL: no noise
   if (!logits || !gates || !idx || !w || !lse || !part || !stats || S <= 0) return APERTIS_ERR_ARG;
   if (E < 1 || E > MAXE || K < 1 || K > MAXK || K > E) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nblk = apertis_moe_gate_aux_blocks(S);
   dim3 grid((unsigned)nblk), block(256);
-#define GO(EC) hipLaunchKernelGGL(gate_topk_aux_fwd_k<EC>, grid, block, 0, st, logits, gates, idx, w, lse, part, S, (int)E, (int)K)
+#define GO(EC) hipLaunchKernelGGL(gate_topk_aux_fwd_k<EC>, grid, block, 0, st, logits, w_noise, alpha, seed, gates, idx, w, lse, part, S, (int)E, (int)K)
   if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
 #undef GO
   hipLaunchKernelGGL(gate_aux_fold_k, dim3(1), dim3(1024), 0, st, part, stats, nblk, S, (int)E, lb_coef, rz_coef);
   return apertis_check_launch();
 }
 
-extern "C" int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *idx, const float *dw, const float *lse,
-                                             const float *stats, const float *dlb, const float *drz, float lb_coef,
-                                             float rz_coef, float *dlogits, int64_t S, int64_t E, int64_t K, void *stream) {
-  if (!gates || !idx || !lse || !stats || !dlogits || S < 0) return APERTIS_ERR_ARG;
+extern "C" int apertis_moe_gate_topk_aux_fwd(const float *logits, float *gates, int32_t *idx, float *w, float *lse,
+                                             float *part, float *stats, int64_t S, int64_t E, int64_t K, float lb_coef,
+                                             float rz_coef, void *stream) {
+  return apertis_moe_gate_topk_noisy_aux_fwd(logits, nullptr, 0.f, 0, gates, idx, w, lse, part, stats, S, E, K, lb_coef, rz_coef,
+                                             stream);
+}
+
+extern "C" int apertis_moe_gate_topk_noisy_aux_bwd(const float *gates, const int32_t *idx, const float *dw, const float *lse,
+                                                   const float *stats, const float *dlb, const float *drz, float lb_coef,
+                                                   float rz_coef, const float *w_noise, float alpha, uint64_t seed,
+                                                   float *dlogits, float *npart, float *dw_noise, int64_t S, int64_t E,
+                                                   int64_t K, void *stream) {
+  // w_noise != NULL: npart = workspace [apertis_moe_gate_aux_blocks(S)][E], dw_noise = out [E]
+  if (!gates || !idx || !lse || !stats || !dlogits || S < 0 || (w_noise && (!npart || !dw_noise))) return APERTIS_ERR_ARG;
+  if (!w_noise) npart = nullptr;
   if (E < 1 || E > MAXE || K < 1 || K > MAXK || K > E) return APERTIS_ERR_UNSUPPORTED;
   if (S == 0) return APERTIS_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)ceil_div64(S, 256)), block(256);
-#define GO(EC) hipLaunchKernelGGL(gate_topk_aux_bwd_k<EC>, grid, block, 0, st, gates, idx, dw, lse, stats, dlb, drz, lb_coef, rz_coef, dlogits, S, (int)E, (int)K)
+#define GO(EC) hipLaunchKernelGGL(gate_topk_aux_bwd_k<EC>, grid, block, 0, st, gates, idx, dw, lse, stats, dlb, drz, lb_coef, rz_coef, dlogits, npart, seed, S, (int)E, (int)K)
   if (E == 4) GO(4); else if (E == 8) GO(8); else if (E == 16) GO(16); else GO(0);
 #undef GO
+  if (npart) hipLaunchKernelGGL(gate_noise_fold_k, dim3(1), dim3(1024), 0, st, npart, w_noise, alpha, dw_noise, (int64_t)grid.x, (int)E);
   return apertis_check_launch();
+}
+
+extern "C" int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *idx, const float *dw, const float *lse,
+                                             const float *stats, const float *dlb, const float *drz, float lb_coef,
+                                             float rz_coef, float *dlogits, int64_t S, int64_t E, int64_t K, void *stream) {
+  return apertis_moe_gate_topk_noisy_aux_bwd(gates, idx, dw, lse, stats, dlb, drz, lb_coef, rz_coef, nullptr, 0.f, 0, dlogits,
+                                             nullptr, nullptr, S, E, K, stream);
 }
 
 extern "C" int apertis_dropout_add_layernorm_fwd(const void *blk, const int32_t *slot_of, const float *wk, int64_t K,

@@ -513,14 +513,18 @@ class AdaptiveExpertSystem(nn.Module):
                 logits = ops.skinny_linear(xn, self.router.weight, self.router.bias)      # core.py:482 (fp32 out)
             else:
                 logits = self.router(xn).float()
-        if self.use_noisy_top_k_routing and self.training:                                # core.py:485-488
-            logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
         lb_loss = rz_loss = None
         lb_coef = self.load_balancing_loss_coef if (self.use_load_balancing_loss and self.training) else 0.0
         rz_coef = self.router_z_loss_coef if (self.use_router_z_loss and self.training) else 0.0
-        if logits.is_cuda and S > 0 and (lb_coef > 0 or rz_coef > 0):
-            # gate + both auxiliary losses in one pass (core.py:491-505, 524-529)
-            idx, w, lb, rz = ops.moe_gate_topk_aux(logits, K, lb_coef, rz_coef)
+        noisy = self.use_noisy_top_k_routing and self.training
+        fused_gate = logits.is_cuda and S > 0 and (lb_coef > 0 or rz_coef > 0)
+        if noisy and not fused_gate:                                                      # core.py:485-488
+            logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
+        if fused_gate:
+            # noise + gate + both auxiliary losses in one pass (core.py:485-505, 524-529)
+            nseed = int(torch.empty((), dtype=torch.int64).random_().item()) if noisy else 0
+            idx, w, lb, rz = ops.moe_gate_topk_aux(logits, K, lb_coef, rz_coef, self.w_noise if noisy else None,
+                                                   self.noisy_routing_alpha, nseed)
             lb_loss = lb if lb_coef > 0 else None
             rz_loss = rz if rz_coef > 0 else None
         else:

@@ -498,10 +498,11 @@ class _GateTopK(torch.autograd.Function):
 
 class _GateTopKAux(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, K, lb_coef, rz_coef):
-        _require_gpu(logits)
+    def forward(ctx, logits, K, lb_coef, rz_coef, w_noise, alpha, seed):
+        _require_gpu(logits, w_noise)
         lib = _lib.load()
         logits = logits.float().contiguous()
+        wn = None if w_noise is None else w_noise.detach().float().contiguous()
         S, E = logits.shape
         dev = logits.device
         gates = torch.empty(S, E, device=dev, dtype=torch.float32)
@@ -510,35 +511,41 @@ class _GateTopKAux(torch.autograd.Function):
         lse = torch.empty(S, device=dev, dtype=torch.float32)
         part = torch.empty(lib.apertis_moe_gate_aux_blocks(S), 2 * E + 1, device=dev, dtype=torch.float32)
         stats = torch.empty(2 + E, device=dev, dtype=torch.float32)
-        check(lib.apertis_moe_gate_topk_aux_fwd(ptr(logits), ptr(gates), ptr(idx), ptr(w), ptr(lse), ptr(part), ptr(stats),
-                                                S, E, K, float(lb_coef), float(rz_coef), stream_ptr()),
-              "apertis_moe_gate_topk_aux_fwd")
-        ctx.save_for_backward(gates, idx, lse, stats)
-        ctx.cfg = (K, float(lb_coef), float(rz_coef))
+        check(lib.apertis_moe_gate_topk_noisy_aux_fwd(ptr(logits), ptr(wn), float(alpha), int(seed), ptr(gates), ptr(idx), ptr(w),
+                                                      ptr(lse), ptr(part), ptr(stats), S, E, K, float(lb_coef), float(rz_coef),
+                                                      stream_ptr()), "apertis_moe_gate_topk_noisy_aux_fwd")
+        ctx.save_for_backward(gates, idx, lse, stats, wn)
+        ctx.cfg = (K, float(lb_coef), float(rz_coef), float(alpha), int(seed), None if w_noise is None else w_noise.dtype)
         ctx.mark_non_differentiable(idx)
         return idx, w, stats[0], stats[1]
 
     @staticmethod
     def backward(ctx, _didx, dw, dlb, drz):
         lib = _lib.load()
-        gates, idx, lse, stats = ctx.saved_tensors
-        K, lb_coef, rz_coef = ctx.cfg
+        gates, idx, lse, stats, wn = ctx.saved_tensors
+        K, lb_coef, rz_coef, alpha, seed, wdt = ctx.cfg
         S, E = gates.shape
         dw = None if dw is None else dw.float().contiguous()
         dlb = None if dlb is None else dlb.float().reshape(1).contiguous()
         drz = None if drz is None else drz.float().reshape(1).contiguous()
         dlogits = torch.empty_like(gates)
-        check(lib.apertis_moe_gate_topk_aux_bwd(ptr(gates), ptr(idx), ptr(dw), ptr(lse), ptr(stats), ptr(dlb), ptr(drz),
-                                                lb_coef, rz_coef, ptr(dlogits), S, E, K, stream_ptr()),
-              "apertis_moe_gate_topk_aux_bwd")
-        return dlogits, None, None, None
+        npart = dwn = None
+        if wn is not None:
+            npart = torch.empty(lib.apertis_moe_gate_aux_blocks(S), E, device=gates.device, dtype=torch.float32)
+            dwn = torch.empty(E, device=gates.device, dtype=torch.float32)
+        check(lib.apertis_moe_gate_topk_noisy_aux_bwd(ptr(gates), ptr(idx), ptr(dw), ptr(lse), ptr(stats), ptr(dlb), ptr(drz),
+                                                      lb_coef, rz_coef, ptr(wn), alpha, seed, ptr(dlogits), ptr(npart), ptr(dwn),
+                                                      S, E, K, stream_ptr()), "apertis_moe_gate_topk_noisy_aux_bwd")
+        return dlogits, None, None, None, (None if dwn is None else dwn.to(wdt)), None, None
 
 
-def moe_gate_topk_aux(logits, K, lb_coef, rz_coef):
+def moe_gate_topk_aux(logits, K, lb_coef, rz_coef, w_noise=None, alpha=0.0, seed=0):
     """moe_gate_topk plus the router's two auxiliary losses in the same pass (reference core.py:491-505,
     524-529): returns idx [S,K] int32, w [S,K] fp32, lb_loss and rz_loss (fp32 scalars on the device; a
-    coefficient of 0 switches a loss off)."""
-    return _GateTopKAux.apply(logits, K, lb_coef, rz_coef)
+    coefficient of 0 switches a loss off).  With `w_noise` [E] the reference's noisy top-k routing
+    (core.py:485-488: logits += randn * softplus(w_noise) * alpha) happens inside the kernels, the normals drawn from a
+    counter hash of `seed`; the gradient of w_noise comes back from the backward kernel."""
+    return _GateTopKAux.apply(logits, K, lb_coef, rz_coef, w_noise, alpha, seed)
 
 
 def moe_gate_topk(logits, K):

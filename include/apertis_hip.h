@@ -208,6 +208,23 @@ int apertis_moe_gate_topk_aux_bwd(const float *gates, const int32_t *idx, const 
                                   const float *lse, const float *stats, const float *dlb,
                                   const float *drz, float lb_coef, float rz_coef, float *dlogits,
                                   int64_t S, int64_t E, int64_t K, void *stream);
+/* The same pair with the reference's NOISY top-k routing (core.py:485-488) inside the kernels:
+ *   logits += n * softplus(w_noise[e]) * alpha,  n ~ N(0, 1)
+ * with the normals drawn from a counter hash of (seed, token, expert pair) through Box-Muller, so
+ * the backward regenerates them (same seed) instead of reading a [S, E] tensor.  w_noise [E] fp32
+ * (NULL: no noise - what the plain entry points do).  Backward: npart = workspace
+ * [apertis_moe_gate_aux_blocks(S)][E], dw_noise = out [E], the gradient of w_noise
+ * (block sums of dlogits * n folded in a fixed order, times alpha * sigmoid(w_noise)). */
+int apertis_moe_gate_topk_noisy_aux_fwd(const float *logits, const float *w_noise, float alpha,
+                                        uint64_t seed, float *gates, int32_t *idx, float *w,
+                                        float *lse, float *part, float *stats, int64_t S, int64_t E,
+                                        int64_t K, float lb_coef, float rz_coef, void *stream);
+int apertis_moe_gate_topk_noisy_aux_bwd(const float *gates, const int32_t *idx, const float *dw,
+                                        const float *lse, const float *stats, const float *dlb,
+                                        const float *drz, float lb_coef, float rz_coef,
+                                        const float *w_noise, float alpha, uint64_t seed,
+                                        float *dlogits, float *npart, float *dw_noise, int64_t S,
+                                        int64_t E, int64_t K, void *stream);
 int64_t apertis_moe_gate_aux_blocks(int64_t S);
 
 /* Router projection y[T,N] = x[T,K] W[N,K]^T + b for N in {2,4,8,16}, K % 4 == 0, K <= 1024

@@ -547,6 +547,68 @@ def test_gate_topk_aux_losses(dev, S, E, K):
     assert torch.allclose(ld.grad.cpu(), lo.grad, rtol=1e-4, atol=3e-7), float((ld.grad.cpu() - lo.grad).abs().max())
 
 
+@pytest.mark.parametrize("S,E,K", [(40000, 8, 2), (5001, 5, 1)])
+def test_gate_topk_noisy_routing_in_kernel(dev, S, E, K):
+    """Noisy top-k routing inside the gate kernels (reference core.py:485-488: logits += randn * softplus(w_noise) * alpha).
+    The kernel's normals are recovered from its own outputs (noisy logits = log(gates) + lse), checked for their
+    statistics, and then the reference formulas are run on exactly that noise: indices equal, losses 1e-5, dlogits and the
+    gradient of w_noise against autograd; same seed -> same draw, the backward regenerates it."""
+    from apertis_llm_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(S + E)
+    logits = (torch.randn(S, E) * 2).to(dev)
+    w_noise = (torch.randn(E) * 0.5).to(dev)
+    alpha, seed, lb_coef, rz_coef = 0.7, 987654321, 0.01, 0.001
+    gates = torch.empty(S, E, device=dev)
+    idx = torch.empty(S, K, device=dev, dtype=torch.int32)
+    w = torch.empty(S, K, device=dev)
+    lse = torch.empty(S, device=dev)
+    part = torch.empty(lib.apertis_moe_gate_aux_blocks(S), 2 * E + 1, device=dev)
+    stats = torch.empty(2 + E, device=dev)
+    rc = lib.apertis_moe_gate_topk_noisy_aux_fwd(_lib.ptr(logits), _lib.ptr(w_noise), alpha, seed, _lib.ptr(gates), _lib.ptr(idx),
+                                                 _lib.ptr(w), _lib.ptr(lse), _lib.ptr(part), _lib.ptr(stats), S, E, K, lb_coef,
+                                                 rz_coef, _lib.stream_ptr())
+    assert rc == 0
+    scale = (F.softplus(w_noise) * alpha).double()
+    n = ((gates.double().log() + lse.double()[:, None] - logits.double()) / scale).cpu()      # the kernel's draw
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 1.0) < 0.02, (float(n.mean()), float(n.std()))
+    assert abs(float((n.abs() > 2).double().mean()) - 0.0455) < 0.006          # tails of a normal
+    c = torch.corrcoef(n.T)
+    assert float((c - torch.eye(E, dtype=c.dtype)).abs().max()) < 0.03         # experts (also the two of a Box-Muller pair) uncorrelated
+    assert abs(float((n[1:, 0] * n[:-1, 0]).mean())) < 0.03                    # ... and neighbouring tokens
+
+    # the reference formulas on that noise (float64 noise constants, fp32 math as the reference runs it)
+    gw = torch.randn(S, K)
+    lo = logits.cpu().clone().requires_grad_(True)
+    wn = w_noise.cpu().clone().requires_grad_(True)
+    noisy = lo + n.float() * (F.softplus(wn) * alpha)
+    g_ref = torch.softmax(noisy, dim=-1)
+    pr, idx_ref = torch.topk(g_ref, K, dim=-1)
+    w_ref = pr / (pr.sum(-1, keepdim=True) + 1e-6)
+    frac = torch.zeros(E).index_add_(0, idx_ref.reshape(-1), torch.ones(S * K)) / S
+    lb_ref = lb_coef * E * torch.sum(frac * g_ref.mean(dim=0))
+    rz_ref = rz_coef * torch.mean(torch.logsumexp(noisy, dim=-1) ** 2)
+    ((w_ref * gw).sum() + 3.0 * lb_ref + 0.5 * rz_ref).backward()
+
+    ld, wd = logits.clone().requires_grad_(True), w_noise.clone().requires_grad_(True)
+    idx2, w2, lb, rz = ops.moe_gate_topk_aux(ld, K, lb_coef, rz_coef, wd, alpha, seed)
+    ((w2 * gw.to(dev)).sum() + 3.0 * lb + 0.5 * rz).backward()
+    assert torch.equal(idx2, idx) and torch.equal(w2, w)                       # same seed, same draw
+    same = (idx2.cpu().long() == idx_ref).all(dim=-1)
+    assert float(same.double().mean()) > 0.9995                                # (ties of the reconstructed noise aside)
+    _close(w2[same.to(dev)], w_ref[same], "w", rtol=2e-4, atol_scale=1e-5)
+    assert abs(float(lb) - float(lb_ref)) <= 1e-4 * abs(float(lb_ref)) and abs(float(rz) - float(rz_ref)) <= 1e-4 * abs(float(rz_ref))
+    dl, dl_ref = ld.grad.cpu()[same], lo.grad[same]
+    assert torch.allclose(dl, dl_ref, rtol=2e-3, atol=2e-6), float((dl - dl_ref).abs().max())
+    # (K == 1: w = p / (p + 1e-6) is flat, the gradient through it cancels to ~1e-4 of its terms -> absolute floor)
+    gerr = (wd.grad.cpu() - wn.grad).abs()
+    assert bool((gerr <= 5e-3 * wn.grad.abs() + (5e-6 if K == 1 else 1e-4 * float(wn.grad.abs().max()))).all()), (wd.grad.cpu(), wn.grad)
+    idx3, w3, _, _ = ops.moe_gate_topk_aux(logits, K, lb_coef, rz_coef, w_noise, alpha, seed + 1)
+    assert not torch.equal(w3, w)                                              # another seed, another draw
+    idx0, _, _, _ = ops.moe_gate_topk_aux(logits, K, lb_coef, rz_coef)         # no w_noise: no noise
+    assert float((idx0.long() == torch.topk(torch.softmax(logits, dim=-1), K, dim=-1)[1]).double().mean()) > 0.9999
+
+
 @pytest.mark.parametrize("T,H,dt_res,dt_blk,p", [(1000, 704, torch.float32, torch.bfloat16, 0.1), (333, 32, torch.float32, torch.float32, 0.0),
                                                   (513, 256, torch.float32, torch.float32, 0.25), (77, 64, torch.bfloat16, torch.bfloat16, 0.1)])
 def test_dropout_add_layer_norm_boundary(dev, T, H, dt_res, dt_blk, p):
