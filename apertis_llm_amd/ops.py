@@ -925,11 +925,19 @@ _SPLITK_ROWS = 1024
 _splitk_cache = {}
 
 
-def _splitk_offsets(rows, G, device):
-    key = (rows, G, str(device))
+def _splitk_depth(N, K):
+    """Rows per pseudo-group of a dense weight gradient: deeper groups halve the partial sums (written and folded: as many
+    bytes as the operands at 1024 rows) but leave fewer work-groups; measured at T = 163840 (tools/prof_dense_wgrad.py, us at
+    1024 / 2048 / 4096 rows): dW [352, 704] 153 / 138 / 157, [704, 176] 105 / 93 / 90, [448, 176] 73 / 86 / 80."""
+    tiles = -(-N // 128) * -(-K // 128)
+    return _SPLITK_ROWS if tiles <= 8 else 2 * _SPLITK_ROWS
+
+
+def _splitk_offsets(rows, G, depth, device):
+    key = (rows, G, depth, str(device))
     t = _splitk_cache.get(key)
     if t is None:
-        t = torch.tensor([min(i * _SPLITK_ROWS, rows) for i in range(G + 1)], dtype=torch.int32, device=device)
+        t = torch.tensor([min(i * depth, rows) for i in range(G + 1)], dtype=torch.int32, device=device)
         _splitk_cache[key] = t
     return t
 
@@ -1063,8 +1071,9 @@ class _GroupedLinear(torch.autograd.Function):
                 # partials in a fixed order (deterministic split-K, no atomics).  The dense layers of
                 # this model are narrow (352 / 704 wide): 128x128 tiles waste 8 % of the MFMA work on
                 # them where the 256x256 split-K kernel wastes 37 % (measured 322 vs 144 TF)
-                G = -(-max_rows // _SPLITK_ROWS)
-                soffs = _splitk_offsets(max_rows, G, x.device)
+                depth = _splitk_depth(N, K)
+                G = -(-max_rows // depth)
+                soffs = _splitk_offsets(max_rows, G, depth, x.device)
                 part = torch.empty(G, N, K, device=x.device, dtype=torch.float32)
                 bpart = torch.empty(G, N, device=x.device, dtype=torch.float32) if has_bias else None
                 _launch("apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
