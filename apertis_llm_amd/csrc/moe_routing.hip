@@ -1409,8 +1409,11 @@ __device__ __forceinline__ v2f pk_fma2(v2f a, v2f b, v2f c) { return __builtin_e
 // dbeta accumulators in registers (2 waves per SIMD), the wave's next row prefetched while this one is
 // computed.  (A form with the columns split over the block's waves - small accumulators, more waves - ran
 // twice the instructions per row and was no faster: 304 vs 276 us at 98k rows.)
-template <typename TX, int IT, int NN>
-__global__ void __launch_bounds__(256)
+// MODE 0: everything in one pass.  MODE 1: dx, dgamma, dbeta only; MODE 2: dW, db only - as two launches the first runs
+// without the NN * IT * 4 weight-gradient accumulators (96 of its registers at NN = 8, IT = 3) and fits two waves per SIMD,
+// the second is a short kernel; both read x.  Same arithmetic per output either way.
+template <typename TX, int IT, int NN, int MODE>
+__global__ void __launch_bounds__(256, MODE == 1 ? 2 : 1)
 router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
               const float *__restrict__ mean_i, const float *__restrict__ rstd_i, const float *__restrict__ W,
               const float *__restrict__ dlogits, const TX *__restrict__ dres, TX *__restrict__ dx,
@@ -1442,7 +1445,7 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       const int c = (lane + 64 * i) * 4;
       const bool ok = c < H && r < T;
       xo[i] = ok ? *reinterpret_cast<const raw_t *>(x + r * H + c) : raw_t{};
-      ro[i] = (ok && dres) ? *reinterpret_cast<const raw_t *>(dres + r * H + c) : raw_t{};
+      ro[i] = (MODE != 2 && ok && dres) ? *reinterpret_cast<const raw_t *>(dres + r * H + c) : raw_t{};
     }
   };
   // the row's scalars - NN logit gradients, mean, rstd - ride in ONE register: lane n < NN holds dlogits[r][n],
@@ -1462,7 +1465,7 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
     float g[NN];
 #pragma unroll
     for (int n = 0; n < NN; ++n) g[n] = lane_val(meta, n);
-    if (lane < NN) abias += meta;
+    if (MODE != 1 && lane < NN) abias += meta;
     const float mean = lane_val(meta, NN), rstd = lane_val(meta, NN + 1);
     float4 xh[IT], dn[IT];
     float s1 = 0.f, s2 = 0.f;
@@ -1483,11 +1486,14 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       for (int n = 0; n < NN; ++n) {
         const float4 wn = in ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
         const v2f gn = {g[n], g[n]};
-        d0 = pk_fma2(gn, (v2f){wn.x, wn.y}, d0); d1 = pk_fma2(gn, (v2f){wn.z, wn.w}, d1);
-        v2f a0 = {aw[n][i].x, aw[n][i].y}, a1 = {aw[n][i].z, aw[n][i].w};
-        a0 = pk_fma2(gn, xn0, a0); a1 = pk_fma2(gn, xn1, a1);
-        aw[n][i] = make_float4(a0.x, a0.y, a1.x, a1.y);
+        if constexpr (MODE != 2) { d0 = pk_fma2(gn, (v2f){wn.x, wn.y}, d0); d1 = pk_fma2(gn, (v2f){wn.z, wn.w}, d1); }
+        if constexpr (MODE != 1) {
+          v2f a0 = {aw[n][i].x, aw[n][i].y}, a1 = {aw[n][i].z, aw[n][i].w};
+          a0 = pk_fma2(gn, xn0, a0); a1 = pk_fma2(gn, xn1, a1);
+          aw[n][i] = make_float4(a0.x, a0.y, a1.x, a1.y);
+        }
       }
+      if constexpr (MODE == 2) continue;
       v2f ag0 = pk_fma2(d0, xh0, (v2f){ag[i].x, ag[i].y}), ag1 = pk_fma2(d1, xh1, (v2f){ag[i].z, ag[i].w});
       ag[i] = make_float4(ag0.x, ag0.y, ag1.x, ag1.y);
       const v2f ab0 = (v2f){ab[i].x, ab[i].y} + d0, ab1 = (v2f){ab[i].z, ab[i].w} + d1;
@@ -1497,6 +1503,7 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
       s2 += (dn[i].x * xh[i].x + dn[i].y * xh[i].y) + (dn[i].z * xh[i].z + dn[i].w * xh[i].w);
     }
+    if constexpr (MODE != 2) {
     const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -1507,12 +1514,13 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
                                                 rstd * (dn[i].z - m1 - xh[i].z * m2) + rr.z, rstd * (dn[i].w - m1 - xh[i].w * m2) + rr.w));
       }
     }
+    }
 #pragma unroll
     for (int i = 0; i < IT; ++i) { xc[i] = xn_[i]; rc[i] = rn_[i]; }
     meta = meta_next;
   }
   // block reduction in wave order (waves 1..3 take turns in one LDS buffer), then one partial row per block
-  if (lane < NN) redb[wv][lane] = abias;
+  if (MODE != 1 && lane < NN) redb[wv][lane] = abias;
   for (int turn = 1; turn < 4; ++turn) {
     __syncthreads();
     if (wv == turn) {
@@ -1520,10 +1528,11 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       for (int i = 0; i < IT; ++i) {
         const int cq = lane + 64 * i;
         if (cq < Q) {
+          if constexpr (MODE != 1) {
 #pragma unroll
-          for (int n = 0; n < NN; ++n) red[n * Q + cq] = aw[n][i];
-          red[NN * Q + cq] = ag[i];
-          red[(NN + 1) * Q + cq] = ab[i];
+            for (int n = 0; n < NN; ++n) red[n * Q + cq] = aw[n][i];
+          }
+          if constexpr (MODE != 2) { red[NN * Q + cq] = ag[i]; red[(NN + 1) * Q + cq] = ab[i]; }
         }
       }
     }
@@ -1533,14 +1542,18 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       for (int i = 0; i < IT; ++i) {
         const int cq = lane + 64 * i;
         if (cq < Q) {
+          if constexpr (MODE != 1) {
 #pragma unroll
-          for (int n = 0; n < NN; ++n) {
-            const float4 u = red[n * Q + cq];
-            aw[n][i].x += u.x; aw[n][i].y += u.y; aw[n][i].z += u.z; aw[n][i].w += u.w;
+            for (int n = 0; n < NN; ++n) {
+              const float4 u = red[n * Q + cq];
+              aw[n][i].x += u.x; aw[n][i].y += u.y; aw[n][i].z += u.z; aw[n][i].w += u.w;
+            }
           }
-          const float4 u = red[NN * Q + cq], v = red[(NN + 1) * Q + cq];
-          ag[i].x += u.x; ag[i].y += u.y; ag[i].z += u.z; ag[i].w += u.w;
-          ab[i].x += v.x; ab[i].y += v.y; ab[i].z += v.z; ab[i].w += v.w;
+          if constexpr (MODE != 2) {
+            const float4 u = red[NN * Q + cq], v = red[(NN + 1) * Q + cq];
+            ag[i].x += u.x; ag[i].y += u.y; ag[i].z += u.z; ag[i].w += u.w;
+            ab[i].x += v.x; ab[i].y += v.y; ab[i].z += v.z; ab[i].w += v.w;
+          }
         }
       }
     }
@@ -1551,13 +1564,17 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
     for (int i = 0; i < IT; ++i) {
       const int cq = lane + 64 * i;
       if (cq < Q) {
+        if constexpr (MODE != 1) {
 #pragma unroll
-        for (int n = 0; n < NN; ++n) *reinterpret_cast<float4 *>(dst + (int64_t)n * H + cq * 4) = aw[n][i];
-        *reinterpret_cast<float4 *>(dst + NN * H + NN + cq * 4) = ag[i];
-        *reinterpret_cast<float4 *>(dst + NN * H + NN + H + cq * 4) = ab[i];
+          for (int n = 0; n < NN; ++n) *reinterpret_cast<float4 *>(dst + (int64_t)n * H + cq * 4) = aw[n][i];
+        }
+        if constexpr (MODE != 2) {
+          *reinterpret_cast<float4 *>(dst + NN * H + NN + cq * 4) = ag[i];
+          *reinterpret_cast<float4 *>(dst + NN * H + NN + H + cq * 4) = ab[i];
+        }
       }
     }
-    if (lane < NN) dst[NN * H + lane] = (redb[0][lane] + redb[1][lane]) + (redb[2][lane] + redb[3][lane]);
+    if (MODE != 1 && lane < NN) dst[NN * H + lane] = (redb[0][lane] + redb[1][lane]) + (redb[2][lane] + redb[3][lane]);
   }
 }
 
@@ -2076,10 +2093,14 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
   const int64_t nblk = apertis_router_bwd_blocks(T);
   dim3 grid((unsigned)nblk), block(256);
   const size_t lds3 = (size_t)(2 * N + 2) * H * sizeof(float);
+  // wide rows with many outputs: two launches (see router_bwd3_k) - the one-pass kernel is at one wave per SIMD there
+  const bool split = N * ((H + 255) / 256) >= 16;
   if (dtype_x == APERTIS_BF16) {
-    SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<bf16_t, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<bf16_t, IT, NN>), grid, block, lds3, st, (const bf16_t *)x, gamma, beta, mean, rstd, W, dlogits, (const bf16_t *)dres, (bf16_t *)dx, part, T, (int)H)));
+#define ROUTER_BWD(TXT, MODE_) { auto kf = router_bwd3_k<TXT, IT, NN, MODE_>; if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL(kf, grid, block, lds3, st, (const TXT *)x, gamma, beta, mean, rstd, W, dlogits, (const TXT *)dres, (TXT *)dx, part, T, (int)H); }
+    SKINNY_N(N, SKINNY_IT(H, { if (split) { ROUTER_BWD(bf16_t, 1) ROUTER_BWD(bf16_t, 2) } else ROUTER_BWD(bf16_t, 0) }));
   } else if (dtype_x == APERTIS_F32) {
-    SKINNY_N(N, SKINNY_IT(H, if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)router_bwd3_k<float, IT, NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL((router_bwd3_k<float, IT, NN>), grid, block, lds3, st, (const float *)x, gamma, beta, mean, rstd, W, dlogits, (const float *)dres, (float *)dx, part, T, (int)H)));
+    SKINNY_N(N, SKINNY_IT(H, { if (split) { ROUTER_BWD(float, 1) ROUTER_BWD(float, 2) } else ROUTER_BWD(float, 0) }));
+#undef ROUTER_BWD
   } else return APERTIS_ERR_ARG;
   const int64_t cols = N * H + N + 2 * H;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, grads, nblk, cols);
