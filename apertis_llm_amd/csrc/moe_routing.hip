@@ -486,7 +486,8 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
 // flight, 16 waves per CU; a one-row-at-a-time loop was latency-bound: 180 us for 41k rows of 704).  Affine gradients: per-wave register sums are
 // flushed with float atomics when the expert changes inside the wave's rows (rare: rows are
 // expert-sorted); at the end the block's four waves are combined in LDS first when they all ended
-// in the same expert, so the common case issues one set of atomics per 32 rows.
+// in the same expert, so the common case issues one set of atomics per block of 4 * GLN_RPW rows.
+constexpr int GLN_RPW = 16;   // rows per wave of the gather-LN backward (4 waves per block, one partial row per block)
 template <typename TX, typename TG, int IT>
 __global__ void __launch_bounds__(256, IT <= 3 ? 4 : 1)   // narrow rows: <= 128 VGPRs = four waves per SIMD (IT = 3 took 132)
 gather_ln_bwd2_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token, const int32_t *__restrict__ offsets,
@@ -496,7 +497,7 @@ gather_ln_bwd2_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);          // [3 waves][2][H/4]
   __shared__ int s_e[4];
-  constexpr int RPW = 8;
+  constexpr int RPW = GLN_RPW;
   bool flushed = false;   // this wave crossed an expert boundary and used atomics
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t total = min((int64_t)offsets[E], max_rows);
@@ -626,7 +627,7 @@ gather_ln_fold_k(const float *__restrict__ part, const int32_t *__restrict__ blk
   const int64_t ra = min((int64_t)offsets[e], total), rb = min((int64_t)offsets[e + 1], total);
   float s = 0.f;
   if (c < 2 * H && rb > ra) {
-    const int64_t b0 = ra / 32, b1 = min((rb - 1) / 32, nblk - 1);
+    const int64_t b0 = ra / (4 * GLN_RPW), b1 = min((rb - 1) / (4 * GLN_RPW), nblk - 1);
     for (int64_t b = b0 + seg; b <= b1; b += 16)
       if (blk_expert[b] == e) s += part[b * 2 * H + c];
   }
@@ -1868,7 +1869,7 @@ extern "C" int apertis_moe_gather_ln_fwd(const void *x, const int32_t *row_token
   return apertis_check_launch();
 }
 
-extern "C" int64_t apertis_moe_gather_ln_bwd_blocks(int64_t max_rows) { return ceil_div64(max_rows > 0 ? max_rows : 1, 32); }
+extern "C" int64_t apertis_moe_gather_ln_bwd_blocks(int64_t max_rows) { return ceil_div64(max_rows > 0 ? max_rows : 1, 4 * GLN_RPW); }
 
 extern "C" int apertis_moe_gather_ln_bwd(const void *x, const int32_t *row_token,
                                          const int32_t *expert_offsets, const float *gamma,
