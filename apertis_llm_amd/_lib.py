@@ -95,6 +95,8 @@ SIGNATURES = {
     "apertis_moe_gate_aux_blocks": (_i64, [_i64]),
     "apertis_router_fwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_router_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_router_bwd_rows": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64,
+                                       _i32, _vp]),
     "apertis_router_bwd_blocks": (_i64, [_i64]),
     "apertis_tiny_linear_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_tiny_linear_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),

@@ -1417,8 +1417,12 @@ template <typename TX, int IT, int NN, int MODE>
 __global__ void __launch_bounds__(256, MODE == 1 ? 2 : 1)
 router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
               const float *__restrict__ mean_i, const float *__restrict__ rstd_i, const float *__restrict__ W,
-              const float *__restrict__ dlogits, const TX *__restrict__ dres, TX *__restrict__ dx,
+              const float *__restrict__ dlogits, const TX *__restrict__ dres, const TX *__restrict__ grows,
+              const int32_t *__restrict__ slot_of, int KS, TX *__restrict__ dx,
               float *__restrict__ part, int64_t T, int H) {
+  // grows / slot_of (KS <= 2 slots per row): the gradient reaching x through the expert path as the ROWS the gather-LN
+  // backward wrote - row r receives round_TX(sum_k grows[slot_of[r, k]]), k ascending, exactly what apertis_moe_combine_fwd
+  // would have written into a dense `dres` (231 MB written and read back per layer at the bench shape, and a 128 us kernel)
   typedef typename raw4<TX>::type raw_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *sW = reinterpret_cast<float4 *>(smem);                 // [NN][H/4]
@@ -1440,13 +1444,27 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
   __syncthreads();
   const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
   raw_t xc[IT], rc[IT], xn_[IT], rn_[IT];
-  auto fetch = [&](raw_t (&xo)[IT], raw_t (&ro)[IT], int64_t r) {
+  raw_t gc[2][IT], gn_[2][IT];       // the (up to two) gathered gradient rows of the current / next row
+  // their slots ride in ONE register per row like the row's scalars below (lane k < KS holds slot_of[r, k]), fetched TWO rows
+  // ahead of their use as addresses, read back with v_readlane
+  int sc[2] = {-1, -1}, sn[2] = {-1, -1};
+  const bool gath = MODE != 2 && grows != nullptr;
+  auto fetch_slots = [&](int64_t r) -> int { return (gath && r < T && lane < KS) ? slot_of[r * KS + lane] : -1; };
+  auto slots_of = [&](int v, int (&so)[2]) {
+    so[0] = __builtin_amdgcn_readlane(v, 0);
+    so[1] = __builtin_amdgcn_readlane(v, 1);
+  };
+  int slv_n = -1, slv_n2 = -1;
+  auto fetch = [&](raw_t (&xo)[IT], raw_t (&ro)[IT], raw_t (&go)[2][IT], const int (&so)[2], int64_t r) {
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = (lane + 64 * i) * 4;
       const bool ok = c < H && r < T;
       xo[i] = ok ? *reinterpret_cast<const raw_t *>(x + r * H + c) : raw_t{};
       ro[i] = (MODE != 2 && ok && dres) ? *reinterpret_cast<const raw_t *>(dres + r * H + c) : raw_t{};
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        go[k][i] = (gath && ok && so[k] >= 0) ? *reinterpret_cast<const raw_t *>(grows + (int64_t)so[k] * H + c) : raw_t{};
     }
   };
   // the row's scalars - NN logit gradients, mean, rstd - ride in ONE register: lane n < NN holds dlogits[r][n],
@@ -1459,9 +1477,16 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
   };
   auto lane_val = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
   float meta = 0.f, meta_next = 0.f;
-  if (wave < T) { fetch(xc, rc, wave); meta = fetch_meta(wave); }
+  if (wave < T) {
+    slots_of(fetch_slots(wave), sc);
+    slv_n = fetch_slots(wave + nw);
+    fetch(xc, rc, gc, sc, wave);
+    meta = fetch_meta(wave);
+  }
   for (int64_t r = wave; r < T; r += nw) {
-    fetch(xn_, rn_, r + nw);
+    slv_n2 = fetch_slots(r + 2 * nw);
+    slots_of(slv_n, sn);
+    fetch(xn_, rn_, gn_, sn, r + nw);
     meta_next = fetch_meta(r + nw);
     float g[NN];
 #pragma unroll
@@ -1510,14 +1535,24 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
     for (int i = 0; i < IT; ++i) {
       const int c = (lane + 64 * i) * 4;
       if (c < H) {
-        const float4 rr = raw_to_f4(rc[i]);
+        float4 rr = raw_to_f4(rc[i]);
+        if (gath) {
+          float4 ga = make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (sc[k] >= 0) { const float4 gv = raw_to_f4(gc[k][i]); ga.x += gv.x; ga.y += gv.y; ga.z += gv.z; ga.w += gv.w; }
+          rr.x += to_f32(from_f32<TX>(ga.x)); rr.y += to_f32(from_f32<TX>(ga.y));
+          rr.z += to_f32(from_f32<TX>(ga.z)); rr.w += to_f32(from_f32<TX>(ga.w));
+        }
         store4<TX>(dx + r * H + c, make_float4(rstd * (dn[i].x - m1 - xh[i].x * m2) + rr.x, rstd * (dn[i].y - m1 - xh[i].y * m2) + rr.y,
                                                 rstd * (dn[i].z - m1 - xh[i].z * m2) + rr.z, rstd * (dn[i].w - m1 - xh[i].w * m2) + rr.w));
       }
     }
     }
 #pragma unroll
-    for (int i = 0; i < IT; ++i) { xc[i] = xn_[i]; rc[i] = rn_[i]; }
+    for (int i = 0; i < IT; ++i) { xc[i] = xn_[i]; rc[i] = rn_[i]; gc[0][i] = gn_[0][i]; gc[1][i] = gn_[1][i]; }
+    sc[0] = sn[0]; sc[1] = sn[1];
+    slv_n = slv_n2;
     meta = meta_next;
   }
   // block reduction in wave order (waves 1..3 take turns in one LDS buffer), then one partial row per block
@@ -2084,11 +2119,14 @@ extern "C" int apertis_router_fwd(const void *x, const float *gamma, const float
   return apertis_check_launch();
 }
 
-extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
-                                  const float *W, const float *dlogits, const void *dres, void *dx, float *part,
-                                  float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
+extern "C" int apertis_router_bwd_rows(const void *x, const float *gamma, const float *beta, const float *mean,
+                                       const float *rstd, const float *W, const float *dlogits, const void *dres,
+                                       const void *grows, const int32_t *slot_of, int64_t KS, void *dx, float *part,
+                                       float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
   // part: workspace [apertis_router_bwd_blocks(T)][N*H + N + 2H]; grads: out [N*H dW | N db | H dgamma | H dbeta]
   if (!x || !gamma || !beta || !mean || !rstd || !W || !dlogits || !dx || !part || !grads || T < 0) return APERTIS_ERR_ARG;
+  if (grows && (!slot_of || KS < 1)) return APERTIS_ERR_ARG;
+  if (grows && KS > 2) return APERTIS_ERR_UNSUPPORTED;   // (the caller then forms the dense gradient with apertis_moe_combine_fwd)
   if (H <= 0 || H % 4 || H > 1024 || N < 1 || N > 8) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nblk = apertis_router_bwd_blocks(T);
@@ -2097,7 +2135,7 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
   // wide rows with many outputs: two launches (see router_bwd3_k) - the one-pass kernel is at one wave per SIMD there
   const bool split = N * ((H + 255) / 256) >= 16;
   if (dtype_x == APERTIS_BF16) {
-#define ROUTER_BWD(TXT, MODE_) { auto kf = router_bwd3_k<TXT, IT, NN, MODE_>; if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL(kf, grid, block, lds3, st, (const TXT *)x, gamma, beta, mean, rstd, W, dlogits, (const TXT *)dres, (TXT *)dx, part, T, (int)H); }
+#define ROUTER_BWD(TXT, MODE_) { auto kf = router_bwd3_k<TXT, IT, NN, MODE_>; if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); hipLaunchKernelGGL(kf, grid, block, lds3, st, (const TXT *)x, gamma, beta, mean, rstd, W, dlogits, (const TXT *)dres, (const TXT *)grows, slot_of, (int)KS, (TXT *)dx, part, T, (int)H); }
     SKINNY_N(N, SKINNY_IT(H, { if (split) { ROUTER_BWD(bf16_t, 1) ROUTER_BWD(bf16_t, 2) } else ROUTER_BWD(bf16_t, 0) }));
   } else if (dtype_x == APERTIS_F32) {
     SKINNY_N(N, SKINNY_IT(H, { if (split) { ROUTER_BWD(float, 1) ROUTER_BWD(float, 2) } else ROUTER_BWD(float, 0) }));
@@ -2106,6 +2144,13 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
   const int64_t cols = N * H + N + 2 * H;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, grads, nblk, cols);
   return apertis_check_launch();
+}
+
+extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float *beta, const float *mean, const float *rstd,
+                                  const float *W, const float *dlogits, const void *dres, void *dx, float *part,
+                                  float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
+  return apertis_router_bwd_rows(x, gamma, beta, mean, rstd, W, dlogits, dres, nullptr, nullptr, 0, dx, part, grads, T, H, N,
+                                 dtype_x, stream);
 }
 
 extern "C" int64_t apertis_moe_gate_aux_blocks(int64_t S) { return ceil_div64(S > 0 ? S : 1, 256); }

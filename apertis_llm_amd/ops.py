@@ -716,6 +716,33 @@ def split_cols(x, sizes):
     return outs
 
 
+class _RowsGrad:
+    """Hand-over between the gather-LN backward and the router backward of the SAME pass-through x: instead of a dense
+    [T, H] gradient (written by a combine kernel, read back by the router kernel) the gather op leaves its gradient ROWS and
+    the slot table here and returns a zero placeholder without storage; the router kernel gathers the rows itself.  If
+    autograd adds other consumers' gradients to the placeholder they arrive as an ordinary dense `dres` on top."""
+    __slots__ = ("rows", "slot_of", "K")
+
+    def __init__(self):
+        self.rows = self.slot_of = None
+        self.K = 0
+
+    def take(self):
+        r = (self.rows, self.slot_of, self.K)
+        self.rows = self.slot_of = None
+        return r
+
+
+_ZERO1 = {}
+
+
+def _zero_placeholder(shape, device, dtype):
+    z = _ZERO1.get((device, dtype))
+    if z is None:
+        z = _ZERO1[(device, dtype)] = torch.zeros(1, device=device, dtype=dtype)
+    return z.expand(*shape)
+
+
 class _RouterLN(torch.autograd.Function):
     """(Linear(LayerNorm(x)), x): the router projection with its norm fused in, handing x through so the
     gradient of x's other consumers (the expert path) is added inside the backward kernel."""
@@ -737,15 +764,24 @@ class _RouterLN(torch.autograd.Function):
                                      T, H, N, dtype_code(x), stream_ptr()), "apertis_router_fwd")
         ctx.save_for_backward(x, g, be, mean, rstd, w)
         ctx.cfg = (ln_w.dtype, ln_b.dtype, weight.dtype, None if bias is None else bias.dtype)
-        return logits, x.view_as(x)
+        ctx.link = _RowsGrad()
+        return logits, x.view_as(x), ctx.link
 
     @staticmethod
-    def backward(ctx, dlogits, dpass):
+    def backward(ctx, dlogits, dpass, _dlink=None):
         lib = _lib.load()
         x, g, be, mean, rstd, w = ctx.saved_tensors
         T, H = x.shape
         N = w.shape[0]
+        rows, slot_of, KS = ctx.link.take()
+        if dpass is not None and rows is not None and dpass.stride() == (0,) * dpass.dim():
+            dpass = None                                        # the gather op's placeholder: its gradient is `rows`
         if dlogits is None:
+            if rows is not None:                                # (router output unused: form the dense gradient after all)
+                dense = torch.empty_like(x)
+                check(lib.apertis_moe_combine_fwd(ptr(rows), ptr(slot_of), None, ptr(dense), T, H, KS, 0, dtype_code(rows),
+                                                  dtype_code(dense), stream_ptr()), "apertis_moe_combine_fwd(scatter)")
+                dpass = dense if dpass is None else dpass + dense
             return dpass, None, None, None, None, None
         dlogits = dlogits.float().contiguous()
         if dpass is not None:
@@ -755,8 +791,9 @@ class _RouterLN(torch.autograd.Function):
         cols = N * H + N + 2 * H
         part = torch.empty(nblk, cols, device=x.device, dtype=torch.float32)
         out = torch.empty(cols, device=x.device, dtype=torch.float32)
-        check(lib.apertis_router_bwd(ptr(x), ptr(g), ptr(be), ptr(mean), ptr(rstd), ptr(w), ptr(dlogits), ptr(dpass), ptr(dx),
-                                     ptr(part), ptr(out), T, H, N, dtype_code(x), stream_ptr()), "apertis_router_bwd")
+        check(lib.apertis_router_bwd_rows(ptr(x), ptr(g), ptr(be), ptr(mean), ptr(rstd), ptr(w), ptr(dlogits), ptr(dpass),
+                                          ptr(rows), ptr(slot_of), KS, ptr(dx), ptr(part), ptr(out), T, H, N, dtype_code(x),
+                                          stream_ptr()), "apertis_router_bwd_rows")
         gdt, bedt, wdt, bdt = ctx.cfg
         dW, db = out[:N * H].reshape(N, H), out[N * H:N * H + N]
         dg, dbe = out[N * H + N:N * H + N + H], out[N * H + N + H:]
@@ -770,7 +807,9 @@ def router_ln_linear_supported(x, H, N):
 def router_ln_linear(x, ln_weight, ln_bias, eps, weight, bias=None):
     """(fp32 logits [T,N], x) with logits = Linear(LayerNorm(x)) (reference core.py:481-482) in one pass over
     x; route x's other uses through the returned x so their gradient is folded into this op's backward."""
-    return _RouterLN.apply(x, ln_weight, ln_bias, eps, weight, bias)
+    logits, xp, link = _RouterLN.apply(x, ln_weight, ln_bias, eps, weight, bias)
+    xp._apertis_rows_link = link          # moe_gather_ln(xp, ...) hands its gradient over as rows (see _RowsGrad)
+    return logits, xp
 
 
 def skinny_linear_supported(K, N):
@@ -815,11 +854,12 @@ def moe_plan(idx, w, E, capacity=None, active=None):
 
 class _GatherLN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, plan, eps, out_dtype):
+    def forward(ctx, x, gamma, beta, plan, eps, out_dtype, link):
         _require_gpu(x, gamma, beta)
         lib = _lib.load()
         x = x.contiguous()
         S, H = x.shape
+        ctx.link = link
         g = gamma.detach().float().contiguous()
         b = beta.detach().float().contiguous()
         dev = x.device
@@ -852,16 +892,24 @@ class _GatherLN(torch.autograd.Function):
                                             ptr(dxg), ptr(dxr), ptr(dgamma), ptr(dbeta), ptr(part), ptr(blk_e), plan.max_rows,
                                             H, plan.E, dtype_code(x), dtype_code(dxg), stream_ptr()),
               "apertis_moe_gather_ln_bwd")
+        if ctx.link is not None and plan.K <= 2 and dxr.dtype == x.dtype and ctx.link.rows is None:
+            # the consumer of this gradient is the router op that handed x through: it gathers the rows itself
+            ctx.link.rows, ctx.link.slot_of, ctx.link.K = dxr, plan.slot_of, plan.K
+            return _zero_placeholder((S, H), dev, x.dtype), dgamma, dbeta, None, None, None, None
         dx = torch.empty(S, H, device=dev, dtype=x.dtype)
         check(lib.apertis_moe_combine_fwd(ptr(dxr), ptr(plan.slot_of), None, ptr(dx), S, H, plan.K, 0, dtype_code(dxr),
                                           dtype_code(dx), stream_ptr()), "apertis_moe_combine_fwd(scatter)")
-        return dx, dgamma, dbeta, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+ROWS_GRADIENT = True   # tests switch it off to compare with the dense hand-over
 
 
 def moe_gather_ln(x, gamma, beta, plan, eps, out_dtype=None):
     """xg[r] = LayerNorm_e(x[token(r)]) for every kept row r, expert-sorted (reference core.py:593
     gather + :436 per-expert LayerNorm).  x [S,H]; gamma/beta [E,H]."""
-    return _GatherLN.apply(x, gamma, beta, plan, eps, out_dtype or x.dtype)
+    link = getattr(x, "_apertis_rows_link", None) if ROWS_GRADIENT else None
+    return _GatherLN.apply(x, gamma, beta, plan, eps, out_dtype or x.dtype, link)
 
 
 class _Combine(torch.autograd.Function):

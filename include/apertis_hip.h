@@ -251,6 +251,15 @@ int apertis_router_bwd(const void *x, const float *gamma, const float *beta, con
                        const float *rstd, const float *W, const float *dlogits, const void *dres,
                        void *dx, float *part, float *grads, int64_t T, int64_t H, int64_t N,
                        int dtype_x, void *stream);
+/* apertis_router_bwd with the expert path's gradient given as ROWS: row r additionally receives
+ * round_x(sum_k grows[slot_of[r * KS + k]]) over its kept slots (slot_of < 0: none), k ascending - what
+ * apertis_moe_combine_fwd(with_w = 0) would have put into a dense `dres`, without that tensor's round trip.
+ * grows [rows, H] in x's dtype (the gather-LN backward's dxr), slot_of [T, KS] int32, KS <= 2.  dres may still be
+ * given (both are added).  grows == NULL: apertis_router_bwd. */
+int apertis_router_bwd_rows(const void *x, const float *gamma, const float *beta, const float *mean,
+                            const float *rstd, const float *W, const float *dlogits, const void *dres,
+                            const void *grows, const int32_t *slot_of, int64_t KS, void *dx, float *part,
+                            float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream);
 int64_t apertis_router_bwd_blocks(int64_t T);
 
 /* Tiny linear y[T,N] = x[T,:K] W[N,K]^T + b for K <= 64, N <= 16: the SSM's
