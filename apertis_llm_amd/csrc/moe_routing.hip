@@ -424,10 +424,22 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v) 
   *reinterpret_cast<bf4 *>(p) = o;
 }
 
+// Sum over the 64 lanes, the same value in every lane.  DPP adds inside the rows of 16 (quad swaps, half-row and row
+// mirrors), row broadcasts across them, one v_readlane of lane 63: seven VALU instructions.  As six __shfl_xor steps
+// (ds_bpermute_b32 + s_waitcnt lgkmcnt + add each, ~60 cycles of dependent latency per step) the ten reductions per row of
+// the router forward were most of that kernel.  Fixed order: deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+  v += dpp_f<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_f<0x140, 0xf>(v);   // row_mirror: every lane holds its row's sum
+  v += dpp_f<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_f<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ int expert_of_row(const int32_t *offsets, int E, int r) {
