@@ -1415,6 +1415,140 @@ router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
   }
 }
 
+// Block boundary in front of an MoE feed-forward, forward: y = res + dropout(blk), xn = LayerNorm(y) (dropadd_ln_fwd_k) AND the
+// router's logits = Linear(router_norm(xn)) (router_fwd_k) in ONE pass: xn is in registers when the boundary has normalised
+// the row, so the router costs no second read of it (231 MB and a 164 us kernel per layer at the bench shape).  Same
+// arithmetic, in the same order, as the two kernels it replaces - the router reads xn as stored (rounded to TO).
+// Rows are walked by persistent waves (the next row's blk / res in flight), W and the two norms' affine vectors in LDS.
+template <typename TX, typename TO, int IT, int NN>
+__global__ void __launch_bounds__(256)
+dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, const float *__restrict__ gamma,
+                        const float *__restrict__ beta, float eps, TX *__restrict__ y, TO *__restrict__ xn,
+                        float *__restrict__ mean_o, float *__restrict__ rstd_o, const float *__restrict__ rgamma,
+                        const float *__restrict__ rbeta, float reps, const float *__restrict__ W, const float *__restrict__ rb,
+                        float *__restrict__ logits, float *__restrict__ rmean_o, float *__restrict__ rrstd_o, int64_t T, int H,
+                        float drop_p, uint64_t seed) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Q = H / 4;
+  float4 *sW = reinterpret_cast<float4 *>(smem);   // [NN][Q]
+  float4 *sG = sW + NN * Q, *sB = sG + Q, *sRG = sB + Q, *sRB = sRG + Q;
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < NN * Q; i += 256) sW[i] = reinterpret_cast<const float4 *>(W)[i];
+  for (int i = threadIdx.x; i < Q; i += 256) {
+    sG[i] = reinterpret_cast<const float4 *>(gamma)[i]; sB[i] = reinterpret_cast<const float4 *>(beta)[i];
+    sRG[i] = reinterpret_cast<const float4 *>(rgamma)[i]; sRB[i] = reinterpret_cast<const float4 *>(rbeta)[i];
+  }
+  __syncthreads();
+  const float ks = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t th = (uint32_t)(drop_p * 65536.f);
+  typedef typename raw4<TO>::type rawo_t;
+  typedef typename raw4<TX>::type rawx_t;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  rawo_t bc[IT], bn[IT];
+  rawx_t rc[IT], rn[IT];
+  auto fetch = [&](rawo_t (&bo)[IT], rawx_t (&ro)[IT], int64_t r) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      const bool ok = c < H && r < T;
+      bo[i] = ok ? *reinterpret_cast<const rawo_t *>(blk + r * H + c) : rawo_t{};
+      ro[i] = ok ? *reinterpret_cast<const rawx_t *>(res + r * H + c) : rawx_t{};
+    }
+  };
+  if (wave < T) fetch(bc, rc, wave);
+  for (int64_t r = wave; r < T; r += nw) {
+    fetch(bn, rn, r + nw);
+    // ---- boundary: y = res + dropout(blk); statistics of y as stored
+    float4 v[IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 a = raw_to_f4(bc[i]), rr = raw_to_f4(rc[i]);
+        float e[4] = {a.x, a.y, a.z, a.w};
+        if (drop_p > 0.f) {
+          bool keep[4];
+          drop_keep4(seed, (uint64_t)r * (uint64_t)H + (uint64_t)c, th, keep);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
+        }
+        v[i] = make_float4(rr.x + e[0], rr.y + e[1], rr.z + e[2], rr.w + e[3]);
+        store4<TX>(y + r * H + c, v[i]);
+        v[i] = make_float4(to_f32(from_f32<TX>(v[i].x)), to_f32(from_f32<TX>(v[i].y)), to_f32(from_f32<TX>(v[i].z)), to_f32(from_f32<TX>(v[i].w)));
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    // ---- xn = LayerNorm(y), stored; the router continues on xn AS STORED
+    float rsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 g4 = sG[lane + 64 * i], b4 = sB[lane + 64 * i];
+        const float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                                     (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+        store4<TO>(xn + r * H + c, o);
+        v[i] = make_float4(to_f32(from_f32<TO>(o.x)), to_f32(from_f32<TO>(o.y)), to_f32(from_f32<TO>(o.z)), to_f32(from_f32<TO>(o.w)));
+        rsum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+    // ---- router: logits = Linear(router_norm(xn))  (router_fwd_k)
+    const float rmean = wave_sum(rsum) / (float)H;
+    float rsq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float a = v[i].x - rmean, b = v[i].y - rmean, cc = v[i].z - rmean, d = v[i].w - rmean;
+        rsq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rrstd = rsqrtf(wave_sum(rsq) / (float)H + reps);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const bool in = lane + 64 * i < Q;
+      const float4 g4 = in ? sRG[lane + 64 * i] : make_float4(0, 0, 0, 0), b4 = in ? sRB[lane + 64 * i] : make_float4(0, 0, 0, 0);
+      v[i] = make_float4((v[i].x - rmean) * rrstd * g4.x + b4.x, (v[i].y - rmean) * rrstd * g4.y + b4.y,
+                         (v[i].z - rmean) * rrstd * g4.z + b4.z, (v[i].w - rmean) * rrstd * g4.w + b4.w);
+    }
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const float4 wn = lane + 64 * i < Q ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
+        a += (v[i].x * wn.x + v[i].y * wn.y) + (v[i].z * wn.z + v[i].w * wn.w);
+      }
+      acc[n] = wave_sum(a);
+    }
+    if (lane < NN) {
+      float o = 0.f;
+#pragma unroll
+      for (int n = 0; n < NN; ++n) if (lane == n) o = acc[n];
+      logits[r * NN + lane] = o + (rb ? rb[lane] : 0.f);
+    }
+    if (lane == 0) { rmean_o[r] = rmean; rrstd_o[r] = rrstd; }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { bc[i] = bn[i]; rc[i] = rn[i]; }
+  }
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -2230,5 +2364,25 @@ extern "C" int apertis_dropout_add_layernorm_fwd(const void *blk, const int32_t 
   DISPATCH_2T(dtype_x, dtype_y, DISPATCH_IT(H, hipLaunchKernelGGL((dropadd_ln_fwd_k<TA, TB, IT>), grid, block, 0, st,
       (const TB *)blk, slot_of, wk, (int)K, (const TA *)res, gamma, beta, eps, (TA *)y, (TB *)xn, mean, rstd, T, (int)H, drop_p,
       seed)));
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_dropout_add_layernorm_router_fwd(const void *blk, const void *res, const float *gamma, const float *beta,
+                                                        float eps, void *y, void *xn, float *mean, float *rstd,
+                                                        const float *rgamma, const float *rbeta, float reps, const float *W,
+                                                        const float *rb, float *logits, float *rmean, float *rrstd, int64_t T,
+                                                        int64_t H, int64_t N, float drop_p, uint64_t seed, int dtype_x,
+                                                        int dtype_y, void *stream) {
+  if (!blk || !res || !gamma || !beta || !y || !xn || !mean || !rstd || !rgamma || !rbeta || !W || !logits || !rmean || !rrstd ||
+      T < 0 || drop_p < 0.f || drop_p >= 1.f)
+    return APERTIS_ERR_ARG;
+  if (H <= 0 || H % 4 || H > 1024 || (N != 2 && N != 4 && N != 8)) return APERTIS_ERR_UNSUPPORTED;
+  if (T == 0) return APERTIS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)(N + 4) * H * sizeof(float);
+  dim3 grid((unsigned)std::min<int64_t>(ceil_div64(T, 4), 1024)), block(256);   // persistent waves: four per SIMD resident
+#define BR_GO(NN_) { auto kf = dropadd_ln_router_fwd_k<TA, TB, IT, NN_>; if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kf, grid, block, lds, st, (const TB *)blk, (const TA *)res, gamma, beta, eps, (TA *)y, (TB *)xn, mean, rstd, rgamma, rbeta, reps, W, rb, logits, rmean, rrstd, T, (int)H, drop_p, seed); }
+  DISPATCH_2T(dtype_x, dtype_y, SKINNY_IT(H, { if (N == 2) BR_GO(2) else if (N == 4) BR_GO(4) else BR_GO(8) }));
+#undef BR_GO
   return apertis_check_launch();
 }

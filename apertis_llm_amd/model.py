@@ -209,9 +209,11 @@ class _Pending:
         return _dropout_add(self.drop, out, self.res)
 
 
-def _enter_block(norm, h):
+def _enter_block(norm, h, router=None):
     """(normalised input, residual) of a pre-norm sub-block.  When `h` is a _Pending boundary and the norm is a
-    HipLayerNorm on the GPU, the residual add, its dropout and the norm run as ONE kernel in each direction."""
+    HipLayerNorm on the GPU, the residual add, its dropout and the norm run as ONE kernel in each direction.
+    `router` = (router_norm, router Linear) of the MoE feed-forward this block is: its logits are then formed in the same
+    forward pass and ride on the returned activation (`_apertis_router_logits`; AdaptiveExpertSystem.forward picks them up)."""
     if isinstance(h, _Pending):
         out, res = h.out, h.res
         H = res.shape[-1]
@@ -220,6 +222,14 @@ def _enter_block(norm, h):
         if (isinstance(norm, HipLayerNorm) and res.is_cuda and tuple(out.shape) == tuple(res.shape) and H % 4 == 0 and
                 H <= 4096 and res.dtype in (torch.float32, torch.bfloat16) and
                 (res.dtype == torch.float32 or cd == res.dtype) and (lazy is None or lazy.dtype == lazy.yr.dtype == cd)):
+            if (router is not None and lazy is None and isinstance(router[0], nn.LayerNorm) and H <= 1024 and
+                    router[1].weight.shape[0] in (2, 4, 8) and cd in (torch.float32, torch.bfloat16)):
+                rn, rl = router
+                y, xn, logits = ops.dropout_add_layer_norm_router(out, res, norm.weight, norm.bias, norm.eps, h.drop.p,
+                                                                  h.drop.training, rn.weight, rn.bias, rn.eps, rl.weight,
+                                                                  rl.bias, out_dtype=cd)
+                xn._apertis_router_logits = logits
+                return xn, y
             if lazy is not None:
                 y, xn = ops.dropout_add_layer_norm(lazy.yr, res, norm.weight, norm.bias, norm.eps, h.drop.p,
                                                    h.drop.training, out_dtype=cd, combine=(lazy.w, lazy.plan))
@@ -503,7 +513,13 @@ class AdaptiveExpertSystem(nn.Module):
         B, L, H = hidden_states.shape
         S, E, K = B * L, self.num_experts, self.experts_per_token
         xf = hidden_states.reshape(S, H)
-        if ops.router_ln_linear_supported(xf, H, E):
+        pre_logits = getattr(hidden_states, "_apertis_router_logits", None)
+        if pre_logits is not None:
+            # the boundary kernel in front of this block already formed them (_enter_block); the gather op below hands its
+            # gradient rows to that op through the link that rides on the activation
+            logits = pre_logits.reshape(S, E)
+            xf._apertis_rows_link = getattr(hidden_states, "_apertis_rows_link", None)
+        elif ops.router_ln_linear_supported(xf, H, E):
             # core.py:481-482 in one pass over x; xf comes back as the pass-through the expert path reads
             logits, xf = ops.router_ln_linear(xf, self.router_norm.weight, self.router_norm.bias, self.router_norm.eps,
                                               self.router.weight, self.router.bias)
@@ -684,7 +700,10 @@ class ApertisFeedForward(nn.Module):
         self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
 
     def forward(self, hidden_s, defer=False):
-        x, hidden_s = _enter_block(self.pre_norm, hidden_s)
+        router = None
+        if self.is_expert_system and self.ffn.router is not None and self.ffn.num_experts > 0:
+            router = (self.ffn.router_norm, self.ffn.router)
+        x, hidden_s = _enter_block(self.pre_norm, hidden_s, router=router)
         if self.is_expert_system:
             out, lb, rz = self.ffn(x, lazy_combine=defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"),
                                    aux_dtype=hidden_s.dtype)

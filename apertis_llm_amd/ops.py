@@ -1286,6 +1286,90 @@ class _DropoutAddLN(torch.autograd.Function):
         return dblk_in, dx.reshape(shape), dg.to(wdt), db.to(bdt), None, None, None, None, dwk, None
 
 
+class _DropoutAddLNRouter(torch.autograd.Function):
+    """_DropoutAddLN (dense block output) with the MoE router's projection of its normalised output in the same forward
+    pass: (y, xn, logits) = (res + dropout(blk), LayerNorm(y), Linear(router_norm(xn))).  The backward is the two existing
+    kernels in sequence: the router backward turns dlogits (+ whatever reached xn: the expert path's gradient rows, see
+    _RowsGrad, and any dense term) into the total gradient of xn, the boundary backward takes it from there."""
+
+    @staticmethod
+    def forward(ctx, blk, res, weight, bias, eps, p, seed, out_dtype, r_ln_w, r_ln_b, r_eps, r_w, r_b):
+        _require_gpu(blk, res, weight, bias, r_ln_w, r_ln_b, r_w, r_b)
+        lib = _lib.load()
+        shape = res.shape
+        H = shape[-1]
+        N = r_w.shape[0]
+        blk2 = blk.reshape(-1, H).to(out_dtype).contiguous()
+        res2 = res.reshape(-1, H).contiguous()
+        T = res2.shape[0]
+        dev = res.device
+        g, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        rg, rbe = r_ln_w.detach().float().contiguous(), r_ln_b.detach().float().contiguous()
+        rw = r_w.detach().float().contiguous()
+        rbias = None if r_b is None else r_b.detach().float().contiguous()
+        y = torch.empty_like(res2)
+        xn = torch.empty(T, H, device=dev, dtype=out_dtype)
+        mean, rstd = torch.empty(T, device=dev, dtype=torch.float32), torch.empty(T, device=dev, dtype=torch.float32)
+        rmean, rrstd = torch.empty(T, device=dev, dtype=torch.float32), torch.empty(T, device=dev, dtype=torch.float32)
+        logits = torch.empty(T, N, device=dev, dtype=torch.float32)
+        check(lib.apertis_dropout_add_layernorm_router_fwd(ptr(blk2), ptr(res2), ptr(g), ptr(b), float(eps), ptr(y), ptr(xn),
+                                                           ptr(mean), ptr(rstd), ptr(rg), ptr(rbe), float(r_eps), ptr(rw),
+                                                           ptr(rbias), ptr(logits), ptr(rmean), ptr(rrstd), T, H, N, float(p),
+                                                           int(seed), dtype_code(res2), dtype_code(xn), stream_ptr()),
+              "apertis_dropout_add_layernorm_router_fwd")
+        ctx.save_for_backward(y, g, mean, rstd, xn, rg, rbe, rmean, rrstd, rw)
+        ctx.plan = None
+        ctx.cfg = (shape, float(p), int(seed), weight.dtype, bias.dtype, blk.dtype, out_dtype, tuple(blk.shape))
+        ctx.rcfg = (r_ln_w.dtype, r_ln_b.dtype, r_w.dtype, None if r_b is None else r_b.dtype)
+        ctx.link = _RowsGrad()
+        return y.reshape(shape), xn.reshape(shape), logits, ctx.link
+
+    @staticmethod
+    def backward(ctx, dy, dxn, dlogits, _dlink=None):
+        lib = _lib.load()
+        y, g, mean, rstd, xn, rg, rbe, rmean, rrstd, rw = ctx.saved_tensors
+        T, H = y.shape
+        N = rw.shape[0]
+        rows, slot_of, KS = ctx.link.take()
+        if dxn is not None and rows is not None and dxn.stride() == (0,) * dxn.dim():
+            dxn = None                                            # the gather op's placeholder: its gradient is `rows`
+        r_grads = (None, None, None, None, None)
+        if dlogits is not None:
+            dres = None if dxn is None else dxn.reshape(T, H).to(xn.dtype).contiguous()
+            dxn_t = torch.empty_like(xn)
+            nblk = lib.apertis_router_bwd_blocks(T)
+            cols = N * H + N + 2 * H
+            part = torch.empty(nblk, cols, device=y.device, dtype=torch.float32)
+            out = torch.empty(cols, device=y.device, dtype=torch.float32)
+            check(lib.apertis_router_bwd_rows(ptr(xn), ptr(rg), ptr(rbe), ptr(rmean), ptr(rrstd), ptr(rw),
+                                              ptr(dlogits.float().contiguous()), ptr(dres), ptr(rows), ptr(slot_of), KS,
+                                              ptr(dxn_t), ptr(part), ptr(out), T, H, N, dtype_code(xn), stream_ptr()),
+                  "apertis_router_bwd_rows")
+            gdt, bedt, wdt, bdt = ctx.rcfg
+            r_grads = (out[N * H + N:N * H + N + H].to(gdt), out[N * H + N + H:].to(bedt), None,
+                       out[:N * H].reshape(N, H).to(wdt), (out[N * H:N * H + N].to(bdt) if bdt is not None else None))
+            dxn = dxn_t
+        elif rows is not None:                                    # router output unused: form the dense gradient after all
+            dense = torch.empty_like(xn)
+            check(lib.apertis_moe_combine_fwd(ptr(rows), ptr(slot_of), None, ptr(dense), T, H, KS, 0, dtype_code(rows),
+                                              dtype_code(dense), stream_ptr()), "apertis_moe_combine_fwd(scatter)")
+            dxn = dense if dxn is None else dxn.reshape(T, H) + dense
+        base = _DropoutAddLN.backward(ctx, dy, dxn)               # (dblk, dres, dgamma, dbeta, None x 4, dwk, None)
+        return base[:8] + r_grads
+
+
+def dropout_add_layer_norm_router(blk, residual, weight, bias, eps, p, training, r_ln_w, r_ln_b, r_eps, r_w, r_b, out_dtype=None):
+    """dropout_add_layer_norm for the boundary in front of an MoE feed-forward, with the router's logits
+    (reference core.py:481-482 on the normalised output) formed in the same pass.  Returns (y, xn, logits); xn carries
+    the hand-over for moe_gather_ln's gradient rows like router_ln_linear's pass-through does."""
+    p = float(p) if training else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p > 0 else 0
+    y, xn, logits, link = _DropoutAddLNRouter.apply(blk, residual, weight, bias, eps, p, seed, out_dtype or residual.dtype,
+                                                    r_ln_w, r_ln_b, r_eps, r_w, r_b)
+    xn._apertis_rows_link = link
+    return y, xn, logits
+
+
 def dropout_add_layer_norm(blk, residual, weight, bias, eps, p, training, out_dtype=None, combine=None):
     """(residual + dropout(blk), LayerNorm(of that)) in one pass each way (reference core.py:698 + :847, :888 +
     :667 of the next layer, :1294).  combine=(w, plan): blk is the MoE expert output [rows,H] and the block output

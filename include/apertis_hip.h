@@ -342,6 +342,16 @@ int apertis_dropout_add_layernorm_fwd(const void *blk, const int32_t *slot_of, c
                                       const float *beta, float eps, void *y, void *xn, float *mean,
                                       float *rstd, int64_t T, int64_t H, float drop_p, uint64_t seed,
                                       int dtype_x, int dtype_y, void *stream);
+/* The same boundary in front of an MoE feed-forward, with the router projection of apertis_router_fwd in the same
+ * pass: logits [T, N] = Linear(LayerNorm_r(xn)) (rgamma / rbeta / reps: the router's norm; W [N, H], rb [N] or NULL),
+ * rmean / rrstd [T] = the router norm's statistics (what apertis_router_bwd wants).  blk is a dense [T, H] tensor here.
+ * Bit-identical to apertis_dropout_add_layernorm_fwd followed by apertis_router_fwd on xn; N in {2, 4, 8}, H <= 1024. */
+int apertis_dropout_add_layernorm_router_fwd(const void *blk, const void *res, const float *gamma,
+                                             const float *beta, float eps, void *y, void *xn, float *mean,
+                                             float *rstd, const float *rgamma, const float *rbeta, float reps,
+                                             const float *W, const float *rb, float *logits, float *rmean,
+                                             float *rrstd, int64_t T, int64_t H, int64_t N, float drop_p,
+                                             uint64_t seed, int dtype_x, int dtype_y, void *stream);
 
 /* Combine (core.py:594,605 weights * expert_output, index_add_):
  *   out[s,:] = sum_{k asc, slot_of[s,k]>=0} wk[s,k] * yr[slot_of[s,k],:]   (zeros if none)

@@ -547,6 +547,39 @@ def test_gate_topk_aux_losses(dev, S, E, K):
     assert torch.allclose(ld.grad.cpu(), lo.grad, rtol=1e-4, atol=3e-7), float((ld.grad.cpu() - lo.grad).abs().max())
 
 
+@pytest.mark.parametrize("T,H,E,dt_blk,p", [(3001, 704, 8, torch.bfloat16, 0.1), (513, 256, 4, torch.float32, 0.0)])
+def test_boundary_with_router_logits_in_one_pass(dev, T, H, E, dt_blk, p):
+    """ops.dropout_add_layer_norm_router = dropout_add_layer_norm followed by router_ln_linear on its normalised output, as one
+    forward kernel (the backward is the two existing kernels in sequence): outputs bit-identical, gradients equal."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(T + H)
+    blk, res = torch.randn(T, H).to(dt_blk), torch.randn(T, H)
+    w, b = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    rw, rb = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    W, wb = torch.randn(E, H) / H ** 0.5, torch.randn(E) * 0.1
+    gy, gx, gl = torch.randn(T, H), torch.randn(T, H).to(dt_blk), torch.randn(T, E)
+    seed_state = torch.get_rng_state()
+
+    def run(fused):
+        torch.set_rng_state(seed_state)                # the same dropout seed is drawn on both paths
+        L = [t.to(dev).requires_grad_(True) for t in (blk, res, w, b, rw, rb, W, wb)]
+        if fused:
+            y, xn, logits = ops.dropout_add_layer_norm_router(L[0], L[1], L[2], L[3], 1e-5, p, True, L[4], L[5], 1e-5, L[6], L[7],
+                                                              out_dtype=dt_blk)
+        else:
+            y, xn = ops.dropout_add_layer_norm(L[0], L[1], L[2], L[3], 1e-5, p, True, out_dtype=dt_blk)
+            logits, xn = ops.router_ln_linear(xn, L[4], L[5], 1e-5, L[6], L[7])
+        ((y * gy.to(dev)).sum() + (xn.float() * gx.to(dev).float()).sum() + (logits * gl.to(dev)).sum()).backward()
+        torch.cuda.synchronize()
+        return (y, xn, logits), [t.grad for t in L]
+
+    (y0, x0, l0), g0 = run(False)
+    (y1, x1, l1), g1 = run(True)
+    assert torch.equal(y0, y1) and torch.equal(x0, x1) and torch.equal(l0, l1)
+    for name, a, c in zip(("dblk", "dres", "dw", "db", "drw", "drb", "dW", "dwb"), g0, g1):
+        assert torch.equal(a, c), (name, float((a.float() - c.float()).abs().max()))
+
+
 @pytest.mark.parametrize("dt,extra_consumer", [(torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)])
 def test_gather_gradient_reaches_the_router_as_rows(dev, dt, extra_consumer):
     """The gather-LN backward hands its gradient to the router backward as rows + slot table (ops._RowsGrad) instead of a
