@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libapertis_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+ACT_SAVE_GRAD, ACT_MUL_SAVED = 0x100, 0x200      # flags of apertis_grouped_gemm_nt's `act` (apertis_hip.h)
 
 
 class ApertisHipError(RuntimeError):
@@ -78,6 +79,7 @@ SIGNATURES = {
                                        _i32, _i32, _vp]),
     "apertis_grouped_gemm_nt": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
                                        _i32, _i32, _vp]),
+    "apertis_grouped_gemm_nt_saves_grad": (_i32, [_i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32]),
     "apertis_grouped_gemm_nt_q": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
                                          _i32, _i32, _vp, _vp]),
     "apertis_grouped_gemm_tn_workspace_bytes": (_i64, [_i64, _i32]),

@@ -101,6 +101,20 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
   return fmaf(x * 0.3989422804014327f, e, x >= 0.f ? 1.f - q : q);
 }
 
+// both at once: the folded terms are the same
+__device__ __forceinline__ void gelu_both_fast(float x, float &g, float &dg) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * LOG2E_F));
+  const float q = p * t * e;
+  g = fmaf(-ax, q, fmaxf(x, 0.f));
+  dg = fmaf(x * 0.3989422804014327f, e, x >= 0.f ? 1.f - q : q);
+}
+
 template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
@@ -669,7 +683,75 @@ __device__ __forceinline__ void lds_dma16s(const v4i &rs, uint32_t lds_addr, uin
 
 // one staging pass of the 256 x 128 tile through the ring (256-byte rows, 16-byte chunks XOR-swizzled with
 // the row) and out to `dst`; raw = the pre-activation pass
-template <typename TO, bool raw, int ACT, bool DROP, bool MULPRE = false>
+// eight bf16 products (fp32 multiply, rounded once)
+__device__ __forceinline__ uint4 mul_chunk_bf16(uint4 a, uint4 b) {
+  const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float p0 = __builtin_bit_cast(float, x[w] << 16) * __builtin_bit_cast(float, y[w] << 16);
+    const float p1 = __builtin_bit_cast(float, x[w] & 0xffff0000u) * __builtin_bit_cast(float, y[w] & 0xffff0000u);
+    o[w] = (uint32_t)__builtin_bit_cast(uint16_t, from_f32<bf16_t>(p0)) | ((uint32_t)__builtin_bit_cast(uint16_t, from_f32<bf16_t>(p1)) << 16);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// Forward with APERTIS_ACT_SAVE_GRAD (GELU): ONE evaluation per element yields the activation output h = gelu(pre) * mask /
+// (1-p) and g' = gelu'(pre) * mask / (1-p); the tile leaves in two row halves (accumulator sub-tiles j < 4, then j >= 4), each
+// staging both outputs side by side in the ring (2 x 32 KiB) and copying them out as whole 256-byte row segments.  (Two
+// passes that each evaluated their own function and mask hash cost the forward +285 us inside the step; writing h back into
+// the accumulator registers made hipcc spill inside the K loop.)
+template <typename TO, bool DROP>
+__device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst_h,
+                                              TO *__restrict__ dst_g, char *stg, int64_t row0, int rows_valid, int n0,
+                                              int cols_valid, int N, uint64_t seed, float keep_scale, uint32_t thresh16, int tid,
+                                              int wm, int wn, int frow, int fg) {
+  static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
+  char *stg_g = stg + 128 * 256;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = half * 4 + jj;
+        const int m = wm * 128 + j * 16 + frow;            // tile row
+        const int sr = wm * 64 + jj * 16 + frow;           // its row in the half's staging image
+        const int chunk = wn * 8 + i * 2 + (fg >> 1);
+        bool keep[4] = {true, true, true, true};
+        if (DROP) drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
+        uint32_t oh[4], og[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x = to_f32(from_f32<TO>(acc[i][j][q] + bv[i][q]));   // the pre-activation as the other form stores it
+          float hv, gv;
+          gelu_both_fast(x, hv, gv);
+          oh[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? hv * keep_scale : 0.f));
+          og[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? gv * keep_scale : 0.f));
+        }
+        const int off = sr * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8;
+        *reinterpret_cast<uint2 *>(stg + off) = make_uint2(oh[0] | (oh[1] << 16), oh[2] | (oh[3] << 16));
+        *reinterpret_cast<uint2 *>(stg_g + off) = make_uint2(og[0] | (og[1] << 16), og[2] | (og[3] << 16));
+      }
+    lds_barrier();
+#pragma unroll 4
+    for (int it = 0; it < 8; ++it) {
+      const int c4 = it * NT3 + tid;
+      const int sr = c4 >> 4, c = c4 & 15;
+      const int row = (sr >> 6) * 128 + half * 64 + (sr & 63);
+      if (row < rows_valid && c * 8 < cols_valid) {
+        const int off = sr * 256 + ((c ^ (sr & 15)) << 4);
+        *reinterpret_cast<uint4 *>(dst_h + (row0 + row) * N + n0 + c * 8) = *reinterpret_cast<const uint4 *>(stg + off);
+        *reinterpret_cast<uint4 *>(dst_g + (row0 + row) * N + n0 + c * 8) = *reinterpret_cast<const uint4 *>(stg_g + off);
+      }
+    }
+    lds_barrier();
+  }
+}
+
+// MULPRE: 0 plain, 1 data gradient times act'(pre) * mask (pre = the saved pre-activation), 2 data gradient times the saved
+// tensor itself (the g' of nt2x_out_both)
+template <typename TO, bool raw, int ACT, bool DROP, int MULPRE = 0>
 __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst,
                                          const TO *__restrict__ mul_pre, char *stg, int64_t row0, int rows_valid, int n0, int cols_valid, int N, int act, float drop_p,
                                          uint64_t seed, float keep_scale, uint32_t thresh16, int tid, int wm, int wn,
@@ -727,8 +809,11 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
         const int row = c4 >> 4, c = c4 & 15;
         if (row < rows_valid && c * 8 < cols_valid) {
           const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
-          *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
-              actbwd_chunk<TO, true, ACT, DROP>(v, pc[u], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16);
+          if constexpr (MULPRE == 2)
+            *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) = mul_chunk_bf16(v, pc[u]);
+          else
+            *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
+                actbwd_chunk<TO, true, ACT, DROP>(v, pc[u], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16);
         }
       }
     };
@@ -752,10 +837,14 @@ template <typename TO, bool RAGGED = false>
 __global__ void __launch_bounds__(NT3, 2)
 grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                    const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act, float drop_p,
+                    const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act_flags, float drop_p,
                     uint64_t seed) {
   typedef bf16x8 frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // act_flags: the activation code, | APERTIS_ACT_SAVE_GRAD (forward, GELU: pre_act receives gelu'(pre) * mask / (1-p) instead
+  // of pre) or == APERTIS_ACT_MUL_SAVED (data gradient: the output is multiplied by that saved tensor, passed as mul_pre)
+  const bool save_grad = (act_flags & APERTIS_ACT_SAVE_GRAD) != 0, mul_saved = (act_flags & APERTIS_ACT_MUL_SAVED) != 0;
+  const int act = act_flags & 0xff;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
@@ -875,11 +964,19 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     }
 #define OUT(RAW, A, D, DST, ...) \
   nt2x_out<TO, RAW, A, D, ##__VA_ARGS__>(acc, bv, DST, mul_pre, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
+  if (save_grad && pre_act) {   // (GELU: launch_nt refuses the flag for other activations)
+    if (drop_p > 0.f)
+      nt2x_out_both<TO, true>(acc, bv, C, pre_act, smem, row0, rows_valid, n0, cols_valid, N, seed, keep_scale, thresh16, tid, wm, wn, frow, fg);
+    else
+      nt2x_out_both<TO, false>(acc, bv, C, pre_act, smem, row0, rows_valid, n0, cols_valid, N, seed, keep_scale, thresh16, tid, wm, wn, frow, fg);
+    return;
+  }
   if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);
   if (mul_pre) {
-    if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C, true);
-    else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C, true);
-    else OUT(false, -1, false, C, true);
+    if (mul_saved) OUT(false, APERTIS_ACT_NONE, false, C, 2);
+    else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C, 1);
+    else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C, 1);
+    else OUT(false, -1, false, C, 1);
   } else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
   else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C);
   else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C);
@@ -1532,6 +1629,12 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
   if (!aligned16<T>(A, K) || !aligned16<T>(W, ldw) || !aligned16<TO>(C, N) || (pre_act && !aligned16<TO>(pre_act, N)) ||
       (mul_pre && !aligned16<TO>(mul_pre, N)))
     return APERTIS_ERR_UNSUPPORTED;
+  // the saved-gradient forms of the epilogue exist in the two-per-CU kernel only
+  const int act_flags = act;
+  const bool flagged = (act & (APERTIS_ACT_SAVE_GRAD | APERTIS_ACT_MUL_SAVED)) != 0;
+  act &= 0xff;
+  if (flagged && ((act_flags & APERTIS_ACT_SAVE_GRAD) ? !pre_act : !mul_pre)) return APERTIS_ERR_ARG;
+  if ((act_flags & APERTIS_ACT_SAVE_GRAD) && act != APERTIS_ACT_GELU) return APERTIS_ERR_UNSUPPORTED;
   const int n_tiles = (int)ceil_div64(N, BN);
   const int64_t m_tiles = ceil_div64(max_rows, BM) + E;  // each group adds at most one partial tile
   const int64_t grid = m_tiles * n_tiles;
@@ -1563,10 +1666,11 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         auto k3 = ragged2x ? grouped_gemm_nt2x_k<TO, true> : grouped_gemm_nt2x_k<TO, false>;
         hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         hipLaunchKernelGGL(k3, dim3((unsigned)grid3), dim3(NT3), RING3, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
-                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act, drop_p, seed);
+                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act_flags, drop_p, seed);
         return apertis_check_launch();
       }
     }
+    if (flagged) return APERTIS_ERR_UNSUPPORTED;
     if (kpad_ok && (N >= 512 || (E == 1 && N >= 128)) && max_rows >= 4096 && E <= 1024) {
       const int nt2 = (int)ceil_div64(N, BN2);
       const int64_t grid2 = (ceil_div64(max_rows, BM2) + E) * nt2;
@@ -1585,6 +1689,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       }
     }
   }
+  if (flagged) return APERTIS_ERR_UNSUPPORTED;
   const size_t cstage = (size_t)BM * (BN * sizeof(TO) + 16);
   size_t lds = std::max<size_t>(4 * TILE_BYTES, cstage);
   auto kern = grouped_gemm_nt_k<T, TO>;
@@ -1595,6 +1700,17 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
 }
 
 }  // namespace
+
+// 1 when apertis_grouped_gemm_nt takes the APERTIS_ACT_SAVE_GRAD / APERTIS_ACT_MUL_SAVED forms for this problem (the
+// two-per-CU kernel's conditions in launch_nt: bf16, GELU, short K, wide N, enough rows); callers keep the pre-activation otherwise
+extern "C" int apertis_grouped_gemm_nt_saves_grad(int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E, int act,
+                                                  int dtype, int dtype_out) {
+  if (dtype != APERTIS_BF16 || dtype_out != APERTIS_BF16 || N <= 0 || K <= 0 || E <= 0 || act != APERTIS_ACT_GELU) return 0;
+  if (ldw == 0) ldw = K;
+  const bool ragged2x = K % 32 != 0;
+  return K <= 1024 && N >= 512 && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 &&
+         max_rows >= 4096 && E <= 1024 && (ceil_div64(max_rows, BM3) + E) * ceil_div64(N, BN3) < 0x7fffffffLL;
+}
 
 extern "C" int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias, const int32_t *offsets,
                                          void *C, void *pre_act, const void *act_bwd_pre, int64_t max_rows, int64_t N, int64_t K,

@@ -1392,6 +1392,7 @@ def layer_norm_pass(x, weight, bias, eps, out_dtype=None):
 
 
 FUSE_ACT_BWD = not _os.environ.get("APERTIS_NO_FUSE_ACT_BWD")
+SAVE_ACT_GRAD = True    # expert MLP: the forward leaves act'(pre) * mask / (1-p) instead of pre (tests switch it off to compare)
 
 
 def grad_destination(param, shape, device):
@@ -1423,15 +1424,22 @@ class _ExpertMLP(torch.autograd.Function):
         R = xg.shape[0]
         h = torch.empty(R, I, device=xg.device, dtype=cd)
         pre = torch.empty_like(h) if need else None
+        # second output: the pre-activation, or - where the kernel offers it - g' = act'(pre) * keep / (1-p) itself, which
+        # the data-gradient epilogue of the backward then only multiplies by (no activation derivative, no mask hash there;
+        # one evaluation per element yields both outputs in the forward)
+        saved_grad = bool(need and FUSE_ACT_BWD and SAVE_ACT_GRAD and
+                          lib.apertis_grouped_gemm_nt_saves_grad(max_rows, I, H, w1c.shape[-1], E, act_code, code, code))
         _launch_nt("apertis_grouped_gemm_nt", lib,
-                (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, w1c.shape[-1], E, act_code,
-                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H), xg.device)
+                (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, w1c.shape[-1], E,
+                 act_code | (_lib.ACT_SAVE_GRAD if saved_grad else 0), float(drop_p), int(seed), code, code, stream_ptr()),
+                _RowsWork(offsets, E, 2.0 * I * H), xg.device)
         yr = torch.empty(R, H, device=xg.device, dtype=cd)
         _launch_nt("apertis_grouped_gemm_nt", lib,
                 (ptr(h), ptr(w2c), ptr(b2f), ptr(offsets), ptr(yr), None, None, max_rows, H, I, w2c.shape[-1], E, _lib.ACT_NONE,
                  0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * I * H), h.device)
         ctx.save_for_backward(xg, pre, h, w1t, w2t, offsets)
         ctx.cfg = (E, I, H, max_rows, act_code, float(drop_p), int(seed), w1.dtype, w2.dtype)
+        ctx.saved_grad = saved_grad
         ctx.wparams = (w1, w2)     # for grad_destination() in the backward
         return yr
 
@@ -1445,7 +1453,12 @@ class _ExpertMLP(torch.autograd.Function):
         dyr = dyr.to(xg.dtype).contiguous()
         work = _RowsWork(offsets, E, 2.0 * I * H)
         dpre = torch.empty_like(h)
-        if FUSE_ACT_BWD:
+        if ctx.saved_grad:
+            # dpre = (dyr @ W2) * g' with the g' the forward left in `pre`
+            _launch_nt("apertis_grouped_gemm_nt", lib,
+                    (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, w2t.shape[-1], E,
+                     _lib.ACT_MUL_SAVED, 0.0, 0, code, code, stream_ptr()), work, dyr.device)
+        elif FUSE_ACT_BWD:
             # dpre = (dyr @ W2) * keep/(1-p) * act'(pre): layer 1's activation backward in the dgrad epilogue
             _launch_nt("apertis_grouped_gemm_nt", lib,
                     (ptr(dyr), ptr(w2t), None, ptr(offsets), ptr(dpre), None, ptr(pre), max_rows, I, H, w2t.shape[-1], E, act_code,

@@ -37,6 +37,13 @@ extern "C" {
 #define APERTIS_ACT_GELU 1 /* erf GELU, torch.nn.GELU() default */
 #define APERTIS_ACT_RELU 2
 #define APERTIS_ACT_SILU 3
+/* Flags of apertis_grouped_gemm_nt's `act` (bf16, GELU, shapes the two-per-CU kernel takes: K <= 1024, N >= 512, rows >= 4096;
+ * anything else returns APERTIS_ERR_UNSUPPORTED and the caller keeps the pre-activation form):
+ *   forward  act | APERTIS_ACT_SAVE_GRAD: `pre_act` receives g' = act'(pre) * keep / (1-p) instead of pre;
+ *   dgrad    act = APERTIS_ACT_MUL_SAVED with `act_bwd_pre` = that g': out = (A W^T) * g' - one multiply per element in
+ *            the epilogue instead of the activation derivative and the mask hash. */
+#define APERTIS_ACT_SAVE_GRAD 0x100
+#define APERTIS_ACT_MUL_SAVED 0x200
 
 /* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes. */
 int apertis_abi_version(void);
@@ -402,6 +409,9 @@ int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
  * its tiles from that counter instead of a static stride, so a work-group whose CU was held by a concurrent kernel (an
  * RCCL collective on the communication stream of the data-parallel step) does not finish a full share alone.
  * tile_queue == NULL: static schedule (what apertis_grouped_gemm_nt does). */
+/* 1 when the APERTIS_ACT_SAVE_GRAD / APERTIS_ACT_MUL_SAVED forms are available for this problem, else 0. */
+int apertis_grouped_gemm_nt_saves_grad(int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E,
+                                       int act, int dtype, int dtype_out);
 int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias,
                               const int32_t *offsets, void *C, void *pre_act,
                               const void *act_bwd_pre,

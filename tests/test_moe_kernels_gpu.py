@@ -547,6 +547,42 @@ def test_gate_topk_aux_losses(dev, S, E, K):
     assert torch.allclose(ld.grad.cpu(), lo.grad, rtol=1e-4, atol=3e-7), float((ld.grad.cpu() - lo.grad).abs().max())
 
 
+@pytest.mark.parametrize("act,p", [("gelu", 0.1), ("gelu", 0.0)])
+def test_expert_mlp_saved_activation_gradient(dev, act, p):
+    """Expert MLP whose forward leaves g' = act'(pre) * keep / (1-p) for the backward (APERTIS_ACT_SAVE_GRAD /
+    APERTIS_ACT_MUL_SAVED) against the form that keeps the pre-activation: the same output bits (same mask: both forward
+    outputs come from one evaluation and one hash), gradients equal to bf16 rounding of g', and both against fp64 math on the same mask."""
+    from apertis_llm_amd import _lib, ops
+    torch.manual_seed(7)
+    sizes = [3000, 2000, 1500, 1692]
+    E, R, H, I = len(sizes), sum(sizes), 128, 512
+    assert _lib.load().apertis_grouped_gemm_nt_saves_grad(R, I, H, H, E, _lib.ACT_GELU, _lib.BF16, _lib.BF16) == 1
+    x = torch.randn(R, H).bfloat16()
+    w1, b1 = torch.randn(E, I, H) / H ** 0.5, torch.randn(E, I) * 0.1
+    w2, b2 = torch.randn(E, H, I) / I ** 0.5, torch.randn(E, H) * 0.1
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=dev)
+    dy = torch.randn(R, H).bfloat16()
+
+    def run(saved):
+        ops.SAVE_ACT_GRAD = saved
+        try:
+            L = [t.to(dev).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+            yr = ops.expert_mlp(L[0], L[1], L[2], L[3], L[4], offs, R, act=act, drop_p=p, seed=4242, compute_dtype=torch.bfloat16)
+            yr.backward(dy.to(dev))
+            torch.cuda.synchronize()
+            return yr.detach(), [t.grad for t in L]
+        finally:
+            ops.SAVE_ACT_GRAD = True
+
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    assert torch.equal(y0, y1)
+    for name, a, c in zip(("dx", "dw1", "db1", "dw2", "db2"), g0, g1):
+        a, c = a.float(), c.float()
+        assert torch.allclose(a, c, rtol=3e-2, atol=1e-2 * float(a.abs().max())), (name, float((a - c).abs().max()), float(a.abs().max()))
+    assert torch.equal(g0[3], g1[3]) and torch.equal(g0[4], g1[4])      # layer 2's gradients do not see the difference
+
+
 @pytest.mark.parametrize("T,H,E,dt_blk,p", [(3001, 704, 8, torch.bfloat16, 0.1), (513, 256, 4, torch.float32, 0.0)])
 def test_boundary_with_router_logits_in_one_pass(dev, T, H, E, dt_blk, p):
     """ops.dropout_add_layer_norm_router = dropout_add_layer_norm followed by router_ln_linear on its normalised output, as one
