@@ -433,11 +433,32 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct PTile { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
 
 // Dynamic tile queue of the persistent kernel (queue != NULL): after its first (static, XCD-affine) tile a work-group
-// takes tile indices from a device counter, so a work-group that starts late - its CU was held by another kernel, e.g. an
-// RCCL collective on the communication stream - simply finds the queue drained instead of walking a full static share on
-// its own after everybody else has finished.  The counter is ONE int32 owned by the caller (stream-owned workspace); the
-// entry point zeroes it on the launch stream in front of the kernel, so nothing survives a launch - no process-global
+// takes tile indices from device counters, so a work-group that starts late - its CU was held by another kernel, e.g. an
+// RCCL collective on the communication stream - simply finds the queues drained instead of walking a full static share on
+// its own after everybody else has finished.  ONE COUNTER PER XCD (NTQ_STRIDE ints apart): a work-group first draws from
+// its own XCD's counter, whose tickets enumerate exactly the tiles the static walk gives that XCD (round r >= 1, position
+// j * 8 + xcd), so neighbouring tiles still meet in one L2 - with a single counter for the whole chip they did not, and
+// the queue cost 3-10 % when nothing competed for the CUs; only when its own counter has run past the last tile does a
+// work-group steal from the next XCD's.  The counters are owned by the caller (stream-owned workspace, NTQ_INTS ints); the
+// entry point zeroes them on the launch stream in front of the kernel, so nothing survives a launch - no process-global
 // state, and an aborted launch cannot leave a dirty slot behind.
+constexpr int NTQ_STRIDE = 64, NTQ_INTS = 8 * NTQ_STRIDE;
+// next tile index (>= G) for a work-group of XCD `home`, or n_valid when every queue is drained
+__device__ __forceinline__ int ntq_next(int *queue, int home, int G, int n_valid) {
+  const int per = (G + 7) / 8;
+  for (int s = 0; s < 8; ++s) {
+    const int x = (home + s) & 7;
+    while (true) {
+      const int k = atomicAdd(queue + x * NTQ_STRIDE, 1);
+      const int r = 1 + k / per, within = (k - (r - 1) * per) * 8 + x;
+      const int64_t t = (int64_t)r * G + within;
+      if (within >= G) { if ((int64_t)r * G >= n_valid) break; continue; }   // a position past a ragged G: skip it
+      if (t < n_valid) return (int)t;
+      break;   // this XCD's tiles are gone (tickets grow with k)
+    }
+  }
+  return n_valid;
+}
 // raw = the pre-activation pass, r = round; ACT >= 0 fixes the activation and DROP the dropout at
 // compile time (a per-value runtime switch costs more than the conversion itself), ACT < 0 = runtime
 template <typename TO, bool raw, int r, int ACT, bool DROP>
@@ -620,7 +641,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     }
     if (!nxt.valid) break;
     cur = nxt;
-    if (queue && tid == 0) *s_next = G + atomicAdd(queue, 1);   // (its latency hides under the K loop)
+    if (queue && tid == 0) *s_next = ntq_next(queue, (int)(blockIdx.x & 7), G, n_valid);   // (its latency hides under the K loop)
 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1679,7 +1700,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         const int gp = (int)std::min<int64_t>(grid2, ncu);          // one persistent work-group per CU
         size_t ldsp = 4 * TILE2_BYTES + 4096 + 16;                   // ring + group offsets
         constexpr int solo = 4;   // K steps of a tile whose DMA the non-store waves issue alone (measured best of 2..6)
-        if (tile_queue && hipMemsetAsync(tile_queue, 0, sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
+        if (tile_queue && hipMemsetAsync(tile_queue, 0, NTQ_INTS * sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
         auto kp = (K % 64 == 0 && ldw == K) ? grouped_gemm_nt256p_k<TO, false> : grouped_gemm_nt256p_k<TO, true>;
         hipFuncSetAttribute((const void *)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp);
         hipLaunchKernelGGL(kp, dim3((unsigned)gp), dim3(NT2), ldsp, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,

@@ -1027,7 +1027,7 @@ def _nt_queue(device):
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     q = _NT_QUEUE.get(key)
     if q is None:
-        q = _NT_QUEUE[key] = torch.zeros(16, device=device, dtype=torch.int32)
+        q = _NT_QUEUE[key] = torch.zeros(512, device=device, dtype=torch.int32)     # APERTIS_NT_QUEUE_INTS: one counter per XCD
     return q
 
 

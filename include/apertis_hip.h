@@ -404,14 +404,16 @@ int apertis_grouped_gemm_nt(const void *A, const void *W, const float *bias,
                             int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E,
                             int act, float drop_p, uint64_t seed,
                             int dtype, int dtype_out, void *stream);
-/* The same with a dynamic tile queue for the persistent 256 x 256 kernel: tile_queue = ONE caller-owned int32 (per
- * stream; the entry point zeroes it on `stream` in front of the launch).  After its first tile a work-group then takes
- * its tiles from that counter instead of a static stride, so a work-group whose CU was held by a concurrent kernel (an
- * RCCL collective on the communication stream of the data-parallel step) does not finish a full share alone.
- * tile_queue == NULL: static schedule (what apertis_grouped_gemm_nt does). */
 /* 1 when the APERTIS_ACT_SAVE_GRAD / APERTIS_ACT_MUL_SAVED forms are available for this problem, else 0. */
 int apertis_grouped_gemm_nt_saves_grad(int64_t max_rows, int64_t N, int64_t K, int64_t ldw, int64_t E,
                                        int act, int dtype, int dtype_out);
+/* The same with a dynamic tile queue for the persistent 256 x 256 kernel: tile_queue = APERTIS_NT_QUEUE_INTS caller-owned
+ * int32 (per stream; the entry point zeroes them on `stream` in front of the launch): one counter per XCD.  After its
+ * first tile a work-group then draws its tiles from its XCD's counter - the tiles the static walk gives that XCD, so the
+ * L2 sharing of neighbouring tiles is kept - and steals from the other XCDs' once that is drained, so a work-group whose
+ * CU was held by a concurrent kernel (an RCCL collective on the communication stream of the data-parallel step) does not
+ * finish a full share alone.  tile_queue == NULL: static schedule (what apertis_grouped_gemm_nt does). */
+#define APERTIS_NT_QUEUE_INTS 512
 int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias,
                               const int32_t *offsets, void *C, void *pre_act,
                               const void *act_bwd_pre,

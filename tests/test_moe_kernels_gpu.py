@@ -453,6 +453,40 @@ def test_grouped_gemm_tn_bf16(dev, sizes, M, N, with_bias):
             assert errb <= 2e-5 * scale * 8, f"ws={ws_mode}: bias max abs err {errb:.3e}"
 
 
+@pytest.mark.parametrize("sizes,N,K", [([9000, 4100, 0, 7000, 12000, 300, 5000, 8000], 704, 2816), ([70000], 704, 352),
+                                        ([5000] * 8, 2816, 704)])
+def test_grouped_gemm_nt_tile_queue_equals_static_walk(dev, sizes, N, K):
+    """apertis_grouped_gemm_nt_q (per-XCD tile counters with stealing, what the data-parallel step uses) against
+    apertis_grouped_gemm_nt through the C ABI: which work-group computes a tile changes nothing - bit-identical, every
+    tile computed exactly once (NaN-prefilled output), twice in a row on the same queue buffer."""
+    from apertis_llm_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(N + K)
+    E, R = len(sizes), sum(sizes)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=dev)
+    A = torch.randn(R, K, device=dev).bfloat16()
+    W = (torch.randn(E, N, K, device=dev) / K ** 0.5).bfloat16()
+    queue = torch.full((512,), 12345, device=dev, dtype=torch.int32)      # dirty on purpose: the entry point zeroes it
+
+    def run(q):
+        C = torch.full((R, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        if q is None:
+            rc = lib.apertis_grouped_gemm_nt(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(offs), _lib.ptr(C), None, None, R, N, K, K, E,
+                                             _lib.ACT_NONE, 0.0, 0, _lib.BF16, _lib.BF16, _lib.stream_ptr())
+        else:
+            rc = lib.apertis_grouped_gemm_nt_q(_lib.ptr(A), _lib.ptr(W), None, _lib.ptr(offs), _lib.ptr(C), None, None, R, N, K, K, E,
+                                               _lib.ACT_NONE, 0.0, 0, _lib.BF16, _lib.BF16, _lib.ptr(q), _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return C
+
+    ref = run(None)
+    assert torch.isfinite(ref.float()).all()
+    for _ in range(2):
+        got = run(queue)
+        assert torch.equal(got, ref)
+
+
 def test_grouped_gemm_tn_is_deterministic(dev):
     torch.manual_seed(5)
     sizes = [4000, 3000, 5000, 2000]

@@ -88,6 +88,7 @@ int main(int argc, char **argv) {
   timeit("fc1 shape: GELU + pre out (no dropout)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc2 dgrad * act'(pre) * mask", fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc1 fwd: GELU + dropout + g' out (SAVE_GRAD)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU | APERTIS_ACT_SAVE_GRAD, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
+  timeit("fc1 fwd: GELU + g' out, no dropout (SAVE_GRAD)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU | APERTIS_ACT_SAVE_GRAD, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc2 dgrad * saved g' (MUL_SAVED)", fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_MUL_SAVED, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc2 fwd (N=H, K=I), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   return 0;

@@ -31,7 +31,7 @@ int main(int argc, char **argv) {
   bf16_t *x, *w2t, *h, *y, *dyr, *dpre; float *dw1, *dw2, *db1, *db2; int32_t *offs, *queue; unsigned *sink; void *ws;
   hipMalloc(&x, rows * H * 2); hipMalloc(&w2t, E * I * H * 2); hipMalloc(&h, rows * I * 2); hipMalloc(&y, rows * H * 2);
   hipMalloc(&dyr, rows * H * 2); hipMalloc(&dpre, rows * I * 2); hipMalloc(&dw1, E * I * H * 4); hipMalloc(&dw2, E * I * H * 4);
-  hipMalloc(&db1, E * I * 4); hipMalloc(&db2, E * H * 4); hipMalloc(&offs, (E + 1) * 4); hipMalloc(&queue, 64); hipMalloc(&sink, 64);
+  hipMalloc(&db1, E * I * 4); hipMalloc(&db2, E * H * 4); hipMalloc(&offs, (E + 1) * 4); hipMalloc(&queue, 4 * APERTIS_NT_QUEUE_INTS); hipMalloc(&sink, 64);
   const int64_t wsb = apertis_grouped_gemm_tn_workspace_bytes(E, 2);
   hipMalloc(&ws, wsb);
   fill_k<<<2048, 256>>>(x, rows * H, 1.f, 1); fill_k<<<2048, 256>>>(w2t, E * I * H, 0.05f, 3); fill_k<<<2048, 256>>>(h, rows * I, 1.f, 5);
