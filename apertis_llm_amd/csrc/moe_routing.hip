@@ -428,6 +428,10 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v) 
 // mirrors), row broadcasts across them, one v_readlane of lane 63: seven VALU instructions.  As six __shfl_xor steps
 // (ds_bpermute_b32 + s_waitcnt lgkmcnt + add each, ~60 cycles of dependent latency per step) the ten reductions per row of
 // the router forward were most of that kernel.  Fixed order: deterministic.
+// 1 / H once per kernel (the compiler hoists it): the statistics of a row are sums TIMES this instead of sums divided by H -
+// an IEEE division is ~10 instructions, and the row kernels did two to four of them per row
+__device__ __forceinline__ float inv_h(int H) { return 1.f / (float)H; }
+
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
@@ -468,7 +472,7 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
     v[i] = c < H ? load4<TX>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
-  const float mean = wave_sum(sum) / (float)H;
+  const float mean = wave_sum(sum) * inv_h(H);
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
@@ -478,7 +482,7 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
       sq += (a * a + b * b) + (cc * cc + d * d);
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+  const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
   const float *ga = gamma + (int64_t)e * H, *be = beta + (int64_t)e * H;
   TO *dst = xg + r * H;
 #pragma unroll
@@ -574,7 +578,7 @@ gather_ln_bwd2_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token
           s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
         }
       }
-      const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+      const float m1 = wave_sum(s1) * inv_h(H), m2 = wave_sum(s2) * inv_h(H);
       if (dxr) {   // NULL: only the affine gradients are wanted
         TG *dst = dxr + (r + q) * H;
 #pragma unroll
@@ -778,7 +782,7 @@ dropadd_ln_fwd_k(const TO *__restrict__ blk, const int32_t *__restrict__ slot_of
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  const float mean = wave_sum(sum) / (float)H;
+  const float mean = wave_sum(sum) * inv_h(H);
   float sq = 0.f;
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
@@ -788,7 +792,7 @@ dropadd_ln_fwd_k(const TO *__restrict__ blk, const int32_t *__restrict__ slot_of
       sq += (a * a + b * b) + (cc * cc + d * d);
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+  const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int c = (lane + 64 * i) * 4;
@@ -852,7 +856,7 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
           s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
         }
       }
-      const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+      const float m1 = wave_sum(s1) * inv_h(H), m2 = wave_sum(s2) * inv_h(H);
       TX *dst = dx + (r + q) * H;
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
@@ -1377,7 +1381,7 @@ router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
       v[i] = raw_to_f4(cur[i]);
       sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
-    const float mean = wave_sum(sum) / (float)H;
+    const float mean = wave_sum(sum) * inv_h(H);
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -1387,7 +1391,7 @@ router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
         sq += (a * a + bb * bb) + (cc * cc + d * d);
       }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
 #pragma unroll
     for (int i = 0; i < IT; ++i) cur[i] = nxt[i];
 #pragma unroll
@@ -1481,7 +1485,7 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    const float mean = wave_sum(sum) / (float)H;
+    const float mean = wave_sum(sum) * inv_h(H);
     float sq = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -1491,7 +1495,7 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
         sq += (a * a + b * b) + (cc * cc + d * d);
       }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
     // ---- xn = LayerNorm(y), stored; the router continues on xn AS STORED
     float rsum = 0.f;
 #pragma unroll
@@ -1508,7 +1512,7 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
     }
     if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
     // ---- router: logits = Linear(router_norm(xn))  (router_fwd_k)
-    const float rmean = wave_sum(rsum) / (float)H;
+    const float rmean = wave_sum(rsum) * inv_h(H);
     float rsq = 0.f;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -1518,7 +1522,7 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
         rsq += (a * a + b * b) + (cc * cc + d * d);
       }
     }
-    const float rrstd = rsqrtf(wave_sum(rsq) / (float)H + reps);
+    const float rrstd = rsqrtf(wave_sum(rsq) * inv_h(H) + reps);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const bool in = lane + 64 * i < Q;
@@ -1676,7 +1680,7 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
       s2 += (dn[i].x * xh[i].x + dn[i].y * xh[i].y) + (dn[i].z * xh[i].z + dn[i].w * xh[i].w);
     }
     if constexpr (MODE != 2) {
-    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+    const float m1 = wave_sum(s1) * inv_h(H), m2 = wave_sum(s2) * inv_h(H);
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = (lane + 64 * i) * 4;
