@@ -26,7 +26,9 @@ template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t *p, float4 v) {
   *reinterpret_cast<bf4 *>(p) = o;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// sigmoid on the hardware exp2 / rcp (1 ulp each, ~3e-7 relative: far inside the 1e-4 parity bar), as scan_gate.hip's;
+// expf + an IEEE division were ~30 VALU instructions per value
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f)); }
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_grad(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
 
@@ -192,7 +194,6 @@ template <> struct Pc16<bf16_t> {
     return v;
   }
 };
-__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f)); }
 
 // global -> LDS: `total` 16-byte pieces of `nrow` rows (row r of the tile = token t_first + r; rows outside [0, L) are zeros)
 __device__ __forceinline__ void conv_tile_in(char *lds, const char *g, int64_t rs_bytes, int64_t t_first, int64_t L, int nrow,
@@ -258,7 +259,7 @@ dwconv_silu_fwd_tile_k(const T *__restrict__ x, int64_t x_rs, const float *__res
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
       const float s = to_f32(from_f32<T>(acc[j]));  // conv output is stored in the activation dtype before SiLU
-      o[j] = s * sigmoid_fast(s);
+      o[j] = s * sigmoidf_(s);
     }
     *reinterpret_cast<uint4 *>(ob + (int64_t)r * out_rs * (int64_t)sizeof(T)) = PC::pack(o);
   }
