@@ -459,6 +459,8 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
                 const int32_t *__restrict__ offsets, const float *__restrict__ gamma,
                 const float *__restrict__ beta, float eps, TO *__restrict__ xg,
                 float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t max_rows, int H, int E) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= max_rows || (offsets && r >= offsets[E])) return;
@@ -510,6 +512,8 @@ gather_ln_bwd2_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token
                  const float *__restrict__ gamma, const float *__restrict__ mean_i, const float *__restrict__ rstd_i,
                  const TG *__restrict__ dxg, TG *__restrict__ dxr, float *__restrict__ dgamma, float *__restrict__ dbeta,
                  float *__restrict__ part, int32_t *__restrict__ blk_expert, int64_t max_rows, int H, int E) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);          // [3 waves][2][H/4]
   __shared__ int s_e[4];
@@ -738,6 +742,8 @@ dropadd_ln_fwd_k(const TO *__restrict__ blk, const int32_t *__restrict__ slot_of
                  const TX *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
                  TX *__restrict__ y, TO *__restrict__ xn, float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t T,
                  int H, float drop_p, uint64_t seed) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= T) return;
@@ -811,6 +817,8 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
                 const float *__restrict__ rstd_i, const TG *__restrict__ dy, const TX *__restrict__ dres,
                 TX *__restrict__ dx, TG *__restrict__ dblk, float drop_p, uint64_t seed, float *__restrict__ part,
                 int64_t T, int H) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);  // [3 waves][2][H/4]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1349,6 +1357,8 @@ __global__ void __launch_bounds__(256)
 router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
              const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ logits,
              float *__restrict__ mean_o, float *__restrict__ rstd_o, int64_t T, int H) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *sW = reinterpret_cast<float4 *>(smem);   // [NN][H/4]: in registers the weight would cost NN*IT*4 VGPRs and two waves per SIMD
   const int lane = threadIdx.x & 63, Q = H / 4;
@@ -1432,6 +1442,8 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
                         const float *__restrict__ rbeta, float reps, const float *__restrict__ W, const float *__restrict__ rb,
                         float *__restrict__ logits, float *__restrict__ rmean_o, float *__restrict__ rrstd_o, int64_t T, int H,
                         float drop_p, uint64_t seed) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int Q = H / 4;
   float4 *sW = reinterpret_cast<float4 *>(smem);   // [NN][Q]
@@ -1570,6 +1582,8 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
               const float *__restrict__ dlogits, const TX *__restrict__ dres, const TX *__restrict__ grows,
               const int32_t *__restrict__ slot_of, int KS, TX *__restrict__ dx,
               float *__restrict__ part, int64_t T, int H) {
+  // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   // grows / slot_of (KS <= 2 slots per row): the gradient reaching x through the expert path as the ROWS the gather-LN
   // backward wrote - row r receives round_TX(sum_k grows[slot_of[r, k]]), k ascending, exactly what apertis_moe_combine_fwd
   // would have written into a dense `dres` (231 MB written and read back per layer at the bench shape, and a 128 us kernel)
