@@ -667,6 +667,7 @@ template <typename TY, typename TO, int IT>
 __global__ void __launch_bounds__(256)
 combine_fwd_k(const TY *__restrict__ yr, const int32_t *__restrict__ slot_of, const float *__restrict__ wk,
               TO *__restrict__ out, int64_t S, int H, int K, int with_w) {
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));   // IT = ceil(H / 256): only the last chunk needs its bounds test
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= S) return;
@@ -703,6 +704,7 @@ combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int3
               const int32_t *__restrict__ row_k, const int32_t *__restrict__ offsets,
               const float *__restrict__ wk, TY *__restrict__ dyr, float *__restrict__ dwk, int64_t max_rows,
               int H, int K, int E) {
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));   // IT = ceil(H / 256): only the last chunk needs its bounds test
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= max_rows || r >= offsets[E]) return;
@@ -962,6 +964,7 @@ template <typename TX, int IT, int NN>
 __global__ void __launch_bounds__(256)
 skinny_fwd_k(const TX *__restrict__ x, const float *__restrict__ W, const float *__restrict__ b, float *__restrict__ y,
              int64_t T, int K) {
+  if constexpr (IT <= 4) __builtin_assume(K > 256 * (IT - 1));   // IT = ceil(K / 256): only the last chunk needs its bounds test
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nw = (int64_t)gridDim.x * 4;
@@ -1001,6 +1004,7 @@ template <typename TX, int IT, int NN>
 __global__ void __launch_bounds__(256)
 skinny_bwd_k(const TX *__restrict__ x, const float *__restrict__ W, const float *__restrict__ dy, TX *__restrict__ dx,
              float *__restrict__ part, int64_t T, int K) {
+  if constexpr (IT <= 4) __builtin_assume(K > 256 * (IT - 1));   // IT = ceil(K / 256): only the last chunk needs its bounds test
   // part: [gridDim.x][NN*K + NN] per-block partial sums of dW (row-major [NN][K]) then db
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *red = reinterpret_cast<float4 *>(smem);   // [3 waves][NN][K/4]
