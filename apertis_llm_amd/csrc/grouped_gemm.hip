@@ -510,7 +510,11 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
         if (ACT < 0 && mul_pre && !raw)
           v = actbwd_chunk<TO, true>(v, *reinterpret_cast<const uint4 *>(mul_pre + g), cur.row0 + row, cur.n0 + ncol, N, act,
                                      drop_p, seed, keep_scale, thresh16);
+#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 2   // tools/probes only: the epilogue without its global stores
+        asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(g));
+#else
         *reinterpret_cast<uint4 *>(dst + g) = v;
+#endif
       }
     }
     }
@@ -618,7 +622,17 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     };
     if (nxt.valid) stage(0, 0);
 
+#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 1   // tools/probes only: no epilogue at all (the accumulators stay live)
+    if (cur.valid) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
+    }
+    if (false) {
+#else
     if (cur.valid) {   // epilogue of the previous tile, staged through ring buffer 1
+#endif
       float bv[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -673,6 +687,201 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 8; ++j) mma(acc[i][j], wf[i], xf[j]);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    __syncthreads();   // every wave is done with both ring buffers
+    t = queue ? __builtin_amdgcn_readfirstlane(*s_next) : t + G;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent 256 x 352 NT kernel for outputs whose width is a multiple of 352 (the H = 704 family: fc2 forward and the fc1
+// data gradient at N = 704, the SSM input projection at N = 352).  On 256-wide tiles N = 704 is 256 + 256 + 192: the X
+// panel enters LDS three times and a quarter of the third tile's MFMAs multiply zero columns; two 352-wide tiles read X
+// twice and waste nothing - 17 % less L2 -> LDS fill (what bounds these GEMMs) and 8 % fewer MFMA slots
+// per output.  Same ring, DMA, store-wave and queue scheme as grouped_gemm_nt256p_k; what differs: 8 waves as 4 (M) x 2 (N),
+// wave tile 64 x 176 = 4 x 11 MFMA tiles (176 accumulator registers), a 76 KiB stage (32 KiB of X + 44 KiB of W), and the
+// epilogue in four rounds of 64 rows (one m-subtile of every wave; 768-byte staging rows, chunk XOR row as before).
+// Plain epilogue only (bias, conversion): the activation / dropout / second-output forms stay on the kernels above.
+// ------------------------------------------------------------------------------------------
+constexpr int BN5 = 352, W5_BYTES = BN5 * ROWB, BUF5 = TILE2_BYTES + W5_BYTES;   // 44 KiB of W, 76 KiB per stage
+constexpr int STG5_PITCH = 768;                                                   // 44 chunks of 16 B + 4 of slack for the swizzle
+
+template <typename TO>
+__global__ void __launch_bounds__(NT2)
+grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                      const int32_t *__restrict__ offsets, TO *__restrict__ C, int N, int K, int E, int n_tiles,
+                      int total_tiles, int solo, int *__restrict__ queue) {
+  typedef bf16_t T;
+  typedef bf16x8 frag;
+  static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
+  constexpr int BK = 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char *stg = smem + BUF5;                             // ring buffer 1 doubles as the C staging area
+  int32_t *s_off = reinterpret_cast<int32_t *>(smem + 2 * BUF5);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int G = gridDim.x;
+  for (int i = tid; i <= E; i += NT2) s_off[i] = offsets[i];
+  __syncthreads();
+
+  int mt_valid = 0;
+  for (int e = 0; e < E; ++e) mt_valid += (s_off[e + 1] - s_off[e] + BM2 - 1) / BM2;
+  const int n_valid = __builtin_amdgcn_readfirstlane(min(total_tiles, mt_valid * n_tiles));
+  const int nk = K / BK;   // K % 64 == 0 (launcher)
+
+  f32x4 acc[11][4];
+  PTile cur; cur.valid = 0; cur.e = 0; cur.rows_valid = 0; cur.n0 = 0; cur.cols_valid = 0; cur.row0 = 0;
+  int *s_next = s_off + 1026;
+  for (int t = blockIdx.x;;) {
+    PTile nxt; nxt.valid = 0;
+    if (t < n_valid) {
+      const int r = t / G, within = t - r * G, gr = min(G, n_valid - r * G);
+      const int tile = r * G + xcd_remap(within, gr);
+      const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
+      int accm = 0;
+      for (int e = 0; e < E; ++e) {
+        const int r0 = s_off[e], r1 = s_off[e + 1];
+        const int nt = (r1 - r0 + BM2 - 1) / BM2;
+        if (mt < accm + nt) {
+          const int m0 = (mt - accm) * BM2;
+          nxt.valid = 1;
+          nxt.e = __builtin_amdgcn_readfirstlane(e);
+          nxt.row0 = (int64_t)__builtin_amdgcn_readfirstlane(r0 + m0);
+          nxt.rows_valid = __builtin_amdgcn_readfirstlane(min(BM2, r1 - r0 - m0));
+          nxt.n0 = __builtin_amdgcn_readfirstlane(ntile * BN5);
+          nxt.cols_valid = __builtin_amdgcn_readfirstlane(min(BN5, N - ntile * BN5));
+          break;
+        }
+        accm += nt;
+      }
+    }
+    const int ldb = K * (int)sizeof(T);   // both operands: rows of K elements (ldw == K, launcher)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(X + nxt.row0 * K), 0, nxt.rows_valid * ldb, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T *>(W + ((int64_t)nxt.e * N + nxt.n0) * K), 0, nxt.cols_valid * ldb, 0x00020000);
+    const int voff0 = (lane >> 3) * ldb + (((lane & 7) ^ (lane >> 3)) << 4);
+    // a run of `cnt` consecutive pieces (8 rows x 128 B each) of one operand from piece p0 on; the lane offset (which carries the
+    // piece's row term - the hardware range check covers nothing else) is a running sum, pinned so that hipcc does not keep a
+    // table of all of a wave's offsets alive across the K loop (it spilled them)
+    auto run = [&](const __amdgpu_buffer_rsrc_t &rs, char *dst, int p0, int cnt, int kt) {
+      int v = voff0 + p0 * 8 * ldb;
+      asm volatile("" : "+v"(v));
+      char *d = dst + p0 * 1024;
+#pragma unroll
+      for (int j = 0; j < cnt; ++j) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(d + j * 1024), 16, v,
+                                                 kt * BK * (int)sizeof(T), 0, 0);
+        v += 8 * ldb;
+      }
+    };
+    // K step kt's operands (32 X pieces + 44 W pieces): by waves 0-3 alone while kt <= solo
+    auto stage = [&](int buf, int kt) {
+      char *xs = smem + buf * BUF5;
+      if (kt > solo) {
+        run(xrs, xs, wave * 4, 4, kt);
+        if (wave < 4) run(wrs, xs + TILE2_BYTES, wave * 6, 6, kt);
+        else run(wrs, xs + TILE2_BYTES, 24 + (wave - 4) * 5, 5, kt);
+      } else if (wave < 4) {
+        run(xrs, xs, wave * 8, 8, kt);
+        run(wrs, xs + TILE2_BYTES, wave * 11, 11, kt);
+      }
+    };
+    if (nxt.valid) stage(0, 0);
+
+#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 1   // tools/probes only: no epilogue at all (the accumulators stay live)
+    if (cur.valid) {
+#pragma unroll
+      for (int i = 0; i < 11; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
+    }
+    if (false) {
+#else
+    if (cur.valid) {   // epilogue of the previous tile: four rounds of 64 rows through ring buffer 1
+#endif
+      int frow_e = frow, tid_e = tid;   // (pinned: the staging addresses are not to live across the K loop)
+      asm volatile("" : "+v"(frow_e), "+v"(tid_e));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+          const int ncol = wn * 176 + i * 16 + fg * 4;            // column inside the tile (N % 4 == 0: valid in fours)
+          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (bias && ncol < cur.cols_valid) b = *reinterpret_cast<const float4 *>(bias + (int64_t)cur.e * N + cur.n0 + ncol);
+          const float bq[4] = {b.x, b.y, b.z, b.w};
+          uint32_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float a = acc[i][r][q];
+            asm volatile("" : "+v"(a));   // pins the conversion inside its round
+            o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(a + bq[q]));
+          }
+          const int srow = wm * 16 + frow_e, chunk = wn * 22 + i * 2 + (fg >> 1);
+          *reinterpret_cast<uint2 *>(stg + srow * STG5_PITCH + ((chunk ^ frow_e) << 4) + (fg & 1) * 8) =
+              make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        }
+        __syncthreads();
+        if (tid >= NT2 / 2) {   // store waves: 64 rows x 44 chunks
+#pragma unroll
+          for (int it = 0; it < 11; ++it) {
+            const int c4 = it * (NT2 / 2) + tid_e - NT2 / 2;
+            const int srow = c4 / 44, c = c4 - srow * 44;
+            const int row = (srow >> 4) * 64 + r * 16 + (srow & 15);
+            if (row < cur.rows_valid && c * 8 < cur.cols_valid) {
+              const uint4 v = *reinterpret_cast<const uint4 *>(stg + srow * STG5_PITCH + ((c ^ (srow & 15)) << 4));
+#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 2   // tools/probes only: the epilogue without its global stores
+              asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#else
+              *reinterpret_cast<uint4 *>(C + (cur.row0 + row) * N + cur.n0 + c * 8) = v;
+#endif
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (!nxt.valid) break;
+    cur = nxt;
+    if (queue && tid == 0) *s_next = ntq_next(queue, (int)(blockIdx.x & 7), G, n_valid);
+
+#pragma unroll
+    for (int i = 0; i < 11; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+      if (wave < 4 || kt > solo) wait_vmcnt<0>();
+      __syncthreads();
+      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      const char *xs = smem + (kt & 1) * BUF5, *ws = xs + TILE2_BYTES;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        // 176 accumulator registers leave room for the four X fragments and a few W fragments, not for all eleven: the W
+        // fragments are read three ahead of the MFMAs that consume them
+        frag xf[4], wf[11];
+        const int chunk = kk * 4 + fg;
+        auto wread = [&](int i) {
+          const int wrow = wn * 176 + i * 16 + frow;
+          return *reinterpret_cast<const frag *>(ws + wrow * ROWB + ((chunk ^ (wrow & 7)) << 4));
+        };
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int xrow = wm * 64 + j * 16 + frow;
+          xf[j] = *reinterpret_cast<const frag *>(xs + xrow * ROWB + ((chunk ^ (xrow & 7)) << 4));
+        }
+        wf[0] = wread(0); wf[1] = wread(1); wf[2] = wread(2);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+          if (i + 3 < 11) wf[i + 3] = wread(i + 3);
+          __builtin_amdgcn_sched_barrier(0);   // keeps the reads from being hoisted into one block of 44 live registers
+#pragma unroll
+          for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
+        }
         __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -1669,7 +1878,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop).
     // ... and for the SSM block's dense projections (one group, short K, HBM-bound): 92 vs 114 us at N=352/K=704, 72 vs 89
     // at N=704/K=176, 56 vs 64 at N=400/K=176; the N=176 data gradients stay on the 256-wide tile (63 vs 60 us)
-#ifdef NT_PROBE_FORCE   // tools/probes only: 1 = two-per-CU kernel wherever it applies, 2 = never
+#ifdef NT_PROBE_FORCE   // tools/probes only: 1 = two-per-CU kernel wherever it applies, 2 = never, 3 = never and no 352-wide tile
     const bool use2x = NT_PROBE_FORCE == 1;
     (void)act; (void)drop_p;
 #else
@@ -1679,6 +1888,28 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
                        // 67 us here, 77 on the 256 x 256 tile, 90 on the 128 x 128 kernel they used to fall to
                        (K <= 1024 && N >= 256 && N < 512);
 #endif
+    // outputs a multiple of 352 wide with a plain epilogue: the 256 x 352 tile (two passes over X for N = 704 instead of three)
+#if defined(NT_PROBE_FORCE) && NT_PROBE_FORCE == 3
+    const bool use352 = false;
+#else
+    const bool use352 = !use2x && act == APERTIS_ACT_NONE && drop_p <= 0.f && !pre_act && !mul_pre && N % BN5 == 0 && K % 64 == 0 &&
+                        ldw == K && K >= 128 && max_rows >= 4096 && E <= 1024;
+#endif
+    if (use352) {
+      const int nt5 = (int)(N / BN5);
+      const int64_t grid5 = (ceil_div64(max_rows, BM2) + E) * nt5;
+      if (grid5 < 0x7fffffffLL) {
+        const int gp = (int)std::min<int64_t>(grid5, device_cu_count());   // one persistent work-group per CU
+        const size_t lds5 = 2 * BUF5 + 4096 + 16;                           // ring + group offsets
+        constexpr int solo = 4;
+        if (tile_queue && hipMemsetAsync(tile_queue, 0, NTQ_INTS * sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
+        auto k5 = grouped_gemm_nt352p_k<TO>;
+        hipFuncSetAttribute((const void *)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);
+        hipLaunchKernelGGL(k5, dim3((unsigned)gp), dim3(NT2), lds5, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C,
+                           (int)N, (int)K, (int)E, nt5, (int)grid5, solo, (int *)tile_queue);
+        return apertis_check_launch();
+      }
+    }
     const bool ragged2x = K % 32 != 0;
     if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);

@@ -487,6 +487,39 @@ def test_grouped_gemm_nt_tile_queue_equals_static_walk(dev, sizes, N, K):
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("sizes,N,K,with_bias", [([9000, 4100, 0, 7000, 300, 257, 1, 5000], 704, 2816, True), ([4000, 3000], 352, 1088, False),
+                                                  ([4096], 1056, 2048, True), ([6000, 255, 256], 704, 128, False)])
+def test_grouped_gemm_nt_352_wide_tile(dev, sizes, N, K, with_bias):
+    """Outputs a multiple of 352 wide with a plain epilogue run on the persistent 256 x 352 tile (grouped_gemm_nt352p_k: fc2 forward
+    and the fc1 data gradient of the H = 704 family): against fp64 math on the same bf16 operands, ragged / empty / one-row groups,
+    every output element written exactly once (NaN prefill), static walk and tile queue bit-identical."""
+    from apertis_llm_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(N + K)
+    E, R = len(sizes), sum(sizes)
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), device=dev)
+    A = torch.randn(R, K, device=dev).bfloat16()
+    W = (torch.randn(E, N, K, device=dev) / K ** 0.5).bfloat16()
+    b = torch.randn(E, N, device=dev) if with_bias else None
+    queue = torch.zeros(512, device=dev, dtype=torch.int32)
+    outs = []
+    for q in (None, queue):
+        C = torch.full((R, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        args = (_lib.ptr(A), _lib.ptr(W), _lib.ptr(b) if with_bias else None, _lib.ptr(offs), _lib.ptr(C), None, None, R, N, K, K, E,
+                _lib.ACT_NONE, 0.0, 0, _lib.BF16, _lib.BF16)
+        rc = lib.apertis_grouped_gemm_nt(*args, _lib.stream_ptr()) if q is None else lib.apertis_grouped_gemm_nt_q(*args, _lib.ptr(q), _lib.stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.empty(R, N, dtype=torch.float64)
+    Ad, Wd = A.double().cpu(), W.double().cpu()
+    for e in range(E):
+        r0, r1 = int(offs[e]), int(offs[e + 1])
+        ref[r0:r1] = Ad[r0:r1] @ Wd[e].T + (b[e].double().cpu() if with_bias else 0.0)
+    _close(outs[0], ref, "out", rtol=1e-2, atol_scale=6e-3)
+
+
 def test_grouped_gemm_tn_is_deterministic(dev):
     torch.manual_seed(5)
     sizes = [4000, 3000, 5000, 2000]

@@ -26,6 +26,22 @@
 //       out_proj dgrad (176, 704) 85 / 87, floor 58: 54 % of the floor on the better kernel; L2 -> LDS fill (X re-read once per
 //       128-wide n-tile) and the per-tile prologue / epilogue latency with two work-groups per CU, not HBM, bound them.
 //   (e) config 3 (`gemm_probe.bin 16 256 1024`): DESIGN.md "Config 3".
+//   (f) where the persistent kernel's time goes (`PROBE_SHORT=1 gemm_probe.bin 40`, -DNT_PROBE_FORCE=2 with -DNT_PROBE_EPI=1: no
+//       epilogue, =2: epilogue without its global stores; B=40, cold caches, one box):
+//         256 x 256 tile   fc1 shape (N=2816, K=704): 1044-1057 us | no stores 876 | no epilogue 738
+//                          fc2 shape (N=704, K=2816):  818-849 us   | no stores 755 | no epilogue 708
+//         256 x 352 tile   fc1 shape: 1050-1064                     | no stores 954 | no epilogue 670
+//                          fc2 shape:  786-817                      | no stores 735 | no epilogue 690
+//       i.e. on the 256-wide tile the exposed epilogue is 310 us (7.2 us per tile: 3.3 staging + barriers, 4.0 store issue) of the
+//       short-K shape and 120 us of the long-K shape; a 128 KiB tile's stores issue at ~32 GB/s per CU whoever else is storing:
+//       starting the work-groups of an XCD in 2 / 4 / 8 phases of a tile period (a spin on the wall clock before the first tile)
+//       changed nothing (1056 / 1049 / 1085 us, 862 / 867 / 890) - it is not a chip-wide burst.  The K loops alone run at 53-60 %
+//       of the MFMA peak: 64 (76) KiB of LDS-DMA per 1.6 (2.0) us step and CU = ~10 TB/s chip-wide on either tile - the 352-wide
+//       tile moves 17 % fewer bytes per output and its K loop is 2.6 % (fc2) to 9 % (fc1 shape) shorter, not 17 %: the fill RATE a CU
+//       reaches with one stage in flight (between the guide's 8.6 TB/s from the Infinity Cache and 17-19 from L2), not the byte
+//       count, sets the step.  The two-per-CU kernel has 96 KiB in flight per CU and reaches 11.7 TB/s on 1.5x the bytes.
+//       Tile order on the 352-wide kernel, m fastest inside an XCD's 32 tiles (one W panel per XCD, X shared through the Infinity
+//       Cache) against n fastest (X shared in L2): 814-819 vs 798-802 us (fc2), 1106 vs 1053 (fc1 shape) - n fastest kept.
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
 #include <vector>
@@ -80,6 +96,11 @@ int main(int argc, char **argv) {
     return 0;
   }
   const double fl = 2.0 * rows * H * I;
+  if (getenv("PROBE_SHORT")) {   // the two plain shapes only (epilogue probes: -DNT_PROBE_FORCE=2 -DNT_PROBE_EPI=1|2)
+    timeit("fc1 fwd shape (N=I, K=H), plain (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+    timeit("fc2 fwd (N=H, K=I), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+    return 0;
+  }
   timeit("fc1 fwd: GELU + dropout + pre-activation out", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc1 fwd shape, plain (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
   timeit("fc1 shape: + pre-activation out only", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
