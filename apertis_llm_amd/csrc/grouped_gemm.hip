@@ -666,7 +666,9 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
       // must not wait there (its output stores are still draining)
       if (wave < 4 || kt > solo) wait_vmcnt<0>();
       __syncthreads();
+#ifndef NT_PROBE_NODMA   // (tools/probes only: the K loop on stale LDS contents - what the steps cost without their fills)
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#endif
       const char *xs = smem + (kt & 1) * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -856,7 +858,9 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     for (int kt = 0; kt < nk; ++kt) {
       if (wave < 4 || kt > solo) wait_vmcnt<0>();
       __syncthreads();
+#ifndef NT_PROBE_NODMA   // (tools/probes only: the K loop on stale LDS contents - what the steps cost without their fills)
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+#endif
       const char *xs = smem + (kt & 1) * BUF5, *ws = xs + TILE2_BYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {

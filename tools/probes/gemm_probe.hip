@@ -42,6 +42,16 @@
 //       count, sets the step.  The two-per-CU kernel has 96 KiB in flight per CU and reaches 11.7 TB/s on 1.5x the bytes.
 //       Tile order on the 352-wide kernel, m fastest inside an XCD's 32 tiles (one W panel per XCD, X shared through the Infinity
 //       Cache) against n fastest (X shared in L2): 814-819 vs 798-802 us (fc2), 1106 vs 1053 (fc1 shape) - n fastest kept.
+//   (g) what the K steps cost without their fills (-DNT_PROBE_EPI=1 -DNT_PROBE_NODMA: the K loop on stale LDS contents): fc2 shape
+//       529 us (256-wide; 699 with the fills) and 496 us (352-wide; 683) - LDS reads, MFMAs and the barrier alone are 61-65 % of
+//       the MFMA peak, the fills add 0.4-0.5 us to every 64-deep step although they are asynchronous: a stage issued at the top of
+//       step k must have landed by the top of step k+1.  Tried on that evidence: the 352-wide kernel with a four-slot ring of
+//       32-deep stages (38 KiB each, stage s+3 issued at the top of sub-step s: 114 KiB in flight per CU instead of 76; LDS image,
+//       16-row x 64-byte pieces and in-order `vmcnt` bookkeeping of the two-per-CU kernel; correct in all tests).  SLOWER:
+//       1278-1304 us against 786-817 (fc2 shape), 1353-1382 against 1050 (fc1 shape); without its fills 651 us (the doubled
+//       barriers cost ~60 us) - the fills themselves are what is slow in that form: pieces of 16 rows x 64 B (half a cache line
+//       per row and request) fill at about half the rate of 8 rows x 128 B from these operands.  A 64-deep stage cannot be
+//       triple-buffered in 160 KiB at this tile size (3 x 76 KiB).  Removed.
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
 #include <vector>
