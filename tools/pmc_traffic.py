@@ -12,6 +12,7 @@ import sys
 out = sys.argv[1]
 ENTRY = {  # kernel-name fragment -> C-ABI entry point
     "grouped_gemm_nt256p_k": "apertis_grouped_gemm_nt",
+    "grouped_gemm_nt352p_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_nt2x_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_tn3_k": "apertis_grouped_gemm_tn", "tn3_fold_k": "apertis_grouped_gemm_tn",
     "grouped_gemm_tn2_k": "apertis_grouped_gemm_tn",
