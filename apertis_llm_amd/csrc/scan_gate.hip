@@ -483,6 +483,35 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
   }
 }
 
+// N consecutive fp32 of an LDS tile (N a power of two, the address aligned to 4*N bytes) as 16- / 8- / 4-byte accesses
+template <int N> struct lds_vec {
+  static_assert(N == 1 || N == 2 || N % 4 == 0, "piece widths are powers of two");
+  __device__ static __forceinline__ void load(const float *p, float (&v)[N]) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < N / 4; ++k) {
+        const float4 t = reinterpret_cast<const float4 *>(p)[k];
+        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+      }
+    } else if constexpr (N == 2) {
+      const float2 t = *reinterpret_cast<const float2 *>(p);
+      v[0] = t.x; v[1] = t.y;
+    } else {
+      v[0] = p[0];
+    }
+  }
+  __device__ static __forceinline__ void store(float *p, const float (&v)[N]) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < N / 4; ++k) reinterpret_cast<float4 *>(p)[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else if constexpr (N == 2) {
+      *reinterpret_cast<float2 *>(p) = make_float2(v[0], v[1]);
+    } else {
+      p[0] = v[0];
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // backward.  dv = dout*silu(z) (= d/dy) is formed row-major from the 16-byte pieces of dout and z as they arrive and
 // lives in an fp32 LDS tile; the column walk turns that tile into y in place; dz = dout*silu'(z)*(y + D*xc) and
@@ -712,21 +741,26 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
   for (int it = 0; it < TR::ITERS; ++it) {
     {
       const int row = TR::row0(tid) + it * TR::RSTEP, cb = TR::cb0(tid), e0 = cb / (int)sizeof(T);
-      float gv[EPC], zv[EPC], xv[EPC], oz[EPC], ox[EPC];
+      float gv[EPC], zv[EPC], xv[EPC], oz[EPC], ox[EPC], yv[EPC], dc[EPC], pv[EPC];
       PC::unpack(rg.r[it], gv);
       PC::unpack(rz.r[it], zv);
       PC::unpack(rx.r[it], xv);
+      // the thread's EPC consecutive fp32 of the y tile, the D table and the dv*xc tile move as whole vectors: one element
+      // at a time the lanes' 4*EPC-byte stride is an EPC-way bank conflict on every access (8-way at 16-byte bf16 pieces)
+      lds_vec<EPC>::load(dvt + row * CWC + e0, yv);
+      lds_vec<EPC>::load(dtab + e0, dc);
 #pragma unroll
       for (int k = 0; k < EPC; ++k) {
         float f, df;
         silu_both(zv[k], f, df);
-        const float dv = gv[k] * f, dcol = dtab[e0 + k];
+        const float dv = gv[k] * f, dcol = dc[k];
         const float dx = dcol * xv[k];
-        const float v = dvt[row * CWC + e0 + k] + dx;
+        const float v = yv[k] + dx;
         oz[k] = gv[k] * df * v;
         ox[k] = dv * dcol;
-        pt[row * CWC + e0 + k] = dv * xv[k];               // zero for rows / channels outside the tensor (staged zeros)
+        pv[k] = dv * xv[k];                                 // zero for rows / channels outside the tensor (staged zeros)
       }
+      lds_vec<EPC>::store(pt + row * CWC + e0, pv);
       if (row < rows_valid && cb < vb) {
         *reinterpret_cast<typename PC::V *>(zg + (int64_t)row * dz_rs * sizeof(T) + cb) = PC::pack(oz);
         *reinterpret_cast<typename PC::V *>(xg + (int64_t)row * dxc_rs * sizeof(T) + cb) = PC::pack(ox);
