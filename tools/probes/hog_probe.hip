@@ -4,6 +4,9 @@
 // the wall clock for `hog_us`; a GEMM work-group (128+ KiB of LDS, a full register file) cannot share a CU with it.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/probes/hog_probe.hip -o tools/probes/hog_probe.bin
 // run:   hog_probe.bin [B=32] [nhog=32] [hog_us=4000]
+// Also measured with it (B=40, no hog): the weight-gradient kernel with 32 work-groups per (problem, expert) group instead of the
+// CUs' equal share of 16 (one round of 32 tiles + one tile split 32 ways, the grid in two dispatch waves; per K step 16
+// operand panels instead of 20 would reach L2 from HBM): 1928-1939 us against 1771-1789 - slower, not kept.
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
 #include <vector>
