@@ -115,6 +115,27 @@ __device__ __forceinline__ void gelu_both_fast(float x, float &g, float &dg) {
   dg = fmaf(x * 0.3989422804014327f, e, x >= 0.f ? 1.f - q : q);
 }
 
+// the same, two elements per instruction where the packed fp32 pipe has one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
+// IEEE operation per element, in the same order - bit-identical to gelu_both_fast); rcp, exp2, max and the select stay per element
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float v) { return (v2f){v, v}; }
+__device__ __forceinline__ void gelu_both_fast2(v2f x, v2f &g, v2f &dg) {
+  const v2f ax = {fabsf(x.x), fabsf(x.y)};
+  const v2f ta = pk_fma(splat2(0.3275911f * 0.70710678118654752f), ax, splat2(1.f));
+  const v2f t = {__builtin_amdgcn_rcpf(ta.x), __builtin_amdgcn_rcpf(ta.y)};
+  v2f p = pk_fma(splat2(0.5f * 1.061405429f), t, splat2(0.5f * -1.453152027f));
+  p = pk_fma(p, t, splat2(0.5f * 1.421413741f));
+  p = pk_fma(p, t, splat2(0.5f * -0.284496736f));
+  p = pk_fma(p, t, splat2(0.5f * 0.254829592f));
+  const v2f ea = (x * x) * splat2(-0.5f * LOG2E_F);
+  const v2f e = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
+  const v2f q = (p * t) * e;
+  g = pk_fma(-ax, q, (v2f){fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)});
+  const v2f omq = splat2(1.f) - q;
+  dg = pk_fma(x * splat2(0.3989422804014327f), e, (v2f){x.x >= 0.f ? omq.x : q.x, x.y >= 0.f ? omq.y : q.y});
+}
+
 template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
@@ -956,12 +977,18 @@ __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const fl
         if (DROP) drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
         uint32_t oh[4], og[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float x = to_f32(from_f32<TO>(acc[i][j][q] + bv[i][q]));   // the pre-activation as the other form stores it
-          float hv, gv;
-          gelu_both_fast(x, hv, gv);
-          oh[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? hv * keep_scale : 0.f));
-          og[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? gv * keep_scale : 0.f));
+        for (int q = 0; q < 4; q += 2) {   // two elements per packed instruction
+          const v2f pre = (v2f){acc[i][j][q], acc[i][j][q + 1]} + (v2f){bv[i][q], bv[i][q + 1]};
+          // the pre-activation as the other form stores it
+          const v2f x = {to_f32(from_f32<TO>(pre.x)), to_f32(from_f32<TO>(pre.y))};
+          v2f hv, gv;
+          gelu_both_fast2(x, hv, gv);
+          hv = hv * splat2(keep_scale);
+          gv = gv * splat2(keep_scale);
+          oh[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? hv.x : 0.f));
+          oh[q + 1] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q + 1] ? hv.y : 0.f));
+          og[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? gv.x : 0.f));
+          og[q + 1] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q + 1] ? gv.y : 0.f));
         }
         const int off = sr * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8;
         *reinterpret_cast<uint2 *>(stg + off) = make_uint2(oh[0] | (oh[1] << 16), oh[2] | (oh[3] << 16));
