@@ -1914,10 +1914,11 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     (void)act; (void)drop_p;
 #else
     const bool use2x = ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
-                       (E == 1 && K <= 1024 && N >= 256) ||
+                       // (one 352-wide n-tile reads X once: 114 vs 121 us on the SSM input projection, N = 352, K = 704)
+                       (E == 1 && K <= 1024 && N >= 256 && !(N == BN5 && K % 64 == 0 && ldw == K)) ||
                        // narrow expert outputs (the H = 256 family's fc2 forward / fc1 data gradient, N = 256, K = 1024):
                        // 67 us here, 77 on the 256 x 256 tile, 90 on the 128 x 128 kernel they used to fall to
-                       (K <= 1024 && N >= 256 && N < 512);
+                       (E > 1 && K <= 1024 && N >= 256 && N < 512);
 #endif
     // outputs a multiple of 352 wide with a plain epilogue: the 256 x 352 tile (two passes over X for N = 704 instead of three)
 #if defined(NT_PROBE_FORCE) && NT_PROBE_FORCE == 3
