@@ -61,9 +61,9 @@ int main(int argc, char **argv) {
   };
   printf("B=%d rows=%ld; hog = %d work-groups (one CU each) for %.0f us\n", B, (long)rows, nhog, hog_us);
   for (int hog = 0; hog < 2; ++hog) {
-    timeit("NT persistent 256x256 (fc2 fwd N=704 K=2816), static walk", hog, [&](hipStream_t s) {
+    timeit("NT persistent 256x352 (fc2 fwd N=704 K=2816), static walk", hog, [&](hipStream_t s) {
       return apertis_grouped_gemm_nt_q(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr, s); });
-    timeit("NT persistent 256x256 (fc2 fwd N=704 K=2816), tile queue", hog, [&](hipStream_t s) {
+    timeit("NT persistent 256x352 (fc2 fwd N=704 K=2816), tile queue", hog, [&](hipStream_t s) {
       return apertis_grouped_gemm_nt_q(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, queue, s); });
     timeit("NT two-per-CU (fc1 fwd N=2816 K=704, GELU+dropout+pre)", hog, [&](hipStream_t s) {
       return apertis_grouped_gemm_nt_q(x, w2t, nullptr, offs, h, dpre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr, s); });
