@@ -38,6 +38,14 @@ template <typename T> struct frag_t;
 template <> struct frag_t<bf16_t> { typedef bf16x8 type; };
 template <> struct frag_t<float> { typedef f32x4 type; };
 
+// 16-byte output store of the epilogues: non-temporal.  The outputs of a layer's GEMMs are 0.3 - 1.2 GB each; written through
+// the caches they only displace what the next kernel reads (+1 % on the step by themselves, A/B inside one gpurun call; the
+// row kernels' stores are non-temporal for the same reason, moe_routing.hip)
+__device__ __forceinline__ void out_store16(void *p, uint4 v) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  u4 o = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(o, reinterpret_cast<u4 *>(p));
+}
 __device__ __forceinline__ void mma(f32x4 &acc, const bf16x8 &a, const bf16x8 &b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
 }
@@ -352,7 +360,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
         if (mulp)
           v = actbwd_chunk<TO, sizeof(T) == 2>(v, *reinterpret_cast<const uint4 *>(mulp + g), tc.row0 + row, n0 + ncol,
                                                 N, act, drop_p, seed, keep_scale, thresh16);
-        *reinterpret_cast<uint4 *>(dst + g) = v;
+        out_store16(dst + g, v);
       }
     }
     __syncthreads();
@@ -534,7 +542,7 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
 #if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 2   // tools/probes only: the epilogue without its global stores
         asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(g));
 #else
-        *reinterpret_cast<uint4 *>(dst + g) = v;
+        out_store16(dst + g, v);
 #endif
       }
     }
@@ -860,7 +868,7 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
 #if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 2   // tools/probes only: the epilogue without its global stores
               asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
 #else
-              *reinterpret_cast<uint4 *>(C + (cur.row0 + row) * N + cur.n0 + c * 8) = v;
+              out_store16(C + (cur.row0 + row) * N + cur.n0 + c * 8, v);
 #endif
             }
           }
@@ -1002,8 +1010,8 @@ __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const fl
       const int row = (sr >> 6) * 128 + half * 64 + (sr & 63);
       if (row < rows_valid && c * 8 < cols_valid) {
         const int off = sr * 256 + ((c ^ (sr & 15)) << 4);
-        *reinterpret_cast<uint4 *>(dst_h + (row0 + row) * N + n0 + c * 8) = *reinterpret_cast<const uint4 *>(stg + off);
-        *reinterpret_cast<uint4 *>(dst_g + (row0 + row) * N + n0 + c * 8) = *reinterpret_cast<const uint4 *>(stg_g + off);
+        out_store16(dst_h + (row0 + row) * N + n0 + c * 8, *reinterpret_cast<const uint4 *>(stg + off));
+        out_store16(dst_g + (row0 + row) * N + n0 + c * 8, *reinterpret_cast<const uint4 *>(stg_g + off));
       }
     }
     lds_barrier();
@@ -1047,8 +1055,7 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
       const int c4 = it * NT3 + tid;
       const int row = c4 >> 4, c = c4 & 15;
       if (row < rows_valid && c * 8 < cols_valid)
-        *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
-            *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
+        out_store16(dst + (row0 + row) * N + n0 + c * 8, *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4)));
     }
   } else {
     // dgrad fusion: the tile was staged as plain dh; each 16-byte chunk becomes dpre on the way out with the
@@ -1071,10 +1078,10 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
         if (row < rows_valid && c * 8 < cols_valid) {
           const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
           if constexpr (MULPRE == 2)
-            *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) = mul_chunk_bf16(v, pc[u]);
+            out_store16(dst + (row0 + row) * N + n0 + c * 8, mul_chunk_bf16(v, pc[u]));
           else
-            *reinterpret_cast<uint4 *>(dst + (row0 + row) * N + n0 + c * 8) =
-                actbwd_chunk<TO, true, ACT, DROP>(v, pc[u], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16);
+            out_store16(dst + (row0 + row) * N + n0 + c * 8,
+                        actbwd_chunk<TO, true, ACT, DROP>(v, pc[u], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16));
         }
       }
     };

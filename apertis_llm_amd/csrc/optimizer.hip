@@ -84,6 +84,16 @@ __device__ __forceinline__ void adamw_one(float &p, float g, float &m, float &v,
   p -= a.step_size * (m / denom);                   // step_size = lr / (1 - beta1^step)
 }
 
+typedef __attribute__((ext_vector_type(4))) float opt_f4;
+__device__ __forceinline__ float4 ntload4(const float *p) {
+  const opt_f4 t = __builtin_nontemporal_load(reinterpret_cast<const opt_f4 *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void ntstore4(float *p, float4 v) {
+  opt_f4 o = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(o, reinterpret_cast<opt_f4 *>(p));
+}
+
 __global__ void __launch_bounds__(OPT_NT)
 adamw_step_k(const OptTensor *__restrict__ tensors, const int32_t *__restrict__ chunk_tensor,
              const int32_t *__restrict__ chunk_index, AdamArgs a, const float *__restrict__ coef_ptr) {
@@ -98,11 +108,12 @@ adamw_step_k(const OptTensor *__restrict__ tensors, const int32_t *__restrict__ 
   if (vec) {
     const int64_t n4 = n >> 2;
     for (int64_t i = threadIdx.x; i < n4; i += OPT_NT) {
-      float4 pp = reinterpret_cast<float4 *>(p)[i], mm = reinterpret_cast<float4 *>(m)[i], vv = reinterpret_cast<float4 *>(v)[i];
-      const float4 gg = reinterpret_cast<const float4 *>(g)[i];
+      // every element is read once and written once per step: non-temporal both ways (nothing here is worth a cache line)
+      float4 pp = ntload4(p + 4 * i), mm = ntload4(m + 4 * i), vv = ntload4(v + 4 * i);
+      const float4 gg = ntload4(g + 4 * i);
       adamw_one(pp.x, gg.x, mm.x, vv.x, a, coef); adamw_one(pp.y, gg.y, mm.y, vv.y, a, coef);
       adamw_one(pp.z, gg.z, mm.z, vv.z, a, coef); adamw_one(pp.w, gg.w, mm.w, vv.w, a, coef);
-      reinterpret_cast<float4 *>(p)[i] = pp; reinterpret_cast<float4 *>(m)[i] = mm; reinterpret_cast<float4 *>(v)[i] = vv;
+      ntstore4(p + 4 * i, pp); ntstore4(m + 4 * i, mm); ntstore4(v + 4 * i, vv);
     }
     done = n4 << 2;
   }

@@ -37,6 +37,20 @@ template <> struct vec_bytes<8> { typedef uint2 type; };
 template <> struct vec_bytes<4> { typedef uint32_t type; };
 template <> struct vec_bytes<2> { typedef uint16_t type; };
 
+// streaming output store of VB bytes: non-temporal (these outputs are larger than what the caches can hand to their consumer;
+// written through them they displace what the next kernels read - measured on the whole step)
+template <int VB> __device__ __forceinline__ void nt_store(void *p, const typename vec_bytes<VB>::type &v) {
+  if constexpr (VB == 16) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    __builtin_nontemporal_store(__builtin_bit_cast(u4, v), reinterpret_cast<u4 *>(p));
+  } else if constexpr (VB == 8) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    __builtin_nontemporal_store(__builtin_bit_cast(u2, v), reinterpret_cast<u2 *>(p));
+  } else {
+    __builtin_nontemporal_store(v, reinterpret_cast<typename vec_bytes<VB>::type *>(p));
+  }
+}
+
 template <int VB> __device__ __forceinline__ typename vec_bytes<VB>::type zero_vec() {
   typename vec_bytes<VB>::type z;
   __builtin_memset(&z, 0, VB);

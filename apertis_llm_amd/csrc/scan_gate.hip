@@ -101,7 +101,7 @@ struct TileRegs {
     char *p = g + (int64_t)r0 * rsb + c0;
 #pragma unroll
     for (int q = 0; q < ITERS; ++q)
-      if (r0 + q * RSTEP < rows_valid) *reinterpret_cast<V *>(p + (int64_t)(q * RSTEP) * rsb) = *reinterpret_cast<const V *>(l + q * RSTEP * ROWB);
+      if (r0 + q * RSTEP < rows_valid) nt_store<VB>(p + (int64_t)(q * RSTEP) * rsb, *reinterpret_cast<const V *>(l + q * RSTEP * ROWB));
   }
 };
 
@@ -475,7 +475,7 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
             const float v = yk[k] + dx;
             o[k] = v * silu_g(zv[k]);
           }
-          *reinterpret_cast<typename PC::V *>(og + (int64_t)row * out_rs * sizeof(T) + cb) = PC::pack(o);
+          nt_store<VB>(og + (int64_t)row * out_rs * sizeof(T) + cb, PC::pack(o));
         }
       }
     }
@@ -762,8 +762,8 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
       }
       lds_vec<EPC>::store(pt + row * CWC + e0, pv);
       if (row < rows_valid && cb < vb) {
-        *reinterpret_cast<typename PC::V *>(zg + (int64_t)row * dz_rs * sizeof(T) + cb) = PC::pack(oz);
-        *reinterpret_cast<typename PC::V *>(xg + (int64_t)row * dxc_rs * sizeof(T) + cb) = PC::pack(ox);
+        nt_store<VB>(zg + (int64_t)row * dz_rs * sizeof(T) + cb, PC::pack(oz));
+        nt_store<VB>(xg + (int64_t)row * dxc_rs * sizeof(T) + cb, PC::pack(ox));
       }
     }
     __builtin_amdgcn_sched_barrier(0);
