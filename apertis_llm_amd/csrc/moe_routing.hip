@@ -414,35 +414,37 @@ template <> __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t *p) {
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
                      __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
-// Row stores are NON-TEMPORAL by default: every tensor these kernels write is 0.2 - 0.5 GB, larger than what the caches can
-// hand to the consumer, and written through them it displaces what the NEXT kernels read - with `nt` stores in the row
-// kernels the expert GEMMs that follow them run 1.5 - 2.5 % faster and the step 1.6 % (A/B inside one gpurun call).  The
-// LayerNorm backward and the boundary + router forward measured 2 % slower with them and keep plain stores (NT = false).
-template <typename T, bool NT = true> struct Store4;
-template <bool NT> struct Store4<float, NT> {
-  static __device__ __forceinline__ void st(float *p, float4 v) {
-    if constexpr (NT) {
-      typedef __attribute__((ext_vector_type(4))) float f4;
-      f4 o = {v.x, v.y, v.z, v.w};
-      __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p));
-    } else {
-      *reinterpret_cast<float4 *>(p) = v;
-    }
-  }
-};
-template <bool NT> struct Store4<bf16_t, NT> {
-  static __device__ __forceinline__ void st(bf16_t *p, float4 v) {
-    typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
-    bf4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-    if constexpr (NT) {
-      typedef __attribute__((ext_vector_type(2))) unsigned u2;
-      __builtin_nontemporal_store(__builtin_bit_cast(u2, o), reinterpret_cast<u2 *>(p));
-    } else {
-      *reinterpret_cast<bf4 *>(p) = o;
-    }
-  }
-};
-template <typename T, bool NT = true> __device__ __forceinline__ void store4(T *p, float4 v) { Store4<T, NT>::st(p, v); }
+// Streaming row data, read once and written once: NON-TEMPORAL both ways.  Every tensor these kernels read or write is 0.2 - 0.5
+// GB, larger than what the caches can hand from producer to consumer; moved through them it displaces what the next kernels
+// read.  Measured on the whole step (A/B inside one gpurun call, sums of kernel times): `nt` stores in the row kernels alone
+// -7 ms per step, most of it in the expert GEMMs that FOLLOW them (they run 1.5 - 2.5 % faster); with the GEMM epilogues',
+// the scan outputs' and AdamW's accesses non-temporal as well 479.6 -> 468.9 ms.  Which kernel gains depends on its
+// neighbours (the LayerNorm backward is 2 % slower with nt stores, the combine backward behind it 15 % faster), so the
+// choice was made on the step, not per kernel.  The affine vectors (gamma, beta, W) stay on plain loads: they are re-read.
+template <typename T> __device__ __forceinline__ float4 load4s(const T *p);
+template <> __device__ __forceinline__ float4 load4s<float>(const float *p) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+template <> __device__ __forceinline__ float4 load4s<bf16_t>(const bf16_t *p) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  const u2 u = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p));
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                     __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
+template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  f4 o = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p));
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v) {
+  typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  bf4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+  __builtin_nontemporal_store(__builtin_bit_cast(u2, o), reinterpret_cast<u2 *>(p));
+}
 
 // Sum over the 64 lanes, the same value in every lane.  DPP adds inside the rows of 16 (quad swaps, half-row and row
 // mirrors), row broadcasts across them, one v_readlane of lane 63: seven VALU instructions.  As six __shfl_xor steps
@@ -491,7 +493,7 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     int c = (lane + 64 * i) * 4;
-    v[i] = c < H ? load4<TX>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[i] = c < H ? load4s<TX>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   }
   const float mean = wave_sum(sum) * inv_h(H);
@@ -578,7 +580,7 @@ gather_ln_bwd2_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         int c = (lane + 64 * i) * 4;
-        if (c < H) { xv[q][i] = load4<TX>(src + c); dv[q][i] = load4<TG>(dxg + rr * H + c); }
+        if (c < H) { xv[q][i] = load4s<TX>(src + c); dv[q][i] = load4s<TG>(dxg + rr * H + c); }
         else { xv[q][i] = make_float4(0, 0, 0, 0); dv[q][i] = make_float4(0, 0, 0, 0); }
       }
     }
@@ -703,7 +705,7 @@ combine_fwd_k(const TY *__restrict__ yr, const int32_t *__restrict__ slot_of, co
     for (int i = 0; i < IT; ++i) {
       int c = (lane + 64 * i) * 4;
       if (c < H) {
-        float4 v = load4<TY>(src + c);
+        float4 v = load4s<TY>(src + c);
         // separate multiply then add, like `expert_output * weights` followed by index_add_
         acc[i].x += v.x * wv; acc[i].y += v.y * wv; acc[i].z += v.z * wv; acc[i].w += v.w * wv;
       }
@@ -739,7 +741,7 @@ combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int3
   for (int i = 0; i < IT; ++i) {
     int c = (lane + 64 * i) * 4;
     if (c < H) {
-      float4 d = load4<TD>(dsrc + c), y = load4<TY>(ysrc + c);
+      float4 d = load4<TD>(dsrc + c), y = load4s<TY>(ysrc + c);
       dot += (d.x * y.x + d.y * y.y) + (d.z * y.z + d.w * y.w);
       store4<TY>(dst + c, make_float4(d.x * wv, d.y * wv, d.z * wv, d.w * wv));
     }
@@ -786,14 +788,14 @@ dropadd_ln_fwd_k(const TO *__restrict__ blk, const int32_t *__restrict__ slot_of
           const int slot = slot_of[r * K + k];
           if (slot < 0) continue;
           const float wv = wk[r * K + k];
-          const float4 v = load4<TO>(blk + (int64_t)slot * H + c);
+          const float4 v = load4s<TO>(blk + (int64_t)slot * H + c);
           acc.x += v.x * wv; acc.y += v.y * wv; acc.z += v.z * wv; acc.w += v.w * wv;
         }
         a = make_float4(to_f32(from_f32<TO>(acc.x)), to_f32(from_f32<TO>(acc.y)), to_f32(from_f32<TO>(acc.z)), to_f32(from_f32<TO>(acc.w)));
       } else {
-        a = load4<TO>(blk + r * H + c);
+        a = load4s<TO>(blk + r * H + c);
       }
-      const float4 rr = load4<TX>(res + r * H + c);
+      const float4 rr = load4s<TX>(res + r * H + c);
       float e[4] = {a.x, a.y, a.z, a.w};
       if (drop_p > 0.f) {
         bool keep[4];
@@ -863,7 +865,7 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         int c = (lane + 64 * i) * 4;
-        if (c < H) { xv[q][i] = load4<TX>(x + rr * H + c); dv[q][i] = load4<TG>(dy + rr * H + c); }
+        if (c < H) { xv[q][i] = load4s<TX>(x + rr * H + c); dv[q][i] = load4s<TG>(dy + rr * H + c); }
         else { xv[q][i] = make_float4(0, 0, 0, 0); dv[q][i] = make_float4(0, 0, 0, 0); }
       }
     }
@@ -894,10 +896,10 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
         if (c < H) {
           // dres: the gradient arriving on the residual branch that bypasses this norm (pre-norm block
           // y = x + f(LN(x))): added here instead of in a separate full-width pass
-          const float4 rr = dres ? load4<TX>(dres + (r + q) * H + c) : make_float4(0, 0, 0, 0);
+          const float4 rr = dres ? load4s<TX>(dres + (r + q) * H + c) : make_float4(0, 0, 0, 0);
           const float4 dt = make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2) + rr.x, rstd[q] * (gd[i].y - m1 - xh[i].y * m2) + rr.y,
                                         rstd[q] * (gd[i].z - m1 - xh[i].z * m2) + rr.z, rstd[q] * (gd[i].w - m1 - xh[i].w * m2) + rr.w);
-          store4<TX, false>(dst + c, dt);
+          store4<TX>(dst + c, dt);
           if (dblk) {
             // block boundary, backward: x was res + dropout(blk), so the block output's gradient is the masked
             // copy of this row's total gradient (what apertis_dropout_bwd computes in a pass of its own)
@@ -911,7 +913,7 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
 #pragma unroll
               for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
             }
-            store4<TG, false>(dblk + (r + q) * H + c, make_float4(e[0], e[1], e[2], e[3]));
+            store4<TG>(dblk + (r + q) * H + c, make_float4(e[0], e[1], e[2], e[3]));
           }
         }
       }
@@ -1001,7 +1003,7 @@ skinny_fwd_k(const TX *__restrict__ x, const float *__restrict__ W, const float 
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       int c = (lane + 64 * i) * 4;
-      xv[i] = c < K ? load4<TX>(x + r * K + c) : make_float4(0, 0, 0, 0);
+      xv[i] = c < K ? load4s<TX>(x + r * K + c) : make_float4(0, 0, 0, 0);
     }
     float acc[NN];
 #pragma unroll
@@ -1052,7 +1054,7 @@ skinny_bwd_k(const TX *__restrict__ x, const float *__restrict__ W, const float 
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       int c = (lane + 64 * i) * 4;
-      xv[i] = c < K ? load4<TX>(x + r * K + c) : make_float4(0, 0, 0, 0);
+      xv[i] = c < K ? load4s<TX>(x + r * K + c) : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
@@ -1370,6 +1372,17 @@ gate_noise_fold_k(const float *__restrict__ npart, const float *__restrict__ w_n
 template <typename TX> struct raw4;
 template <> struct raw4<float> { typedef float4 type; };
 template <> struct raw4<bf16_t> { typedef uint2 type; };
+// a row chunk in its storage form, streamed (non-temporal, see load4s)
+__device__ __forceinline__ float4 raw_load(const float *p) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint2 raw_load(const bf16_t *p) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p));
+  return make_uint2(t.x, t.y);
+}
 __device__ __forceinline__ float4 raw_to_f4(const float4 &v) { return v; }
 __device__ __forceinline__ float4 raw_to_f4(const uint2 &u) {
   return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
@@ -1402,7 +1415,7 @@ router_fwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const fl
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int c = (lane + 64 * i) * 4;
-      o[i] = (c < H && r < T) ? *reinterpret_cast<const raw_t *>(x + r * H + c) : raw_t{};
+      o[i] = (c < H && r < T) ? raw_load(x + r * H + c) : raw_t{};
     }
   };
   if (wave < T) fetch(cur, wave);
@@ -1514,7 +1527,7 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
           for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
         }
         v[i] = make_float4(rr.x + e[0], rr.y + e[1], rr.z + e[2], rr.w + e[3]);
-        store4<TX, false>(y + r * H + c, v[i]);
+        store4<TX>(y + r * H + c, v[i]);
         v[i] = make_float4(to_f32(from_f32<TX>(v[i].x)), to_f32(from_f32<TX>(v[i].y)), to_f32(from_f32<TX>(v[i].z)), to_f32(from_f32<TX>(v[i].w)));
         sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       } else {
@@ -1541,7 +1554,7 @@ dropadd_ln_router_fwd_k(const TO *__restrict__ blk, const TX *__restrict__ res, 
         const float4 g4 = sG[lane + 64 * i], b4 = sB[lane + 64 * i];
         const float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
                                      (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
-        store4<TO, false>(xn + r * H + c, o);
+        store4<TO>(xn + r * H + c, o);
         v[i] = make_float4(to_f32(from_f32<TO>(o.x)), to_f32(from_f32<TO>(o.y)), to_f32(from_f32<TO>(o.z)), to_f32(from_f32<TO>(o.w)));
         rsum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
       }
@@ -1648,11 +1661,11 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
     for (int i = 0; i < IT; ++i) {
       const int c = (lane + 64 * i) * 4;
       const bool ok = c < H && r < T;
-      xo[i] = ok ? *reinterpret_cast<const raw_t *>(x + r * H + c) : raw_t{};
-      ro[i] = (MODE != 2 && ok && dres) ? *reinterpret_cast<const raw_t *>(dres + r * H + c) : raw_t{};
+      xo[i] = ok ? raw_load(x + r * H + c) : raw_t{};
+      ro[i] = (MODE != 2 && ok && dres) ? raw_load(dres + r * H + c) : raw_t{};
 #pragma unroll
       for (int k = 0; k < 2; ++k)
-        go[k][i] = (gath && ok && so[k] >= 0) ? *reinterpret_cast<const raw_t *>(grows + (int64_t)so[k] * H + c) : raw_t{};
+        go[k][i] = (gath && ok && so[k] >= 0) ? raw_load(grows + (int64_t)so[k] * H + c) : raw_t{};
     }
   };
   // the row's scalars - NN logit gradients, mean, rstd - ride in ONE register: lane n < NN holds dlogits[r][n],

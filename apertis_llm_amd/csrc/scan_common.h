@@ -51,6 +51,20 @@ template <int VB> __device__ __forceinline__ void nt_store(void *p, const typena
   }
 }
 
+// streaming input load of VB bytes (read once by this kernel): non-temporal
+template <int VB> __device__ __forceinline__ typename vec_bytes<VB>::type nt_load(const void *p) {
+  typedef typename vec_bytes<VB>::type V;
+  if constexpr (VB == 16) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const u4 *>(p)));
+  } else if constexpr (VB == 8) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u2;
+    return __builtin_bit_cast(V, __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p)));
+  } else {
+    return __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+  }
+}
+
 template <int VB> __device__ __forceinline__ typename vec_bytes<VB>::type zero_vec() {
   typename vec_bytes<VB>::type z;
   __builtin_memset(&z, 0, VB);

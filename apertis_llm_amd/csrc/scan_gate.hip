@@ -85,7 +85,7 @@ struct TileRegs {
 #pragma unroll
     for (int q = 0; q < ITERS; ++q) {
       const bool ok = r0 + q * RSTEP < rows_valid && c0 < bytes_valid;
-      r[q] = ok ? *reinterpret_cast<const V *>(p + (int64_t)(q * RSTEP) * rsb) : zero_vec<VB>();
+      r[q] = ok ? nt_load<VB>(p + (int64_t)(q * RSTEP) * rsb) : zero_vec<VB>();
     }
   }
   __device__ __forceinline__ void store(char *lds, int tid) const {
