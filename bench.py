@@ -27,12 +27,12 @@ CONFIGS = {
     # name: (target params, moe, multimodal, seq, default per-GPU batch)   BASELINE.json configs[1..4]
     "125m": ("125M", False, False, 2048, 32),
     "350m-moe": ("350M", True, False, 4096, 16),
-    # per-GPU batch 40 x 4096 tokens: 214 GiB of the 288 GB HBM3E (measured, r2: the LM head + loss no longer hold the
-    # [B, L, 32000] logits); 32: 300.0k tokens/s at 175 GiB, 40: 305.3k, 48: 306.4k at 252 GiB (same box, mid round 2).
-    # End of round 2, one box: 34: 328.8k, 38: 333.7k, 40: 330.1-334.3k, 42: 332.4-337.3k (223 GiB), 46: 331.7-335.1k (242
-    # GiB) - the differences follow the tile counts of the persistent kernels (60 * B tiles on 256 CUs) and stay inside
-    # the box-to-box spread; 40 leaves the most head-room for the data-parallel buckets
-    "1.5b-moe": ("1.5B", True, False, 4096, 40),
+    # per-GPU batch 44 x 4096 tokens: ~232 GiB of the HBM3E (40: 214 GiB, 46: 242 GiB measured; the LM head + loss no longer
+    # hold the [B, L, 32000] logits).  The batch follows the tile counts of the persistent expert GEMMs: with the 256 x 352
+    # tile fc2 forward / fc1 dgrad have 40 * B tiles on 256 CUs - 6.25 rounds at B = 40 (run as 7), 6.875 at B = 44.  Same
+    # box, end of round 2, 10 timed steps: 36: 348.3k tokens/s, 40: 348.5-352.6k, 44: 357.9-358.2k.  (Before that tile:
+    # 34: 328.8k, 38: 333.7k, 40: 330.1-334.3k, 42: 332.4-337.3k, 46: 331.7-335.1k - inside the box-to-box spread.)
+    "1.5b-moe": ("1.5B", True, False, 4096, 44),
     "1.5b-moe-mm": ("1.5B", True, True, 2048, 16),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
