@@ -111,7 +111,7 @@ SIGNATURES = {
     "apertis_act_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _u64, _i32, _vp]),
     "apertis_opt_chunk_elems": (_i64, []),
     "apertis_grad_sumsq": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "apertis_clip_coef": (_i32, [_vp, _i64, _f32, _vp, _vp]),
+    "apertis_clip_coef": (_i32, [_vp, _i64, _f32, _vp, _vp, _vp]),
     "apertis_adamw_step": (_i32, [_vp, _vp, _vp, _i64, _f64, _f64, _f64, _f64, _f64, _i64, _vp, _vp]),
 }
 

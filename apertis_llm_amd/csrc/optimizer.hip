@@ -52,7 +52,7 @@ grad_sumsq_k(const OptTensor *__restrict__ tensors, const int32_t *__restrict__ 
 
 // one work-group: sum of the partials in index order (double accumulation), then norm and clip coefficient
 __global__ void __launch_bounds__(1024) clip_coef_k(const float *__restrict__ partials, int64_t n, float max_norm,
-                                                    float *__restrict__ out) {
+                                                    float *__restrict__ out, const int32_t *__restrict__ poison) {
   __shared__ double sm[1024];
   double acc = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) acc += (double)partials[i];
@@ -69,6 +69,9 @@ __global__ void __launch_bounds__(1024) clip_coef_k(const float *__restrict__ pa
     // turn it into 1 and apply an unclipped step on non-finite gradients)
     const float c = max_norm / (norm + 1e-6f);
     out[1] = (c != c) ? c : fminf(c, 1.f);
+    // a non-zero poison word (the single-pass scan's look-back time-out flag, scan_gate.hip) makes the step as visible as a
+    // non-finite gradient norm: norm and coefficient become NaN and the AdamW pass hands that to every parameter
+    if (poison && *poison != 0) out[0] = out[1] = __builtin_nanf("");
   }
 }
 
@@ -134,9 +137,10 @@ extern "C" int apertis_grad_sumsq(const void *tensors, const int32_t *chunk_tens
   return apertis_check_launch();
 }
 
-extern "C" int apertis_clip_coef(const float *partials, int64_t n, float max_norm, float *norm_coef, void *stream) {
+extern "C" int apertis_clip_coef(const float *partials, int64_t n, float max_norm, float *norm_coef, const int32_t *poison,
+                                 void *stream) {
   if (!norm_coef || n < 0 || (n > 0 && !partials) || !(max_norm >= 0.f)) return APERTIS_ERR_ARG;
-  hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, n, max_norm, norm_coef);
+  hipLaunchKernelGGL(clip_coef_k, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials, n, max_norm, norm_coef, poison);
   return apertis_check_launch();
 }
 

@@ -212,6 +212,27 @@ def scan_gate_error(device=None):
     return bad
 
 
+def scan_gate_error_word(device):
+    """The look-back error word(s) of `device`'s single-pass scan workspaces as ONE device int32 tensor of shape [1]
+    (None when no single-pass scan has run there) - no host sync.  `ApertisAdamW.step` hands its address to
+    `apertis_clip_coef` as the poison word, `TrainStep` turns the returned loss into NaN with it."""
+    words = [ent[0][8:12].view(torch.int32) for (dev, _), ent in _gate_ws.items() if torch.device(dev) == torch.device(device)]
+    if not words:
+        return None
+    if len(words) == 1:
+        return words[0]
+    return torch.cat(words).ne(0).any().to(torch.int32).reshape(1)
+
+
+def scan_gate_raise_on_error(device=None):
+    """Raise ApertisHipError if a single-pass scan launch timed out in its look-back (host sync: call it where the host
+    waits anyway, e.g. behind `loss.item()`); the activations of such a launch are wrong."""
+    bad = scan_gate_error(device)
+    if bad:
+        raise ApertisHipError(f"single-pass scan: look-back wait timed out (error word {bad:#x}); the step's activations "
+                              "are invalid - rerun with APERTIS_SCAN_SINGLE_PASS=0 (two-launch form, same bits)")
+
+
 class _ScanGate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last):

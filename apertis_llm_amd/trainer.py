@@ -33,6 +33,7 @@ import torch.distributed as dist
 from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
+from . import ops
 from .data import ApertisFineTuneDataset, ApertisPretrainDataset, load_vocabulary
 from .model import ApertisConfig, ApertisForCausalLM, create_apertis_model
 from .parallel import BucketedDataParallel
@@ -174,6 +175,8 @@ class ApertisTrainer:
                         loss.backward()
                     window_loss += loss.item()
                     window_n += 1
+                    if loss.is_cuda:      # the host has just waited for this micro-step: a timed-out scan look-back stops the run
+                        ops.scan_gate_raise_on_error(loss.device)
                     if boundary:
                         self._optimizer_step()
                         global_step += 1
@@ -229,6 +232,8 @@ class ApertisTrainer:
                 if loss is not None:
                     total += loss.item()
                     n += 1
+                    if loss.is_cuda:
+                        ops.scan_gate_raise_on_error(loss.device)
         self.model.train()
         return total / n if n else float("inf")
 

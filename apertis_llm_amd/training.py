@@ -123,7 +123,7 @@ class ApertisAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm: Optional[float] = None):
-        from . import _lib
+        from . import _lib, ops
         from ._lib import check, ptr, stream_ptr
         loss = None
         if closure is not None:
@@ -141,8 +141,10 @@ class ApertisAdamW(torch.optim.Optimizer):
                 for g in T["groups"]:
                     check(lib.apertis_grad_sumsq(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"],
                                                  ptr(T["partials"][g["first"]:]), stream_ptr()), "apertis_grad_sumsq")
+                # the scan's look-back time-out word poisons the coefficient (NaN step, like a non-finite norm): no sync
+                poison = ops.scan_gate_error_word(T["partials"].device)
                 check(lib.apertis_clip_coef(ptr(T["partials"]), T["n_total"], float(max_grad_norm), ptr(T["norm_coef"]),
-                                            stream_ptr()), "apertis_clip_coef")
+                                            ptr(poison), stream_ptr()), "apertis_clip_coef")
                 coef = T["norm_coef"]
                 self.last_grad_norm = coef[0]
             for g in T["groups"]:
@@ -200,7 +202,13 @@ class TrainStep:
                 self.dp.zero_grad()
             else:
                 self.optimizer.zero_grad(set_to_none=True)
-        return loss.detach()
+        loss = loss.detach()
+        if loss.is_cuda:
+            from . import ops
+            word = ops.scan_gate_error_word(loss.device)      # a timed-out scan look-back makes the loss NaN (no host sync)
+            if word is not None:
+                loss = torch.where(word[0] != 0, torch.full_like(loss, float("nan")), loss)
+        return loss
 
 
 class _null:

@@ -246,6 +246,11 @@ def main():
         log(f"DP wrapper: {step.dp.copied_bytes / 2**30:.2f} GiB of gradients moved into buckets by hooks so far "
             f"({step.dp.gradient_bytes() / 2**30:.2f} GiB of gradients per step)")
     last_loss = float(loss)
+    # the single-pass scan's bounded look-back wait leaves a non-zero word when it times out (its activations would be wrong;
+    # TrainStep turns the loss into NaN and the clip coefficient rejects the step): a line from such a run is not reported
+    scan_err = ops.scan_gate_error(dev)
+    if scan_err:
+        raise SystemExit(f"bench.py: rank {rank}: single-pass scan look-back timed out (error word {scan_err:#x})")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -265,7 +270,7 @@ def main():
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                    "allreduce_bytes_per_step": (step.dp.reduced_bytes // max(args.steps + args.warmup, 1)
                                                 if getattr(step, "dp", None) is not None else 0),
-                   "final_loss": last_loss},
+                   "final_loss": last_loss, "scan_lookback_error_word": scan_err},
     }
     if rank == 0 and timer is not None:
         summ = timer.summary()
@@ -274,7 +279,7 @@ def main():
         # (tools/run_pmc.sh benchmix -> profiles/r2_pmc_traffic_*.json); only valid for the workload
         # those passes were taken on, else null
         traffic = {}
-        tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic_{args.config}_b{B}.json") for r in (2, 1))
+        tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic_{args.config}_b{B}.json") for r in (3, 2, 1))
                    if os.path.exists(f)), "")
         if os.path.exists(tf):
             with open(tf) as fh:

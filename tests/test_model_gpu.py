@@ -154,7 +154,7 @@ def test_model_gradients_vs_oracle_autograd(dev):
     for k, p in model.named_parameters():
         ours[k] = p.grad
     msd = model.state_dict(keep_vars=False)
-    checked = 0
+    checked, worst = 0, 0.0
     for k, ref in sd.items():
         if ref.grad is None:
             continue
@@ -168,8 +168,13 @@ def test_model_gradients_vs_oracle_autograd(dev):
         if got is None:
             assert float(ref.grad.abs().max()) == 0.0, k
             continue
-        _close(got, ref.grad, "grad " + k, rtol=2e-3, atol_scale=2e-4)
+        # achieved error on the record (profiles/r3_parity_report.jsonl); the bound asserted is what the fp32 kernels reach
+        # against fp64 autograd through the oracle: rtol 5e-4 with an absolute floor of 5e-5 of the tensor's largest entry
+        rec = rel_error_report("grad " + k, got, ref.grad, rtol=5e-4, atol_scale=5e-5, check=False)
+        worst = max(worst, rec["worst_excess"])
+        assert rec["worst_excess"] <= 1.0, rec
         checked += 1
+    print(f"whole-model gradients: {checked} tensors, worst excess over (rtol 5e-4, atol 5e-5*max) = {worst:.3f}")
     assert checked > 40
 
 
@@ -471,3 +476,40 @@ def test_generate_matches_reference_tokens_and_step_logits(dev, name):
     logits = torch.stack(steps, dim=1)
     assert logits.shape == g["step_logits"].shape
     rel_error_report(f"{name}: last-position logits of all 16 generate() steps vs reference capture", logits, g["step_logits"])
+
+
+def test_scan_lookback_timeout_word_rejects_the_step(dev):
+    """The single-pass scan's bounded look-back wait leaves a non-zero error word in its workspace when it times out
+    (scan_gate.hip); the activations of such a launch are wrong.  The product path must not train on them silently:
+    with the word planted, TrainStep returns a NaN loss, apertis_clip_coef turns norm and coefficient into NaN (the
+    optimizer step is visibly rejected, as for a non-finite gradient norm) - all without a host sync - and the
+    checker ApertisTrainer calls behind its loss.item() raises."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops
+    from apertis_llm_amd._lib import ApertisHipError
+    from apertis_llm_amd.training import TrainStep
+    torch.manual_seed(0)
+    cfg = A.ApertisConfig(vocab_size=256, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                          attention_type="selective_ssm")
+    model = A.ApertisForCausalLM(cfg).to(dev).train()
+    step = TrainStep(model, total_steps=8)
+    ids = torch.randint(4, 256, (2, 128), device=dev)
+    loss = step(input_ids=ids, labels=ids)
+    assert torch.isfinite(loss) and torch.isfinite(step.optimizer.last_grad_norm)
+    assert ops.scan_gate_error(dev) == 0
+    ops.scan_gate_raise_on_error(dev)                      # clean: no exception
+    word = ops.scan_gate_error_word(dev)
+    assert word is not None and word.dtype == torch.int32 and word.numel() == 1
+    before = [p.detach().clone() for p in model.parameters()]
+    try:
+        word.fill_(1)                                      # what a timed-out wait leaves
+        loss = step(input_ids=ids, labels=ids)
+        assert torch.isnan(loss), "the returned loss must show the failure"
+        assert torch.isnan(step.optimizer.last_grad_norm), "norm / clip coefficient must be poisoned"
+        assert all(torch.isnan(p).all() for p in model.parameters()), "the AdamW pass hands the NaN to every parameter"
+        with pytest.raises(ApertisHipError, match="look-back"):
+            ops.scan_gate_raise_on_error(dev)
+    finally:
+        word.zero_()
+    assert ops.scan_gate_error(dev) == 0
+    assert all(torch.isfinite(b).all() for b in before)

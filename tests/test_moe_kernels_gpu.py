@@ -881,15 +881,17 @@ def test_grouped_gemm_nt_two_per_cu_kernel(dev, sizes, N, K):
     _close(drop.float()[kept], (act.float() / 0.75)[kept], "kept values rescaled", rtol=8e-3, atol_scale=1e-5)
 
 
-def test_moe_full_size_properties(dev):
-    """BASELINE sizes (1.5B MoE: 32 x 4096 tokens, H=704, I=2816, 8 experts, top-2, capacity 1.25): the kernels the
+@pytest.mark.parametrize("batch", [32, 44])
+def test_moe_full_size_properties(dev, batch):
+    """BASELINE sizes (1.5B MoE: 44 x 4096 tokens - the bench's batch, 225 280 routed rows - and the earlier 32 x 4096;
+    H=704, I=2816, 8 experts, top-2, capacity 1.25): the kernels the
     launch heuristics pick at THIS size (two-per-CU and persistent NT, TN v3 pair, radix select, fused activation backward)
     checked through size-independent properties - the plan is a bijection onto the kept assignments in canonical order
     under the capacity, and sampled rows / one expert's weight gradient of the expert MLP equal dense fp64 / fp32 math on
     the same bf16-rounded operands."""
     from apertis_llm_amd import ops
     torch.manual_seed(0)
-    S, H, I, E, K = 32 * 4096, 704, 2816, 8, 2
+    S, H, I, E, K = batch * 4096, 704, 2816, 8, 2
     logits = torch.randn(S, E, device=dev)
     logits[:, 0] += 0.7                                    # skew: experts 0 overflows, others vary
     _, idx, w = ops.moe_gate_topk(logits, K)
@@ -956,3 +958,64 @@ def test_moe_full_size_properties(dev):
     dpre_e = torch.autograd.grad(torch.nn.functional.gelu(pre_g), pre_g, dh_e)[0].bfloat16().float()
     _close(w1.grad[e], dpre_e.T @ xe, "dW1[e]", rtol=2e-2, atol_scale=1e-2)
     _close(b1.grad[e], dpre_e.sum(0), "db1[e]", rtol=2e-2, atol_scale=1e-2)
+
+
+@pytest.mark.parametrize("batch", [44])
+def test_expert_mlp_full_size_dropout_mask_recovered(dev, batch):
+    """Dropout ON (p = 0.1, the reference default core.py:439) at the bench's full size: 225 280 capacity-filled rows, the
+    two-per-CU kernel's saved-gradient epilogue.  The mask is recovered from the tensors the forward leaves for the
+    backward (h = gelu(pre) * keep / (1-p), g' = gelu'(pre) * keep / (1-p): an element is dropped iff both are exactly 0),
+    its statistics are checked (rate, per-column and per-row rates inside binomial bounds, no correlation between
+    neighbours), and on sampled rows the KEPT elements equal dense fp64 math on the same bf16-rounded operands, the dropped
+    ones are exact zeros; the layer output and the input gradient are then checked against dense math that uses the
+    recovered mask."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(1)
+    H, I, E, p = 704, 2816, 8, 0.1
+    per = int((batch * 4096 / E) * 1.25)
+    rows = per * E
+    offs = torch.arange(E + 1, device=dev, dtype=torch.int32) * per
+    xg = torch.randn(rows, H, device=dev).bfloat16().requires_grad_(True)
+    w1 = (torch.randn(E, I, H, device=dev) * 0.03).requires_grad_(True)
+    b1 = (torch.randn(E, I, device=dev) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(E, H, I, device=dev) * 0.03).requires_grad_(True)
+    b2 = (torch.randn(E, H, device=dev) * 0.1).requires_grad_(True)
+    y = ops.expert_mlp(xg, w1, b1, w2, b2, offs, rows, act="gelu", drop_p=p, seed=12345, compute_dtype=torch.bfloat16)
+    assert y.grad_fn.saved_grad, "the saved-gradient epilogue is the form the bench runs at this size"
+    _xg, gsv, h = y.grad_fn.saved_tensors[:3]
+    keep = (h != 0) | (gsv != 0)
+    # ---- statistics of the mask
+    rate = float(keep.float().mean())
+    assert abs(rate - (1 - p)) < 5e-4, rate
+    col = keep.float().mean(0)
+    row = keep[:: max(1, rows // 65536)].float().mean(1)
+    sd_c, sd_r = (p * (1 - p) / rows) ** 0.5, (p * (1 - p) / I) ** 0.5
+    assert float((col - (1 - p)).abs().max()) < 6 * sd_c, float((col - (1 - p)).abs().max()) / sd_c
+    assert float((row - (1 - p)).abs().max()) < 6.5 * sd_r, float((row - (1 - p)).abs().max()) / sd_r
+    kf = keep[: 1 << 15].float() - (1 - p)
+    for shifted in (kf[:, 1:] * kf[:, :-1], kf[1:] * kf[:-1], kf[:, 4:] * kf[:, :-4]):   # neighbours in a row, a column, a hash group
+        assert abs(float(shifted.mean())) < 6 * p * (1 - p) / shifted.numel() ** 0.5
+    # ---- kept elements = dense math, dropped = exact zeros (sampled rows)
+    sample = torch.from_numpy(np.random.default_rng(2).choice(rows, 320, replace=False)).to(dev)
+    exp_of = (sample // per).long()
+    w1q, w2q = w1.detach().bfloat16().double(), w2.detach().bfloat16().double()
+    xs = xg.detach()[sample].double()
+    pre = (torch.einsum("rh,rih->ri", xs, w1q[exp_of]) + b1.detach().double()[exp_of]).bfloat16().double().requires_grad_(True)
+    act = torch.nn.functional.gelu(pre)
+    dact = torch.autograd.grad(act.sum(), pre)[0]
+    ks = keep[sample]
+    assert bool((h[sample][~ks] == 0).all()) and bool((gsv[sample][~ks] == 0).all())
+    _close(h[sample].double()[ks], (act.detach() / (1 - p))[ks], "kept h = gelu(pre)/(1-p)", rtol=1.2e-2, atol_scale=2e-3)
+    _close(gsv[sample].double()[ks], (dact / (1 - p))[ks], "kept g' = gelu'(pre)/(1-p)", rtol=1.2e-2, atol_scale=2e-3)
+    # ---- the layer output and the input gradient with the recovered mask
+    ref = torch.einsum("ri,rhi->rh", h[sample].double(), w2q[exp_of]) + b2.detach().double()[exp_of]
+    _close(y.detach()[sample].double(), ref, "y rows (sampled, dropout on)", rtol=2e-2, atol_scale=1e-2)
+    dy = torch.randn(rows, H, device=dev).bfloat16()
+    y.backward(dy)
+    dh = torch.einsum("rh,rhi->ri", dy[sample].double(), w2q[exp_of]).bfloat16().double()
+    dpre = (dh * gsv[sample].double()).bfloat16().double()
+    _close(xg.grad[sample].double(), torch.einsum("ri,rih->rh", dpre, w1q[exp_of]), "dx rows (sampled, dropout on)",
+           rtol=3e-2, atol_scale=2e-2)
+    e = 5
+    a, b = e * per, (e + 1) * per
+    _close(w2.grad[e], dy[a:b].float().T @ h[a:b].float(), "dW2[e] (dropout on)", rtol=2e-2, atol_scale=1e-2)

@@ -168,13 +168,15 @@ def test_scan_gate_bf16_config4_shape(dev):
         assert torch.equal(res[False][2][k], res[True][2][k]), k
 
 
-def test_scan_gate_single_pass_stress_full_size(dev):
-    """The single-launch form at the bench's full per-GPU size (B=32, L=4096, Dn=176: 3072 forward and 6144 backward
-    work-groups, far more than are resident at once) run back to back on one workspace: the ticket order must keep
-    every wait on an already started work-group (no time-out in the error word), the alternating ticket counters must
-    hand over cleanly from launch to launch, and every repetition must give the same bits."""
+@pytest.mark.parametrize("batch", [32, 44])
+def test_scan_gate_single_pass_stress_full_size(dev, batch):
+    """The single-launch form at the bench's full per-GPU size (B=44 - the batch the bench line is quoted on - and the
+    earlier B=32; L=4096, Dn=176: thousands of forward and backward work items, far more than are resident at once) run
+    back to back on one workspace: the ticket order must keep every wait on an already started work-group (no time-out
+    in the error word), the alternating ticket counters must hand over cleanly from launch to launch, and every
+    repetition must give the same bits."""
     from apertis_llm_amd import ops
-    i = _inputs(32, 4096, 11, 16, seed=9, dtype=torch.bfloat16)
+    i = _inputs(batch, 4096, 11, 16, seed=9, dtype=torch.bfloat16)
     Dn, Wb = i["Dn"], i["Wb"]
     lv = {k: i[k].to(dev).requires_grad_(True) for k in ("p", "xz", "xc", "logits", "A_log", "D")}
     dout = i["dout"].to(dev)
