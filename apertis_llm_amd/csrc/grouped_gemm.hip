@@ -195,6 +195,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// Order of the (m-tile, n-tile) pairs of a grid of MT x NTL tiles: m-tiles in groups of G; inside a group the n-tiles in
+// panels of NB; inside a panel m outer, n inner.  Tiles that share an activation row block are then neighbours (they start
+// together and read it in step: one L2 fill for NB tiles) and tiles that share a weight tile are NB apart, i.e. the XCD's
+// ~64 resident work-groups of the two-per-CU kernel work under ONE weight panel of NB x 128 rows that stays in its L2, where
+// the n-fastest walk over all NTL n-tiles streamed the whole W[e] (3.96 MB at N=2816, K=704 = the XCD's entire L2) past
+// every 256-row block.  G bounds how far apart the NTL/NB passes over an activation block are (it comes back from the
+// Infinity Cache).  G <= 0 or NB >= NTL: the n-fastest walk.
+__device__ __forceinline__ void tile_walk(int t, int MT, int NTL, int G, int NB, int &mt, int &nt) {
+  if (G <= 0 || NB <= 0 || NB >= NTL) { mt = t / NTL; nt = t - mt * NTL; return; }
+  const int g = t / (G * NTL), r = t - g * G * NTL;
+  const int gg = min(G, MT - g * G);           // m-tiles of this group (the last one may be short)
+  const int per = gg * NB, pn = r / per, rr = r - pn * per;
+  const int wp = min(NB, NTL - pn * NB);       // width of this panel (the last one may be narrow)
+  const int mi = rr / wp;
+  mt = g * G + mi;
+  nt = pn * NB + (rr - mi * wp);
+}
+
 template <typename T>
 __device__ __forceinline__ void load_tile_regs(uint4 (&regs)[4], const T *base, int64_t ld, int rows_valid,
                                                int k0, int K, int tid) {
@@ -752,7 +770,7 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
   char *stg = smem + BUF5;                             // ring buffer 1 doubles as the C staging area
   int32_t *s_off = reinterpret_cast<int32_t *>(smem + 2 * BUF5);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the DMA piece arithmetic stays scalar)
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
   const int G = gridDim.x;
@@ -884,12 +902,53 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     for (int i = 0; i < 11; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (the tile's fields went through the loop-carried `cur`: hipcc no longer knows that they are wave-uniform and would
+    // build every piece's descriptor in VGPRs behind a waterfall loop)
+    auto uni_ptr = [](const T *q) {
+      const uint64_t v = (uint64_t)q;
+      return (const T *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                         (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    const int pw0 = wave < 4 ? wave * 6 : 24 + (wave - 4) * 5;     // this wave's first W piece (the split of `stage`)
+    const int rows_w = __builtin_amdgcn_readfirstlane(cur.rows_valid) - wave * 32;
+    const int cols_w = __builtin_amdgcn_readfirstlane(cur.cols_valid) - pw0 * 8;
+    const T *fxw = uni_ptr(X + (cur.row0 + wave * 32) * K), *fww = uni_ptr(W + ((int64_t)cur.e * N + cur.n0 + pw0 * 8) * K);
     for (int kt = 0; kt < nk; ++kt) {
       if (wave < 4 || kt > solo) wait_vmcnt<0>();
       __syncthreads();
+      // While waves 0-3 fill alone (the next tile's first `solo` steps) the next K step's pieces are issued here, as ever.
+      // In the steady state they are NOT issued in one run: a wave sits in each `buffer_load ... lds` until the CU's
+      // address unit has taken it (16 cycles per KiB piece; 76 pieces per step and CU, all eight waves at once right
+      // behind the barrier = ~1200 cycles in which no MFMA issues - the 0.4-0.5 us that round 2's probes saw the
+      // "asynchronous" fills add to every step).  They go out one at a time behind every second group of four MFMAs
+      // below: this wave's four X pieces, then its six W pieces (waves 4-7 have five).
+      const int nkt = kt + 1;
+      const bool spread = nkt < nk && nkt > solo;
 #ifndef NT_PROBE_NODMA   // (tools/probes only: the K loop on stale LDS contents - what the steps cost without their fills)
-      if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+      if (nkt < nk && nkt <= solo) stage(nkt & 1, nkt);
 #endif
+      char *fxs = smem + (nkt & 1) * BUF5 + wave * 4 * 1024, *fws = smem + (nkt & 1) * BUF5 + TILE2_BYTES + pw0 * 1024;
+      // a piece's row term goes into its buffer descriptor (base advanced and range shortened by 8 rows per piece: scalar
+      // arithmetic), so that every piece uses the SAME lane offset voff0 - a running per-lane offset cost two registers the
+      // kernel does not have (hipcc spilled it around every DMA)
+      auto fill_piece = [&](int q) {   // q = 0..9, a compile-time constant at every call site
+#ifndef NT_PROBE_NODMA
+        if (q < 4) {
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<T *>(fxw + q * 8 * K), 0, max(rows_w - q * 8, 0) * ldb, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(fxs + q * 1024), 16, voff0,
+                                                   nkt * BK * (int)sizeof(T), 0, 0);
+        } else {
+          // (waves 4-7 have five W pieces: their sixth slot repeats the fifth - the same bytes to the same place; a piece
+          // from beyond the range would still WRITE its zeros, over the next wave's first piece)
+          const int j = (q == 9 && wave >= 4) ? 4 : q - 4;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<T *>(fww + j * 8 * K), 0, max(cols_w - j * 8, 0) * ldb, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(fws + j * 1024), 16, voff0,
+                                                   nkt * BK * (int)sizeof(T), 0, 0);
+        }
+#endif
+      };
       const char *xs = smem + (kt & 1) * BUF5, *ws = xs + TILE2_BYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -914,6 +973,12 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
           __builtin_amdgcn_sched_barrier(0);   // keeps the reads from being hoisted into one block of 44 live registers
 #pragma unroll
           for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
+          const int g = kk * 11 + i;           // MFMA group 0..21 of the step
+          if (!(g & 1) && g < 20) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (spread) fill_piece(g >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         __builtin_amdgcn_s_setprio(0);
       }
@@ -982,7 +1047,9 @@ __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const fl
         const int sr = wm * 64 + jj * 16 + frow;           // its row in the half's staging image
         const int chunk = wn * 8 + i * 2 + (fg >> 1);
         bool keep[4] = {true, true, true, true};
+#ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
         if (DROP) drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
+#endif
         uint32_t oh[4], og[4];
 #pragma unroll
         for (int q = 0; q < 4; q += 2) {   // two elements per packed instruction
@@ -990,9 +1057,18 @@ __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const fl
           // the pre-activation as the other form stores it
           const v2f x = {to_f32(from_f32<TO>(pre.x)), to_f32(from_f32<TO>(pre.y))};
           v2f hv, gv;
+#if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
+          hv = x * splat2(keep_scale); gv = x * splat2(0.5f * keep_scale);
+#elif defined(NT_PROBE_NOPK)   // tools/probes only: the scalar evaluation (same bits) instead of the packed-fp32 one
+          float h0, g0, h1, g1;
+          gelu_both_fast(x.x, h0, g0);
+          gelu_both_fast(x.y, h1, g1);
+          hv = (v2f){h0 * keep_scale, h1 * keep_scale}; gv = (v2f){g0 * keep_scale, g1 * keep_scale};
+#else
           gelu_both_fast2(x, hv, gv);
           hv = hv * splat2(keep_scale);
           gv = gv * splat2(keep_scale);
+#endif
           oh[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? hv.x : 0.f));
           oh[q + 1] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q + 1] ? hv.y : 0.f));
           og[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? gv.x : 0.f));
@@ -1106,7 +1182,7 @@ __global__ void __launch_bounds__(NT3, 2)
 grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
                     const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int act_flags, float drop_p,
-                    uint64_t seed) {
+                    uint64_t seed, int walk_g, int walk_nb, int spread_fill) {
   typedef bf16x8 frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // act_flags: the activation code, | APERTIS_ACT_SAVE_GRAD (forward, GELU: pre_act receives gelu'(pre) * mask / (1-p) instead
@@ -1117,9 +1193,11 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
 
-  // tile of this work-group (XCD-aware order; n fastest so neighbours share activation rows)
+  // tile of this work-group: an XCD takes a contiguous run of the tile order (xcd_remap); inside it the walk is
+  // n-panel-stationary (tile_walk below) so that the W panel the XCD's resident work-groups share stays in its L2
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int mt = tile / n_tiles, ntile = tile - mt * n_tiles;
+  int mt, ntile;
+  tile_walk(tile, gridDim.x / n_tiles, n_tiles, walk_g, walk_nb, mt, ntile);
   int e = -1, rows_valid = 0, accm = 0;
   int64_t row0 = 0;
   for (int g = 0; g < E; ++g) {
@@ -1147,16 +1225,19 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const uint32_t vx0 = (uint32_t)((wave * 64 + (lane >> 2)) * ldb + (((lane & 3) ^ fsw) << 4));
   const uint32_t vw0 = (uint32_t)((wave * 32 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
   const uint32_t lds0 = lds_addr_of(smem);
-  auto issue = [&](uint32_t slot_off, int s) {   // sub-step s: this wave's 4 X pieces and 2 W pieces
+  // piece q of this wave's share of sub-step s: q = 0..3 its X pieces, 4..5 its W pieces
+  auto issue_piece = [&](uint32_t slot_off, int s, int q) {
     const uint32_t kb = (uint32_t)s * ROWB3, base = lds0 + slot_off;
     const uint32_t kv = RAGGED ? kb : 0u, ks = RAGGED ? 0u : kb;
+    if (q < 4) lds_dma16s(xrs, base + (wave * 4 + q) * 1024, vx0 + (uint32_t)(q * 16 * ldb) + kv, ks);
+    else lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + (q - 4)) * 1024, vw0 + (uint32_t)((q - 4) * 16 * ldwb) + kv, ks);
+  };
+  auto issue = [&](uint32_t slot_off, int s) {   // sub-step s: this wave's 4 X pieces and 2 W pieces
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lds_dma16s(xrs, base + (wave * 4 + j) * 1024, vx0 + (uint32_t)(j * 16 * ldb) + kv, ks);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + j) * 1024, vw0 + (uint32_t)(j * 16 * ldwb) + kv, ks);
+    for (int q = 0; q < 6; ++q) issue_piece(slot_off, s, q);
   };
   const int nk = (K + 31) / 32;   // >= 3 (launcher)
+  (void)spread_fill;
   issue(0, 0); issue(SLOT3, 1); issue(2 * SLOT3, 2);
 
   f32x4 acc[4][8];
@@ -1173,6 +1254,22 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const frag *>(wbase + slot_off + i * 16 * ROWB3);
   };
+  // the same with the DMA pieces of sub-step `fs` (into the slot at fill_off; fs < 0: none) going out one by one behind the
+  // first six MFMA groups instead of in one run behind the barrier: a wave sits in each `buffer_load ... lds` until the
+  // CU's address unit has taken it (16 cycles per KiB piece, 24 pieces per sub-step and work-group, all four waves at once)
+  auto sub_step_fill = [&](const frag (&wcur)[4], frag (&wnxt)[4], int nxt_off, uint32_t fill_off, int fs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j == 0) { wnxt[0] = *reinterpret_cast<const frag *>(wbase + nxt_off); wnxt[1] = *reinterpret_cast<const frag *>(wbase + nxt_off + 16 * ROWB3); }
+      if (j == 1) { wnxt[2] = *reinterpret_cast<const frag *>(wbase + nxt_off + 32 * ROWB3); wnxt[3] = *reinterpret_cast<const frag *>(wbase + nxt_off + 48 * ROWB3); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mma(acc[i][j], wcur[i], xf[j]);
+      xf[j] = *reinterpret_cast<const frag *>(xbase + nxt_off + j * 16 * ROWB3);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j < 6 && fs >= 0) issue_piece(fill_off, fs, j);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   // 32 MFMAs on (wcur, xf) while (wnxt, xf) are refilled from the slot at nxt_off
   auto sub_step = [&](const frag (&wcur)[4], frag (&wnxt)[4], int nxt_off) {
     load_w(wnxt, nxt_off);
@@ -1188,6 +1285,18 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     SGB(3) SGB(3) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1)
 #undef SGB
   };
+#ifdef NT_PROBE_SPREAD2X   // tools/probes only: measured in round 3 at N = 2816, K = 704 - no difference (1486 vs 1491 us, 1244 vs 1249)
+#define NT2X_STEP(S, WC, WN)                                                                             \
+      __builtin_amdgcn_s_setprio(1);                                                                     \
+      sub_step_fill(WC, WN, nxt, (uint32_t)cur, (S) + 3 < nk ? (S) + 3 : -1);                            \
+      __builtin_amdgcn_s_setprio(0);
+#else
+#define NT2X_STEP(S, WC, WN)                                                                             \
+      if ((S) + 3 < nk) issue((uint32_t)cur, (S) + 3);                                                   \
+      __builtin_amdgcn_s_setprio(1);                                                                     \
+      sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
+      __builtin_amdgcn_s_setprio(0);
+#endif
   wait_vmcnt<12>();   // stage 0 (vmcnt retires in order)
   lds_barrier();
   load_w(wf[0], 0);
@@ -1203,10 +1312,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
       if ((S) + 2 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();                                           \
       lds_barrier();                                                                                   \
-      if ((S) + 3 < nk) issue((uint32_t)cur, (S) + 3);                                                   \
-      __builtin_amdgcn_s_setprio(1);                                                                     \
-      sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
-      __builtin_amdgcn_s_setprio(0);                                                                     \
+      NT2X_STEP(S, WC, WN)                                                                               \
       cur = nxt;                                                                                         \
     }
     SUB(s, wf[0], wf[1])
@@ -1216,6 +1322,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       for (int i = 0; i < 4; ++i) wf[0][i] = wf[1][i];
     }
 #undef SUB
+#undef NT2X_STEP
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lds_barrier();   // every wave is done with the ring: it becomes the output staging area
@@ -1642,6 +1749,7 @@ __host__ __device__ inline Tn3Sched tn3_sched(int m_tiles, int n_tiles, int cpg)
   return c;
 }
 
+template <bool RING, bool STAGGER = false>
 __global__ void __launch_bounds__(NT2)
 grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
   typedef bf16_t T;
@@ -1678,6 +1786,7 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) ones[q] = (bf16_t)1.0f;
   const int wn_u = __builtin_amdgcn_readfirstlane(wn);
+  const bool lagger = __builtin_amdgcn_readfirstlane(wave) >= 4;
 
   // A group's items in order: the full tiles round by round, then the row slices of the remainder tiles.
   //  static walk (a.ctr == NULL): work-group j takes items j, j + cpg, ... and the slice j.
@@ -1731,47 +1840,126 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
       for (int im = 0; im < 8; ++im) acc[jn][im] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 accb[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 
-    if (s0 < s1) stage(0, s0);
-    for (int st = s0; st < s1; ++st) {
-      wait_vmcnt<0>();
-      __syncthreads();
-      if (st + 1 < s1) stage((st + 1 - s0) & 1, st + 1);
-      const char *as = smem + ((st - s0) & 1) * 2 * OPB, *bs = as + OPB;
+    // one 32-deep k-block: transposed fragment reads from the images at (as, bs), then 32 MFMAs (+ the bias MFMAs)
+    bf16x8 af[8], bf[4];
+    auto read_frags = [&](const char *as, const char *bs) {
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        bf16x8 af[8], bf[4];
+      for (int im = 0; im < 8; ++im) {
+        union { bf16x8 v; s16x4 h[2]; } u;
 #pragma unroll
-        for (int im = 0; im < 8; ++im) {
-          union { bf16x8 v; s16x4 h[2]; } u;
+        for (int hh = 0; hh < 2; ++hh)
+          u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+              as + rd0 + (((wm * 8 + im) ^ lane_sw) << 5) + (4 * hh) * KROWB));
+        af[im] = u.v;
+      }
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-            u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
-                as + rd0 + (((wm * 8 + im) ^ lane_sw) << 5) + (kb * 32 + 4 * hh) * KROWB));
-          af[im] = u.v;
+      for (int jn = 0; jn < 4; ++jn) {
+        union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+          u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+              bs + rd0 + (((wn * 4 + jn) ^ lane_sw) << 5) + (4 * hh) * KROWB));
+        bf[jn] = u.v;
+      }
+    };
+    auto mma_frags = [&](auto &&between) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int jn = 0; jn < 4; ++jn) {
+#pragma unroll
+        for (int im = 0; im < 8; ++im) mma(acc[jn][im], bf[jn], af[im]);
+        between(jn);
+      }
+      if (want_bias) {
+        // this wave's two m-subtiles, picked without indexing the register array.  wn_u is in an
+        // SGPR on purpose: MFMA ignores EXEC, and hipcc drops the execz skip around a short
+        // divergent block, so an `if (lane-derived wn == ...)` here runs the MFMA in every wave
+#pragma unroll
+        for (int im = 0; im < 8; ++im)
+          if ((im >> 1) == wn_u) mma(accb[im & 1], ones, af[im]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto nothing = [](int) {};
+    auto kblock = [&](const char *as, const char *bs) { read_frags(as, bs); mma_frags(nothing); };
+    if constexpr (RING) {
+      // four slots of 32 k-rows (16 KiB per operand), THREE stages in flight (96 KiB per CU instead of the 64 of the
+      // double buffer below): a stage of this kernel comes from HBM - every k-row of the group is read once per round -
+      // and with one 64-deep stage in flight the step took as long as the stage's latency (2.2 us against 0.9 us of
+      // MFMA work).  The DMA pieces are whole 512-byte k-rows either way, so the shallower stage costs the fill nothing
+      // (unlike the NT kernels, whose rows would shrink to 64 bytes).
+      constexpr int OPH = 32 * KROWB;
+      const int nsub = 2 * (s1 - s0);
+      // piece q (0..3) of this wave's share of stage u: q & 1 picks the operand, q >> 1 the piece (two k-rows of 512 B).
+      // Past the item's last stage the piece is still issued, from beyond the descriptor's range (it writes zeros into a
+      // slot nobody reads again and moves no data): the loop then has ONE shape and one vmcnt count
+      auto piece32 = [&](int u, int q) {
+        const uint32_t as = lds0 + (u & 3) * 2 * OPH, bs = as + OPH;
+        const int p = (q >> 1) * 8 + wave;
+#ifdef TN_PROBE_WRAP   // tools/probes only: every k-row from the group's first 256 rows - the kernel with all fills hitting in L2
+        const uint32_t row = (uint32_t)((s0 * BKR + u * 32 + 2 * p) & 255);
+#else
+        const uint32_t row = (uint32_t)(s0 * BKR + u * 32 + 2 * p);
+#endif
+        const bool live = u < nsub;
+        if (q & 1) lds_dma16(brs, bs + p * 1024, live ? vb0 + row * (uint32_t)ldB : 0xfffffff0u);
+        else lds_dma16(ars, as + p * 1024, live ? va0 + row * (uint32_t)ldA : 0xfffffff0u);
+      };
+      auto stage32 = [&](int u) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) piece32(u, q);
+      };
+      for (int u = 0; u < 3; ++u) stage32(u);
+      // top of interval u: stage u has landed once only the DMAs of the two younger stages are outstanding (vmcnt retires
+      // in order); behind the barrier every wave's share of stage u is in and nobody still reads slot (u - 1) & 3, which
+      // stage u + 3 then overwrites.  The four DMA instructions of that stage are NOT issued here in one run: a wave sits
+      // in each of them until the CU's address unit has taken it (16 cycles per KiB piece, 32 pieces per interval and CU,
+      // all eight waves at once right behind the barrier - the 0.4-0.5 us per 64-deep step that "asynchronous" fills cost
+      // every persistent kernel of this file in round 2's probes); they go out one by one between the MFMA groups
+      auto top = [&]() {
+        wait_vmcnt<8>();
+        lds_barrier();
+      };
+      auto mma_and_fill = [&](int u) {   // the MFMAs of the fragments in registers, stage u + 3 on its way between them
+        mma_frags([&](int jn) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece32(u + 3, jn);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      };
+      if (!STAGGER || !lagger) {
+        for (int u = 0; u < nsub; ++u) {
+          top();
+          const char *as = smem + (u & 3) * 2 * OPH;
+          read_frags(as, as + OPH);
+          mma_and_fill(u);
         }
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn) {
-          union { bf16x8 v; s16x4 h[2]; } u;
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-            u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
-                bs + rd0 + (((wn * 4 + jn) ^ lane_sw) << 5) + (kb * 32 + 4 * hh) * KROWB));
-          bf[jn] = u.v;
+      } else if (nsub > 0) {
+        // waves 4-7 (the SIMD partners of waves 0-3) run half an interval out of phase: the MFMAs of the fragments they
+        // read in the previous interval first - while their partners, who start with the reads, leave the matrix pipe
+        // alone - then this interval's reads under the partners' MFMAs (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+        // A loop of its own: with the role test inside one loop hipcc kept both roles' registers live (772 B of scratch)
+        top();
+        stage32(3);
+        read_frags(smem, smem + OPH);
+        for (int u = 1; u < nsub; ++u) {
+          top();
+          mma_and_fill(u);
+          const char *as = smem + (u & 3) * 2 * OPH;
+          read_frags(as, as + OPH);
         }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int jn = 0; jn < 4; ++jn)
-#pragma unroll
-          for (int im = 0; im < 8; ++im) mma(acc[jn][im], bf[jn], af[im]);
-        if (want_bias) {
-          // this wave's two m-subtiles, picked without indexing the register array.  wn_u is in an
-          // SGPR on purpose: MFMA ignores EXEC, and hipcc drops the execz skip around a short
-          // divergent block, so an `if (lane-derived wn == ...)` here runs the MFMA in every wave
-#pragma unroll
-          for (int im = 0; im < 8; ++im)
-            if ((im >> 1) == wn_u) mma(accb[im & 1], ones, af[im]);
-        }
-        __builtin_amdgcn_s_setprio(0);
+        mma_frags(nothing);
+      }
+      wait_vmcnt<0>();   // the zero-fill pieces past the last stage: the ring must be quiet before the next item's first DMA
+    } else {
+      if (s0 < s1) stage(0, s0);
+      for (int st = s0; st < s1; ++st) {
+        wait_vmcnt<0>();
+        __syncthreads();
+        if (st + 1 < s1) stage((st + 1 - s0) & 1, st + 1);
+        const char *as = smem + ((st - s0) & 1) * 2 * OPB, *bs = as + OPB;
+        kblock(as, bs);
+        kblock(as + 32 * KROWB, bs + 32 * KROWB);
       }
     }
     // the next ticket rides on the barrier that ends the K loop; two slots in turn, so the slot written now was last read
@@ -1874,8 +2062,13 @@ int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t ma
   a.ctr = item_queue ? reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + slots_bytes) : nullptr;
   if (a.ctr && hipMemsetAsync(a.ctr, 0, (size_t)groups * TN3_CTR_STRIDE * sizeof(int), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
   const size_t lds = 4 * 64 * 512 + 16;
-  hipFuncSetAttribute((const void *)grouped_gemm_tn3_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(grouped_gemm_tn3_k, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
+  int ring = 2;
+#ifdef TN_PROBE_RING   // tools/probes only: TN_RING=0 selects the double-buffered 64-deep form, 1 the ring without the stagger
+  if (const char *rv = getenv("TN_RING")) ring = atoi(rv);
+#endif
+  auto k3 = ring == 2 ? grouped_gemm_tn3_k<true, true> : ring == 1 ? grouped_gemm_tn3_k<true, false> : grouped_gemm_tn3_k<false, false>;
+  hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k3, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
   bool split = false;
   for (int q = 0; q < nprob; ++q) {
     const Tn3Problem &pp = q ? a.p1 : a.p0;
@@ -1956,8 +2149,19 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       if (grid3 < 0x7fffffffLL) {
         auto k3 = ragged2x ? grouped_gemm_nt2x_k<TO, true> : grouped_gemm_nt2x_k<TO, false>;
         hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
+        // tile walk (tile_walk above): groups of 8 m-tiles under panels of 4 n-tiles when there are enough n-tiles - at
+        // K = 704 the group's activation blocks (8 x 360 KB) and the weight panel (0.7 MB) together fit the XCD's 4 MiB L2.
+        // Measured at 225 280 rows, N = 2816, K = 704 (tools/probes/gemm_probe.hip, PROBE_R3): n-fastest 1597-1653 us (fc1
+        // forward) / 1255-1293 (fc2 data gradient); (8,4) 1379 / 1190; (32,4) 1374 / 1230; (12,11) 1400 / 1181; (16,8) 1471 / 1236
+        int walk_g = nt3 > 8 ? 8 : 0, walk_nb = 4;
+        int spread_fill = 0;
+#ifdef NT_PROBE_WALK   // tools/probes only: NT_WALK="G,NB" and NT_SPREAD=0|1 from the environment
+        if (const char *wv = getenv("NT_WALK")) sscanf(wv, "%d,%d", &walk_g, &walk_nb);
+        if (const char *sv = getenv("NT_SPREAD")) spread_fill = atoi(sv);
+#endif
         hipLaunchKernelGGL(k3, dim3((unsigned)grid3), dim3(NT3), RING3, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
-                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act_flags, drop_p, seed);
+                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act_flags, drop_p, seed,
+                           walk_g, walk_nb, spread_fill);
         return apertis_check_launch();
       }
     }

@@ -54,6 +54,9 @@
 //       triple-buffered in 160 KiB at this tile size (3 x 76 KiB).  Removed.
 #include "../../apertis_llm_amd/csrc/grouped_gemm.hip"
 #include <cstdio>
+#include <cstring>
+#include <string>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 __global__ void flush_read_k(const uint4 *p, size_t n, unsigned *sink) {
@@ -82,7 +85,8 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](const char *name, double flops, auto fn) {
     float best = 1e9, sum = 0; int n = 0;
-    for (int rep = 0; rep < 6; ++rep) {
+    const int reps = getenv("PROBE_REPS") ? atoi(getenv("PROBE_REPS")) : 6;
+    for (int rep = 0; rep < reps; ++rep) {
       flush_read_k<<<4096, 256>>>((const uint4 *)flush, ((size_t)1 << 30) / 16, sink);
       hipEventRecord(e0); int rc = fn(); hipEventRecord(e1); hipEventSynchronize(e1);
       if (rc) { printf("%s rc=%d\n", name, rc); return; }
@@ -106,6 +110,45 @@ int main(int argc, char **argv) {
     return 0;
   }
   const double fl = 2.0 * rows * H * I;
+  if (getenv("PROBE_R3")) {   // round 3 (build with -DNT_PROBE_WALK -DTN_PROBE_RING): tile walks of the two-per-CU kernel, TN ring
+    float *dw1, *dw2, *db1, *db2, *ws;
+    hipMalloc(&dw1, E * I * H * 4); hipMalloc(&dw2, E * I * H * 4); hipMalloc(&db1, E * I * 4); hipMalloc(&db2, E * H * 4);
+    const int64_t wsb = apertis_grouped_gemm_tn_workspace_bytes(E, 2);
+    hipMalloc(&ws, wsb);
+    fill_k<<<2048, 256>>>(h, rows * I, 1.f, 5); fill_k<<<2048, 256>>>(dpre, rows * I, 1.f, 6);
+    const char *only = getenv("PROBE_ONLY");
+    if (!only || !strcmp(only, "walk")) {
+      std::vector<std::string> walks = {"0,0", "16,11", "32,4", "16,4", "8,11", "32,11", "24,11", "8,4", "64,4", "16,3", "16,2", "32,2", "12,11", "16,11"};
+      if (const char *wl = getenv("PROBE_WALKS")) {   // e.g. PROBE_WALKS="0,0;16,11"
+        walks.clear();
+        std::string t(wl); size_t a = 0;
+        while (a <= t.size()) { size_t b = t.find(';', a); if (b == std::string::npos) b = t.size(); if (b > a) walks.push_back(t.substr(a, b - a)); a = b + 1; }
+      }
+      for (const std::string &wks : walks) {
+        const char *wk = wks.c_str();
+        setenv("NT_WALK", wk, 1);
+        char nm[3][96];
+        snprintf(nm[0], 96, "walk %-8s fc1 fwd GELU+drop+g' (SAVE_GRAD)", wk);
+        snprintf(nm[1], 96, "walk %-8s fc2 dgrad * saved g' (MUL_SAVED)", wk);
+        snprintf(nm[2], 96, "walk %-8s fc1 shape plain", wk);
+        timeit(nm[0], fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU | APERTIS_ACT_SAVE_GRAD, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
+        timeit(nm[1], fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_MUL_SAVED, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+        timeit(nm[2], fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+      }
+    }
+    if (!only || !strcmp(only, "tn")) {
+      for (const char *rg : {"0", "2", "0", "2"}) {
+        setenv("TN_RING", rg, 1);
+        char nm[96]; snprintf(nm, 96, "TN pair (dW2 = dy^T h, dW1 = dpre^T x), ring=%s", rg);
+        timeit(nm, 2 * fl, [&] { return apertis_grouped_gemm_tn_pair(y, h, dw2, db2, H, I, dpre, x, dw1, db1, I, H, offs, rows, E, ws, wsb, APERTIS_BF16, nullptr); });
+        snprintf(nm, 96, "TN as two launches (32 CUs per expert), ring=%s", rg);
+        timeit(nm, 2 * fl, [&] {
+          int rc = apertis_grouped_gemm_tn(y, h, offs, dw2, db2, rows, H, I, E, ws, wsb, APERTIS_BF16, nullptr);
+          return rc ? rc : apertis_grouped_gemm_tn(dpre, x, offs, dw1, db1, rows, I, H, E, ws, wsb, APERTIS_BF16, nullptr); });
+      }
+    }
+    return 0;
+  }
   if (getenv("PROBE_SHORT")) {   // the two plain shapes only (epilogue probes: -DNT_PROBE_FORCE=2 -DNT_PROBE_EPI=1|2)
     timeit("fc1 fwd shape (N=I, K=H), plain (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
     timeit("fc2 fwd (N=H, K=I), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
