@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapertis_hip.so")
+# APERTIS_HIP_LIB: developer switch - another build of the same library (tools/ A/B runs); never a fallback
+LIB_PATH = os.environ.get("APERTIS_HIP_LIB") or os.path.join(_HERE, "libapertis_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
@@ -42,6 +43,7 @@ SIGNATURES = {
                                     _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "apertis_ssm_gate_bwd_blocks": (_i64, [_i64, _i64]),
     "apertis_scan_gate_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "apertis_scan_gate_chunk_len": (_i64, []),
     "apertis_scan_gate_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp,
                                      _vp, ctypes.c_uint32, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_scan_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp,

@@ -53,7 +53,10 @@ __device__ unsigned long long g_probe[8192 * 8];
 #define PROBE(k) do { } while (0)
 #endif
 
-constexpr int LTG = 64;    // tokens per item = apertis_scan_chunk_len(): the granularity of h_in and of the aggregates
+#ifndef SCAN_GATE_LT
+#define SCAN_GATE_LT 64
+#endif
+constexpr int LTG = SCAN_GATE_LT;   // tokens per item = apertis_scan_gate_chunk_len(): the granularity of h_in and of the aggregates
 constexpr int SUP = 8;     // chunks per super-chunk of the two-level look-back
 
 // silu and its derivative on the hardware exp2 / rcp (1 ulp each: ~3e-7 relative, far inside the 1e-4 parity bar); the
@@ -155,7 +158,7 @@ template <int EPC> struct YGet<bf16_t, EPC> {
 
 // geometry of a work-group: CW channel groups x NS token segments (waves), 64 tokens
 template <int CW> struct Geo {
-  static constexpr int NS = CW <= 2 ? 8 : 4, CWC = 64 * CW, NTH = CWC * NS, TS = LTG / NS;
+  static constexpr int NS = (CW <= 2 ? 8 : 4) * LTG / 64, CWC = 64 * CW, NTH = CWC * NS, TS = LTG / NS;
 };
 
 // Compose the published records [j0, j1) (granule index = record index) in composition order into (P, S):
@@ -970,6 +973,8 @@ template <typename T> int gate_align(std::initializer_list<std::pair<const void 
 
 }  // namespace
 
+extern "C" int64_t apertis_scan_gate_chunk_len(void) { return LTG; }
+
 extern "C" int64_t apertis_scan_gate_workspace_bytes(int64_t B, int64_t L, int64_t Dn) {
   // 64-byte head (two ticket counters, error word) + per (batch, channel super-tile): one record per chunk of 64 tokens and
   // one per super-chunk of 8 chunks, each 64*CW lanes x 2 granules x 8 bytes; sized for the padded channel count
@@ -988,6 +993,7 @@ extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const
             (hipStream_t)stream};
   int rc = make_dims(a.d, B, L, h, N, delta_softplus);
   if (rc) return rc;
+  a.d.nchunks = (int)ceil_div64(L, LTG);
   const int64_t Dn = a.d.Dn;
   if (bt_rs < Dn || c_rs < Dn || xc_rs < Dn || z_rs < Dn || out_rs < Dn) return APERTIS_ERR_ARG;
   if (dtype == APERTIS_F32) {
@@ -1020,6 +1026,7 @@ extern "C" int apertis_scan_gate_bwd(const float *dlt, const float *A_log, const
             dxc_rs, dz, dz_rs, d_dlt, dA_dD, agg, fold, part, ws, epoch, {}, single_pass, (hipStream_t)stream};
   int rc = make_dims(a.d, B, L, h, N, delta_softplus);
   if (rc) return rc;
+  a.d.nchunks = (int)ceil_div64(L, LTG);
   const int64_t Dn = a.d.Dn;
   if (bt_rs < Dn || c_rs < Dn || xc_rs < Dn || z_rs < Dn || dout_rs < Dn || dxc_rs < Dn || dz_rs < Dn) return APERTIS_ERR_ARG;
   // dBt / dC may be zero-extended up to the next multiple of 64 channels (the padded slices of the projection output)

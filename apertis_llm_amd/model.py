@@ -362,8 +362,11 @@ class SelectiveLinearAttention(nn.Module):
         have_window = (conv_prev is not None and use_cache and conv_prev.shape[1] == Dn and conv_prev.shape[2] == kw - 1)
         # in_proj_x and in_proj_z share their input: one GEMM with the stacked weight, outputs are
         # column views (core.py:366-367)
-        xz = _mfma_linear(hidden_states, torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
-        wp, Wb, Wr = self._padded_param_weight()
+        # (under no_grad - generate() - the stacked and the padded weight are prepared once, not per token)
+        w_xz = ops.cached_prep("in_proj_xz", (self.in_proj_x.weight, self.in_proj_z.weight),
+                               lambda: torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
+        xz = _mfma_linear(hidden_states, w_xz)
+        wp, Wb, Wr = ops.cached_prep("x_param_padded", (self.x_param_proj.weight,), self._padded_param_weight)
         if (L == 1 and have_window and ssm_prev is not None and not output_attentions and not torch.is_grad_enabled()
                 and hidden_states.is_cuda and kw > 1):
             # single-token decode step (generate(), core.py:1578-1603): two small kernels around the projections

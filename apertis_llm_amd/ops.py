@@ -255,7 +255,7 @@ class _ScanGate(torch.autograd.Function):
             h0 = h0.float().reshape(B, Dn).contiguous()
         ctx.slots = (_slot_of(Bt), _slot_of(C), _slot_of(z), _slot_of(xc))
         (Bt, bt_rs), (C, c_rs), (xc, xc_rs), (z, z_rs) = _rows(Bt, wB), _rows(C, wC), _rows(xc, Dn), _rows(z, Dn)
-        nch = lib.apertis_scan_num_chunks(B, L, Dn)
+        nch = -(-L // int(lib.apertis_scan_gate_chunk_len()))
         dev = dlt.device
         out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
         h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
@@ -969,10 +969,70 @@ def moe_combine(yr, w, plan, out_dtype=None):
     return _Combine.apply(yr, w, plan, out_dtype or yr.dtype)
 
 
-def cast_transpose(w, dtype, want_plain=True, want_transposed=True):
+# Prepared-weight cache of the INFERENCE path (generate() / chat decode every token through the same weights; reference
+# core.py:1578-1603).  An entry belongs to one SOURCE tensor object - a parameter, or a tensor an earlier cached_prep call
+# produced and therefore keeps alive - and is valid while that object is the same (weak reference: a temporary that happens
+# to be allocated where a dead tensor lived never hits), its version counter has not moved and WEIGHT_EPOCH is the one it
+# was made in: ApertisAdamW bumps the epoch on every step, because its kernels update parameters through raw pointers,
+# which the version counter does not see.  Training never reads the cache (autograd Functions pass cache=False when an
+# input needs a gradient): its compute copies change with every optimizer step anyway.
+WEIGHT_EPOCH = 0
+_prep_cache = {}
+
+
+def note_weights_changed():
+    """Parameters were updated behind torch's back (a HIP optimizer kernel): prepared inference copies are stale."""
+    global WEIGHT_EPOCH
+    WEIGHT_EPOCH += 1
+    _prep_cache.clear()
+
+
+def _stable_source(t):
+    """The tensor object whose identity may key the cache: t itself or the tensor it is a view of, if that is a parameter
+    or the product of a cached_prep call; else None."""
+    base = t._base if t._base is not None else t
+    return base if (isinstance(base, torch.nn.Parameter) or getattr(base, "_apertis_prepared", False)) else None
+
+
+def cached_prep(tag, tensors, make, enable=None):
+    """`make()` memoised on (tag, the source tensors' identity + version); only under torch.no_grad (`enable` overrides:
+    inside an autograd Function's forward grad mode is off although the call may belong to a training step) and only
+    for stable sources (_stable_source) - otherwise just `make()`."""
+    import weakref
+    if enable is None:
+        enable = not torch.is_grad_enabled()
+    srcs = [_stable_source(t) for t in tensors] if enable else [None]
+    if any(x is None for x in srcs):
+        return make()
+    key = (tag, tuple(id(x) for x in srcs))
+    state = tuple((t.data_ptr(), x._version, tuple(t.shape), t.dtype) for t, x in zip(tensors, srcs)) + (WEIGHT_EPOCH,)
+    ent = _prep_cache.get(key)
+    if ent is None or ent[0] != state or any(r() is not x for r, x in zip(ent[1], srcs)):
+        if len(_prep_cache) > 8192:      # (models come and go in one process: do not keep their copies for ever)
+            _prep_cache.clear()
+        val = make()
+        for v in (val if isinstance(val, (tuple, list)) else (val,)):
+            if isinstance(v, torch.Tensor):
+                v._apertis_prepared = True          # kept alive by the entry: a stable source for the next level
+        ent = _prep_cache[key] = (state, [weakref.ref(x) for x in srcs], val)
+    return ent[2]
+
+
+def cast_transpose(w, dtype, want_plain=True, want_transposed=True, cache=False):
     """Compute copies of an fp32 master weight [E,R,C]: ([E,R,C'], [E,C,R']) in `dtype`.  In bf16 the
     last dimension is zero-padded to a multiple of 64 (C', R'): the GEMM's W operand then has whole
-    64-wide K steps whatever K is; pass `.shape[-1]` as its row pitch (ldw)."""
+    64-wide K steps whatever K is; pass `.shape[-1]` as its row pitch (ldw).  cache=True (inference: no input of the
+    calling op needs a gradient): the result is kept per weight (cached_prep), and an fp32 plain copy of an fp32 weight
+    is the weight itself."""
+    if cache and w.is_cuda:
+        if dtype == torch.float32 and w.dtype == torch.float32 and want_plain and not want_transposed and w.is_contiguous():
+            return w.detach(), None
+        return cached_prep(("cast", dtype, want_plain, want_transposed), (w,),
+                           lambda: _cast_transpose(w, dtype, want_plain, want_transposed), enable=True)
+    return _cast_transpose(w, dtype, want_plain, want_transposed)
+
+
+def _cast_transpose(w, dtype, want_plain=True, want_transposed=True):
     _require_gpu(w)
     lib = _lib.load()
     w = w.detach()
@@ -1101,7 +1161,7 @@ class _GroupedLinear(torch.autograd.Function):
             wc = weight.detach()
             wt = cast_transpose(weight, compute_dtype, want_plain=False)[1] if need_grad else None
         else:
-            wc, wt = cast_transpose(weight, compute_dtype, want_transposed=need_grad)
+            wc, wt = cast_transpose(weight, compute_dtype, want_transposed=need_grad, cache=not need_grad)
         bf = None if bias is None else bias.detach().float().contiguous()
         code = dtype_code(x)
         act_code = _ACTS[act]
@@ -1438,8 +1498,8 @@ class _ExpertMLP(torch.autograd.Function):
         E, I, H = w1.shape
         xg = xg.to(cd).contiguous()
         need = any(ctx.needs_input_grad[:5])
-        w1c, w1t = cast_transpose(w1, cd, want_transposed=need)
-        w2c, w2t = cast_transpose(w2, cd, want_transposed=need)
+        w1c, w1t = cast_transpose(w1, cd, want_transposed=need, cache=not need)
+        w2c, w2t = cast_transpose(w2, cd, want_transposed=need, cache=not need)
         b1f, b2f = b1.detach().float().contiguous(), b2.detach().float().contiguous()
         code, act_code = dtype_code(xg), _ACTS[act]
         R = xg.shape[0]

@@ -156,6 +156,7 @@ class ApertisAdamW(torch.optim.Optimizer):
                 check(lib.apertis_adamw_step(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"], float(group["lr"]), float(b1),
                                              float(b2), float(group["eps"]), float(group["weight_decay"]), step, ptr(coef),
                                              stream_ptr()), "apertis_adamw_step")
+        ops.note_weights_changed()      # (the kernels write the parameters through raw pointers: no version bump)
         return loss
 
 

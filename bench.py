@@ -136,6 +136,57 @@ def launcher_selftest(args, rank, world):
     return 0
 
 
+def decode_bench(args, model, dev, seq, log):
+    """generate() as a measured path (reference core.py:1474-1644): prefill of 2048 random tokens, then 128
+    greedy tokens through the cached single-token step.  tokens/s counts NEW tokens of all sequences; the roofline is the
+    weight-streaming floor: every token step reads the model's active weights once (experts: the expected fraction
+    1 - (1 - K/E)^B that B sequences' top-K choices touch under uniform routing) in the compute dtype."""
+    import torch
+    from apertis_llm_amd import ops
+    cfg = model.config
+    model = model.to(dev).eval()
+    prefill, new = min(2048, seq), 128
+    n_total = sum(p.numel() for p in model.parameters())
+    n_exp = sum(p.numel() for n, p in model.named_parameters() if "expert_w" in n)
+    e_b = 2 if args.decode_dtype == "bf16" else 4
+    K, E = max(cfg.experts_per_token, 1), max(cfg.num_experts, 1)
+    lines = []
+    for B in ([args.batch] if args.batch else [1, 16]):
+        gen = torch.Generator(device=dev).manual_seed(7)
+        ids = torch.randint(4, cfg.vocab_size, (B, prefill), device=dev, generator=gen)
+
+        def run(n_new):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.decode_dtype == "bf16"):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out = model.generate(ids, max_new_tokens=n_new, eos_token_id=[-1], use_cache=True)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0, out
+        run(4)                                        # warm-up: prepared weights, allocator, kernels
+        t_pre, _ = run(1)                             # prefill + first token
+        t_all, out = run(new)
+        assert out.shape == (B, prefill + new)
+        per_tok = (t_all - t_pre) / (new - 1)
+        frac = 1.0 - (1.0 - K / E) ** B if n_exp else 0.0
+        wbytes = e_b * ((n_total - n_exp) + n_exp * frac)
+        lines.append({"batch": B, "prefill_ms": 1e3 * t_pre, "ms_per_token_step": 1e3 * per_tok, "tokens_per_s": B / per_tok,
+                      "weight_bytes_per_step": wbytes, "weight_stream_GBps": wbytes / per_tok / 1e9,
+                      "frac_of_hbm_peak": wbytes / per_tok / 1e9 / HBM_PEAK_GBS})
+        log(f"decode B={B}: prefill {1e3 * t_pre:.1f} ms, {1e3 * per_tok:.2f} ms per token step, {B / per_tok:.1f} tokens/s, "
+            f"{wbytes / per_tok / 1e9:.0f} GB/s of weights")
+    best = max(lines, key=lambda d: d["tokens_per_s"])
+    err = ops.scan_gate_error(dev)
+    print(json.dumps({"metric": f"generate() new tokens/sec ({args.config}, {prefill}-token prefill, {new} new tokens, greedy)",
+                      "value": best["tokens_per_s"], "unit": "tokens/s", "n_gpus": 1, "higher_is_better": True,
+                      "dtype": args.decode_dtype, "data": "synthetic",
+                      "config": {"workload": f"{args.config} decode", "prefill": prefill, "new_tokens": new,
+                                 "scan_lookback_error_word": err},
+                      "roofline": {"bound": "hbm", "achieved": best["weight_stream_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": best["frac_of_hbm_peak"], "traffic": None, "kernel": "weight stream of one token step"},
+                      "per_batch": lines}), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +198,11 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--reduce-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--logits-path", action="store_true", help="A/B: materialise the [B, L, V] logits (LM head, then the loss)")
+    ap.add_argument("--decode", action="store_true",
+                    help="measure generate() instead of the training step: 2048-token prefill, then 128 greedy tokens "
+                         "(reference core.py:1520-1644), per-GPU batch --batch (default 1 and 16), --decode-dtype")
+    ap.add_argument("--decode-dtype", default="bf16", choices=["bf16", "fp32"],
+                    help="bf16 = autocast (prepared bf16 weight copies, cached across tokens); fp32 = the model's own dtype")
     ap.add_argument("--launcher-selftest", action="store_true",
                     help="CPU/gloo self-test of the rank launcher and the timing protocol (tests/): no GPU work, "
                          "the line says so and is not a measurement")
@@ -195,6 +251,8 @@ def main():
                                    attention_type_override="selective_ssm")
     cfg = model.config
     log("model built on host")
+    if args.decode:
+        raise SystemExit(decode_bench(args, model, dev, seq, log))
     model = model.to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     step = TrainStep(model, lr=5e-5, weight_decay=0.01, max_grad_norm=1.0, total_steps=args.steps + args.warmup + 1,

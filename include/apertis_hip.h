@@ -131,7 +131,8 @@ int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn);
  *     caller, then reused by ONE stream at a time) and `epoch` (non-zero, incremented by exactly 1 per launch that uses
  *     `ws`: the two ticket counters in its head alternate).  The int32 at byte 8 of `ws` is an error word (non-zero: a
  *     bounded wait timed out and the outputs of that launch are invalid).
- *   agg, h_in, h_last, h0: as for apertis_selective_scan_fwd (h_in is saved per apertis_scan_chunk_len() tokens).
+ *   agg, h_in, h_last, h0: as for apertis_selective_scan_fwd (h_in is saved per apertis_scan_gate_chunk_len() tokens;
+ *   nchunks here = ceil(L / apertis_scan_gate_chunk_len())).
  * Backward:
  *   dout [B,L,Dn]; dBt, dC [B,L,store_w] with Dn <= store_w <= ceil(Dn/64)*64: columns [Dn, store_w) are written as
  *   zeros (the zero-padded slices of the projection output's gradient buffer); dxc, dz [B,L,Dn]; d_dlt [B,L,h] fp32;
@@ -139,6 +140,9 @@ int64_t apertis_ssm_gate_bwd_blocks(int64_t T, int64_t Dn);
  *   [64, 2*Dn] fp32.
  * ------------------------------------------------------------------------------------------ */
 int64_t apertis_scan_gate_workspace_bytes(int64_t B, int64_t L, int64_t Dn);
+/* Tokens per work item of the fused kernels: h_in, agg and the backward's partial sums (`part`: [B * chunks][2 * Dn]) are
+ * laid out per chunk of this many tokens (ceil(L / len) chunks per sequence). */
+int64_t apertis_scan_gate_chunk_len(void);
 int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
                           const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
                           void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, void *ws, uint32_t epoch,
