@@ -2031,6 +2031,293 @@ __global__ void __launch_bounds__(256) tn3_fold_k(Tn3Args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// TN v5 (bf16): 256 x 352 / 352 x 256 output tiles for weight gradients with a 704-wide side (the H = 704 family:
+// dW1 [2816, 704], dW2 [704, 2816]).  On 256 x 256 tiles 704 is 256 + 256 + 192: 33 tiles per (problem, expert), a quarter
+// of every third tile's MFMAs multiply zeros (8.3 % of the work) and every 32-deep interval carries the same barrier /
+// fragment-read / DMA-issue overhead under 32 MFMAs per wave.  Here an interval has 44 MFMAs per wave under the same
+// overhead, a group has 22 tiles, and a tile moves 17 % fewer operand bytes per flop.  Scheme of v3 (CUs dealt to the
+// (problem, expert) groups, lock-step rounds, row-split remainder tiles folded in slice order, optional item queue,
+// bias gradient from the matrix pipe); what differs:
+//  - the 352-wide operand's k-rows (704 B) sit on a 768-byte LDS pitch, so the 32-byte window swizzle f(k) of v3 stays
+//    inside the row (windows 16..21 map into 16..23) and the bank pattern of the transposed reads is v3's;
+//  - its DMA pieces (1 KiB of LDS = 1 1/3 rows) take a per-lane source offset from a table of three (the pattern
+//    repeats every three pieces = four rows); pad positions repeat the row's last chunk;
+//  - 8 waves as 2 (M) x 4 (N) of 176 x 64 (WIDE_M) or 4 (M) x 2 (N) of 64 x 176: 176 accumulator registers, so the
+//    eleven fragments of the wide side are read two ahead of the MFMAs that consume them (as grouped_gemm_nt352p_k
+//    does; v3's half-interval stagger would have to hold all fifteen fragments across the barrier);
+//  - three slots of 32 k-rows (40 KiB each), two stages in flight, the five DMA pieces of a wave per interval issued
+//    one by one between the MFMA groups (see v3).
+// ------------------------------------------------------------------------------------------
+constexpr int TN5_PW = 768;                         // LDS pitch of a 352-wide k-row
+constexpr int TN5_STAGE = 32 * (TN5_PW + 512);      // A image then B image
+constexpr int TN5_SLOT = 256 * 352 + 352;           // floats per partial tile (+ its partial bias sums)
+struct Tn5Args {
+  Tn3Problem p0, p1;   // (m_tiles / n_tiles in units of this kernel's tiles)
+  int wide_m0, wide_m1;
+  int nprob, E, cpg;
+  float *ws;
+  int *ctr;
+};
+
+template <bool WIDE_M>
+__device__ __forceinline__ void tn5_body(const Tn5Args &a, const int32_t *__restrict__ offsets, char *smem, int g, int j,
+                                         bool second) {
+  typedef bf16_t T;
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  constexpr int IM = WIDE_M ? 11 : 4, JN = WIDE_M ? 4 : 11;       // 16-wide subtiles of a wave along m / n
+  constexpr int TMx = WIDE_M ? 352 : 256, TNx = WIDE_M ? 256 : 352;
+  constexpr int PA = WIDE_M ? TN5_PW : 512, PB = WIDE_M ? 512 : TN5_PW;
+  constexpr int OPA = 32 * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = WIDE_M ? wave >> 2 : wave >> 1, wn = WIDE_M ? wave & 3 : wave & 1;
+  const int e = second ? g - a.E : g;
+  const T *__restrict__ A = second ? a.p1.A : a.p0.A, *__restrict__ Bm = second ? a.p1.Bm : a.p0.Bm;
+  float *__restrict__ dW = second ? a.p1.dW : a.p0.dW, *__restrict__ dbias = second ? a.p1.dbias : a.p0.dbias;
+  const int M = second ? a.p1.M : a.p0.M, N = second ? a.p1.N : a.p0.N;
+  const int m_tiles = second ? a.p1.m_tiles : a.p0.m_tiles, n_tiles = second ? a.p1.n_tiles : a.p0.n_tiles;
+  const Tn3Sched sc = tn3_sched(m_tiles, n_tiles, a.cpg);
+  const int r_begin = offsets[e], rows = offsets[e + 1] - r_begin;
+  const int nsteps = (rows + 63) / 64;
+  const int ldA = M * (int)sizeof(T), ldB = N * (int)sizeof(T);
+
+  // per-lane source offsets of the DMA pieces.  512-byte rows: piece p = two k-rows (v3's scheme).  768-pitch rows: lane i
+  // of piece p fills LDS byte 1024 p + 16 i = row r, position pos; it fetches chunk pos ^ (f(r) << 1) of that row.
+  const int hi = lane >> 5;
+  const int nchunk = (lane & 31) ^ (hi << 1) ^ ((wave & 1) << 2) ^ (((wave >> 2) & 1) << 3);
+  const int ld_narrow = WIDE_M ? ldB : ldA, ld_wide = WIDE_M ? ldA : ldB;
+  const uint32_t vn0 = (uint32_t)(hi * ld_narrow + nchunk * 16);
+  uint32_t vw[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int o = 1024 * (wave + 8 * q) + 16 * lane;
+    const int r = o / TN5_PW, pos = (o - r * TN5_PW) >> 4;
+    const int fk = (r & 3) | (((r >> 3) & 1) << 2);
+    const int c = min(pos ^ (fk << 1), 43);
+    vw[q] = (uint32_t)r * (uint32_t)ld_wide + (uint32_t)(c * 16);
+  }
+  const int frow = lane & 15, fg = lane >> 4;
+  const int trow = frow >> 2, tcol4 = (frow & 3) * 4;
+  const int lane_sw = trow | ((fg & 1) << 2);
+  const int rd_a = (8 * fg + trow) * PA + tcol4 * 2, rd_b = (8 * fg + trow) * PB + tcol4 * 2;
+  const int wn_u = wn;
+
+  int *s_next = reinterpret_cast<int *>(smem + 3 * TN5_STAGE);
+  const int n_full = sc.full * a.cpg, n_items = n_full + (sc.rem ? sc.rem * sc.s : 0);
+  int item = j;
+  for (int par = 1; item < n_items; par ^= 1) {
+    int nxt = 0;
+    if (a.ctr && tid == 0) nxt = a.cpg + atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);
+    int tile, s0 = 0, s1 = nsteps, slot = 0;
+    bool partial = false;
+    if (item < n_full) {
+      tile = item;
+    } else {
+      const int r = item - n_full, ri = r / sc.s;
+      const int sl = r - ri * sc.s, per = (nsteps + sc.s - 1) / sc.s;
+      tile = n_full + ri;
+      s0 = min(sl * per, nsteps);
+      s1 = min(s0 + per, nsteps);
+      partial = sc.s > 1;
+      slot = g * a.cpg + r;
+    }
+    int mt, nt;
+    tn3_tile_coord(tile, m_tiles, n_tiles, mt, nt);
+    const int m0 = mt * TMx, n0 = nt * TNx;
+    const bool want_bias = dbias != nullptr && nt == 0;
+    const v4i ars = raw_buffer_rsrc(A + (int64_t)r_begin * M + m0, rows > 0 ? (uint32_t)(rows * ldA - m0 * (int)sizeof(T)) : 0u);
+    const v4i brs = raw_buffer_rsrc(Bm + (int64_t)r_begin * N + n0, rows > 0 ? (uint32_t)(rows * ldB - n0 * (int)sizeof(T)) : 0u);
+    const v4i &wrs = WIDE_M ? ars : brs, &nrs = WIDE_M ? brs : ars;
+    const uint32_t lds0 = lds_addr_of(smem);
+    const int nsub = 2 * (s1 - s0);
+
+    f32x4 acc[JN][IM];
+#pragma unroll
+    for (int jn = 0; jn < JN; ++jn)
+#pragma unroll
+      for (int im = 0; im < IM; ++im) acc[jn][im] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int NB = WIDE_M ? 3 : 2;   // m-subtiles whose bias sums this wave forms
+    f32x4 accb[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) accb[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma_ones = [&](f32x4 &d, const bf16x8 &b) {   // (the all-ones fragment is rebuilt where it is used: four registers less)
+      bf16x8 ones;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ones[q] = (bf16_t)1.0f;
+      mma(d, ones, b);
+    };
+
+    // piece q (0..4) of this wave's share of stage u: 0..2 the 768-pitch image, 3..4 the 512-pitch image.  Past the item's
+    // last stage the piece is still issued, from beyond the descriptor's range: zeros into a slot nobody reads again
+    auto piece = [&](int u, uint32_t slot_off, int q) {   // slot_off = (u % 3) * TN5_STAGE, kept as a running value by the caller
+      const uint32_t wimg = lds0 + slot_off + (WIDE_M ? 0 : OPA), nimg = lds0 + slot_off + (WIDE_M ? OPA : 0);
+      const uint32_t row0 = (uint32_t)(s0 * 64 + u * 32);
+      const bool live = u < nsub;
+      if (q < 3) lds_dma16(wrs, wimg + (wave + 8 * q) * 1024, live ? vw[q] + row0 * (uint32_t)ld_wide : 0xfffffff0u);
+      else {
+        const int p = (q - 3) * 8 + wave;
+        lds_dma16(nrs, nimg + p * 1024, live ? vn0 + (row0 + 2 * p) * (uint32_t)ld_narrow : 0xfffffff0u);
+      }
+    };
+    // (the swizzle key is laundered once per interval: the fifteen window offsets are loop invariants that hipcc would
+    // otherwise keep in registers across the K loop - and spill: 200-270 B of scratch, reloaded every interval)
+    int lsw = lane_sw;
+    auto read_a = [&](const char *as, int im) {
+      union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+            as + rd_a + (((wm * IM + im) ^ lsw) << 5) + (4 * hh) * PA));
+      return u.v;
+    };
+    auto read_b = [&](const char *bs, int jn) {
+      union { bf16x8 v; s16x4 h[2]; } u;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+        u.h[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(
+            bs + rd_b + (((wn * JN + jn) ^ lsw) << 5) + (4 * hh) * PB));
+      return u.v;
+    };
+#pragma unroll
+    for (int q = 0; q < 5; ++q) piece(0, 0u, q);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) piece(1, (uint32_t)TN5_STAGE, q);
+    uint32_t off_cur = 0u, off_nxt = TN5_STAGE, off_fill = 2 * TN5_STAGE;   // slots of stages u, u + 1, u + 2
+    for (int u = 0; u < nsub; ++u) {
+      wait_vmcnt<5>();   // stage u has landed once only stage u + 1's five pieces are outstanding (vmcnt retires in order)
+      lds_barrier();     // ... for every wave, and nobody still reads slot (u - 1) % 3, which stage u + 2 overwrites
+      const char *as = smem + off_cur, *bs = as + OPA;
+      asm volatile("" : "+v"(lsw));
+      bf16x8 af[IM], bf[JN];
+      __builtin_amdgcn_s_setprio(1);
+      if constexpr (WIDE_M) {
+#pragma unroll
+        for (int jn = 0; jn < JN; ++jn) bf[jn] = read_b(bs, jn);
+        af[0] = read_a(as, 0); af[1] = read_a(as, 1);
+#pragma unroll
+        for (int im = 0; im < IM; ++im) {
+          if (im + 2 < IM) af[im + 2] = read_a(as, im + 2);
+          __builtin_amdgcn_sched_barrier(0);   // keeps the reads from being hoisted into one block of 44 live registers
+#pragma unroll
+          for (int jn = 0; jn < JN; ++jn) mma(acc[jn][im], bf[jn], af[im]);
+          if (want_bias && (im & 3) == wn_u) mma_ones(accb[im >> 2], af[im]);   // (wave-uniform: MFMA ignores EXEC)
+          if (!(im & 1) && im < 10) {
+            __builtin_amdgcn_sched_barrier(0);
+            piece(u + 2, off_fill, im >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int im = 0; im < IM; ++im) af[im] = read_a(as, im);
+        bf[0] = read_b(bs, 0); bf[1] = read_b(bs, 1);
+#pragma unroll
+        for (int jn = 0; jn < JN; ++jn) {
+          if (jn + 2 < JN) bf[jn + 2] = read_b(bs, jn + 2);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int im = 0; im < IM; ++im) mma(acc[jn][im], bf[jn], af[im]);
+          if (jn == 0 && want_bias) {
+#pragma unroll
+            for (int im = 0; im < IM; ++im)
+              if ((im >> 1) == wn_u) mma_ones(accb[im & 1], af[im]);
+          }
+          if (!(jn & 1) && jn < 10) {
+            __builtin_amdgcn_sched_barrier(0);
+            piece(u + 2, off_fill, jn >> 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      { const uint32_t t = off_cur; off_cur = off_nxt; off_nxt = off_fill; off_fill = t; }
+    }
+    wait_vmcnt<0>();   // the zero-fill pieces past the last stage: the ring must be quiet before the next item's first DMA
+    if (a.ctr && tid == 0) s_next[par] = nxt;
+    __syncthreads();
+    int item_next;
+    if (a.ctr) item_next = __builtin_amdgcn_readfirstlane(s_next[par]);
+    else if (item + a.cpg < n_full) item_next = item + a.cpg;
+    else item_next = (item < n_full && j < n_items - n_full) ? n_full + j : n_items;
+
+    // D rows = n (fg*4 + r within subtile jn), D cols = m (frow within subtile im)
+    float *out;
+    int64_t ldo;
+    bool bounded;
+    if (partial) { out = a.ws + (int64_t)slot * TN5_SLOT; ldo = TNx; bounded = false; }
+    else { out = dW + (int64_t)e * M * N + (int64_t)m0 * N + n0; ldo = N; bounded = true; }
+#pragma unroll
+    for (int jn = 0; jn < JN; ++jn)
+#pragma unroll
+      for (int im = 0; im < IM; ++im) {
+        const int m = (wm * IM + im) * 16 + frow, n = (wn * JN + jn) * 16 + fg * 4;
+        if (!bounded || (m0 + m < M && n0 + n < N)) *reinterpret_cast<f32x4 *>(out + (int64_t)m * ldo + n) = acc[jn][im];
+      }
+    if (want_bias && fg == 0) {
+#pragma unroll
+      for (int im = 0; im < IM; ++im) {
+        const bool mine = WIDE_M ? (im & 3) == wn_u : (im >> 1) == wn_u;
+        if (mine) {
+          const int m = (wm * IM + im) * 16 + frow;
+          const float v = accb[WIDE_M ? im >> 2 : im & 1][0];
+          if (partial) a.ws[(int64_t)slot * TN5_SLOT + TMx * TNx + m] = v;
+          else if (m0 + m < M) dbias[(int64_t)e * M + m0 + m] = v;
+        }
+      }
+    }
+    item = item_next;
+  }
+}
+
+__global__ void __launch_bounds__(NT2)
+grouped_gemm_tn5_k(Tn5Args a, const int32_t *__restrict__ offsets) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int id = xcd_remap(blockIdx.x, gridDim.x);
+  const int g = id / a.cpg, j = id - g * a.cpg;
+  const bool second = g >= a.E;
+  if (second ? a.wide_m1 : a.wide_m0) tn5_body<true>(a, offsets, smem, g, j, second);
+  else tn5_body<false>(a, offsets, smem, g, j, second);
+}
+
+// sums the row-slices of the split tiles in slice order.  grid = (groups * max(1, cpg/2), 22)
+__global__ void __launch_bounds__(256) tn5_fold_k(Tn5Args a) {
+  const int half = max(1, a.cpg / 2);
+  const int g = blockIdx.x / half, ri = blockIdx.x - g * half;
+  const bool second = g >= a.E;
+  const int e = second ? g - a.E : g;
+  const Tn3Problem &pp = second ? a.p1 : a.p0;
+  const bool wide_m = second ? a.wide_m1 : a.wide_m0;
+  const int TMx = wide_m ? 352 : 256, TNx = wide_m ? 256 : 352;
+  const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, a.cpg);
+  if (ri >= sc.rem || sc.s <= 1) return;
+  const int tile = sc.full * a.cpg + ri;
+  int mt, nt;
+  tn3_tile_coord(tile, pp.m_tiles, pp.n_tiles, mt, nt);
+  const int m0 = mt * TMx, n0 = nt * TNx;
+  const float *src = a.ws + (int64_t)(g * a.cpg + ri * sc.s) * TN5_SLOT;
+  float *out = pp.dW + (int64_t)e * pp.M * pp.N;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = (blockIdx.y * 1024 + q * 256 + threadIdx.x) * 4;   // < 256 * 352 = 22 * 4096
+    const int m = idx / TNx, n = idx - m * TNx;
+    if (m0 + m >= pp.M || n0 + n >= pp.N) continue;
+    float4 sum = *reinterpret_cast<const float4 *>(src + idx);
+    for (int sl = 1; sl < sc.s; ++sl) {
+      const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)sl * TN5_SLOT + idx);
+      sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(out + (int64_t)(m0 + m) * pp.N + n0 + n) = sum;
+  }
+  if (pp.dbias && nt == 0 && blockIdx.y == 0) {
+    for (int m = threadIdx.x; m < TMx; m += 256) {
+      if (m0 + m >= pp.M) continue;
+      float sum = src[TMx * TNx + m];
+      for (int sl = 1; sl < sc.s; ++sl) sum += src[(int64_t)sl * TN5_SLOT + TMx * TNx + m];
+      pp.dbias[(int64_t)e * pp.M + m0 + m] = sum;
+    }
+  }
+}
+
 int device_cu_count() {
   static const int ncu = [] {   // queried once: hipGetDeviceProperties costs ~1 ms of host time per call
     int n = 256, dev_id = 0;
@@ -2076,6 +2363,48 @@ int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t ma
     split |= sc.rem && sc.s > 1;
   }
   if (split) hipLaunchKernelGGL(tn3_fold_k, dim3((unsigned)(groups * std::max(1, cpg / 2)), 16), dim3(256), 0, st, a);
+  return apertis_check_launch();
+}
+
+// which tile shape of v5 suits an [M, N] weight gradient: 1 = 352 x 256, 0 = 256 x 352, -1 = neither (v3's 256 x 256
+// tiles waste no more than 5 % less)
+int tn5_variant(int64_t M, int64_t N) {
+  auto area = [&](int64_t tm, int64_t tn) { return ceil_div64(M, tm) * ceil_div64(N, tn) * tm * tn; };
+  const int64_t a3 = area(256, 256), aw = area(352, 256), an = area(256, 352);
+  if (M < 256 || N < 256 || std::min(aw, an) * 100 > a3 * 95) return -1;
+  return aw < an ? 1 : 0;
+}
+
+// returns APERTIS_ERR_UNSUPPORTED when the shapes do not suit v5 (the caller falls back to v3)
+int launch_tn5(Tn3Problem q0, Tn3Problem q1, int64_t E, int64_t max_rows, const int32_t *offsets, float *ws, int64_t ws_bytes,
+               bool item_queue, hipStream_t st) {
+  const int v0 = tn5_variant(q0.M, q0.N), v1 = tn5_variant(q1.M, q1.N);
+  const int64_t groups = 2 * E;
+  const int ncu = device_cu_count();
+  if (!ws || v0 < 0 || v1 < 0 || groups > ncu) return APERTIS_ERR_UNSUPPORTED;
+  const int cpg = (int)(ncu / groups);
+  const int grid = (int)(groups * cpg);
+  const int64_t slots_bytes = (int64_t)grid * TN5_SLOT * (int64_t)sizeof(float);
+  if (ws_bytes < slots_bytes + TN3_CTR_BYTES || (((uintptr_t)ws) & 15)) return APERTIS_ERR_UNSUPPORTED;
+  const int64_t ldmax = std::max<int64_t>(std::max(q0.M, q0.N), std::max(q1.M, q1.N)) * 2;
+  if ((max_rows + 256) * ldmax >= 0xffffffffLL) return APERTIS_ERR_UNSUPPORTED;   // 32-bit buffer offsets
+  q0.m_tiles = (int)ceil_div64(q0.M, v0 ? 352 : 256); q0.n_tiles = (int)ceil_div64(q0.N, v0 ? 256 : 352);
+  q1.m_tiles = (int)ceil_div64(q1.M, v1 ? 352 : 256); q1.n_tiles = (int)ceil_div64(q1.N, v1 ? 256 : 352);
+  Tn5Args a;
+  a.p0 = q0; a.p1 = q1; a.wide_m0 = v0; a.wide_m1 = v1;
+  a.nprob = 2; a.E = (int)E; a.cpg = cpg; a.ws = ws;
+  a.ctr = item_queue ? reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + slots_bytes) : nullptr;
+  if (a.ctr && hipMemsetAsync(a.ctr, 0, (size_t)groups * TN3_CTR_STRIDE * sizeof(int), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
+  const size_t lds = 3 * TN5_STAGE + 16;
+  hipFuncSetAttribute((const void *)grouped_gemm_tn5_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(grouped_gemm_tn5_k, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
+  bool split = false;
+  for (int q = 0; q < 2; ++q) {
+    const Tn3Problem &pp = q ? a.p1 : a.p0;
+    const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, cpg);
+    split |= sc.rem && sc.s > 1;
+  }
+  if (split) hipLaunchKernelGGL(tn5_fold_k, dim3((unsigned)(groups * std::max(1, cpg / 2)), 22), dim3(256), 0, st, a);
   return apertis_check_launch();
 }
 
@@ -2245,7 +2574,7 @@ extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_prob
   const int ncu = device_cu_count();
   const int64_t groups = E * n_problems;
   if (groups > ncu) return 0;   // v3 does not apply; no workspace needed
-  return (ncu / groups) * groups * (int64_t)TN3_SLOT * (int64_t)sizeof(float) + TN3_CTR_BYTES;
+  return (ncu / groups) * groups * (int64_t)std::max(TN3_SLOT, TN5_SLOT) * (int64_t)sizeof(float) + TN3_CTR_BYTES;
 }
 
 extern "C" int apertis_grouped_gemm_tn_q(const void *A, const void *Bm, const int32_t *offsets, float *dW,
@@ -2323,6 +2652,14 @@ extern "C" int apertis_grouped_gemm_tn_pair_q(const void *A0, const void *B0, fl
                   (int)ceil_div64(N0, 256)};
     Tn3Problem p1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, (int)ceil_div64(M1, 256),
                   (int)ceil_div64(N1, 256)};
+    bool v5 = true;
+#ifdef TN_PROBE_RING   // tools/probes only: TN_V5=0 keeps the 256 x 256 kernel
+    if (const char *ev = getenv("TN_V5")) v5 = atoi(ev) != 0;
+#endif
+    if (v5) {   // the 704-wide family: 256 x 352 / 352 x 256 tiles
+      const int rc5 = launch_tn5(p0, p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);
+      if (rc5 != APERTIS_ERR_UNSUPPORTED) return rc5;
+    }
     const int rc = launch_tn3(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);
     if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
   }

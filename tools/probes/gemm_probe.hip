@@ -137,9 +137,10 @@ int main(int argc, char **argv) {
       }
     }
     if (!only || !strcmp(only, "tn")) {
-      for (const char *rg : {"0", "2", "0", "2"}) {
-        setenv("TN_RING", rg, 1);
-        char nm[96]; snprintf(nm, 96, "TN pair (dW2 = dy^T h, dW1 = dpre^T x), ring=%s", rg);
+      for (const char *rg : {"0", "2", "5", "2", "5"}) {   // 0 / 2: v3 double buffer / ring + stagger; 5: v5 (256 x 352 tiles)
+        setenv("TN_V5", rg[0] == '5' ? "1" : "0", 1);
+        setenv("TN_RING", rg[0] == '5' ? "2" : rg, 1);
+        char nm[96]; snprintf(nm, 96, "TN pair (dW2 = dy^T h, dW1 = dpre^T x), kernel=%s", rg);
         timeit(nm, 2 * fl, [&] { return apertis_grouped_gemm_tn_pair(y, h, dw2, db2, H, I, dpre, x, dw1, db1, I, H, offs, rows, E, ws, wsb, APERTIS_BF16, nullptr); });
         snprintf(nm, 96, "TN as two launches (32 CUs per expert), ring=%s", rg);
         timeit(nm, 2 * fl, [&] {
