@@ -190,6 +190,13 @@ __device__ __forceinline__ TileCoord find_tile(const int32_t *offsets, int E, in
 // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
 // contiguous run of tiles so neighbouring tiles (same activation rows, next weight columns)
 // meet in one L2.  Bijective for any grid size.
+// two floats -> one dword of bf16 (one v_cvt_pk_bf16_f32; a conversion per element wastes half of each)
+__device__ __forceinline__ uint32_t pack_bf16x2_any(float a, float b) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+}
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -863,16 +870,16 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
           float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
           if (bias && ncol < cur.cols_valid) b = *reinterpret_cast<const float4 *>(bias + (int64_t)cur.e * N + cur.n0 + ncol);
           const float bq[4] = {b.x, b.y, b.z, b.w};
-          uint32_t o[4];
+          float o[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float a = acc[i][r][q];
             asm volatile("" : "+v"(a));   // pins the conversion inside its round
-            o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(a + bq[q]));
+            o[q] = a + bq[q];
           }
           const int srow = wm * 16 + frow_e, chunk = wn * 22 + i * 2 + (fg >> 1);
           *reinterpret_cast<uint2 *>(stg + srow * STG5_PITCH + ((chunk ^ frow_e) << 4) + (fg & 1) * 8) =
-              make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+              make_uint2(pack_bf16x2_any(o[0], o[1]), pack_bf16x2_any(o[2], o[3]));
         }
         __syncthreads();
         if (tid >= NT2 / 2) {   // store waves: 64 rows x 44 chunks
@@ -1019,7 +1026,7 @@ __device__ __forceinline__ uint4 mul_chunk_bf16(uint4 a, uint4 b) {
   for (int w = 0; w < 4; ++w) {
     const float p0 = __builtin_bit_cast(float, x[w] << 16) * __builtin_bit_cast(float, y[w] << 16);
     const float p1 = __builtin_bit_cast(float, x[w] & 0xffff0000u) * __builtin_bit_cast(float, y[w] & 0xffff0000u);
-    o[w] = (uint32_t)__builtin_bit_cast(uint16_t, from_f32<bf16_t>(p0)) | ((uint32_t)__builtin_bit_cast(uint16_t, from_f32<bf16_t>(p1)) << 16);
+    o[w] = pack_bf16x2_any(p0, p1);
   }
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -1029,6 +1036,32 @@ __device__ __forceinline__ uint4 mul_chunk_bf16(uint4 a, uint4 b) {
 // staging both outputs side by side in the ring (2 x 32 KiB) and copying them out as whole 256-byte row segments.  (Two
 // passes that each evaluated their own function and mask hash cost the forward +285 us inside the step; writing h back into
 // the accumulator registers made hipcc spill inside the K loop.)
+// Helpers of the saved-gradient epilogue below (round 3: its VALU work - 65 instructions per element pair, a sixth of them
+// bit fiddling around the mask and the conversions - is what the fc1 forward spends its time on next to the MFMAs).
+// Two floats -> one dword of bf16 (one v_cvt_pk_bf16_f32; a conversion per element wastes half of each).
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// 0xFFFF in each DROPPED half of a hash word: keep <=> r16 >= thresh16 (drop_keep4's rule) <=> clamp(thresh - r, 0) == 0,
+// on the packed 16-bit pipe (three instructions per two elements instead of two extractions, two compares and a select
+// per output)
+__device__ __forceinline__ uint32_t drop_mask2(uint32_t h, uint32_t thresh16) {
+  const u16x2_t r = __builtin_bit_cast(u16x2_t, h), t = {(unsigned short)thresh16, (unsigned short)thresh16};
+  const u16x2_t d = __builtin_elementwise_sub_sat(t, r), one = {1, 1}, ff = {0xffff, 0xffff};
+  return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_elementwise_min(d, one) * ff));
+}
+// drop_hash_pair for pair indices below 2^32 (the launcher offers the saved-gradient form only then)
+__device__ __forceinline__ uint32_t drop_hash_pair32(uint64_t seed, uint32_t pair) {
+  uint32_t h = pair ^ (uint32_t)seed;
+  h += (uint32_t)(seed >> 32);
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
 template <typename TO, bool DROP>
 __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst_h,
                                               TO *__restrict__ dst_g, char *stg, int64_t row0, int rows_valid, int n0,
@@ -1046,16 +1079,22 @@ __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const fl
         const int m = wm * 128 + j * 16 + frow;            // tile row
         const int sr = wm * 64 + jj * 16 + frow;           // its row in the half's staging image
         const int chunk = wn * 8 + i * 2 + (fg >> 1);
-        bool keep[4] = {true, true, true, true};
+        // mask words: 0xFFFF where the element is dropped (elements 0,1 in dm[0], 2,3 in dm[1])
+        uint32_t dm[2] = {0u, 0u};
 #ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
-        if (DROP) drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
+        if (DROP) {
+          const uint32_t pair = ((uint32_t)(row0 + m) * (uint32_t)N + (uint32_t)(n0 + wn * 64 + i * 16 + fg * 4)) >> 1;
+          dm[0] = drop_mask2(drop_hash_pair32(seed, pair), thresh16);
+          dm[1] = drop_mask2(drop_hash_pair32(seed, pair + 1u), thresh16);
+        }
 #endif
-        uint32_t oh[4], og[4];
+        uint32_t oh[2], og[2];
 #pragma unroll
         for (int q = 0; q < 4; q += 2) {   // two elements per packed instruction
           const v2f pre = (v2f){acc[i][j][q], acc[i][j][q + 1]} + (v2f){bv[i][q], bv[i][q + 1]};
-          // the pre-activation as the other form stores it
-          const v2f x = {to_f32(from_f32<TO>(pre.x)), to_f32(from_f32<TO>(pre.y))};
+          // the pre-activation as the other form stores it (rounded to bf16)
+          const uint32_t xpk = pack_bf16x2(pre.x, pre.y);
+          const v2f x = {__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
           v2f hv, gv;
 #if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
           hv = x * splat2(keep_scale); gv = x * splat2(0.5f * keep_scale);
@@ -1069,14 +1108,12 @@ __device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const fl
           hv = hv * splat2(keep_scale);
           gv = gv * splat2(keep_scale);
 #endif
-          oh[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? hv.x : 0.f));
-          oh[q + 1] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q + 1] ? hv.y : 0.f));
-          og[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q] ? gv.x : 0.f));
-          og[q + 1] = __builtin_bit_cast(uint16_t, from_f32<TO>(keep[q + 1] ? gv.y : 0.f));
+          oh[q >> 1] = pack_bf16x2(hv.x, hv.y) & ~dm[q >> 1];
+          og[q >> 1] = pack_bf16x2(gv.x, gv.y) & ~dm[q >> 1];
         }
         const int off = sr * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8;
-        *reinterpret_cast<uint2 *>(stg + off) = make_uint2(oh[0] | (oh[1] << 16), oh[2] | (oh[3] << 16));
-        *reinterpret_cast<uint2 *>(stg_g + off) = make_uint2(og[0] | (og[1] << 16), og[2] | (og[3] << 16));
+        *reinterpret_cast<uint2 *>(stg + off) = make_uint2(oh[0], oh[1]);
+        *reinterpret_cast<uint2 *>(stg_g + off) = make_uint2(og[0], og[1]);
       }
     lds_barrier();
 #pragma unroll 4
@@ -1108,7 +1145,7 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
     for (int j = 0; j < 8; ++j) {
       const int m = wm * 128 + j * 16 + frow;
       const int chunk = wn * 8 + i * 2 + (fg >> 1);
-      uint32_t o[4];
+      float o[4];
       bool keep[4] = {true, true, true, true};
       if (!raw && !MULPRE && (ACT >= 0 ? DROP : drop_p > 0.f))
         drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
@@ -1119,10 +1156,11 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
           if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(from_f32<TO>(v)), ACT >= 0 ? ACT : act);
           v = keep[q] ? v * keep_scale : 0.f;   // keep_scale is 1 without dropout
         }
-        o[q] = __builtin_bit_cast(uint16_t, from_f32<TO>(v));
+        o[q] = v;
       }
+      // (two elements per conversion instruction)
       *reinterpret_cast<uint2 *>(stg + m * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8) =
-          make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+          make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
     }
   lds_barrier();
   if constexpr (!MULPRE) {
@@ -2424,7 +2462,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
   const bool flagged = (act & (APERTIS_ACT_SAVE_GRAD | APERTIS_ACT_MUL_SAVED)) != 0;
   act &= 0xff;
   if (flagged && ((act_flags & APERTIS_ACT_SAVE_GRAD) ? !pre_act : !mul_pre)) return APERTIS_ERR_ARG;
-  if ((act_flags & APERTIS_ACT_SAVE_GRAD) && act != APERTIS_ACT_GELU) return APERTIS_ERR_UNSUPPORTED;
+  if ((act_flags & APERTIS_ACT_SAVE_GRAD) && (act != APERTIS_ACT_GELU || (max_rows + 256) * N >= 0x100000000LL)) return APERTIS_ERR_UNSUPPORTED;
   const int n_tiles = (int)ceil_div64(N, BN);
   const int64_t m_tiles = ceil_div64(max_rows, BM) + E;  // each group adds at most one partial tile
   const int64_t grid = m_tiles * n_tiles;
@@ -2532,8 +2570,10 @@ extern "C" int apertis_grouped_gemm_nt_saves_grad(int64_t max_rows, int64_t N, i
   if (dtype != APERTIS_BF16 || dtype_out != APERTIS_BF16 || N <= 0 || K <= 0 || E <= 0 || act != APERTIS_ACT_GELU) return 0;
   if (ldw == 0) ldw = K;
   const bool ragged2x = K % 32 != 0;
+  // ((max_rows + 256) * N < 2^32: the epilogue's mask hash takes 32-bit element indices)
   return K <= 1024 && N >= 512 && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 &&
-         max_rows >= 4096 && E <= 1024 && (ceil_div64(max_rows, BM3) + E) * ceil_div64(N, BN3) < 0x7fffffffLL;
+         max_rows >= 4096 && E <= 1024 && (ceil_div64(max_rows, BM3) + E) * ceil_div64(N, BN3) < 0x7fffffffLL &&
+         (max_rows + 256) * N < 0x100000000LL;
 }
 
 extern "C" int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias, const int32_t *offsets,

@@ -158,7 +158,10 @@ template <int EPC> struct YGet<bf16_t, EPC> {
 
 // geometry of a work-group: CW channel groups x NS token segments (waves), 64 tokens
 template <int CW> struct Geo {
-  static constexpr int NS = (CW <= 2 ? 8 : 4) * LTG / 64, CWC = 64 * CW, NTH = CWC * NS, TS = LTG / NS;
+#ifndef SCAN_GATE_NS3
+#define SCAN_GATE_NS3 4
+#endif
+  static constexpr int NS = (CW <= 2 ? 8 : SCAN_GATE_NS3) * LTG / 64, CWC = 64 * CW, NTH = CWC * NS, TS = LTG / NS;
 };
 
 // Compose the published records [j0, j1) (granule index = record index) in composition order into (P, S):

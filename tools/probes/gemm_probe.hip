@@ -92,6 +92,7 @@ int main(int argc, char **argv) {
       if (rc) { printf("%s rc=%d\n", name, rc); return; }
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (rep) { best = std::min(best, ms); sum += ms; ++n; }
+      if (getenv("PROBE_ALL")) printf("   rep %d: %.1f us\n", rep, ms * 1e3);
     }
     printf("%-46s best %7.1f us  avg %7.1f us  %6.0f TF (best)\n", name, best * 1e3, sum / n * 1e3, flops / best / 1e9);
   };
