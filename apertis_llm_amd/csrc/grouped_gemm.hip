@@ -981,11 +981,19 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
 #pragma unroll
           for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
           const int g = kk * 11 + i;           // MFMA group 0..21 of the step
+#ifdef NT_PROBE_FILL_EARLY   // tools/probes only: the ten pieces behind the FIRST ten groups (the last one then has 12 groups to land)
+          if (g < 10) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (spread) fill_piece(g);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+#else
           if (!(g & 1) && g < 20) {
             __builtin_amdgcn_sched_barrier(0);
             if (spread) fill_piece(g >> 1);
             __builtin_amdgcn_sched_barrier(0);
           }
+#endif
         }
         __builtin_amdgcn_s_setprio(0);
       }
@@ -2500,7 +2508,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       if (grid5 < 0x7fffffffLL) {
         const int gp = (int)std::min<int64_t>(grid5, device_cu_count());   // one persistent work-group per CU
         const size_t lds5 = 2 * BUF5 + 4096 + 16;                           // ring + group offsets
-        constexpr int solo = 4;
+        constexpr int solo = 4;   // (re-measured with the spread fills, round 3: 0..6 all within noise)
         if (tile_queue && hipMemsetAsync(tile_queue, 0, NTQ_INTS * sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
         auto k5 = grouped_gemm_nt352p_k<TO>;
         hipFuncSetAttribute((const void *)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5);

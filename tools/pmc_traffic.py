@@ -15,6 +15,7 @@ ENTRY = {  # kernel-name fragment -> C-ABI entry point
     "grouped_gemm_nt352p_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_nt2x_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_tn3_k": "apertis_grouped_gemm_tn", "tn3_fold_k": "apertis_grouped_gemm_tn",
+    "grouped_gemm_tn5_k": "apertis_grouped_gemm_tn", "tn5_fold_k": "apertis_grouped_gemm_tn",
     "grouped_gemm_tn2_k": "apertis_grouped_gemm_tn",
     "scan_fwd_state": "apertis_selective_scan_fwd", "scan_fwd_replay": "apertis_selective_scan_fwd",
     "scan_bwd_state": "apertis_selective_scan_bwd", "scan_bwd_replay": "apertis_selective_scan_bwd",
@@ -52,7 +53,7 @@ for tag, v in entry.items():
     # reps = launches of the per-call-once kernel / calls per rep
     n_calls = None
     for frag, e in ENTRY.items():
-        if e == tag and frag not in ("colsum_kernel", "tn3_fold_k"):
+        if e == tag and frag not in ("colsum_kernel", "tn3_fold_k", "tn5_fold_k"):
             ks = [k for k in agg if frag in k and "FETCH_SIZE" in agg[k]]
             if ks:
                 n = sum(len(agg[k]["FETCH_SIZE"]) for k in ks)
