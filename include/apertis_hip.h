@@ -431,7 +431,10 @@ int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias,
  * item counters of the _q entry points below.)  ws == NULL, a too-small buffer
  * or E * n_problems > #CUs select the 128x128-tile kernel, which needs none.  The choice is the caller's: the 256x256
  * kernel pays off from about 2048 rows per group (below that a 256-row-deep slice per CU does not amortise the tile
- * prologue / epilogue and the fold); the library applies no threshold of its own and reads no environment variable. */
+ * prologue / epilogue and the fold); the library applies no threshold of its own and reads no environment variable.
+ * With a workspace the pair entry points run 256x352 / 352x256 tiles when both problems have a side that those tile
+ * without zero columns where 256x256 tiles would waste >= 5 % (the 704-wide family: [2816, 704] and [704, 2816]); the
+ * workspace size covers either kernel. */
 int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
