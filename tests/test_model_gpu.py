@@ -168,13 +168,14 @@ def test_model_gradients_vs_oracle_autograd(dev):
         if got is None:
             assert float(ref.grad.abs().max()) == 0.0, k
             continue
-        # achieved error on the record (profiles/r3_parity_report.jsonl); the bound asserted is what the fp32 kernels reach
-        # against fp64 autograd through the oracle: rtol 5e-4 with an absolute floor of 5e-5 of the tensor's largest entry
-        rec = rel_error_report("grad " + k, got, ref.grad, rtol=5e-4, atol_scale=5e-5, check=False)
+        # achieved error on the record (profiles/r3_parity_report.jsonl: worst 1.05e-5 relative on the significant elements,
+        # worst excess 0.16 of this bound); the bound asserted is the BASELINE bar for logits, held for every gradient too:
+        # rtol 1e-4 with an absolute floor of 1e-5 of the tensor's largest entry (fp32 kernels vs fp64 autograd through the oracle)
+        rec = rel_error_report("grad " + k, got, ref.grad, rtol=1e-4, atol_scale=1e-5, check=False)
         worst = max(worst, rec["worst_excess"])
         assert rec["worst_excess"] <= 1.0, rec
         checked += 1
-    print(f"whole-model gradients: {checked} tensors, worst excess over (rtol 5e-4, atol 5e-5*max) = {worst:.3f}")
+    print(f"whole-model gradients: {checked} tensors, worst excess over (rtol 1e-4, atol 1e-5*max) = {worst:.3f}")
     assert checked > 40
 
 
