@@ -314,3 +314,38 @@ def test_config1_125m_on_cpu_matches_reference_capture():
     rel_error_report("config1_125m selective_ssm ORACLE (CPU) logits sample", o_logits[:, ::37, ::251],
                      g["selective_ssm::logits_sample"], rtol=1e-4)      # bit-equal at the capture's thread count (4)
     assert abs(float(o_loss) - float(g["selective_ssm::loss"])) <= 1e-5 * float(g["selective_ssm::loss"])
+
+
+def test_prepared_weight_cache_is_identity_safe():
+    """ops.cached_prep (the inference path's prepared-weight cache, round 3): memoises per SOURCE PARAMETER object (weak
+    reference + version counter + the epoch ApertisAdamW bumps), follows views of a parameter and products of an earlier
+    cached_prep call, and never caches a temporary or anything while gradients are enabled - its first form keyed on
+    data_ptr and handed the training path a stale copy whenever a temporary was allocated where a dead one had lived."""
+    from apertis_llm_amd import ops
+    w = torch.nn.Parameter(torch.randn(4, 4))
+    calls = [0]
+
+    def make():
+        calls[0] += 1
+        return w.detach() * 2
+    with torch.no_grad():
+        a, b = ops.cached_prep("t", (w,), make), ops.cached_prep("t", (w,), make)
+        assert a is b and calls[0] == 1
+        c, d = ops.cached_prep("u", (w.unsqueeze(0),), make), ops.cached_prep("u", (w.unsqueeze(0),), make)
+        assert c is d and calls[0] == 2                                  # a view of a parameter is a stable source
+        ops.cached_prep("v", (w * 1,), make), ops.cached_prep("v", (w * 1,), make)
+        assert calls[0] == 4                                            # temporaries: never cached
+        e, f = ops.cached_prep("x", (a,), make), ops.cached_prep("x", (a.unsqueeze(0),), make)
+        assert calls[0] in (5, 6)                                       # products of cached_prep are stable sources
+        w.add_(1)
+        assert ops.cached_prep("t", (w,), make) is not a                # version counter moved
+        g = ops.cached_prep("t", (w,), make)
+        ops.note_weights_changed()                                      # what ApertisAdamW.step does (raw-pointer updates)
+        assert ops.cached_prep("t", (w,), make) is not g
+        for i in range(6):                                              # a dead parameter's address may be reused: no stale hit
+            p = torch.nn.Parameter(torch.full((4, 4), float(i)))
+            assert float(ops.cached_prep("z", (p,), lambda: p.detach() * 1.0)[0, 0]) == i
+            del p
+    before = calls[0]
+    ops.cached_prep("t", (w,), make)
+    assert calls[0] == before + 1                                       # gradients enabled: plain make()
