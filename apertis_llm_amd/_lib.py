@@ -160,13 +160,26 @@ def check(rc, what):
 
 
 def ptr(t):
-    """Device pointer of a tensor (or None)."""
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer of a tensor (or None) as a plain integer: every entry point has its argtypes declared, so ctypes
+    converts it itself (a c_void_p object per argument was a third of the Python time of a launch)."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = None
 
 
 def stream_ptr():
-    import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current stream of the current device, as the integer the C ABI takes.  torch.cuda.current_stream() builds a
+    Stream object through three Python layers (5 us; a step makes thousands of launches): ask the binding directly."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        get_dev, get_raw = getattr(torch._C, "_cuda_getDevice", None), getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        if get_dev is not None and get_raw is not None:
+            _raw_stream = lambda: get_raw(get_dev())                            # noqa: E731
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream       # noqa: E731
+    return _raw_stream()
 
 
 def dtype_code(t):

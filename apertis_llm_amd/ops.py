@@ -29,17 +29,26 @@ class KernelTimer:
         self.records = []
 
     def summary(self):
+        """{name: {launches, ms, work, by_shape}}; `by_shape` splits the calls that gave a shape tag (the dense
+        projections: {tag: {launches, ms, work, bytes}} with the call's algorithmic bytes)."""
         torch.cuda.synchronize()
         out = {}
-        for name, s, e, work in self.records:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+        for name, s, e, work, detail, nbytes in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "by_shape": {}})
+            ms, wk = s.elapsed_time(e), float(work() if callable(work) else work)
             d["launches"] += 1
-            d["ms"] += s.elapsed_time(e)
-            d["work"] += float(work() if callable(work) else work)
+            d["ms"] += ms
+            d["work"] += wk
+            if detail is not None:
+                b = d["by_shape"].setdefault(detail, {"launches": 0, "ms": 0.0, "work": 0.0, "bytes": 0.0})
+                b["launches"] += 1
+                b["ms"] += ms
+                b["work"] += wk
+                b["bytes"] += float(nbytes)
         return out
 
 
-def _launch(name, fn, args, work=0.0):
+def _launch(name, fn, args, work=0.0, detail=None, nbytes=0.0):
     t = _TIMER
     if t is None or name not in t.names:
         check(fn(*args), name.split("[")[0])
@@ -49,7 +58,7 @@ def _launch(name, fn, args, work=0.0):
     rc = fn(*args)
     e.record()
     check(rc, name.split("[")[0])
-    t.records.append((name, s, e, work))
+    t.records.append((name, s, e, work, detail, nbytes))
 
 
 def _require_gpu(*ts):
@@ -1112,13 +1121,13 @@ def _nt_queue(device):
     return q
 
 
-def _launch_nt(name, lib, args, work, device):
+def _launch_nt(name, lib, args, work, device, detail=None, nbytes=0.0):
     """apertis_grouped_gemm_nt, or its _q form with the stream's tile-queue counter when GEMM_DYNAMIC_QUEUE is on.
     `args` ends with the stream pointer."""
     if GEMM_DYNAMIC_QUEUE:
-        _launch(name, lib.apertis_grouped_gemm_nt_q, args[:-1] + (ptr(_nt_queue(device)), args[-1]), work)
+        _launch(name, lib.apertis_grouped_gemm_nt_q, args[:-1] + (ptr(_nt_queue(device)), args[-1]), work, detail, nbytes)
     else:
-        _launch(name, lib.apertis_grouped_gemm_nt, args, work)
+        _launch(name, lib.apertis_grouped_gemm_nt, args, work, detail, nbytes)
 
 
 _ACTS = {None: _lib.ACT_NONE, "none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU, "relu": _lib.ACT_RELU,
@@ -1145,6 +1154,13 @@ def _tn_workspace(E, n_problems, device, max_rows=None):
     return buf, nbytes
 
 
+def _dense_tag(E, rows, N, K, esize):
+    """(shape tag, algorithmic bytes) of a one-group NT call for the kernel timer: X read once, Y written once, W once."""
+    if E != 1:
+        return None, 0.0
+    return f"rows={rows} N={N} K={K}", float(rows) * (N + K) * esize + float(N) * K * esize
+
+
 class _GroupedLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype):
@@ -1169,7 +1185,8 @@ class _GroupedLinear(torch.autograd.Function):
         pre = torch.empty_like(out) if (act_code != _lib.ACT_NONE and need_grad) else None
         _launch_nt("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib,
                 (ptr(x), ptr(wc), ptr(bf), ptr(offsets), ptr(out), ptr(pre), None, max_rows, N, K, wc.shape[-1], E, act_code,
-                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), x.device)
+                 float(drop_p), int(seed), code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), x.device,
+                *_dense_tag(E, max_rows, N, K, x.element_size()))
         ctx.save_for_backward(x, wt, pre, offsets)
         ctx.cfg = (E, N, K, max_rows, act_code, float(drop_p), int(seed), bias is not None, weight.dtype)
         return out
@@ -1192,7 +1209,8 @@ class _GroupedLinear(torch.autograd.Function):
             dx = torch.empty_like(x)
             _launch_nt("apertis_grouped_gemm_nt" if E > 1 else "apertis_grouped_gemm_nt[dense]", lib,
                     (ptr(dpre), ptr(wt), None, ptr(offsets), ptr(dx), None, None, max_rows, K, N, wt.shape[-1], E, _lib.ACT_NONE,
-                     0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), dpre.device)
+                     0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), dpre.device,
+                    *_dense_tag(E, max_rows, K, N, x.element_size()))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
                 # dense layer: the K dimension of the weight gradient is ALL rows; cut it into
@@ -1207,7 +1225,8 @@ class _GroupedLinear(torch.autograd.Function):
                 bpart = torch.empty(G, N, device=x.device, dtype=torch.float32) if has_bias else None
                 _launch("apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
                         (ptr(dpre), ptr(x), ptr(soffs), ptr(part), ptr(bpart), max_rows, N, K, G, None, 0, code, stream_ptr()),
-                        2.0 * max_rows * N * K)
+                        2.0 * max_rows * N * K, f"rows={max_rows} M={N} N={K}",
+                        float(max_rows) * (N + K) * x.element_size() + 4.0 * G * N * K)
                 dw = torch.empty(1, N, K, device=x.device, dtype=torch.float32)
                 check(lib.apertis_colsum_f32(ptr(part), ptr(dw), G, N * K, stream_ptr()), "apertis_colsum_f32")
                 db = None

@@ -59,31 +59,22 @@ class ApertisAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._tables = None
 
-    def _key(self):
-        """Everything the cached device tables depend on: parameter, gradient and both moment addresses, and the
-        per-parameter step (parameters that share a step share a launch)."""
-        key = []
-        for g in self.param_groups:
-            for p in g["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state.get(p) or {}
-                m, v, stp = st.get("exp_avg"), st.get("exp_avg_sq"), st.get("step")
-                key.append((p.data_ptr(), p.grad.data_ptr(), None if m is None else m.data_ptr(),
-                            None if v is None else v.data_ptr(), None if stp is None else id(stp)))
-        return key
-
     def _build_tables(self):
+        """Device tables of the three kernels: per launch (= parameters of one group that share a step count) a record
+        array `{p, g, m, v, numel}` and the chunk -> (tensor, chunk) maps.  Everything but the gradient addresses is fixed
+        between optimizer steps, so the tables are built ONCE; `_refresh` only rewrites the gradient column when autograd
+        handed out other buffers, through pinned staging and a non-blocking copy (the first form rebuilt the tables from
+        pageable numpy arrays on every step: a synchronous copy, i.e. a full host <-> GPU sync per step, and 7-20 ms of
+        Python on the 76-layer configuration)."""
         from . import _lib
         import numpy as np
         lib = _lib.load()
         chunk = int(lib.apertis_opt_chunk_elems())
-        tables, n_total = [], 0
+        launches, recs, cts, cis, plist, n_total = [], [], [], [], [], 0
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.grad is not None]
             for p in ps:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and p.is_contiguous()
-                        and p.grad.is_contiguous()):
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise _lib.ApertisHipError("ApertisAdamW needs contiguous fp32 CUDA parameters and gradients")
                 st = self.state[p]
                 if not st:
@@ -102,24 +93,82 @@ class ApertisAdamW(torch.optim.Optimizer):
                 ct, ci = [], []
                 for i, p in enumerate(sub):
                     st = self.state[p]
-                    rec[i] = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
-                              p.numel())
+                    rec[i] = (p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
                     nc = -(-p.numel() // chunk)
                     ct.append(np.full(nc, i, dtype=np.int32))
                     ci.append(np.arange(nc, dtype=np.int32))
-                dev = sub[0].device
                 ct, ci = np.concatenate(ct), np.concatenate(ci)
-                tables.append(dict(group=gi, params=sub, n=len(ct), first=n_total,
-                                   rec=torch.from_numpy(rec.view(np.uint8).reshape(-1)).to(dev),
-                                   ct=torch.from_numpy(ct).to(dev), ci=torch.from_numpy(ci).to(dev)))
+                launches.append(dict(group=gi, params=sub, steps=[self.state[p]["step"] for p in sub], step0=step0,
+                                     n=len(ct), first=n_total, row0=len(plist), chunk0=sum(len(c) for c in cts)))
+                recs.append(rec), cts.append(ct), cis.append(ci)
+                plist.extend(sub)
                 n_total += len(ct)
-        dev = next((t["params"][0].device for t in tables), None)
-        self._tables = dict(groups=tables, key=self._key(), n_total=n_total,
-                            partials=torch.empty(max(n_total, 1), device=dev, dtype=torch.float32) if dev is not None else None,
-                            norm_coef=torch.zeros(2, device=dev, dtype=torch.float32) if dev is not None else None)
+        if not plist:
+            self._tables = dict(launches=[], plist=[], pp=[], mv=[], partials=None,
+                                none=[p for g in self.param_groups for p in g["params"]])
+            return
+        dev = plist[0].device
+        if any(p.device != dev for p in plist):
+            raise _lib.ApertisHipError("ApertisAdamW: parameters on more than one device")
+        rec = np.concatenate(recs)
+        pins = [torch.from_numpy(rec.copy()).pin_memory() for _ in range(2)]       # staging, used alternately
+        T = dict(launches=launches, plist=plist, n_total=n_total,
+                 none=[p for g in self.param_groups for p in g["params"] if p.grad is None],
+                 pp=[p.data_ptr() for p in plist],
+                 mv=[(self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"]) for p in plist],
+                 gp=None, pins=pins, pin_np=[t.numpy() for t in pins], pin_ev=[None, None], turn=0,
+                 rec=torch.empty(rec.shape, dtype=torch.int64, device=dev),
+                 ct=torch.from_numpy(np.concatenate(cts)).to(dev), ci=torch.from_numpy(np.concatenate(cis)).to(dev),
+                 partials=torch.empty(max(n_total, 1), device=dev, dtype=torch.float32),
+                 norm_coef=torch.zeros(2, device=dev, dtype=torch.float32))
+        for g in launches:                                   # each launch's slices of the shared device tables
+            g["rec"] = T["rec"][g["row0"]:]
+            g["ct"], g["ci"] = T["ct"][g["chunk0"]:], T["ci"][g["chunk0"]:]
+        self._tables = T
 
     def _tables_current(self):
-        return self._tables is not None and self._key() == self._tables["key"]
+        """The fixed part of the tables still describes the optimizer: the same parameters have gradients, parameters
+        and moments live where they did, and every launch's parameters still share their step count."""
+        T = self._tables
+        if T is None:
+            return False
+        state = self.state
+        try:
+            if any(p.grad is None for p in T["plist"]) or any(p.grad is not None for p in T["none"]):
+                return False
+            if [p.data_ptr() for p in T["plist"]] != T["pp"]:
+                return False
+            for p, (m, v) in zip(T["plist"], T["mv"]):
+                st = state[p]
+                if st["exp_avg"] is not m or st["exp_avg_sq"] is not v:
+                    return False
+            for g in T["launches"]:
+                if any(state[p]["step"] is not s for p, s in zip(g["params"], g["steps"])):
+                    return False
+        except KeyError:
+            return False
+        n_groups = sum(len(g["params"]) for g in self.param_groups)
+        return n_groups == len(T["plist"]) + len(T["none"])
+
+    def _refresh(self):
+        """Gradient addresses into the device tables (only when they moved since the last step)."""
+        from . import _lib
+        T = self._tables
+        grads = [p.grad for p in T["plist"]]
+        gp = [g.data_ptr() for g in grads]
+        if gp == T["gp"]:
+            return
+        for g, p in zip(grads, T["plist"]):
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+                raise _lib.ApertisHipError("ApertisAdamW needs contiguous fp32 CUDA parameters and gradients")
+        i = T["turn"] = T["turn"] ^ 1
+        if T["pin_ev"][i] is not None:
+            T["pin_ev"][i].synchronize()          # the copy issued from this staging buffer two refreshes ago has run
+        T["pin_np"][i][:, 1] = gp
+        T["rec"].copy_(T["pins"][i], non_blocking=True)
+        ev = T["pin_ev"][i] = T["pin_ev"][i] or torch.cuda.Event()
+        ev.record()
+        T["gp"] = gp
 
     @torch.no_grad()
     def step(self, closure=None, max_grad_norm: Optional[float] = None):
@@ -129,7 +178,7 @@ class ApertisAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self._tables_current():       # gradients / moments were reallocated, a parameter joined, or first call
+        if not self._tables_current():       # moments were replaced, a parameter joined or moved, or first call
             self._build_tables()
         T = self._tables
         if T["partials"] is None:
@@ -137,8 +186,9 @@ class ApertisAdamW(torch.optim.Optimizer):
         lib = _lib.load()
         coef = None
         with torch.cuda.device(T["partials"].device):
+            self._refresh()
             if max_grad_norm is not None:
-                for g in T["groups"]:
+                for g in T["launches"]:
                     check(lib.apertis_grad_sumsq(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"],
                                                  ptr(T["partials"][g["first"]:]), stream_ptr()), "apertis_grad_sumsq")
                 # the scan's look-back time-out word poisons the coefficient (NaN step, like a non-finite norm): no sync
@@ -147,14 +197,13 @@ class ApertisAdamW(torch.optim.Optimizer):
                                             ptr(poison), stream_ptr()), "apertis_clip_coef")
                 coef = T["norm_coef"]
                 self.last_grad_norm = coef[0]
-            for g in T["groups"]:
+            for g in T["launches"]:
                 group = self.param_groups[g["group"]]
-                step = int(self.state[g["params"][0]]["step"].item()) + 1
-                for p in g["params"]:
-                    self.state[p]["step"] += 1
+                g["step0"] += 1
+                torch._foreach_add_(g["steps"], 1)           # the per-parameter `step` tensors of torch.optim.AdamW's state
                 b1, b2 = group["betas"]
                 check(lib.apertis_adamw_step(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"], float(group["lr"]), float(b1),
-                                             float(b2), float(group["eps"]), float(group["weight_decay"]), step, ptr(coef),
+                                             float(b2), float(group["eps"]), float(group["weight_decay"]), g["step0"], ptr(coef),
                                              stream_ptr()), "apertis_adamw_step")
         ops.note_weights_changed()      # (the kernels write the parameters through raw pointers: no version bump)
         return loss

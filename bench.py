@@ -357,6 +357,17 @@ def main():
                 rl[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name), "launches": d["launches"], "avg_ms": avg_ms,
                             "total_ms": d["ms"]}
+        # the SSM block's dense projections are narrow (N, K <= 704: 88 - 235 flop per byte against the chip's 312): their
+        # bound is HBM, so each shape is ALSO priced on its algorithmic bytes (X once, Y once, W once; weight gradient: both
+        # operands once + the split-K partials)
+        for name, d in summ.items():
+            for tag, b in sorted(d.get("by_shape", {}).items()):
+                if b["launches"] and b["ms"] > 0:
+                    ach = b["bytes"] / (b["ms"] * 1e-3) / 1e9
+                    rl[f"{name} {tag}"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "launches": b["launches"],
+                                           "avg_ms": b["ms"] / b["launches"], "total_ms": b["ms"],
+                                           "tflops": b["work"] / (b["ms"] * 1e-3) / 1e12}
         if rl:
             dom = max((k for k in rl if "[dense]" not in k), key=lambda k: rl[k]["total_ms"])
             result["roofline"] = dict(rl[dom], kernel=dom)
