@@ -1220,6 +1220,9 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
   lds_barrier();
 }
 
+#ifdef NT_PROBE_STAMPS   // tools/probes only: wall-clock (10 ns ticks) sums per phase of the two-per-CU kernel's work-groups
+__device__ unsigned long long nt2x_stamps[8];   // [0] prologue (entry -> stage 0 landed) [1] K loop [2] epilogue issue [3] work-groups
+#endif
 // RAGGED: K % 32 != 0 - W's rows are zero-padded to whole sub-steps (row pitch ldw), X's last sub-step over-reads into
 // the next row (finite values against W's zeros) and the K offset moves into the range-checked lane offset so that
 // the tile's last row reads zeros past the buffer instead
@@ -1283,7 +1286,21 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     for (int q = 0; q < 6; ++q) issue_piece(slot_off, s, q);
   };
   const int nk = (K + 31) / 32;   // >= 3 (launcher)
+#ifdef NT_PROBE_WALK   // tools/probes only (NT_SPREAD = microseconds): the work-groups of the first dispatch round that sit in an odd
+  // wave slot of their SIMD start late, so that the two work-groups of a CU run their K loops and epilogues out of phase
+  if (spread_fill > 0 && blockIdx.x < 512) {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave slot in bits 3:0
+    if (hw & 1) {
+      const uint64_t t0 = wall_clock64();
+      while (wall_clock64() - t0 < (uint64_t)spread_fill * 100) __builtin_amdgcn_s_sleep(32);
+    }
+  }
+#else
   (void)spread_fill;
+#endif
+#ifdef NT_PROBE_STAMPS
+  const uint64_t st0 = wall_clock64();
+#endif
   issue(0, 0); issue(SLOT3, 1); issue(2 * SLOT3, 2);
 
   f32x4 acc[4][8];
@@ -1345,6 +1362,9 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #endif
   wait_vmcnt<12>();   // stage 0 (vmcnt retires in order)
   lds_barrier();
+#ifdef NT_PROBE_STAMPS
+  const uint64_t st1 = wall_clock64();
+#endif
   load_w(wf[0], 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const frag *>(xbase + j * 16 * ROWB3);
@@ -1372,6 +1392,20 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   lds_barrier();   // every wave is done with the ring: it becomes the output staging area
+#ifdef NT_PROBE_STAMPS
+  const uint64_t st2 = wall_clock64();
+  auto stamp_end = [&]() {
+    const uint64_t st3 = wall_clock64();
+    if (tid == 0) {
+      atomicAdd(&nt2x_stamps[0], st1 - st0); atomicAdd(&nt2x_stamps[1], st2 - st1); atomicAdd(&nt2x_stamps[2], st3 - st2);
+      atomicAdd(&nt2x_stamps[3], 1ull);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      atomicAdd(&nt2x_stamps[4], wall_clock64() - st3);   // until this wave's own stores have been acknowledged
+    }
+  };
+#else
+  auto stamp_end = [&]() {};
+#endif
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
@@ -1390,6 +1424,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       nt2x_out_both<TO, true>(acc, bv, C, pre_act, smem, row0, rows_valid, n0, cols_valid, N, seed, keep_scale, thresh16, tid, wm, wn, frow, fg);
     else
       nt2x_out_both<TO, false>(acc, bv, C, pre_act, smem, row0, rows_valid, n0, cols_valid, N, seed, keep_scale, thresh16, tid, wm, wn, frow, fg);
+    stamp_end();
     return;
   }
   if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);
@@ -1403,6 +1438,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C);
   else OUT(false, -1, false, C);
 #undef OUT
+  stamp_end();
 }
 
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])

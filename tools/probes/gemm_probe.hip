@@ -95,6 +95,14 @@ int main(int argc, char **argv) {
       if (getenv("PROBE_ALL")) printf("   rep %d: %.1f us\n", rep, ms * 1e3);
     }
     printf("%-46s best %7.1f us  avg %7.1f us  %6.0f TF (best)\n", name, best * 1e3, sum / n * 1e3, flops / best / 1e9);
+#ifdef NT_PROBE_STAMPS
+    unsigned long long st[8];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(nt2x_stamps), sizeof st);
+    if (st[3]) printf("   two-per-CU work-groups: %llu, per work-group: prologue %.2f us, K loop %.2f us, epilogue %.2f us, own stores acknowledged after %.2f us\n",
+                      st[3] / reps, st[0] * 0.01 / st[3], st[1] * 0.01 / st[3], st[2] * 0.01 / st[3], st[4] * 0.01 / st[3]);
+    memset(st, 0, sizeof st);
+    hipMemcpyToSymbol(HIP_SYMBOL(nt2x_stamps), st, sizeof st);
+#endif
   };
   if (argc > 4) {   // dense projections of the SSM block (one group): gemm_probe.bin B 704 2816 dense
     const int64_t T = (int64_t)B * 4096;
