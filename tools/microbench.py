@@ -54,7 +54,8 @@ def scan(only_bench_shape=False):
 def scan_gate(only_bench_shape=False):
     """The fused scan + gate op (what the model runs), both forms, on the model's padded layout; GB/s on the fused
     variant's own byte count (5*Dn*e + 4h forward, 9*Dn*e + 8h backward)."""
-    shapes = [(32, 4096, 11, 16, torch.bfloat16)] if only_bench_shape else [
+    import os
+    shapes = [(int(os.environ.get("MB_BATCH", "32")), 4096, 11, 16, torch.bfloat16)] if only_bench_shape else [
         (8, 4096, 11, 16, torch.bfloat16), (32, 4096, 11, 16, torch.bfloat16), (16, 4096, 4, 16, torch.bfloat16),
         (32, 2048, 14, 16, torch.bfloat16), (16, 2245, 11, 16, torch.bfloat16), (8, 4096, 11, 16, torch.float32)]
     for (B, L, h, N, dt) in shapes:
