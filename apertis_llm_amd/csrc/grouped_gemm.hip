@@ -1147,6 +1147,23 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
                                          uint64_t seed, float keep_scale, uint32_t thresh16, int tid, int wm, int wn,
                                          int frow, int fg) {
   static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
+  // dgrad fusion: the saved tensor's first two batches of 16-byte chunks leave BEFORE the staging pass (their HBM latency
+  // used to start behind it: the epilogue of the fused fc2 data gradient was 12.9 us of a 30 us tile)
+  [[maybe_unused]] uint4 pa[4], pb[4];
+  [[maybe_unused]] auto fetch = [&](uint4 (&pc)[4], int b) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c4 = (b * 4 + u) * NT3 + tid;
+      const int row = c4 >> 4, c = c4 & 15;
+      pc[u] = (row < rows_valid && c * 8 < cols_valid) ? *reinterpret_cast<const uint4 *>(mul_pre + (row0 + row) * N + n0 + c * 8)
+                                                       : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if constexpr (MULPRE != 0) {
+    fetch(pa, 0);
+    fetch(pb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1183,15 +1200,6 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
     // dgrad fusion: the tile was staged as plain dh; each 16-byte chunk becomes dpre on the way out with the
     // matching chunk of the saved pre-activation.  Four chunks per batch, the next batch's pre-activations in
     // flight under the arithmetic of the current one (a fully interleaved loop spills)
-    auto fetch = [&](uint4 (&pc)[4], int b) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c4 = (b * 4 + u) * NT3 + tid;
-        const int row = c4 >> 4, c = c4 & 15;
-        pc[u] = (row < rows_valid && c * 8 < cols_valid) ? *reinterpret_cast<const uint4 *>(mul_pre + (row0 + row) * N + n0 + c * 8)
-                                                         : make_uint4(0, 0, 0, 0);
-      }
-    };
     auto emit = [&](const uint4 (&pc)[4], int b) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -1207,9 +1215,6 @@ __device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (
         }
       }
     };
-    uint4 pa[4], pb[4];
-    fetch(pa, 0);
-    fetch(pb, 1); __builtin_amdgcn_sched_barrier(0);
     emit(pa, 0);  __builtin_amdgcn_sched_barrier(0);
     fetch(pa, 2); __builtin_amdgcn_sched_barrier(0);
     emit(pb, 1);  __builtin_amdgcn_sched_barrier(0);

@@ -113,63 +113,55 @@ __global__ void gate_topk_bwd_k(const float *__restrict__ gates, const int32_t *
 struct PlanWs {
   int32_t *total, *keep, *mode, *quota, *seg_start;
   uint32_t *thr, *smask;   // radix select: prefix found so far / bits already fixed
-  int32_t *ticket;         // [2] work-groups done (the last one of a launch does the launch's serial tail and resets it)
   int32_t *ghist;          // [P][256] digit histogram of the current radix pass
   int32_t *cnt_g, *cnt_t;  // [P][NCH]
   int P, NCH;
 };
 
-// total | ticket | ghist are adjacent: one memset per plan zeroes all three
 PlanWs carve_ws(void *ws, int64_t S, int64_t E, int64_t K) {
   PlanWs w;
   w.P = (int)(E * K);
   w.NCH = (int)ceil_div64(S, 64);
   int32_t *p = (int32_t *)ws;
+  w.total = p; p += w.P;
   w.keep = p; p += w.P;
   w.mode = p; p += w.P;
   w.quota = p; p += w.P;
   w.seg_start = p; p += w.P;
   w.thr = (uint32_t *)p; p += w.P;
   w.smask = (uint32_t *)p; p += w.P;
-  w.total = p; p += w.P;
-  w.ticket = p; p += 2;
   w.ghist = p; p += (int64_t)w.P * 256;
   w.cnt_g = p; p += (int64_t)w.P * w.NCH;
   w.cnt_t = p;
   return w;
 }
 
-// "Last work-group of the launch": every work-group calls this once after its last global atomic; exactly one of them
-// (the one whose ticket completes the count) gets true, after which the others' atomics are visible to its agent-scope
-// loads.  It resets the ticket for the next launch (visible at the kernel boundary).  The kernels below use it to run
-// their serial tails (capacity per expert, the digit pick of the radix select) in place instead of as 1-block launches.
-__device__ __forceinline__ bool plan_last_block(int32_t *ticket, int *s_flag) {
-  __threadfence();            // this work-group's atomics are performed before its ticket
+__global__ void plan_hist_k(const int32_t *__restrict__ idx, int32_t *__restrict__ total, int64_t SK,
+                            int E, int K) {
+  __shared__ int32_t h[MAXE * MAXK];
+  const int P = E * K;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) h[i] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    *s_flag = (t == (int)gridDim.x - 1);
-    if (*s_flag) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < SK; a += (int64_t)gridDim.x * blockDim.x) {
+    int e = idx[a];
+    int k = (int)(a % K);
+    if (e >= 0 && e < E) atomicAdd(&h[e * K + k], 1);
   }
   __syncthreads();
-  const bool last = *s_flag != 0;
-  if (last) __threadfence();
-  return last;
-}
-__device__ __forceinline__ int plan_ld(const int32_t *p) {   // (another XCD's L2 may hold a stale line: read at agent scope)
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = threadIdx.x; i < P; i += blockDim.x)
+    if (h[i]) atomicAdd(&total[i], h[i]);
 }
 
-// per expert: consume capacity k-major (core.py:547-576); then lay the segments out expert-major.  One wave; `total` is read
-// at agent scope (the caller is the last work-group of plan_hist_k)
-__device__ __forceinline__ void plan_capacity(const PlanWs &w, const uint8_t *__restrict__ active, int64_t capacity,
-                                              int32_t *__restrict__ offsets, int E, int K, int32_t *s_keep) {
-  for (int e = threadIdx.x; e < E; e += blockDim.x) {
+// per expert: consume capacity k-major (core.py:547-576); then lay the segments out expert-major
+__global__ void plan_capacity_k(PlanWs w, const uint8_t *__restrict__ active, int64_t capacity,
+                                int32_t *__restrict__ offsets, int E, int K) {
+  const int e = threadIdx.x;
+  if (e < E) {
     int64_t load = 0;
     const bool on = active ? active[e] != 0 : true;
     for (int k = 0; k < K; ++k) {
       const int p = e * K + k;
-      const int tot = plan_ld(&w.total[p]);
+      const int tot = w.total[p];
       int64_t keep = tot;
       if (!on) keep = 0;
       else if (capacity > 0) {
@@ -177,7 +169,6 @@ __device__ __forceinline__ void plan_capacity(const PlanWs &w, const uint8_t *__
         keep = rem <= 0 ? 0 : (tot < rem ? tot : rem);
       }
       w.keep[p] = (int)keep;
-      s_keep[p] = (int)keep;
       w.mode[p] = keep == 0 ? 0 : (keep == tot ? 1 : 2);
       w.quota[p] = (int)keep;   // radix select: how many of the slot's candidates are still to be taken
       w.thr[p] = 0;
@@ -192,31 +183,11 @@ __device__ __forceinline__ void plan_capacity(const PlanWs &w, const uint8_t *__
       offsets[ee] = run;
       for (int k = 0; k < K; ++k) {
         w.seg_start[ee * K + k] = run;
-        run += s_keep[ee * K + k];
+        run += w.keep[ee * K + k];
       }
     }
     offsets[E] = run;
   }
-}
-
-// candidates per (expert, k) slot; the last work-group to finish then fixes what every slot keeps (plan_capacity)
-__global__ void __launch_bounds__(256)
-plan_hist_k(PlanWs w, const int32_t *__restrict__ idx, const uint8_t *__restrict__ active, int64_t capacity,
-            int32_t *__restrict__ offsets, int64_t SK, int E, int K) {
-  __shared__ int32_t h[MAXE * MAXK];
-  __shared__ int s_last;
-  const int P = E * K;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) h[i] = 0;
-  __syncthreads();
-  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < SK; a += (int64_t)gridDim.x * blockDim.x) {
-    int e = idx[a];
-    int k = (int)(a % K);
-    if (e >= 0 && e < E) atomicAdd(&h[e * K + k], 1);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < P; i += blockDim.x)
-    if (h[i]) atomicAdd(&w.total[i], h[i]);
-  if (plan_last_block(w.ticket, &s_last)) plan_capacity(w, active, capacity, offsets, E, K, h);
 }
 
 // overflowing (e,k) slot: find the keep-th largest gate weight T (radix select on the float
@@ -267,15 +238,14 @@ plan_select_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict
   if (threadIdx.x == 0) { w.thr[p] = s_prefix; w.quota[p] = s_need; }
 }
 
-// The same radix select spread over the chip (one launch per 8-bit digit): every work-group histograms
+// The same radix select spread over the chip (one launch pair per 8-bit digit): every work-group histograms
 // its share of the tokens for ALL overflowing slots in LDS and adds the non-empty bins to the global
-// histogram (integer atomics: exact, order-free); the last work-group to finish then fixes the digit per slot.  The
+// histogram (integer atomics: exact, order-free); plan_sel_pick_k then fixes the digit per slot.  The
 // one-block-per-slot kernel above walks all S tokens four times with at most E*K blocks busy (154 us at
 // S = 131k with 8 overflowing slots); kept for P > 32 slots (LDS).
 __global__ void __launch_bounds__(256)
 plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk, int64_t S, int E, int K, int shift) {
   extern __shared__ int32_t lh[];   // [P][256]
-  __shared__ int s_last;
   const int P = w.P;
   for (int i = threadIdx.x; i < P * 256; i += 256) lh[i] = 0;
   __syncthreads();
@@ -301,40 +271,40 @@ plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restri
   __syncthreads();
   for (int i = threadIdx.x; i < P * 256; i += 256)
     if (lh[i]) atomicAdd(&w.ghist[i], lh[i]);
-  // the digit pick, by the last work-group to finish (it used to be a launch of its own per digit): one wave per slot -
-  // the bucket (from the top) where the running count reaches the slot's remaining need
-  if (!plan_last_block(w.ticket, &s_last)) return;
-  const int lane = threadIdx.x & 63;
-  for (int p = threadIdx.x >> 6; p < P; p += 4) {
-    if (w.mode[p] != 2) continue;
-    int32_t *h = w.ghist + p * 256;
-    // lane l owns bins 255-4l .. 252-4l (descending)
-    int c[4];
+}
+
+// one wave per slot: the bucket (from the top) where the running count reaches the slot's remaining need
+__global__ void __launch_bounds__(64)
+plan_sel_pick_k(PlanWs w, int shift) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  if (w.mode[p] != 2) return;
+  int32_t *h = w.ghist + p * 256;
+  // lane l owns bins 255-4l .. 252-4l (descending)
+  int c[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = plan_ld(&h[255 - 4 * lane - j]);
-    const int mine = (c[0] + c[1]) + (c[2] + c[3]);
-    int incl = mine;   // inclusive prefix over lanes 0..l
+  for (int j = 0; j < 4; ++j) c[j] = h[255 - 4 * lane - j];
+  const int mine = (c[0] + c[1]) + (c[2] + c[3]);
+  int incl = mine;   // inclusive prefix over lanes 0..l
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const int v = __shfl_up(incl, off);
-      if (lane >= off) incl += v;
-    }
-    const int need = w.quota[p];
-    const int before = incl - mine;
-    if (before < need && incl >= need) {   // exactly one lane
-      int cum = before, b = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (cum < need && cum + c[j] >= need) { b = 255 - 4 * lane - j; break; }
-        cum += c[j];
-      }
-      w.quota[p] = need - cum;
-      w.thr[p] = w.thr[p] | ((uint32_t)b << shift);
-      w.smask[p] = w.smask[p] | (255u << shift);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) __hip_atomic_store(&h[255 - 4 * lane - j], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next digit
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
   }
+  const int need = w.quota[p];
+  const int before = incl - mine;
+  if (before < need && incl >= need) {   // exactly one lane
+    int cum = before, b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cum < need && cum + c[j] >= need) { b = 255 - 4 * lane - j; break; }
+      cum += c[j];
+    }
+    w.quota[p] = need - cum;
+    w.thr[p] = w.thr[p] | ((uint32_t)b << shift);
+    w.smask[p] = w.smask[p] | (255u << shift);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[255 - 4 * lane - j] = 0;   // ready for the next digit
 }
 
 __device__ __forceinline__ void plan_flags(const PlanWs &w, const int32_t *idx, const float *wk, int64_t s,
@@ -2078,7 +2048,7 @@ extern "C" int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx,
 
 extern "C" int64_t apertis_moe_plan_workspace_bytes(int64_t S, int64_t E, int64_t K) {
   int64_t P = E * K, NCH = ceil_div64(S > 0 ? S : 1, 64);
-  return (7 * P + 2 + 256 * P + 2 * P * NCH) * 4 + 64;
+  return (7 * P + 256 * P + 2 * P * NCH) * 4 + 64;
 }
 
 extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_t *active,
@@ -2090,22 +2060,23 @@ extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_
   if (S * K > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   PlanWs pw = carve_ws(ws, S > 0 ? S : 1, E, K);
-  // 9 launches (was 15): one memset for the counters and the digit histogram; the capacity step and the four digit picks
-  // run in the last work-group of the histogram launch before them (plan_last_block)
-  const bool select = S > 0 && capacity > 0 && pw.P <= 32;
-  hipMemsetAsync(pw.total, 0, sizeof(int32_t) * (pw.P + 2 + (select ? (int64_t)pw.P * 256 : 0)), st);
-  {
-    const int64_t nb = ceil_div64(std::max<int64_t>(S * K, 1), 256);
-    hipLaunchKernelGGL(plan_hist_k, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, pw, idx, active, capacity,
-                       expert_offsets, S * K, (int)E, (int)K);
+  hipMemsetAsync(pw.total, 0, sizeof(int32_t) * pw.P, st);
+  if (S > 0) {
+    int64_t nb = ceil_div64(S * K, 256);
+    hipLaunchKernelGGL(plan_hist_k, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, idx, pw.total, S * K,
+                       (int)E, (int)K);
   }
+  hipLaunchKernelGGL(plan_capacity_k, dim3(1), dim3(64), 0, st, pw, active, capacity, expert_offsets, (int)E, (int)K);
   if (S > 0) {
     if (capacity > 0) {
       if (pw.P <= 32) {
+        hipMemsetAsync(pw.ghist, 0, sizeof(int32_t) * pw.P * 256, st);
         const unsigned nbh = (unsigned)std::min<int64_t>(ceil_div64(S * K, 1024), 512);
-        for (int shift = 24; shift >= 0; shift -= 8)
+        for (int shift = 24; shift >= 0; shift -= 8) {
           hipLaunchKernelGGL(plan_sel_hist_k, dim3(nbh), dim3(256), (size_t)pw.P * 256 * sizeof(int32_t), st, pw, idx, w, S,
                              (int)E, (int)K, shift);
+          hipLaunchKernelGGL(plan_sel_pick_k, dim3(pw.P), dim3(64), 0, st, pw, shift);
+        }
       } else {
         hipLaunchKernelGGL(plan_select_k, dim3(pw.P), dim3(1024), 0, st, pw, idx, w, S, (int)K);
       }
