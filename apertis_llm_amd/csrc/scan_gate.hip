@@ -792,353 +792,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Pipelined single-launch backward (round 3; bf16, 16-byte aligned slices).  The kernel above runs ONE work-group per CU
-// (121 KB of LDS, 143 VGPRs: three waves per SIMD) and each work-group waits 6.5 us of its 18.9 us for its first tiles with
-// nothing else on the CU to overlap it.  Here a work-group is persistent (tickets in the same chunk-major order, so the
-// look-back's progress argument is unchanged) and brings the NEXT item's first-phase operands in under the current item's
-// adjoint walk (5 us of LDS and VALU work, no vector-memory instruction): the C tile by LDS-DMA into a second buffer (no
-// registers), dout / z / delta into 16 + DLI registers.  One `s_waitcnt vmcnt(0)` right behind the walk retires all of
-// them together - they were issued 5 us earlier - and is the only wait the prefetch needs; every work-group barrier of the
-// kernel is LDS-only (`s_waitcnt lgkmcnt(0); s_barrier`): hipcc's __syncthreads() puts `vmcnt(0)` in front of the barrier,
-// which drained the output stores of the previous phase every time.  The dv*xc tile replaces y IN PLACE (each thread
-// overwrites the elements it has just read) instead of taking the Bt / C tiles' place, so the spare C buffer stays valid
-// through the epilogue.  Arithmetic, composition order and every stored bit are those of scan_gate_bwd_k<.., 1>.
-typedef int sg_v4i __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ sg_v4i sg_rsrc(const void *base, uint32_t bytes) {
-  const uint64_t a = (uint64_t)base;
-  sg_v4i r;
-  r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-  r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));   // stride 0: raw buffer
-  r[2] = __builtin_amdgcn_readfirstlane((int)bytes);                              // num_records: reads past it return 0
-  r[3] = 0x00020000;
-  return r;
-}
-__device__ __forceinline__ uint32_t sg_lds_addr(const void *p) {
-  return (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)p;
-}
-// 64 lanes x 16 B from buffer offset voff (per lane) to LDS lds_addr + 16 * lane (lds_addr wave-uniform)
-__device__ __forceinline__ void sg_dma16(const sg_v4i &rs, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs) : "memory", "m0");
-}
-__device__ __forceinline__ void sg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void sg_launder(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
-
-struct BwdItem { int chunk, cs, b, c0, rows_valid, ch_valid, ch_store, vb, head0; int64_t tok0; };
-
-template <typename T, int CW>
-__global__ void __launch_bounds__(Geo<CW>::NTH)
-scan_gate_bwd_pipe_k(const float *__restrict__ dlt, const float *__restrict__ A_log, const T *__restrict__ Bt, int64_t bt_rs,
-                     const T *__restrict__ C, int64_t c_rs, const T *__restrict__ xc, int64_t xc_rs, const T *__restrict__ z,
-                     int64_t z_rs, const float *__restrict__ Dv, const T *__restrict__ dout, int64_t do_rs,
-                     const float *__restrict__ h_in, GateWsHead *__restrict__ head, gran_t *__restrict__ gran, uint32_t epoch,
-                     T *__restrict__ dBt, int64_t dbt_rs, T *__restrict__ dC, int64_t dc_rs, int64_t store_w,
-                     T *__restrict__ dxc, int64_t dxc_rs, T *__restrict__ dz, int64_t dz_rs, float *__restrict__ d_dlt,
-                     float *__restrict__ part, ScanDims d, int ncs, int total) {
-  static_assert(sizeof(T) == 2, "bf16 tiles");
-  typedef Geo<CW> G;
-  constexpr int VB = 16;
-  constexpr int NS = G::NS, CWC = G::CWC, NTH = G::NTH, TS = G::TS, LT = LTG;
-  constexpr int ROWB = CWC * sizeof(T), CPR = ROWB / 16;
-  constexpr int PIECES = LT * ROWB / 1024, PPW = PIECES / (NTH / 64);   // 1 KB DMA pieces of a tile, per wave
-  static_assert(PIECES % (NTH / 64) == 0 && PPW >= 1, "whole DMA pieces per wave");
-  typedef TileRegs<VB, ROWB, LT, NTH> TR;
-  typedef Piece<T, VB> PC;
-  constexpr int EPC = PC::EPC;
-  const int HTC = CW * d.HT;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  T *bt = reinterpret_cast<T *>(smem);
-  T *cc0 = bt + LT * CWC;
-  float *dvt = reinterpret_cast<float *>(smem + 2 * LT * ROWB);    // dv, then y, then dv*xc: [64][CWC] fp32
-  float *dl = dvt + LT * CWC;
-  float *ddl = dl + LT * HTC;
-  float *segs = ddl + LT * HTC;                                     // [NS][CWC][3] = (P, S, M) of the token segments
-  float2 *lkA = reinterpret_cast<float2 *>(segs + NS * CWC * 3), *lkX = lkA + CWC;
-  float2 *red = lkX + CWC;                                          // [NS][CWC] partial sums (dA_log, dD)
-  float *dtab = reinterpret_cast<float *>(red + NS * CWC);
-  int *item_s = reinterpret_cast<int *>(dtab + CWC);               // [0], [1]: tickets of alternate items
-  T *cc1 = reinterpret_cast<T *>(reinterpret_cast<char *>(item_s) + 16);   // the second C buffer (16-byte aligned: all sizes above are)
-  char *junk = reinterpret_cast<char *>(cc1 + LT * CWC);                   // [waves][1 KB]: landing zone of the L2 warm-up DMAs
-
-  const int tid0 = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid0 >> 6), cw = w / NS, seg = w - cw * NS;
-  int tid = tid0, lane = tid0 & 63, cl = cw * 64 + lane;
-  const int bcs = (int)d.B * ncs, nsup = (d.nchunks + SUP - 1) / SUP;
-  auto take = [&](int slot) {
-    if (tid == 0) {
-      const unsigned t = atomicAdd(&head->ctr[epoch & 1], 1u);
-      if (t == 0) atomicExch(&head->ctr[(epoch + 1) & 1], 0u);   // the next launch's counter (its last user has finished)
-      item_s[slot] = (int)t;
-    }
-  };
-  auto item_of = [&](int item) {
-    BwdItem q;
-    const int k = item / bcs, r = item - k * bcs;
-    q.chunk = d.nchunks - 1 - k;                                   // chunks right to left
-    q.b = r / ncs;
-    q.cs = r - q.b * ncs;
-    q.c0 = q.cs * CWC;
-    const int64_t t0 = (int64_t)q.chunk * LT;
-    q.rows_valid = (int)min((int64_t)LT, d.L - t0);
-    q.ch_valid = (int)min((int64_t)CWC, d.Dn - q.c0);
-    q.ch_store = (int)max((int64_t)0, min((int64_t)CWC, store_w - q.c0));
-    q.vb = q.ch_valid * (int)sizeof(T);
-    q.head0 = q.c0 >> d.log2N;
-    q.tok0 = (int64_t)q.b * d.L + t0;
-    return q;
-  };
-  // the next item's operands: the C tile by LDS-DMA into `ccd` (used from there); the rows of dout, z, Bt and xc by LDS-DMA
-  // into one junk kilobyte per wave - their lines are then in this XCD's L2 when the item's own loads ask for them (no
-  // registers: holding dout / z of two items in registers spills at three waves per SIMD - 168 VGPRs - and a spilling
-  // build of this kernel ran 322 us against 203)
-  auto prefetch = [&](const BwdItem &q, T *ccd) {
-    const uint32_t l0 = sg_lds_addr(ccd), lj = sg_lds_addr(junk) + (uint32_t)w * 1024u;
-    auto tile = [&](const T *base, int64_t rs_el, uint32_t dst, bool keep) {
-      const uint32_t rsb = (uint32_t)(rs_el * (int64_t)sizeof(T));
-      const sg_v4i rs = sg_rsrc(base + q.tok0 * rs_el + q.c0, (uint32_t)(q.rows_valid - 1) * rsb + (uint32_t)q.vb);
-#pragma unroll
-      for (int j = 0; j < PPW; ++j) {
-        const int piece = w * PPW + j, qi = piece * 64 + lane, row = qi / CPR, cb = (qi - row * CPR) * 16;
-        const bool ok = row < q.rows_valid && cb < q.vb;
-        sg_dma16(rs, keep ? dst + piece * 1024 : dst, ok ? (uint32_t)row * rsb + (uint32_t)cb : 0xfffffff0u);   // (out of range: zeros)
-      }
-    };
-    tile(C, c_rs, l0, true);
-    tile(dout, do_rs, lj, false);
-    tile(z, z_rs, lj, false);
-    tile(Bt, bt_rs, lj, false);
-    tile(xc, xc_rs, lj, false);
-  };
-
-  take(0);
-  sg_lds_barrier();
-  int cur = __builtin_amdgcn_readfirstlane(item_s[0]);
-  if (cur >= total) return;
-  TR rg, rz, rb, rx;
-  {
-    const BwdItem q0 = item_of(cur);
-    prefetch(q0, cc0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  int par = 0;
-  while (true) {
-    // (per trip the thread index goes through an empty asm: hipcc otherwise hoists every per-thread offset and address of
-    //  the item body out of the loop and spills them - 240 bytes of scratch per lane)
-    tid = tid0;
-    asm volatile("" : "+v"(tid));
-    lane = tid & 63;
-    cl = cw * 64 + lane;
-    const BwdItem q = item_of(cur);
-    T *cc = par ? cc1 : cc0, *ccn = par ? cc0 : cc1;
-    take(par ^ 1);                                                   // the next item's ticket (read behind the first barrier)
-    const int chunk = q.chunk, cs = q.cs, b = q.b, c0 = q.c0, c = c0 + cl, rows_valid = q.rows_valid, vb = q.vb;
-    const int64_t tok0 = q.tok0;
-    const bool chan_ok = c < d.Dn;
-    rg.load(reinterpret_cast<const char *>(dout + tok0 * do_rs + c0), do_rs * sizeof(T), rows_valid, vb, tid);
-    rz.load(reinterpret_cast<const char *>(z + tok0 * z_rs + c0), z_rs * sizeof(T), rows_valid, vb, tid);
-    stage_delta<LT, NTH>(dl, dlt, tok0, rows_valid, q.head0, (int)d.h, HTC, d.softplus, tid);
-    rb.load(reinterpret_cast<const char *>(Bt + tok0 * bt_rs + c0), bt_rs * sizeof(T), rows_valid, vb, tid);
-    rx.load(reinterpret_cast<const char *>(xc + tok0 * xc_rs + c0), xc_rs * sizeof(T), rows_valid, vb, tid);
-    if (tid < CWC) dtab[tid] = (c0 + tid < d.Dn) ? Dv[c0 + tid] : 0.f;
-    const float Ac = chan_ok ? -expf(A_log[c]) : 0.f;
-    const float A2 = Ac * LOG2E_F;
-    const int64_t abase = (int64_t)b * d.nchunks * d.Dn + c;
-    float hcar = chan_ok ? h_in[abase + (int64_t)chunk * d.Dn] : 0.f;
-#pragma unroll
-    for (int it = 0; it < TR::ITERS; ++it) {                          // dv tile, row-major
-      {
-        const int row = TR::row0(tid) + it * TR::RSTEP, e0 = TR::cb0(tid) / (int)sizeof(T);
-        float gv[EPC], zv[EPC];
-        PC::unpack(rg.r[it], gv);
-        PC::unpack(rz.r[it], zv);
-#pragma unroll
-        for (int k = 0; k < EPC; ++k) dvt[row * CWC + e0 + k] = gv[k] * silu_g(zv[k]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    sg_lds_barrier();   // C (DMA, waited for by its issuing waves), dv, delta tiles are in LDS
-    const int nxt = __builtin_amdgcn_readfirstlane(item_s[par ^ 1]);
-
-    const int hh = cl >> d.log2N;
-    auto a_of = [&](int t) { return __builtin_amdgcn_exp2f(dl[t * HTC + hh] * A2); };
-    float P = 1.f, M = 0.f;
-#pragma unroll 4
-    for (int i = TS - 1; i >= 0; --i) {
-      const int t = seg * TS + i;
-      const float av = a_of(t);
-      const float u = dvt[t * CWC + cl] * to_f32(cc[t * CWC + cl]);
-      M = av * (u + M);
-      P *= av;
-    }
-    segs[(seg * CWC + cl) * 3 + 0] = P;
-    segs[(seg * CWC + cl) * 3 + 2] = M;
-    sg_lds_barrier();
-
-    // composite of the segments behind this wave's (right to left)
-    float Psuf = 1.f, Msuf = 0.f;
-    for (int s = NS - 1; s > seg; --s) {
-      const float px = segs[(s * CWC + cl) * 3 + 0], mx = segs[(s * CWC + cl) * 3 + 2];
-      Msuf = fmaf(px, Msuf, mx);
-      Psuf *= px;
-    }
-    // mu entering from the right = [composites of the later super-chunks] then [aggregates of the later chunks of this one]
-    const int sup = chunk / SUP, top = min(sup * SUP + SUP, d.nchunks);
-    {
-      const int nrec = d.nchunks + nsup;
-      gran_t *gb = gran + ((int64_t)(b * ncs + cs) * nrec) * CWC * 2;
-      if (seg == 0 && chunk > 0 && chan_ok) {                        // the whole chunk: this wave's segment after everything behind it
-        gran_store(gb + ((int64_t)chunk * CWC + cl) * 2 + 0, epoch, Psuf * P);
-        gran_store(gb + ((int64_t)chunk * CWC + cl) * 2 + 1, epoch, fmaf(P, Msuf, M));
-      }
-      if (seg == 1) {
-        float PA, MA;
-        gather_published(gb, CWC, chunk + 1, top, true, cl, chan_ok, epoch, &head->err, PA, MA);
-        if (chunk == sup * SUP && sup > 0 && chan_ok) {              // first chunk of its super-chunk: publish the composite
-          float Po = 1.f, Mo = 0.f;
-          for (int s = NS - 1; s >= 0; --s) {
-            const float px = segs[(s * CWC + cl) * 3 + 0], mx = segs[(s * CWC + cl) * 3 + 2];
-            Mo = fmaf(px, Mo, mx);
-            Po *= px;
-          }
-          gran_store(gb + ((int64_t)(d.nchunks + sup) * CWC + cl) * 2 + 0, epoch, PA * Po);
-          gran_store(gb + ((int64_t)(d.nchunks + sup) * CWC + cl) * 2 + 1, epoch, fmaf(Po, MA, Mo));
-        }
-        lkA[cl] = make_float2(PA, MA);
-      } else if (seg == 2) {
-        float PX, MX;
-        gather_published(gb, CWC, d.nchunks + sup + 1, d.nchunks + nsup, true, cl, chan_ok, epoch, &head->err, PX, MX);
-        lkX[cl] = make_float2(PX, MX);
-      }
-    }
-    rb.store(reinterpret_cast<char *>(bt), tid);
-    sg_lds_barrier();   // Bt tile and the look-back records are in LDS
-
-    // forward segment aggregates (need Bt) for the states inside the chunk
-    float S = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < TS; ++i) S = fmaf(a_of(seg * TS + i), S, to_f32(bt[(seg * TS + i) * CWC + cl]));
-    segs[(seg * CWC + cl) * 3 + 1] = S;
-    float mcar = 0.f;
-    { const float2 rX = lkX[cl], rA = lkA[cl]; mcar = fmaf(rX.x, mcar, rX.y); mcar = fmaf(rA.x, mcar, rA.y); }
-    mcar = fmaf(Psuf, mcar, Msuf);
-    sg_lds_barrier();
-    for (int s = 0; s < seg; ++s) hcar = fmaf(segs[(s * CWC + cl) * 3 + 0], hcar, segs[(s * CWC + cl) * 3 + 1]);
-
-    // the next item's first-phase operands leave now and land under the adjoint walk
-    const bool more = nxt < total;
-    if (more) {
-      const BwdItem qn = item_of(nxt);
-      prefetch(qn, ccn);
-    }
-
-    // adjoint, right to left (scan_gate_bwd_k)
-    constexpr int HF = TS / 2;
-    float hmid = hcar;
-#pragma unroll 4
-    for (int i = 0; i < HF; ++i) hmid = fmaf(a_of(seg * TS + i), hmid, to_f32(bt[(seg * TS + i) * CWC + cl]));
-    float mu = mcar, dA_acc = 0.f;
-#pragma unroll 1
-    for (int half = 1; half >= 0; --half) {
-      const float h0v = half ? hmid : hcar;                  // state entering this half
-      float hs[HF];
-      float hst = h0v;
-#pragma unroll
-      for (int i = 0; i < HF; ++i) {
-        const int t = seg * TS + half * HF + i;
-        hst = fmaf(a_of(t), hst, to_f32(bt[t * CWC + cl]));
-        hs[i] = hst;
-      }
-#pragma unroll
-      for (int i = HF - 1; i >= 0; --i) {
-        const int t = seg * TS + half * HF + i;
-        const float av = a_of(t);
-        const float dv = dvt[t * CWC + cl], Cv = to_f32(cc[t * CWC + cl]);
-        const float lam = fmaf(dv, Cv, mu);
-        const float hprev = i > 0 ? hs[i - 1] : h0v;
-        const float qq = lam * hprev * av * Ac;               // da_t * a_t * A
-        const float dlv = dl[t * HTC + hh];
-        dA_acc = fmaf(qq, dlv, dA_acc);
-        const float qs = group_sum(qq, (int)d.N);
-        if ((lane & ((int)d.N - 1)) == 0) ddl[t * HTC + hh] = qs;
-        cc[t * CWC + cl] = from_f32<T>(dv * hs[i]);           // dC_t (in place: own column only)
-        bt[t * CWC + cl] = from_f32<T>(lam);                  // dBt_t
-        dvt[t * CWC + cl] = Cv * hs[i];                       // y_t takes dv_t's place (the epilogue recomputes dv)
-        mu = av * lam;
-      }
-    }
-    // everything this wave has in flight was issued before the walk: the prefetch (and the Bt / xc / h_in loads) are done
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sg_lds_barrier();   // dBt / dC / y / ddl tiles complete; the next item's C tile is in its buffer
-    // (the output addresses are formed here, not at the top of the item: hipcc otherwise keeps the 64-bit address of every
-    //  piece of every output live across the walk - the token offset goes through an empty asm first)
-    int64_t tok_o = tok0;
-    asm volatile("" : "+s"(tok_o));
-    TR::tile_out(reinterpret_cast<const char *>(bt), reinterpret_cast<char *>(dBt + tok_o * dbt_rs + c0), dbt_rs * sizeof(T), rows_valid,
-                 q.ch_store * (int)sizeof(T), tid);
-    TR::tile_out(reinterpret_cast<const char *>(cc), reinterpret_cast<char *>(dC + tok_o * dc_rs + c0), dc_rs * sizeof(T), rows_valid,
-                 q.ch_store * (int)sizeof(T), tid);
-    for (int idx = tid; idx < LT * HTC; idx += NTH) {
-      const int t = idx / HTC, hx = idx - t * HTC;
-      if (t < rows_valid && q.head0 + hx < d.h) {
-        float v = ddl[idx];
-        if (d.softplus) v *= 1.f - expf(-dl[idx]);            // sigmoid(x) = 1 - exp(-softplus(x))
-        d_dlt[(tok_o + t) * d.h + q.head0 + hx] = v;
-      }
-    }
-
-    // row-major epilogue: dz = dout*silu'(z)*(y + D*xc), dxc = dv*D straight to global memory; dv*xc over y, in place
-    asm volatile("" : "+s"(tok_o));
-    char *zg = reinterpret_cast<char *>(dz + tok_o * dz_rs + c0), *xg = reinterpret_cast<char *>(dxc + tok_o * dxc_rs + c0);
-#pragma unroll
-    for (int it = 0; it < TR::ITERS; ++it) {
-      {
-        const int row = TR::row0(tid) + it * TR::RSTEP, cb = TR::cb0(tid), e0 = cb / (int)sizeof(T);
-        float gv[EPC], zv[EPC], xv[EPC], oz[EPC], ox[EPC], yv[EPC], dc[EPC], pv[EPC];
-        PC::unpack(rg.r[it], gv);
-        PC::unpack(rz.r[it], zv);
-        PC::unpack(rx.r[it], xv);
-        lds_vec<EPC>::load(dvt + row * CWC + e0, yv);
-        lds_vec<EPC>::load(dtab + e0, dc);
-#pragma unroll
-        for (int k = 0; k < EPC; ++k) {
-          float f, df;
-          silu_both(zv[k], f, df);
-          const float dv = gv[k] * f, dcol = dc[k];
-          const float dx = dcol * xv[k];
-          const float v = yv[k] + dx;
-          oz[k] = gv[k] * df * v;
-          ox[k] = dv * dcol;
-          pv[k] = dv * xv[k];                                 // zero for rows / channels outside the tensor (staged zeros)
-        }
-        lds_vec<EPC>::store(dvt + row * CWC + e0, pv);
-        if (row < rows_valid && cb < vb) {
-          nt_store<VB>(zg + (int64_t)row * dz_rs * sizeof(T) + cb, PC::pack(oz));
-          nt_store<VB>(xg + (int64_t)row * dxc_rs * sizeof(T) + cb, PC::pack(ox));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    sg_lds_barrier();
-    {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < TS; ++i) s += dvt[(seg * TS + i) * CWC + cl];
-      red[seg * CWC + cl] = make_float2(dA_acc, s);
-    }
-    sg_lds_barrier();
-    if (seg < 2 && chan_ok) {                                  // segment-0 waves: dA_log partial, segment-1 waves: dD partial
-      float s = 0.f;
-#pragma unroll
-      for (int k = 0; k < NS; ++k) s += seg == 0 ? red[k * CWC + cl].x : red[k * CWC + cl].y;
-      part[(((int64_t)b * d.nchunks + chunk) * 2 + seg) * d.Dn + c] = s;
-    }
-    if (!more) break;
-    cur = nxt;
-    par ^= 1;
-    sg_lds_barrier();   // red / dvt / dl are free for the next item
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Single-token decode step (reference core.py:364-400 with L = 1 and a cache; generate() core.py:1578-1603):
 //   window = [conv_state (k-1 tokens) | xp_new]; the reference keeps the FIRST conv output of that window
 //   (core.py:369-373 slices [:, :, :L] of the padded conv), i.e. taps over [0, 0, 0, conv_state[0]] ... - reproduced
@@ -1278,35 +931,9 @@ int launch_gate_bwd_cw(const BwdArgs &a, int ncs) {
     a.store_w, (T *)a.dxc, a.dxc_rs, (T *)a.dz, a.dz_rs, a.d_dlt, a.part, d, ncs
   if (a.single_pass) {
     const int64_t items = (int64_t)d.nchunks * d.B * ncs;
-    if (items > 0x3fffffffLL) return APERTIS_ERR_UNSUPPORTED;
-    bool piped = false;
-    if constexpr (sizeof(T) == 2 && VB == 16 && CW == 3) {
-      // persistent work-groups with the next item's first tiles prefetched (scan_gate_bwd_pipe_k): worth it once every CU gets
-      // several items; APERTIS_SCAN_BWD_PIPE=0 keeps the one-item-per-work-group kernel (developer switch, same bits).
-      // Three channel groups only (128 < Dn <= 192): the 1024-thread geometries of narrower tiles cap at 128 VGPRs
-      static const int pipe_on = [] { const char *e = getenv("APERTIS_SCAN_BWD_PIPE"); return e ? atoi(e) : 1; }();
-      const size_t lds_p = lds + (size_t)LTG * G::CWC * sizeof(T) + 16 + (size_t)(G::NTH / 64) * 1024;
-      int ncu = 0, dev_id = 0;
-      if (pipe_on && lds_p <= 160 * 1024 && hipGetDevice(&dev_id) == hipSuccess) {
-        static int ncu_cache[64] = {0};
-        if (dev_id >= 0 && dev_id < 64) {
-          if (!ncu_cache[dev_id]) hipDeviceGetAttribute(&ncu_cache[dev_id], hipDeviceAttributeMultiprocessorCount, dev_id);
-          ncu = ncu_cache[dev_id];
-        }
-      }
-      if (ncu > 0 && items >= 2 * (int64_t)ncu) {
-        allow_lds(scan_gate_bwd_pipe_k<T, CW>, lds_p);
-        hipLaunchKernelGGL((scan_gate_bwd_pipe_k<T, CW>), dim3((unsigned)ncu), dim3(G::NTH), lds_p, a.st, a.dlt, a.A_log,
-                           (const T *)a.Bt, a.bt_rs, (const T *)a.C, a.c_rs, (const T *)a.xc, a.xc_rs, (const T *)a.z, a.z_rs, a.Dv,
-                           (const T *)a.dout, a.do_rs, a.h_in, head, gran, a.epoch, (T *)a.dBt, a.dbt_rs, (T *)a.dC, a.dc_rs,
-                           a.store_w, (T *)a.dxc, a.dxc_rs, (T *)a.dz, a.dz_rs, a.d_dlt, a.part, d, ncs, (int)items);
-        piped = true;
-      }
-    }
-    if (!piped) {
-      allow_lds(scan_gate_bwd_k<T, VB, CW, 1>, lds);
-      hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, CW, 1>), dim3((unsigned)items), dim3(G::NTH), lds, a.st, BWD_ARGS(nullptr));
-    }
+    if (items > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
+    allow_lds(scan_gate_bwd_k<T, VB, CW, 1>, lds);
+    hipLaunchKernelGGL((scan_gate_bwd_k<T, VB, CW, 1>), dim3((unsigned)items), dim3(G::NTH), lds, a.st, BWD_ARGS(nullptr));
   } else {
     dim3 grid(d.nchunks, (unsigned)ncs, (unsigned)d.B);
     allow_lds(scan_gate_bwd_k<T, VB, CW, 2>, lds);
