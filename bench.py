@@ -290,11 +290,16 @@ def main():
     if not args.no_kernel_timers:
         timer = ops.KernelTimer(["apertis_grouped_gemm_nt", "apertis_grouped_gemm_tn", "apertis_selective_scan_fwd",
                                  "apertis_selective_scan_bwd", "apertis_scan_gate_fwd", "apertis_scan_gate_bwd",
-                                 "apertis_grouped_gemm_nt[dense]", "apertis_grouped_gemm_tn[dense]"])
+                                 "apertis_grouped_gemm_nt[dense]", "apertis_grouped_gemm_tn[dense]"],
+                                # per-call HIP events on every 4th timed step once there are enough of them (the event records
+                                # are host work: 24 ms of a 137 ms step on the launch-heavy 350m-moe configuration)
+                                every=4 if args.steps >= 20 else 1)
     sync()
     ops.set_kernel_timer(timer)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if timer is not None:
+            timer.next_step()
         loss = step(**batch())
     sync()
     elapsed = time.perf_counter() - t0
@@ -372,6 +377,7 @@ def main():
             dom = max((k for k in rl if "[dense]" not in k), key=lambda k: rl[k]["total_ms"])
             result["roofline"] = dict(rl[dom], kernel=dom)
             result["roofline_all"] = rl
+            result["roofline_steps"] = args.steps // timer.every    # the steps whose launches carry event pairs (`launches` counts those)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU oracle in a CHILD process (never touches the GPU), bounded sample: one layer of the same shape at
         # B=1 and the benchmark's sequence length, train mode, 1 warm-up + median of 3 (about 20 s of CPU work); a
