@@ -470,6 +470,51 @@ cast_transpose_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__rest
     }
 }
 
+// The same with four columns per thread (round 3): 16-byte loads, 8-byte (bf16) / 16-byte (fp32) stores of both copies - the
+// scalar form above moved its bytes at 2.6 TB/s (2-byte stores, 128 bytes per wave instruction).  Needs C, ld_dst and ld_dstT
+// multiples of 4 and 16-byte aligned bases (the launcher checks).
+template <typename TO> struct out4;
+template <> struct out4<bf16_t> {
+  __device__ static __forceinline__ void store(bf16_t *p, float a, float b, float c, float d) {
+    typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+    const bf4 v = {(bf16_t)a, (bf16_t)b, (bf16_t)c, (bf16_t)d};
+    *reinterpret_cast<bf4 *>(p) = v;
+  }
+};
+template <> struct out4<float> {
+  __device__ static __forceinline__ void store(float *p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a, b, c, d);
+  }
+};
+template <typename TO>
+__global__ void __launch_bounds__(256)
+cast_transpose4_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__restrict__ dstT, int R, int C, int ld_dst,
+                  int ld_dstT) {
+  __shared__ float tile[64][65];
+  const int64_t e = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const float *s = src + e * (int64_t)R * C;
+  const int q = threadIdx.x & 15, g = threadIdx.x >> 4;        // column quad, row (resp. column) within a pass of 16
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = g + 16 * i, r = r0 + rl, c = c0 + q * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R && c < C) v = *reinterpret_cast<const float4 *>(s + (int64_t)r * C + c);
+    tile[rl][q * 4 + 0] = v.x; tile[rl][q * 4 + 1] = v.y; tile[rl][q * 4 + 2] = v.z; tile[rl][q * 4 + 3] = v.w;
+    if (dst && r < R && c < ld_dst) out4<TO>::store(dst + e * (int64_t)R * ld_dst + (int64_t)r * ld_dst + c, v.x, v.y, v.z, v.w);   // pad columns: 0
+  }
+  __syncthreads();
+  if (dstT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cl = g + 16 * i, c = c0 + cl, r = r0 + q * 4;
+      if (r < ld_dstT && c < C)
+        out4<TO>::store(dstT + e * (int64_t)C * ld_dstT + (int64_t)c * ld_dstT + r, tile[q * 4 + 0][cl], tile[q * 4 + 1][cl],
+                        tile[q * 4 + 2][cl], tile[q * 4 + 3][cl]);
+    }
+  }
+}
+
 int gate_blocks(int64_t T, int64_t Dn) {
   Geo g = make_geo(Dn);
   int64_t nb = ceil_div64(T, (int64_t)g.RP * 8);
@@ -601,14 +646,17 @@ extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, i
   if (R > 0x3fffffff || C > 0x3fffffff || E > 65535 || ceil_div64(R, 64) > 65535) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)ceil_div64(C, 64), (unsigned)ceil_div64(R, 64), (unsigned)E), block(256);
-  if (dtype_out == APERTIS_BF16)
-    hipLaunchKernelGGL(cast_transpose_k<bf16_t>, grid, block, 0, st, src, (bf16_t *)dst, (bf16_t *)dstT, (int)R, (int)C, (int)ld_dst,
-                       (int)ld_dstT);
-  else if (dtype_out == APERTIS_F32)
-    hipLaunchKernelGGL(cast_transpose_k<float>, grid, block, 0, st, src, (float *)dst, (float *)dstT, (int)R, (int)C, (int)ld_dst,
-                       (int)ld_dstT);
-  else
+  const bool vec4 = C % 4 == 0 && ld_dst % 4 == 0 && ld_dstT % 4 == 0 && (R * C) % 4 == 0 && ((uintptr_t)src) % 16 == 0 &&
+                    ((uintptr_t)dst) % 16 == 0 && ((uintptr_t)dstT) % 16 == 0;
+#define CT_GO(KERN, TO) hipLaunchKernelGGL(KERN<TO>, grid, block, 0, st, src, (TO *)dst, (TO *)dstT, (int)R, (int)C, (int)ld_dst, (int)ld_dstT)
+  if (dtype_out == APERTIS_BF16) {
+    if (vec4) CT_GO(cast_transpose4_k, bf16_t); else CT_GO(cast_transpose_k, bf16_t);
+  } else if (dtype_out == APERTIS_F32) {
+    if (vec4) CT_GO(cast_transpose4_k, float); else CT_GO(cast_transpose_k, float);
+  } else {
     return APERTIS_ERR_ARG;
+  }
+#undef CT_GO
   return apertis_check_launch();
 }
 

@@ -1022,3 +1022,21 @@ def test_expert_mlp_full_size_dropout_mask_recovered(dev, batch):
     e = 5
     a, b = e * per, (e + 1) * per
     _close(w2.grad[e], dy[a:b].float().T @ h[a:b].float(), "dW2[e] (dropout on)", rtol=2e-2, atol_scale=1e-2)
+
+
+@pytest.mark.parametrize("E,R,C", [(1, 704, 704), (8, 2816, 704), (8, 704, 2816), (1, 448, 176), (3, 70, 36), (2, 65, 130), (1, 7, 5)])
+def test_cast_transpose_plain_and_transposed(dev, E, R, C):
+    """apertis_cast_transpose (the GEMM operands' preparation, reference: the autocast of core.py's nn.Linear weights): the
+    bf16 copy with its K padded to 64 and the transposed copy, bit-exact against torch's rounding, pads exactly zero - both the
+    four-column kernel (C % 4 == 0) and the scalar one, partial 64 x 64 tiles, more than one group."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(E * 1000 + R + C)
+    w = torch.randn(E, R, C, device=dev)
+    plain, tr = ops.cast_transpose(w, torch.bfloat16)
+    Cp, Rp = -(-C // 64) * 64, -(-R // 64) * 64
+    assert plain.shape == (E, R, Cp) and tr.shape == (E, C, Rp)
+    ref = w.to(torch.bfloat16)
+    assert torch.equal(plain[:, :, :C], ref) and (Cp == C or bool((plain[:, :, C:] == 0).all()))
+    assert torch.equal(tr[:, :, :R], ref.transpose(1, 2)) and (Rp == R or bool((tr[:, :, R:] == 0).all()))
+    p32, t32 = ops.cast_transpose(w, torch.float32)
+    assert torch.equal(p32, w) and torch.equal(t32, w.transpose(1, 2))
