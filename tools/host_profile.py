@@ -71,7 +71,11 @@ def main():
         print(s.getvalue())
 
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    try:
+        xc = torch._C._profiler._ExperimentalConfig(verbose=True)
+    except Exception:
+        xc = None
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, experimental_config=xc) as prof:
         step(**batch())
         torch.cuda.synchronize()
     names = ("aten::zeros", "aten::zero_", "aten::fill_", "aten::copy_", "aten::cat", "aten::index", "aten::zeros_like",
@@ -79,9 +83,10 @@ def main():
              "aten::clone", "aten::contiguous", "aten::index_copy_", "aten::index_add_", "aten::gather", "aten::where")
     groups = collections.Counter()
     for ev in prof.events():
-        if ev.name in names and ev.device_time_total > 0 or (ev.name in ("aten::fill_", "aten::copy_", "aten::cat")):
-            frames = [f for f in (ev.stack or []) if "apertis_llm_amd" in f or "bench" in f or "autograd" in f.lower()]
-            where = " <- ".join(f.split("apertis_llm_amd/")[-1] for f in frames[:3]) or "(no python frame: autograd engine)"
+        if ev.name in ("aten::fill_", "aten::zero_", "aten::copy_", "aten::cat") and ev.device_time_total > 0:
+            frames = [f for f in (ev.stack or []) if "apertis_llm_amd" in f or "bench" in f]
+            allf = [f for f in (ev.stack or [])]
+            where = " <- ".join(f.split("apertis_llm_amd/")[-1] for f in frames[:3]) or ("(no package frame) " + " <- ".join(a.split("/")[-1] for a in allf[:3]))
             groups[(ev.name, where)] += 1
     print("== framework ops that launch kernels, one step, by call site")
     for (name, where), n in sorted(groups.items(), key=lambda kv: -kv[1])[:80]:
