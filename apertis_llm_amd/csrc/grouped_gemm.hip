@@ -1446,323 +1446,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   stamp_end();
 }
 
-// ------------------------------------------------------------------------------------------
-// Warp-specialised form of the two-per-CU kernel (round 3, late).  Phase stamps on the kernel above say what its tiles are:
-// 15.8 us of K loop and 20.1 us of epilogue (saved-gradient form; 12.9 us for the fused data gradient) per 38.7 us tile and
-// slot - the epilogue's VALU work and stores, not the MFMA pipe, and its two work-groups per CU drift through the same
-// phase instead of overlapping (a forced start offset changes nothing).  Here the two jobs are two ROLES of one persistent
-// 512-thread work-group per CU: waves 0-3 only ever run K loops (the same 256 x 128 tile, ring, DMA and fragment code;
-// they issue no global store, so their vmcnt bookkeeping stays exact, and the next tile's first three stages leave
-// during the last three sub-steps of the current one), waves 4-7 only ever run epilogues, one tile behind: at a tile's
-// end the MFMA waves leave bf16(acc + bias) - what the epilogue rounds to first anyway - in a 64 KiB staging image, and
-// during the NEXT tile's K loop every epilogue thread turns one 16-byte chunk per sub-step into its outputs (GELU and its
-// derivative, mask, packing; or the product with the saved tensor; or a copy) and stores them row-major.  A SIMD then
-// holds one MFMA wave and one VALU wave for the whole launch; the work-group barrier of every sub-step keeps them in step.
-// Bit-identical to the two-per-CU kernel's outputs (same rounding points, same mask words).
-constexpr int NTW = 512, STGW = BM3 * 256;
-constexpr int WS_SLOTS = 4, RINGW = WS_SLOTS * SLOT3;   // four 24 KiB slots: three stages in flight beside the one being read (96 + 64 KiB = the CU's LDS)
-#ifndef NTWS_DEFAULT
-#define NTWS_DEFAULT 0
-#endif
-struct WsTile { int state, e, rows_valid, n0, cols_valid; int64_t row0; };   // state: 1 a tile, 0 an empty slot of the tile grid, -1 past the end
-
-template <typename TO>
-__global__ void __launch_bounds__(NTW, 2)
-grouped_gemm_ntws_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
-                    const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
-                    const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int total_tiles, int act_flags,
-                    float drop_p, uint64_t seed, int walk_g, int walk_nb, int probe_flags) {
-  // probe_flags (tools/probes only, 0 in the library's own launches): 1 = the epilogue work is skipped (loads and K loops only),
-  // 2 = the MFMA waves stay at priority 0, 4 = waves 4-7 at priority 2, 8 = saved-gradient arithmetic without its stores, 16 = its
-  // stores without the arithmetic
-  static_assert(sizeof(TO) == 2, "bf16 outputs");
-  typedef bf16x8 frag;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *stg = smem + RINGW;
-  const bool save_grad = (act_flags & APERTIS_ACT_SAVE_GRAD) != 0, mul_saved = (act_flags & APERTIS_ACT_MUL_SAVED) != 0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nk = K / 32;   // (launcher: K % 32 == 0, >= WS_SLOTS)
-
-  // this work-group's tiles: its XCD owns a contiguous eighth of the walk order, the XCD's work-groups take consecutive tiles
-  const int xcd = blockIdx.x & 7, li = blockIdx.x >> 3, per_x = gridDim.x >> 3;
-  const int span = (total_tiles + 7) / 8, lo = xcd * span, hi = min(lo + span, total_tiles);
-  auto tile_at = [&](int k) {
-    WsTile t;
-    t.state = -1; t.e = -1; t.rows_valid = 0; t.n0 = 0; t.cols_valid = 0; t.row0 = 0;
-    const int id = lo + k * per_x + li;
-    if (id >= hi) return t;
-    int mt, ntile;
-    tile_walk(id, total_tiles / n_tiles, n_tiles, walk_g, walk_nb, mt, ntile);
-    t.state = 0;
-    int accm = 0;
-    for (int g = 0; g < E; ++g) {
-      const int r0 = offsets[g], r1 = offsets[g + 1];
-      const int nt = (r1 - r0 + BM3 - 1) / BM3;
-      if (mt < accm + nt) {
-        const int m0 = (mt - accm) * BM3;
-        t.e = g; t.row0 = r0 + m0; t.rows_valid = min(BM3, r1 - r0 - m0); t.state = 1;
-        break;
-      }
-      accm += nt;
-    }
-    t.e = __builtin_amdgcn_readfirstlane(t.e);
-    t.state = __builtin_amdgcn_readfirstlane(t.state);
-    t.rows_valid = __builtin_amdgcn_readfirstlane(t.rows_valid);
-    t.row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)t.row0);
-    t.n0 = ntile * BN3;
-    t.cols_valid = min(BN3, N - t.n0);
-    return t;
-  };
-  // first real tile at or behind sequence position k (k is advanced to it); state -1 when there is none
-  auto next_tile = [&](int &k) {
-    WsTile t = tile_at(k);
-    while (t.state == 0) t = tile_at(++k);
-    return t;
-  };
-  // Barriers of a tile, the same for both roles: one at its start (stage 0 is in LDS), one per sub-step (stage s+1 is in LDS;
-  // the slot of stage s may be refilled: its fragments are in registers), one at the hand-over (the staging image is written).
-
-  // Operand fills: ALL eight waves issue them, three 1 KiB pieces per wave and stage (two of X, one of W).  A wave sits in each
-  // `buffer_load ... lds` until the CU's address unit has taken it, and the rate at which a CU fills its LDS grows with the number
-  // of waves that issue: measured on this kernel's skeleton (epilogue work off), 24 KiB per sub-step from four waves take 1090-1250
-  // cycles wherever the pieces are placed (ring depth 3 or 4, pieces behind the barrier or between the MFMAs: the same).
-  const int ldb = K * 2, ldwb = ldw * 2;
-  const int fsw = (4 - ((lane >> 4) & 3)) & 3;                       // F[(row >> 2) & 3] for row = lane >> 2
-  const uint32_t vx0 = (uint32_t)((wave * 32 + (lane >> 2)) * ldb + (((lane & 3) ^ fsw) << 4));
-  const uint32_t vw0 = (uint32_t)((wave * 16 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
-  const uint32_t lds0 = lds_addr_of(smem);
-  struct Desc { v4i xrs, wrs; };
-  auto desc_of = [&](const WsTile &t) {
-    Desc d;
-    d.xrs = raw_buffer_rsrc(X + t.row0 * K, (uint32_t)t.rows_valid * (uint32_t)ldb);
-    d.wrs = raw_buffer_rsrc(W + ((int64_t)t.e * N + t.n0) * ldw, (uint32_t)t.cols_valid * (uint32_t)ldwb);
-    return d;
-  };
-  auto issue = [&](const Desc &d, uint32_t slot_off, int sidx) {   // sub-step sidx of a tile: this wave's 2 X pieces and its W piece
-    const uint32_t kb = (uint32_t)sidx * ROWB3, base = lds0 + slot_off;
-    lds_dma16s(d.xrs, base + (wave * 2 + 0) * 1024, vx0, kb);
-    lds_dma16s(d.xrs, base + (wave * 2 + 1) * 1024, vx0 + (uint32_t)(16 * ldb), kb);
-    lds_dma16s(d.wrs, base + BM3 * ROWB3 + wave * 1024, vw0, kb);
-  };
-  constexpr int PPS = 3;   // DMA pieces per wave and stage
-
-  if (wave < 4) {
-    // ------------------------------------------------------------------ MFMA role: K loops (fills, LDS reads, MFMAs); no stores
-    const int wm = wave >> 1, wn = wave & 1;
-    const int frow = lane & 15, fg = lane >> 4;
-    const int frd = frow * ROWB3 + ((fg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
-    const char *xbase = smem + wm * 128 * ROWB3 + frd, *wbase = smem + BM3 * ROWB3 + wn * 64 * ROWB3 + frd;
-    f32x4 acc[4][8];
-    frag wf[2][4], xf[8];
-    auto load_w = [&](frag (&dst)[4], int slot_off) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const frag *>(wbase + slot_off + i * 16 * ROWB3);
-    };
-    // 32 MFMAs on (wcur, xf) while (wnxt, xf) are refilled from the slot at nxt_off
-    auto sub_step = [&](const frag (&wcur)[4], frag (&wnxt)[4], int nxt_off) {
-      load_w(wnxt, nxt_off);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mma(acc[i][j], wcur[i], xf[j]);
-        xf[j] = *reinterpret_cast<const frag *>(xbase + nxt_off + j * 16 * ROWB3);
-      }
-#define SGB(nr) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, nr, 0);
-      SGB(3) SGB(3) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1)
-#undef SGB
-    };
-    int k = 0;
-    WsTile cur_t = next_tile(k);
-    if (cur_t.state < 0) return;
-    Desc dc = desc_of(cur_t);
-#pragma unroll
-    for (int q = 0; q < WS_SLOTS; ++q) issue(dc, q * SLOT3, q);
-    int cur = 0;   // LDS offset of the current sub-step's slot; runs on across tiles
-    if (!(probe_flags & 2)) __builtin_amdgcn_s_setprio(1);
-    while (true) {
-      int kn = k + 1;
-      const WsTile nxt_t = next_tile(kn);
-      const bool has_next = nxt_t.state > 0;
-      Desc dn = dc;
-      if (has_next) dn = desc_of(nxt_t);
-      float bv[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = cur_t.n0 + wn * 64 + i * 16 + fg * 4 + r;
-          bv[i][r] = (bias && n < N) ? bias[(int64_t)cur_t.e * N + n] : 0.f;
-        }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      wait_vmcnt<PPS * (WS_SLOTS - 1)>();   // this wave's pieces of stage 0 (vmcnt retires in order)
-      lds_barrier();      // tile-start barrier
-      load_w(wf[0], cur);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const frag *>(xbase + cur + j * 16 * ROWB3);
-      for (int sb = 0; sb < nk; sb += 2) {
-#define WS_SUB(S, WC, WN)                                                                                \
-        {                                                                                                \
-          const int nxt = cur + SLOT3 == RINGW ? 0 : cur + SLOT3;                                        \
-          /* stage S+1 has to be there (its fragments are read during this sub-step); S+2, S+3 stay in flight */ \
-          if ((S) + 3 < nk || has_next) wait_vmcnt<2 * PPS>();                                           \
-          else if ((S) + 2 < nk) wait_vmcnt<PPS>();                                                      \
-          else wait_vmcnt<0>();                                                                          \
-          lds_barrier();      /* (lgkmcnt(0) first: this wave's fragment reads of the slot are done) */   \
-          {   /* refill of this sub-step's slot: one of this tile's stages, or one of the next tile's first four */ \
-            const bool own = (S) + WS_SLOTS < nk;                                                        \
-            const int fs = own ? (S) + WS_SLOTS : (has_next ? (S) + WS_SLOTS - nk : -1);                 \
-            Desc df;                                                                                     \
-            df.xrs = own ? dc.xrs : dn.xrs;                                                              \
-            df.wrs = own ? dc.wrs : dn.wrs;                                                              \
-            if (fs >= 0) issue(df, (uint32_t)cur, fs);                                                   \
-          }                                                                                              \
-          sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of the next tile's stage 0) */ \
-          cur = nxt;                                                                                     \
-        }
-        WS_SUB(sb, wf[0], wf[1])
-        if (sb + 1 < nk) WS_SUB(sb + 1, wf[1], wf[0])
-        else {   // odd nk: keep the register roles of the loop
-#pragma unroll
-          for (int i = 0; i < 4; ++i) wf[0][i] = wf[1][i];
-        }
-#undef WS_SUB
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // hand-over: bf16(acc + bias) into the staging image (waves 4-7 finished with the previous tile's image at most 16
-      // sub-steps into this tile's K loop)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int m = wm * 128 + j * 16 + frow;
-          const int chunk = wn * 8 + i * 2 + (fg >> 1);
-          *reinterpret_cast<uint2 *>(stg + m * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8) =
-              make_uint2(pack_bf16x2_any(acc[i][j][0] + bv[i][0], acc[i][j][1] + bv[i][1]),
-                         pack_bf16x2_any(acc[i][j][2] + bv[i][2], acc[i][j][3] + bv[i][3]));
-        }
-      lds_barrier();      // hand-over barrier
-      if (!has_next) break;
-      cur_t = nxt_t; dc = dn; k = kn;
-    }
-  } else {
-    // ------------------------------------------------------------------ waves 4-7: their share of the fills and the epilogue of
-    // the tile before the one in the K loop
-    const int et = tid - 256;
-    if (probe_flags & 4) __builtin_amdgcn_s_setprio(2);
-    const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
-    const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
-    const bool drop = drop_p > 0.f;
-    const int cps = (16 + nk - 1) / nk;   // chunks per thread and sub-step so that a tile's 16 are done inside one K loop
-    // chunk `q` (0..15) of tile t: 16 rows x 16 chunks per pass of the 256 threads; `pc` = its chunk of the saved tensor
-    auto chunk_ok = [&](const WsTile &t, int q, int &row, int &c) {
-      const int c4 = q * 256 + et;
-      row = c4 >> 4; c = c4 & 15;
-      return row < t.rows_valid && c * 8 < t.cols_valid;
-    };
-    auto chunk_out = [&](const WsTile &t, int q, const uint4 &pc) {
-      int row, c;
-      if (!chunk_ok(t, q, row, c) || (probe_flags & 1)) return;
-      const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
-      const int64_t o = (t.row0 + row) * N + t.n0 + c * 8;
-      if (mul_saved) {
-        out_store16(C + o, mul_chunk_bf16(v, pc));
-      } else if (save_grad && (probe_flags & 16)) {   // (probe: the two stores without the arithmetic)
-        out_store16(C + o, v);
-        out_store16(pre_act + o, v);
-      } else if (save_grad) {
-        const uint32_t xw[4] = {v.x, v.y, v.z, v.w};
-        const uint32_t pair0 = (uint32_t)o >> 1;
-        uint32_t oh[4], og[4];
-#pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
-          const uint32_t dm = drop ? drop_mask2(drop_hash_pair32(seed, pair0 + (uint32_t)w2), thresh16) : 0u;
-          const v2f x = {__builtin_bit_cast(float, xw[w2] << 16), __builtin_bit_cast(float, xw[w2] & 0xffff0000u)};
-          v2f hv, gv;
-          gelu_both_fast2(x, hv, gv);
-          hv = hv * splat2(keep_scale);
-          gv = gv * splat2(keep_scale);
-          oh[w2] = pack_bf16x2(hv.x, hv.y) & ~dm;
-          og[w2] = pack_bf16x2(gv.x, gv.y) & ~dm;
-        }
-        if (probe_flags & 8) {   // (probe: the arithmetic without its stores - one lane in a billion writes)
-          if ((oh[0] ^ og[1] ^ oh[2] ^ og[3]) == 0x12345679u) out_store16(C + o, make_uint4(oh[0], oh[1], oh[2], oh[3]));
-        } else {
-          out_store16(C + o, make_uint4(oh[0], oh[1], oh[2], oh[3]));
-          out_store16(pre_act + o, make_uint4(og[0], og[1], og[2], og[3]));
-        }
-      } else {
-        out_store16(C + o, v);
-      }
-    };
-    // the saved tensor's sixteen chunks of a tile leave together, a whole K loop ahead of their use (64 registers)
-    uint4 pcs[16];
-    auto fetch_saved = [&](const WsTile &t) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        int row, c;
-        pcs[q] = make_uint4(0, 0, 0, 0);
-        if (mul_saved && chunk_ok(t, q, row, c)) pcs[q] = *reinterpret_cast<const uint4 *>(mul_pre + (t.row0 + row) * N + t.n0 + c * 8);
-      }
-    };
-    int k = 0;
-    WsTile cur_t = next_tile(k);
-    if (cur_t.state < 0) return;
-    Desc dc = desc_of(cur_t);
-#pragma unroll
-    for (int q = 0; q < WS_SLOTS; ++q) issue(dc, q * SLOT3, q);
-    int cur = 0;   // LDS offset of the slot of the sub-step in the K loop; runs on across tiles
-    WsTile prev_t = cur_t;
-    bool have_prev = false;
-    // vmcnt in these waves counts the DMA pieces AND the epilogue's loads / stores (in issue order): every wait below leaves
-    // at most the pieces of the stages that may stay in flight - what it counts beyond them (stores between those stages)
-    // only makes it wait for a few pieces more, never for fewer.
-    while (true) {
-      int kn = k + 1;
-      const WsTile nxt_t = next_tile(kn);
-      const bool has_next = nxt_t.state > 0;
-      Desc dn = dc;
-      if (has_next) dn = desc_of(nxt_t);
-      if (have_prev) fetch_saved(prev_t);
-      wait_vmcnt<PPS * (WS_SLOTS - 1)>();   // this wave's pieces of stage 0
-      lds_barrier();      // tile-start barrier
-      // per sub-step: wait for stage sidx+1 (its fragments are read during the sub-step; two more stages may stay in flight),
-      // the sub-step's barrier, then the refill of the slot of sub-step sidx - one of this tile's stages or one of the next
-      // tile's first four
-      auto sub_protocol = [&](int sidx) {
-        if (sidx + 3 < nk || has_next) wait_vmcnt<2 * PPS>();
-        else if (sidx + 2 < nk) wait_vmcnt<PPS>();
-        else wait_vmcnt<0>();
-        lds_barrier();    // sub-step barrier
-        const bool own = sidx + WS_SLOTS < nk;
-        const int fs = own ? sidx + WS_SLOTS : (has_next ? sidx + WS_SLOTS - nk : -1);
-        Desc df;
-        df.xrs = own ? dc.xrs : dn.xrs;
-        df.wrs = own ? dc.wrs : dn.wrs;
-        if (fs >= 0) issue(df, (uint32_t)cur, fs);
-        cur = cur + SLOT3 == RINGW ? 0 : cur + SLOT3;
-      };
-      int sidx = 0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        if (q % cps == 0) sub_protocol(sidx++);
-        if (have_prev) chunk_out(prev_t, q, pcs[q]);
-      }
-      for (; sidx < nk; ++sidx) sub_protocol(sidx);      // the K loop's remaining sub-steps
-      lds_barrier();      // hand-over barrier: the staging image now holds cur_t
-      prev_t = cur_t;
-      have_prev = true;
-      if (!has_next) break;
-      cur_t = nxt_t; dc = dn; k = kn;
-    }
-    fetch_saved(prev_t);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) chunk_out(prev_t, q, pcs[q]);   // the last tile: nothing runs beside it
-  }
-}
-
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
 template <typename T>
 __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict__ pre, T *__restrict__ dpre,
@@ -2880,31 +2563,6 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       const int nt3 = (int)ceil_div64(N, BN3);
       const int64_t grid3 = (ceil_div64(max_rows, BM3) + E) * nt3;
       if (grid3 < 0x7fffffffLL) {
-        // the warp-specialised persistent form (grouped_gemm_ntws_k) takes the expert calls whose epilogue it has: saved-gradient
-        // GELU, product with the saved tensor, plain
-        const bool ws_form = (act_flags & APERTIS_ACT_SAVE_GRAD) ? (pre_act != nullptr && act == APERTIS_ACT_GELU)
-                             : (act_flags & APERTIS_ACT_MUL_SAVED) ? (mul_pre != nullptr)
-                                                                   : (act == APERTIS_ACT_NONE && drop_p <= 0.f && !pre_act && !mul_pre);
-        int use_ws = NTWS_DEFAULT;
-#ifdef NT_PROBE_WALK
-        if (const char *wv = getenv("NT_WS")) use_ws = atoi(wv);
-#endif
-        if (use_ws && ws_form && E > 1 && !ragged2x && K / 32 >= WS_SLOTS && (max_rows + 256) * N < 0x100000000LL) {
-          int walk_g = nt3 > 8 ? 8 : 0, walk_nb = 4, probe_flags = 0;
-#ifdef NT_PROBE_WALK
-          if (const char *wv = getenv("NT_WALK")) sscanf(wv, "%d,%d", &walk_g, &walk_nb);
-          if (const char *wv = getenv("NT_WS_FLAGS")) probe_flags = atoi(wv);
-#endif
-          const int ncu = device_cu_count();
-          const int gw = std::max(8, (int)std::min<int64_t>((grid3 + 7) / 8 * 8, ncu / 8 * 8));
-          auto kw = grouped_gemm_ntws_k<TO>;
-          const size_t ldsw = RINGW + STGW;
-          hipFuncSetAttribute((const void *)kw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
-          hipLaunchKernelGGL(kw, dim3((unsigned)gw), dim3(NTW), ldsw, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C,
-                             (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, (int)grid3, act_flags, drop_p,
-                             seed, walk_g, walk_nb, probe_flags);
-          return apertis_check_launch();
-        }
         auto k3 = ragged2x ? grouped_gemm_nt2x_k<TO, true> : grouped_gemm_nt2x_k<TO, false>;
         hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, RING3);
         // tile walk (tile_walk above): groups of 8 m-tiles under panels of 4 n-tiles when there are enough n-tiles - at

@@ -150,37 +150,6 @@ int main(int argc, char **argv) {
         timeit(nm[2], fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
       }
     }
-    if (only && !strcmp(only, "ws")) {   // the warp-specialised NT kernel against the two-per-CU one: bit equality, then times
-      unsigned long long *ck; hipMalloc(&ck, 64);
-      auto cksum = [&](const void *buf, size_t bytes) {
-        unsigned long long hst[2]; hipMemset(ck, 0, 16);
-        checksum_k<<<2048, 256>>>((const uint32_t *)buf, bytes / 4, ck); hipMemcpy(hst, ck, 16, hipMemcpyDeviceToHost);
-        return std::string(std::to_string(hst[0]) + ":" + std::to_string(hst[1]));
-      };
-      fill_k<<<2048, 256>>>(pre, rows * I, 1.f, 9);
-      for (const char *ws : {"0", "1"}) {
-        setenv("NT_WS", ws, 1);
-        hipMemset(h, 0xff, rows * I * 2); hipMemset(dpre, 0xff, rows * I * 2);
-        bf16_t *g2; hipMalloc(&g2, rows * I * 2); hipMemset(g2, 0xff, rows * I * 2);
-        int rc = apertis_grouped_gemm_nt(x, w1, b1, offs, h, g2, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU | APERTIS_ACT_SAVE_GRAD, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr);
-        hipDeviceSynchronize();
-        printf("NT_WS=%s SAVE_GRAD rc=%d  h %s  g' %s\n", ws, rc, cksum(h, rows * I * 2).c_str(), cksum(g2, rows * I * 2).c_str());
-        rc = apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_MUL_SAVED, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr);
-        hipDeviceSynchronize();
-        printf("NT_WS=%s MUL_SAVED rc=%d  dpre %s\n", ws, rc, cksum(dpre, rows * I * 2).c_str());
-        hipFree(g2);
-      }
-      for (const char *ws : {"0", "1", "1:8", "1:16", "1:1"}) {
-        setenv("NT_WS", std::string(ws).substr(0, 1).c_str(), 1);
-        setenv("NT_WS_FLAGS", strlen(ws) > 2 ? ws + 2 : "0", 1);
-        char nm[2][96];
-        snprintf(nm[0], 96, "NT_WS=%s fc1 fwd GELU+drop+g' (SAVE_GRAD)", ws);
-        snprintf(nm[1], 96, "NT_WS=%s fc2 dgrad * saved g' (MUL_SAVED)", ws);
-        timeit(nm[0], fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU | APERTIS_ACT_SAVE_GRAD, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
-        timeit(nm[1], fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_MUL_SAVED, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
-      }
-      return 0;
-    }
     if (!only || !strcmp(only, "tn")) {
       for (const char *rg : {"0", "2", "5", "2", "5"}) {   // 0 / 2: v3 double buffer / ring + stagger; 5: v5 (256 x 352 tiles)
         setenv("TN_V5", rg[0] == '5' ? "1" : "0", 1);
