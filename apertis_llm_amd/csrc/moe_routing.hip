@@ -754,7 +754,10 @@ combine_bwd_k(const TD *__restrict__ dout, const TY *__restrict__ yr, const int3
 // (the row loop is latency-bound otherwise); dx is written in x's dtype (the fp32 residual
 // stream); the affine gradients are reduced over the block's waves in LDS and leave as ONE
 // partial row per block, folded in a fixed order by ln_fold_k (deterministic, no atomics).
-constexpr int LN_RPW = 8;
+#ifndef APERTIS_LN_RPW
+#define APERTIS_LN_RPW 8
+#endif
+constexpr int LN_RPW = APERTIS_LN_RPW;
 
 // Block boundary of the pre-norm stack, forward: y = res + dropout(blk) (the residual stream, core.py:698,888)
 // and xn = LayerNorm(y) (the next sub-block's pre-norm, core.py:667,847) in one pass: as two kernels y is
@@ -947,21 +950,25 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
   }
 }
 
-// out[c] = sum_r part[r][c] over c in [0, 2H): first H -> dgamma, next H -> dbeta (fixed order)
+// out[c] = sum_r part[r][c] over c in [0, 2H): first H -> dgamma, next H -> dbeta (fixed order).  With `fold_out` the launch is
+// the FIRST of two levels: block (x, y) sums the rows [y*rpg, (y+1)*rpg) into fold_out[y][c] (a single level leaves all of
+// `part` - 32 MB per call at 180 k rows - to 2H/64 = 22 work-groups: 31 us, a tenth of the LayerNorm backward itself)
 __global__ void __launch_bounds__(1024)
-ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t nrows, int H) {
+ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__restrict__ dbeta, int64_t nrows, int H,
+          float *__restrict__ fold_out, int64_t rpg) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
+  const int64_t r0 = fold_out ? (int64_t)blockIdx.y * rpg : 0, r1 = fold_out ? min(r0 + rpg, nrows) : nrows;
   float s = 0.f;
   if (c < 2 * H) {
-    int64_t w = seg;
-    for (; w + 48 < nrows; w += 64) {   // four independent loads in flight
+    int64_t w = r0 + seg;
+    for (; w + 48 < r1; w += 64) {   // four independent loads in flight
       float a0 = part[w * 2 * H + c], a1 = part[(w + 16) * 2 * H + c], a2 = part[(w + 32) * 2 * H + c],
             a3 = part[(w + 48) * 2 * H + c];
       s += (a0 + a1) + (a2 + a3);
     }
-    for (; w < nrows; w += 16) s += part[w * 2 * H + c];
+    for (; w < r1; w += 16) s += part[w * 2 * H + c];
   }
   red[seg][lane] = s;
   __syncthreads();
@@ -969,7 +976,8 @@ ln_fold_k(const float *__restrict__ part, float *__restrict__ dgamma, float *__r
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += red[i][lane];
-    if (c < H) dgamma[c] = t; else dbeta[c - H] = t;
+    if (fold_out) fold_out[(int64_t)blockIdx.y * 2 * H + c] = t;
+    else if (c < H) dgamma[c] = t; else dbeta[c - H] = t;
   }
 }
 
@@ -2165,9 +2173,14 @@ extern "C" int apertis_moe_combine_bwd(const void *dout, const void *yr, const i
 // and final_post_norm, reference core.py:669,695,847,888,1040,1294) on the same row kernels:
 // fp32 residual stream in, compute-dtype (bf16 under autocast) activations out in one pass.
 // ------------------------------------------------------------------------------------------
+// rows of the LayerNorm backward's workspace: one partial row per block, and behind them the row groups of the two-level fold
+constexpr int LN_FOLD_GROUPS = 32;
+static int64_t ln_part_rows(int64_t T) { return ceil_div64(T > 0 ? T : 1, 4 * LN_RPW); }
+static bool ln_two_level(int64_t nblk) { return nblk >= 8 * LN_FOLD_GROUPS; }
 extern "C" int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H) {
   (void)H;
-  return ceil_div64(T > 0 ? T : 1, 4 * LN_RPW);   // one partial row per block
+  const int64_t nblk = ln_part_rows(T);
+  return nblk + (ln_two_level(nblk) ? LN_FOLD_GROUPS : 0);
 }
 
 extern "C" int apertis_layernorm_fwd(const void *x, const float *gamma, const float *beta, float eps, void *y,
@@ -2192,13 +2205,20 @@ extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const fl
   if (drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
   if (check_H(H)) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t nblk = apertis_layernorm_bwd_blocks(T, H);
+  const int64_t nblk = ln_part_rows(T);
   dim3 grid((unsigned)nblk), block(256);
   const size_t lds = 3 * 2 * (size_t)H * sizeof(float);
   DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((layernorm_bwd_k<TA, TB, IT>), grid, block, lds, st,
       (const TA *)x, gamma, mean, rstd, (const TB *)dy, (const TA *)dres, (TA *)dx, (TB *)dblk, drop_p, seed, part, T, (int)H)));
-  hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(1024), 0, st, part, dgamma, dbeta, nblk,
-                     (int)H);
+  const unsigned fx = (unsigned)ceil_div64(2 * H, 64);
+  if (ln_two_level(nblk)) {
+    float *fold = part + nblk * 2 * H;
+    const int64_t rpg = ceil_div64(nblk, LN_FOLD_GROUPS), ng = ceil_div64(nblk, rpg);
+    hipLaunchKernelGGL(ln_fold_k, dim3(fx, (unsigned)ng), dim3(1024), 0, st, part, nullptr, nullptr, nblk, (int)H, fold, rpg);
+    hipLaunchKernelGGL(ln_fold_k, dim3(fx), dim3(1024), 0, st, fold, dgamma, dbeta, ng, (int)H, nullptr, (int64_t)0);
+  } else {
+    hipLaunchKernelGGL(ln_fold_k, dim3(fx), dim3(1024), 0, st, part, dgamma, dbeta, nblk, (int)H, nullptr, (int64_t)0);
+  }
   return apertis_check_launch();
 }
 
