@@ -349,3 +349,18 @@ def test_prepared_weight_cache_is_identity_safe():
     before = calls[0]
     ops.cached_prep("t", (w,), make)
     assert calls[0] == before + 1                                       # gradients enabled: plain make()
+
+
+def test_kernel_timer_samples_every_kth_step():
+    """ops.KernelTimer(every=k): the per-call HIP event pairs are taken on every k-th step only (bench.py: every 4th of a long
+    run - two event records per call are host time that a launch-bound configuration cannot hide); by_shape splits tagged calls."""
+    from apertis_llm_amd import ops
+    t = ops.KernelTimer(["a"], every=4)
+    seen = []
+    for _ in range(12):
+        t.next_step()
+        seen.append(t.on)
+    assert seen == [False, False, False, True] * 3
+    t1 = ops.KernelTimer(["a"])
+    t1.next_step()
+    assert t1.on and t1.every == 1
