@@ -110,8 +110,9 @@ __global__ void gate_topk_bwd_k(const float *__restrict__ gates, const int32_t *
 // ------------------------------------------------------------------------------------------
 // dispatch plan
 // ------------------------------------------------------------------------------------------
+constexpr int PLAN_HIST_BLOCKS = 512;   // most work-groups of the candidate histogram (each leaves one row of counts)
 struct PlanWs {
-  int32_t *total, *keep, *mode, *quota, *seg_start;
+  int32_t *total, *keep, *mode, *quota, *seg_start, *bpart;   // bpart [PLAN_HIST_BLOCKS][P]: the histogram launch's rows
   uint32_t *thr, *smask;   // radix select: prefix found so far / bits already fixed
   int32_t *ghist;          // [P][256] digit histogram of the current radix pass
   int32_t *cnt_g, *cnt_t;  // [P][NCH]
@@ -132,29 +133,65 @@ PlanWs carve_ws(void *ws, int64_t S, int64_t E, int64_t K) {
   w.smask = (uint32_t *)p; p += w.P;
   w.ghist = p; p += (int64_t)w.P * 256;
   w.cnt_g = p; p += (int64_t)w.P * w.NCH;
-  w.cnt_t = p;
+  w.cnt_t = p; p += (int64_t)w.P * w.NCH;
+  w.bpart = p;   // [PLAN_HIST_BLOCKS][P]
   return w;
 }
 
-__global__ void plan_hist_k(const int32_t *__restrict__ idx, int32_t *__restrict__ total, int64_t SK,
-                            int E, int K) {
+// Candidates per (expert, k) slot.  Every work-group leaves ONE row of P counts in `bpart` (no global atomics: with the first
+// form's atomicAdd per block and slot, 512-1024 work-groups queued up on the same 16 addresses - 41 us for 1 MB of indices on
+// the H = 256 configuration); inside a work-group a wave counts each slot it holds with one ballot (a 64-lane LDS atomic on
+// <= 16 addresses serialises).  plan_capacity_k sums the rows in block order.
+__global__ void __launch_bounds__(256)
+plan_hist_k(const int32_t *__restrict__ idx, int32_t *__restrict__ bpart, int64_t SK, int E, int K) {
   __shared__ int32_t h[MAXE * MAXK];
-  const int P = E * K;
+  const int P = E * K, lane = threadIdx.x & 63;
   for (int i = threadIdx.x; i < P; i += blockDim.x) h[i] = 0;
   __syncthreads();
-  for (int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; a < SK; a += (int64_t)gridDim.x * blockDim.x) {
-    int e = idx[a];
-    int k = (int)(a % K);
-    if (e >= 0 && e < E) atomicAdd(&h[e * K + k], 1);
+  for (int64_t a0 = (int64_t)blockIdx.x * blockDim.x; a0 < SK; a0 += (int64_t)gridDim.x * blockDim.x) {   // (uniform trip count)
+    const int64_t a = a0 + threadIdx.x;
+    int slot = -1;
+    if (a < SK) {
+      const int e = idx[a];
+      if (e >= 0 && e < E) slot = e * K + (int)(a % K);
+    }
+    unsigned long long todo = __ballot(slot >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int s0 = __shfl(slot, leader);
+      const unsigned long long m = __ballot(slot == s0);
+      if (lane == leader) atomicAdd(&h[s0], __popcll(m));
+      todo &= ~m;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < P; i += blockDim.x)
-    if (h[i]) atomicAdd(&total[i], h[i]);
+  for (int i = threadIdx.x; i < P; i += blockDim.x) bpart[(int64_t)blockIdx.x * P + i] = h[i];
 }
 
 // per expert: consume capacity k-major (core.py:547-576); then lay the segments out expert-major
 __global__ void plan_capacity_k(PlanWs w, const uint8_t *__restrict__ active, int64_t capacity,
-                                int32_t *__restrict__ offsets, int E, int K) {
+                                int32_t *__restrict__ offsets, int E, int K, int nhist) {
+  // totals: the histogram launch's per-work-group rows (integers: any order gives the same sums).  256 threads, 256 / P of them
+  // per slot when the slots are few
+  __shared__ int32_t s_sum[256];
+  {
+    const int P = E * K;
+    const int g = P < 256 ? 256 / P : 1;                 // threads per slot
+    for (int p0 = 0; p0 < P; p0 += 256 / g) {
+      const int p = p0 + (int)threadIdx.x / g, sub = (int)threadIdx.x % g;
+      int t = 0;
+      if (p < P && (int)threadIdx.x / g < 256 / g)
+        for (int b = sub; b < nhist; b += g) t += w.bpart[(int64_t)b * P + p];
+      s_sum[threadIdx.x] = t;
+      __syncthreads();
+      if (p < P && sub == 0 && (int)threadIdx.x / g < 256 / g) {
+        int tt = 0;
+        for (int q = 0; q < g; ++q) tt += s_sum[threadIdx.x + q];
+        w.total[p] = tt;
+      }
+      __syncthreads();
+    }
+  }
   const int e = threadIdx.x;
   if (e < E) {
     int64_t load = 0;
@@ -246,8 +283,11 @@ plan_select_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict
 __global__ void __launch_bounds__(256)
 plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk, int64_t S, int E, int K, int shift) {
   extern __shared__ int32_t lh[];   // [P][256]
+  __shared__ int32_t s_mode[32];     // (P <= 32 on this path) the slots' state, once per work-group instead of three dependent
+  __shared__ uint32_t s_mask[32], s_thr[32];   // global loads per element
   const int P = w.P;
   for (int i = threadIdx.x; i < P * 256; i += 256) lh[i] = 0;
+  if (threadIdx.x < P) { s_mode[threadIdx.x] = w.mode[threadIdx.x]; s_mask[threadIdx.x] = w.smask[threadIdx.x]; s_thr[threadIdx.x] = w.thr[threadIdx.x]; }
   __syncthreads();
   const int64_t SK = S * K;
   for (int64_t a0 = (int64_t)blockIdx.x * 256 + threadIdx.x; a0 < SK; a0 += (int64_t)gridDim.x * 256 * 4) {
@@ -264,7 +304,7 @@ plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restri
       const int64_t a = a0 + (int64_t)u * gridDim.x * 256;
       if (ei[u] >= 0 && ei[u] < E) {
         const int p = ei[u] * K + (int)(a % K);
-        if (w.mode[p] == 2 && (bi[u] & w.smask[p]) == w.thr[p]) atomicAdd(&lh[p * 256 + ((bi[u] >> shift) & 255)], 1);
+        if (s_mode[p] == 2 && (bi[u] & s_mask[p]) == s_thr[p]) atomicAdd(&lh[p * 256 + ((bi[u] >> shift) & 255)], 1);
       }
     }
   }
@@ -2056,7 +2096,7 @@ extern "C" int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx,
 
 extern "C" int64_t apertis_moe_plan_workspace_bytes(int64_t S, int64_t E, int64_t K) {
   int64_t P = E * K, NCH = ceil_div64(S > 0 ? S : 1, 64);
-  return (7 * P + 256 * P + 2 * P * NCH) * 4 + 64;
+  return (7 * P + 256 * P + 2 * P * NCH + PLAN_HIST_BLOCKS * P) * 4 + 64;
 }
 
 extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_t *active,
@@ -2068,13 +2108,12 @@ extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_
   if (S * K > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   PlanWs pw = carve_ws(ws, S > 0 ? S : 1, E, K);
-  hipMemsetAsync(pw.total, 0, sizeof(int32_t) * pw.P, st);
+  int nhist = 0;
   if (S > 0) {
-    int64_t nb = ceil_div64(S * K, 256);
-    hipLaunchKernelGGL(plan_hist_k, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, st, idx, pw.total, S * K,
-                       (int)E, (int)K);
+    nhist = (int)std::min<int64_t>(ceil_div64(S * K, 1024), PLAN_HIST_BLOCKS);   // four elements per thread where there are enough
+    hipLaunchKernelGGL(plan_hist_k, dim3((unsigned)nhist), dim3(256), 0, st, idx, pw.bpart, S * K, (int)E, (int)K);
   }
-  hipLaunchKernelGGL(plan_capacity_k, dim3(1), dim3(64), 0, st, pw, active, capacity, expert_offsets, (int)E, (int)K);
+  hipLaunchKernelGGL(plan_capacity_k, dim3(1), dim3(256), 0, st, pw, active, capacity, expert_offsets, (int)E, (int)K, nhist);
   if (S > 0) {
     if (capacity > 0) {
       if (pw.P <= 32) {
