@@ -2534,7 +2534,10 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
                        (E == 1 && K <= 1024 && N >= 256 && !(N == BN5 && K % 64 == 0 && ldw == K)) ||
                        // narrow expert outputs (the H = 256 family's fc2 forward / fc1 data gradient, N = 256, K = 1024):
                        // 67 us here, 77 on the 256 x 256 tile, 90 on the 128 x 128 kernel they used to fall to
-                       (E > 1 && K <= 1024 && N >= 256 && N < 512);
+                       (E > 1 && K <= 1024 && N >= 256 && N < 512) ||
+                       // narrow dense outputs (the H = 256 family's x_param / out_proj data gradients, N = 64): one half-empty
+                       // 128-wide n-tile of this kernel instead of the 128 x 128 register-staged kernel (29 us for 42 MB there)
+                       (E == 1 && K <= 1024 && N >= 64 && N < 128);
 #endif
     // outputs a multiple of 352 wide with a plain epilogue: the 256 x 352 tile (two passes over X for N = 704 instead of three)
 #if defined(NT_PROBE_FORCE) && NT_PROBE_FORCE == 3
@@ -2559,7 +2562,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       }
     }
     const bool ragged2x = K % 32 != 0;
-    if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 128 && max_rows >= 4096 && E <= 1024) {
+    if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 64 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);
       const int64_t grid3 = (ceil_div64(max_rows, BM3) + E) * nt3;
       if (grid3 < 0x7fffffffLL) {

@@ -261,7 +261,10 @@ def test_linear_mfma_dense(dev):
 @pytest.mark.parametrize("rows,N,K,dt", [(5000, 72, 40, torch.float32), (4608, 352, 704, torch.bfloat16),
                                           # the SSM block's projections incl. K % 32 != 0 (two-per-CU NT kernel, ragged variant)
                                           (4700, 400, 176, torch.bfloat16), (4352, 704, 176, torch.bfloat16),
-                                          (4101, 704, 352, torch.bfloat16), (4096, 264, 104, torch.bfloat16)])
+                                          (4101, 704, 352, torch.bfloat16), (4096, 264, 104, torch.bfloat16),
+                                          # the H = 256 family's narrow data gradients (N = 64 through the two-per-CU kernel)
+                                          (4352, 64, 256, torch.bfloat16), (4200, 256, 64, torch.bfloat16),
+                                          (4608, 192, 64, torch.bfloat16)])
 def test_linear_mfma_splitk_wgrad(dev, rows, N, K, dt):
     """Dense layer backward: the weight gradient is a deterministic split-K over row chunks."""
     from apertis_llm_amd import ops
