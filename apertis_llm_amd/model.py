@@ -702,6 +702,27 @@ class ApertisFeedForward(nn.Module):
                                      nn.Linear(config.intermediate_size, config.hidden_size))
         self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
 
+    def _dense_ffn(self, x):
+        """Linear -> act -> Dropout -> Linear (core.py:861-866).  On the GPU the plain (non-MoE, non-SwiGLU) FFN runs on the
+        expert-MLP kernels as ONE group: activation and dropout in the first GEMM's epilogue, their backward in the second data
+        gradient's (ops.expert_mlp) - as nn.Sequential it was two library GEMMs plus an activation and a dropout kernel each
+        way (13 % of the 125m configuration's step in those four elementwise kernels).  The dropout mask is the counter
+        hash of the other fused kernels, not torch's Philox stream (train-mode RNG cannot match the reference bit-wise either way)."""
+        if isinstance(self.ffn, nn.Sequential) and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16):
+            lin1, _act, drop, lin2 = self.ffn
+            H = x.shape[-1]
+            xf = x.reshape(-1, H)
+            T = xf.shape[0]
+            if T >= 1 and lin1.bias is not None and lin2.bias is not None:
+                cd = _compute_dtype(xf)
+                p_drop = drop.p if self.training else 0.0
+                seed = int(torch.empty((), dtype=torch.int64).random_().item()) if p_drop > 0 else 0
+                out = ops.expert_mlp(xf.to(cd), lin1.weight.unsqueeze(0), lin1.bias.unsqueeze(0), lin2.weight.unsqueeze(0),
+                                     lin2.bias.unsqueeze(0), ops.dense_offsets(T, xf.device), T,
+                                     act=_activation_name(self.config.hidden_act), drop_p=p_drop, seed=seed, compute_dtype=cd)
+                return out.reshape(*x.shape[:-1], lin2.weight.shape[0])
+        return self.ffn(x)
+
     def forward(self, hidden_s, defer=False):
         router = None
         if self.is_expert_system and self.ffn.router is not None and self.ffn.num_experts > 0:
@@ -711,7 +732,7 @@ class ApertisFeedForward(nn.Module):
             out, lb, rz = self.ffn(x, lazy_combine=defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"),
                                    aux_dtype=hidden_s.dtype)
         else:
-            out = self.ffn(x)
+            out = self._dense_ffn(x)
             lb = rz = _zero_scalar(hidden_s.device, hidden_s.dtype)
         if defer:
             return _Pending(out, hidden_s, self.output_dropout), lb, rz

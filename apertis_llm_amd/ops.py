@@ -1753,6 +1753,11 @@ def scatter_rows(w, dst_idx, rows_out):
     return _ScatterRows.apply(w, dst_idx, rows_out)
 
 
+def dense_offsets(rows, device):
+    """Group offsets [0, rows] of a one-group (dense) call of the grouped kernels, cached per (rows, device)."""
+    return _dense_offsets(rows, device)
+
+
 def linear_mfma(x, weight, bias=None, act=None, compute_dtype=None):
     """Dense act(x @ W.T + b) through the same MFMA tile (one group).  Used for the patch-embed
     GEMM and vision_projection (reference multimodal/module.py:102, core.py:1209)."""
