@@ -1007,11 +1007,12 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
 // 256 x 128 NT kernel, TWO work-groups per CU.  The persistent kernel above runs a tile's epilogue
 // (VALU: activation, dropout hash, conversions; then the output stores) with the matrix pipes idle and
 // its K loop with the VALU idle, and keeps at most one 64 KiB stage of operands in flight per CU.  Here
-// a work-group is 4 waves (one per SIMD; wave tile 128 x 64 as above) with its own 72 KiB ring of three
+// a work-group is 4 waves (one per SIMD; wave tile 64 rows x 128 columns, the ACTIVATION rows on the MFMA A
+// operand - nt2x_epilogue says why) with its own 72 KiB ring of three
 // 32-deep stages, so two independent work-groups share a CU: one's epilogue runs under the other's
 // MFMAs, and 2 x 48 KiB of LDS-DMA are in flight per CU.  Inside a wave the fragments of sub-step s+1
-// are read from LDS under the MFMAs of sub-step s (X fragments in place once their four MFMAs have
-// issued, W fragments into a second set).  Rows are 64 B per stage; the 16-byte chunk c of row r sits
+// are read from LDS under the MFMAs of sub-step s (W fragments in place once their four MFMAs have
+// issued, X fragments into a second set).  Rows are 64 B per stage; the 16-byte chunk c of row r sits
 // at chunk position c ^ F[(r >> 2) & 3], F = {0,3,2,1}, which makes both the 1 KiB DMA pieces (16 rows)
 // and the ds_read_b128 fragment reads (lane groups of MI355X_MICROARCH.md's LDS table) conflict-free.
 // ------------------------------------------------------------------------------------------
@@ -1024,8 +1025,6 @@ __device__ __forceinline__ void lds_dma16s(const v4i &rs, uint32_t lds_addr, uin
                :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
 }
 
-// one staging pass of the 256 x 128 tile through the ring (256-byte rows, 16-byte chunks XOR-swizzled with
-// the row) and out to `dst`; raw = the pre-activation pass
 // eight bf16 products (fp32 multiply, rounded once)
 __device__ __forceinline__ uint4 mul_chunk_bf16(uint4 a, uint4 b) {
   const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
@@ -1039,11 +1038,6 @@ __device__ __forceinline__ uint4 mul_chunk_bf16(uint4 a, uint4 b) {
   return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// Forward with APERTIS_ACT_SAVE_GRAD (GELU): ONE evaluation per element yields the activation output h = gelu(pre) * mask /
-// (1-p) and g' = gelu'(pre) * mask / (1-p); the tile leaves in two row halves (accumulator sub-tiles j < 4, then j >= 4), each
-// staging both outputs side by side in the ring (2 x 32 KiB) and copying them out as whole 256-byte row segments.  (Two
-// passes that each evaluated their own function and mask hash cost the forward +285 us inside the step; writing h back into
-// the accumulator registers made hipcc spill inside the K loop.)
 // Helpers of the saved-gradient epilogue below (round 3: its VALU work - 65 instructions per element pair, a sixth of them
 // bit fiddling around the mask and the conversions - is what the fc1 forward spends its time on next to the MFMAs).
 // Two floats -> one dword of bf16 (one v_cvt_pk_bf16_f32; a conversion per element wastes half of each).
@@ -1070,159 +1064,138 @@ __device__ __forceinline__ uint32_t drop_hash_pair32(uint64_t seed, uint32_t pai
   return h;
 }
 
-template <typename TO, bool DROP>
-__device__ __forceinline__ void nt2x_out_both(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst_h,
-                                              TO *__restrict__ dst_g, char *stg, int64_t row0, int rows_valid, int n0,
-                                              int cols_valid, int N, uint64_t seed, float keep_scale, uint32_t thresh16, int tid,
-                                              int wm, int wn, int frow, int fg) {
-  static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
-  char *stg_g = stg + 128 * 256;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j = half * 4 + jj;
-        const int m = wm * 128 + j * 16 + frow;            // tile row
-        const int sr = wm * 64 + jj * 16 + frow;           // its row in the half's staging image
-        const int chunk = wn * 8 + i * 2 + (fg >> 1);
-        // mask words: 0xFFFF where the element is dropped (elements 0,1 in dm[0], 2,3 in dm[1])
-        uint32_t dm[2] = {0u, 0u};
-#ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
-        if (DROP) {
-          const uint32_t pair = ((uint32_t)(row0 + m) * (uint32_t)N + (uint32_t)(n0 + wn * 64 + i * 16 + fg * 4)) >> 1;
-          dm[0] = drop_mask2(drop_hash_pair32(seed, pair), thresh16);
-          dm[1] = drop_mask2(drop_hash_pair32(seed, pair + 1u), thresh16);
-        }
-#endif
-        uint32_t oh[2], og[2];
-#pragma unroll
-        for (int q = 0; q < 4; q += 2) {   // two elements per packed instruction
-          const v2f pre = (v2f){acc[i][j][q], acc[i][j][q + 1]} + (v2f){bv[i][q], bv[i][q + 1]};
-          // the pre-activation as the other form stores it (rounded to bf16)
-          const uint32_t xpk = pack_bf16x2(pre.x, pre.y);
-          const v2f x = {__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
-          v2f hv, gv;
-#if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
-          hv = x * splat2(keep_scale); gv = x * splat2(0.5f * keep_scale);
-#elif defined(NT_PROBE_NOPK)   // tools/probes only: the scalar evaluation (same bits) instead of the packed-fp32 one
-          float h0, g0, h1, g1;
-          gelu_both_fast(x.x, h0, g0);
-          gelu_both_fast(x.y, h1, g1);
-          hv = (v2f){h0 * keep_scale, h1 * keep_scale}; gv = (v2f){g0 * keep_scale, g1 * keep_scale};
-#else
-          gelu_both_fast2(x, hv, gv);
-          hv = hv * splat2(keep_scale);
-          gv = gv * splat2(keep_scale);
-#endif
-          oh[q >> 1] = pack_bf16x2(hv.x, hv.y) & ~dm[q >> 1];
-          og[q >> 1] = pack_bf16x2(gv.x, gv.y) & ~dm[q >> 1];
-        }
-        const int off = sr * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8;
-        *reinterpret_cast<uint2 *>(stg + off) = make_uint2(oh[0], oh[1]);
-        *reinterpret_cast<uint2 *>(stg_g + off) = make_uint2(og[0], og[1]);
-      }
-    lds_barrier();
-#pragma unroll 4
-    for (int it = 0; it < 8; ++it) {
-      const int c4 = it * NT3 + tid;
-      const int sr = c4 >> 4, c = c4 & 15;
-      const int row = (sr >> 6) * 128 + half * 64 + (sr & 63);
-      if (row < rows_valid && c * 8 < cols_valid) {
-        const int off = sr * 256 + ((c ^ (sr & 15)) << 4);
-        out_store16(dst_h + (row0 + row) * N + n0 + c * 8, *reinterpret_cast<const uint4 *>(stg + off));
-        out_store16(dst_g + (row0 + row) * N + n0 + c * 8, *reinterpret_cast<const uint4 *>(stg_g + off));
-      }
-    }
-    lds_barrier();
-  }
-}
+// Epilogue of the two-per-CU kernel, STRAIGHT FROM THE ACCUMULATORS (round 4).  In this kernel the ACTIVATION tile feeds the
+// MFMA A operand and the WEIGHT tile the B operand (the reverse of the other kernels here), the four waves split the tile's
+// rows (wave tile 64 x 128), and W's rows are permuted on their way into LDS (LDS row j*16 + c of the tile holds W row c*8 + j).
+// Lane (c = lane & 15, g = lane >> 4) then holds, for each of its 16 rows m = wave*64 + i*16 + g*4 + q, the EIGHT consecutive
+// columns n = c*8 + j (j = 0..7) - one 16-byte piece of a bf16 output row - and the 16 lanes of a row group cover the row's 256
+// bytes: every wave-instruction stores (or, for the saved tensor, loads) four whole rows of the tile.  No LDS staging pass, no
+// barrier: a wave's first stores leave while it evaluates its later rows, and no wave waits for another in the epilogue.
+// (Round 2 measured a direct form on the OLD operand roles - lane = row, 32-byte pieces, 16 rows per instruction - at the
+// staged form's speed; rounds 2-3: with the 8-byte lane pieces of the accumulators as they stood, partial-line stores lost.)
+// Arithmetic and rounding are those of the staged epilogues this replaces, element for element (outputs bit-identical).
+//   EPI_RAW      dst  = acc + bias                                   (the pre-activation)
+//   EPI_ACT      dst  = dropout(act(bf16(acc + bias)))
+//   EPI_BOTH     dst  = gelu(pre) * mask / (1-p), dst2 = gelu'(pre) * mask / (1-p)   (APERTIS_ACT_SAVE_GRAD: ONE evaluation and
+//                ONE hash per element yield both; gelu and gelu' share their folded erfc terms)
+//   EPI_MULACT   dst  = bf16(acc) * act'(saved pre) * mask / (1-p)   (fused data gradient, pre-activation form)
+//   EPI_MULSAVED dst  = bf16(acc) * saved g'                         (APERTIS_ACT_MUL_SAVED)
+enum { EPI_RAW = 0, EPI_ACT = 1, EPI_BOTH = 2, EPI_MULACT = 3, EPI_MULSAVED = 4 };
 
-// MULPRE: 0 plain, 1 data gradient times act'(pre) * mask (pre = the saved pre-activation), 2 data gradient times the saved
-// tensor itself (the g' of nt2x_out_both)
-template <typename TO, bool raw, int ACT, bool DROP, int MULPRE = 0>
-__device__ __forceinline__ void nt2x_out(const f32x4 (&acc)[4][8], const float (&bv)[4][4], TO *__restrict__ dst,
-                                         const TO *__restrict__ mul_pre, char *stg, int64_t row0, int rows_valid, int n0, int cols_valid, int N, int act, float drop_p,
-                                         uint64_t seed, float keep_scale, uint32_t thresh16, int tid, int wm, int wn,
-                                         int frow, int fg) {
-  static_assert(sizeof(TO) == 2, "staging layout assumes 2-byte outputs");
-  // dgrad fusion: the saved tensor's first two batches of 16-byte chunks leave BEFORE the staging pass (their HBM latency
-  // used to start behind it: the epilogue of the fused fc2 data gradient was 12.9 us of a 30 us tile)
-  [[maybe_unused]] uint4 pa[4], pb[4];
-  [[maybe_unused]] auto fetch = [&](uint4 (&pc)[4], int b) {
+template <typename TO, int MODE, int ACT, bool DROP>
+__device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const float (&bv)[8], TO *__restrict__ dst,
+                                              TO *__restrict__ dst2, const TO *__restrict__ saved, int64_t row0, int rows_valid,
+                                              int n0, int cols_valid, int N, int act, float drop_p, uint64_t seed,
+                                              float keep_scale, uint32_t thresh16, int wave, int frow, int fg) {
+  static_assert(sizeof(TO) == 2, "16-byte pieces of 2-byte outputs");
+  typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+  const int64_t tile0 = row0 * N + n0;                    // wave-uniform: the tile's first element
+  const int rl = wave * 64 + fg * 4;                      // this lane's first tile row (+ i*16 + q)
+  // Raw buffer descriptors over the tile's valid rows: the hardware drops a store (returns zeros for a load) whose lane offset
+  // lies past them, so ragged tiles need neither branches nor exec masks around the 32 stores; lanes past the last valid column
+  // of a partial n-tile start from an offset that no row term brings back into range (a tile spans 256 * N * 2 bytes << 2^30).
+  // (The range check covers the lane offset only: the row term is added to it, not passed as the scalar offset.)
+  const uint32_t voff = frow * 8 < cols_valid ? ((uint32_t)rl * (uint32_t)N + (uint32_t)(frow * 8)) * 2u : 0xC0000000u;
+  const uint32_t tile_bytes = (uint32_t)rows_valid * (uint32_t)N * 2u;
+  const __amdgpu_buffer_rsrc_t o1 = __builtin_amdgcn_make_buffer_rsrc(dst + tile0, 0, tile_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t o2 = __builtin_amdgcn_make_buffer_rsrc(MODE == EPI_BOTH ? dst2 + tile0 : dst + tile0, 0, tile_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t sv = __builtin_amdgcn_make_buffer_rsrc(const_cast<TO *>(MODE >= EPI_MULACT ? saved + tile0 : dst + tile0), 0, tile_bytes, 0x00020000);
+  auto row_off = [&](int r) { return voff + (uint32_t)(r * N) * 2u; };
+  // (non-temporal, like out_store16: the outputs are far larger than the caches and would only displace the operands)
+  auto put = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    __builtin_amdgcn_raw_buffer_store_b128((u4_t){a, b, c, d}, rs, (int)off, 0, 2);
+  };
+  // the saved tensor's pieces: two batches of four rows in flight ahead of the arithmetic
+  [[maybe_unused]] uint4 pc[2][4];
+  [[maybe_unused]] auto fetch = [&](int i) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c4 = (b * 4 + u) * NT3 + tid;
-      const int row = c4 >> 4, c = c4 & 15;
-      pc[u] = (row < rows_valid && c * 8 < cols_valid) ? *reinterpret_cast<const uint4 *>(mul_pre + (row0 + row) * N + n0 + c * 8)
-                                                       : make_uint4(0, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      const u4_t t = __builtin_amdgcn_raw_buffer_load_b128(sv, (int)row_off(i * 16 + q), 0, 0);
+      pc[i & 1][q] = make_uint4(t[0], t[1], t[2], t[3]);
     }
   };
-  if constexpr (MULPRE != 0) {
-    fetch(pa, 0);
-    fetch(pb, 1);
+  if constexpr (MODE >= EPI_MULACT) {
+    fetch(0);
+    fetch(1);
     __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = wm * 128 + j * 16 + frow;
-      const int chunk = wn * 8 + i * 2 + (fg >> 1);
-      float o[4];
-      bool keep[4] = {true, true, true, true};
-      if (!raw && !MULPRE && (ACT >= 0 ? DROP : drop_p > 0.f))
-        drop_keep4(seed, (uint64_t)(row0 + m) * (uint64_t)N + (uint64_t)(n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
+    for (int q = 0; q < 4; ++q) {
+      const int r = i * 16 + q;
+      const uint32_t off = row_off(r);
+      float v[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float v = acc[i][j][q] + bv[i][q];
-        if (!raw && !MULPRE) {
-          if (ACT != APERTIS_ACT_NONE) v = act_fwd<true>(to_f32(from_f32<TO>(v)), ACT >= 0 ? ACT : act);
-          v = keep[q] ? v * keep_scale : 0.f;   // keep_scale is 1 without dropout
+      for (int j = 0; j < 8; ++j) v[j] = acc[i][j][q] + bv[j];
+      uint32_t o[4];
+      if constexpr (MODE == EPI_BOTH) {
+        // mask words: 0xFFFF where the element is dropped (elements 0,1 of a group of four in dm[0], 2,3 in dm[1])
+        uint32_t og[4];
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+          uint32_t dm[2] = {0u, 0u};
+#ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
+          if (DROP) {
+            const uint32_t pair = ((uint32_t)(row0 + rl + r) * (uint32_t)N + (uint32_t)(n0 + frow * 8 + h4 * 4)) >> 1;
+            dm[0] = drop_mask2(drop_hash_pair32(seed, pair), thresh16);
+            dm[1] = drop_mask2(drop_hash_pair32(seed, pair + 1u), thresh16);
+          }
+#endif
+#pragma unroll
+          for (int w = 0; w < 2; ++w) {   // two elements per packed instruction
+            const int j = h4 * 4 + w * 2;
+            // the pre-activation as the other form stores it (rounded to bf16)
+            const uint32_t xpk = pack_bf16x2(v[j], v[j + 1]);
+            const v2f x = {__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
+            v2f hv, gv;
+#if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
+            hv = x * splat2(keep_scale); gv = x * splat2(0.5f * keep_scale);
+#else
+            gelu_both_fast2(x, hv, gv);
+            hv = hv * splat2(keep_scale);
+            gv = gv * splat2(keep_scale);
+#endif
+            o[h4 * 2 + w] = pack_bf16x2(hv.x, hv.y) & ~dm[w];
+            og[h4 * 2 + w] = pack_bf16x2(gv.x, gv.y) & ~dm[w];
+          }
         }
-        o[q] = v;
-      }
-      // (two elements per conversion instruction)
-      *reinterpret_cast<uint2 *>(stg + m * 256 + ((chunk ^ frow) << 4) + (fg & 1) * 8) =
-          make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-    }
-  lds_barrier();
-  if constexpr (!MULPRE) {
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-      const int c4 = it * NT3 + tid;
-      const int row = c4 >> 4, c = c4 & 15;
-      if (row < rows_valid && c * 8 < cols_valid)
-        out_store16(dst + (row0 + row) * N + n0 + c * 8, *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4)));
-    }
-  } else {
-    // dgrad fusion: the tile was staged as plain dh; each 16-byte chunk becomes dpre on the way out with the
-    // matching chunk of the saved pre-activation.  Four chunks per batch, the next batch's pre-activations in
-    // flight under the arithmetic of the current one (a fully interleaved loop spills)
-    auto emit = [&](const uint4 (&pc)[4], int b) {
+        put(o1, off, o[0], o[1], o[2], o[3]);
+        put(o2, off, og[0], og[1], og[2], og[3]);
+      } else {
+        if constexpr (MODE == EPI_ACT) {
+          bool keep[8] = {true, true, true, true, true, true, true, true};
+          if (ACT >= 0 ? DROP : drop_p > 0.f) {
+            const uint64_t lin = (uint64_t)(row0 + rl + r) * (uint64_t)N + (uint64_t)(n0 + frow * 8);
+            bool k4[4];
+            drop_keep4(seed, lin, thresh16, k4);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int c4 = (b * 4 + u) * NT3 + tid;
-        const int row = c4 >> 4, c = c4 & 15;
-        if (row < rows_valid && c * 8 < cols_valid) {
-          const uint4 v = *reinterpret_cast<const uint4 *>(stg + row * 256 + ((c ^ (row & 15)) << 4));
-          if constexpr (MULPRE == 2)
-            out_store16(dst + (row0 + row) * N + n0 + c * 8, mul_chunk_bf16(v, pc[u]));
-          else
-            out_store16(dst + (row0 + row) * N + n0 + c * 8,
-                        actbwd_chunk<TO, true, ACT, DROP>(v, pc[u], row0 + row, n0 + c * 8, N, act, drop_p, seed, keep_scale, thresh16));
+            for (int j = 0; j < 4; ++j) keep[j] = k4[j];
+            drop_keep4(seed, lin + 4, thresh16, k4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep[4 + j] = k4[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (ACT != APERTIS_ACT_NONE) v[j] = act_fwd<true>(to_f32(from_f32<TO>(v[j])), ACT >= 0 ? ACT : act);
+            v[j] = keep[j] ? v[j] * keep_scale : 0.f;   // keep_scale is 1 without dropout
+          }
         }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) o[w] = pack_bf16x2(v[2 * w], v[2 * w + 1]);
+        uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+        if constexpr (MODE == EPI_MULSAVED) ov = mul_chunk_bf16(ov, pc[i & 1][q]);
+        if constexpr (MODE == EPI_MULACT)
+          ov = actbwd_chunk<TO, true, ACT, DROP>(ov, pc[i & 1][q], row0 + rl + r, n0 + frow * 8, N, act, drop_p, seed, keep_scale, thresh16);
+        put(o1, off, ov.x, ov.y, ov.z, ov.w);
       }
-    };
-    emit(pa, 0);  __builtin_amdgcn_sched_barrier(0);
-    fetch(pa, 2); __builtin_amdgcn_sched_barrier(0);
-    emit(pb, 1);  __builtin_amdgcn_sched_barrier(0);
-    fetch(pb, 3); __builtin_amdgcn_sched_barrier(0);
-    emit(pa, 2);  __builtin_amdgcn_sched_barrier(0);
-    emit(pb, 3);
+    }
+    if constexpr (MODE >= EPI_MULACT) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < 4) fetch(i + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  lds_barrier();
 }
 
 #ifdef NT_PROBE_STAMPS   // tools/probes only: wall-clock (10 ns ticks) sums per phase of the two-per-CU kernel's work-groups
@@ -1244,7 +1217,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const bool save_grad = (act_flags & APERTIS_ACT_SAVE_GRAD) != 0, mul_saved = (act_flags & APERTIS_ACT_MUL_SAVED) != 0;
   const int act = act_flags & 0xff;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fg = lane >> 4;
 
   // tile of this work-group: an XCD takes a contiguous run of the tile order (xcd_remap); inside it the walk is
@@ -1277,14 +1249,16 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const v4i wrs = raw_buffer_rsrc(W + ((int64_t)e * N + n0) * ldw, (uint32_t)cols_valid * (uint32_t)ldwb);
   const int fsw = (4 - ((lane >> 4) & 3)) & 3;                       // F[(row >> 2) & 3] for row = lane >> 2
   const uint32_t vx0 = (uint32_t)((wave * 64 + (lane >> 2)) * ldb + (((lane & 3) ^ fsw) << 4));
-  const uint32_t vw0 = (uint32_t)((wave * 32 + (lane >> 2)) * ldwb + (((lane & 3) ^ fsw) << 4));
+  // W's rows are permuted on the way in: LDS row j*16 + c of the tile holds W row c*8 + j (nt2x_epilogue: a lane's eight
+  // accumulator columns are then eight consecutive output columns); piece p = rows p*16 + (lane >> 2), so + p rows per piece
+  const uint32_t vw0 = (uint32_t)((lane >> 2) * 8 * ldwb + (((lane & 3) ^ fsw) << 4));
   const uint32_t lds0 = lds_addr_of(smem);
   // piece q of this wave's share of sub-step s: q = 0..3 its X pieces, 4..5 its W pieces
   auto issue_piece = [&](uint32_t slot_off, int s, int q) {
     const uint32_t kb = (uint32_t)s * ROWB3, base = lds0 + slot_off;
     const uint32_t kv = RAGGED ? kb : 0u, ks = RAGGED ? 0u : kb;
     if (q < 4) lds_dma16s(xrs, base + (wave * 4 + q) * 1024, vx0 + (uint32_t)(q * 16 * ldb) + kv, ks);
-    else lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + (q - 4)) * 1024, vw0 + (uint32_t)((q - 4) * 16 * ldwb) + kv, ks);
+    else lds_dma16s(wrs, base + BM3 * ROWB3 + (wave * 2 + (q - 4)) * 1024, vw0 + (uint32_t)((wave * 2 + (q - 4)) * ldwb) + kv, ks);
   };
   auto issue = [&](uint32_t slot_off, int s) {   // sub-step s: this wave's 4 X pieces and 2 W pieces
 #pragma unroll
@@ -1314,38 +1288,24 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment addresses: the lane part is the same for every 16-row sub-tile
+  // fragment addresses: the lane part is the same for every 16-row sub-tile.  A operand = this wave's 64 activation rows
+  // (4 fragments, double-buffered across sub-steps), B operand = the tile's 128 (permuted) weight rows (8 fragments, refilled
+  // in place once their four MFMAs have issued): acc[i][j] = rows wave*64 + i*16 + (fg*4 + q), column-index frow of W sub-tile j
   const int frd = frow * ROWB3 + ((fg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
-  const char *xbase = smem + wm * 128 * ROWB3 + frd, *wbase = smem + BM3 * ROWB3 + wn * 64 * ROWB3 + frd;
-  frag wf[2][4], xf[8];
-  auto load_w = [&](frag (&dst)[4], int slot_off) {
+  const char *abase = smem + wave * 64 * ROWB3 + frd, *bbase = smem + BM3 * ROWB3 + frd;
+  frag af[2][4], bfr[8];
+  auto load_a = [&](frag (&dst)[4], int slot_off) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const frag *>(wbase + slot_off + i * 16 * ROWB3);
+    for (int i = 0; i < 4; ++i) dst[i] = *reinterpret_cast<const frag *>(abase + slot_off + i * 16 * ROWB3);
   };
-  // the same with the DMA pieces of sub-step `fs` (into the slot at fill_off; fs < 0: none) going out one by one behind the
-  // first six MFMA groups instead of in one run behind the barrier: a wave sits in each `buffer_load ... lds` until the
-  // CU's address unit has taken it (16 cycles per KiB piece, 24 pieces per sub-step and work-group, all four waves at once)
-  auto sub_step_fill = [&](const frag (&wcur)[4], frag (&wnxt)[4], int nxt_off, uint32_t fill_off, int fs) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j == 0) { wnxt[0] = *reinterpret_cast<const frag *>(wbase + nxt_off); wnxt[1] = *reinterpret_cast<const frag *>(wbase + nxt_off + 16 * ROWB3); }
-      if (j == 1) { wnxt[2] = *reinterpret_cast<const frag *>(wbase + nxt_off + 32 * ROWB3); wnxt[3] = *reinterpret_cast<const frag *>(wbase + nxt_off + 48 * ROWB3); }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mma(acc[i][j], wcur[i], xf[j]);
-      xf[j] = *reinterpret_cast<const frag *>(xbase + nxt_off + j * 16 * ROWB3);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j < 6 && fs >= 0) issue_piece(fill_off, fs, j);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  // 32 MFMAs on (wcur, xf) while (wnxt, xf) are refilled from the slot at nxt_off
-  auto sub_step = [&](const frag (&wcur)[4], frag (&wnxt)[4], int nxt_off) {
-    load_w(wnxt, nxt_off);
+  // 32 MFMAs on (acur, bfr) while (anxt, bfr) are refilled from the slot at nxt_off
+  auto sub_step = [&](const frag (&acur)[4], frag (&anxt)[4], int nxt_off) {
+    load_a(anxt, nxt_off);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) mma(acc[i][j], wcur[i], xf[j]);
-      xf[j] = *reinterpret_cast<const frag *>(xbase + nxt_off + j * 16 * ROWB3);
+      for (int i = 0; i < 4; ++i) mma(acc[i][j], acur[i], bfr[j]);
+      bfr[j] = *reinterpret_cast<const frag *>(bbase + nxt_off + j * 16 * ROWB3);
     }
     // issue order: 4 MFMAs, then the LDS reads whose registers they freed (hipcc otherwise sinks the reads to
     // the end of the MFMA run, where their latency is exposed)
@@ -1353,50 +1313,45 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     SGB(3) SGB(3) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1) SGB(1)
 #undef SGB
   };
-#ifdef NT_PROBE_SPREAD2X   // tools/probes only: measured in round 3 at N = 2816, K = 704 - no difference (1486 vs 1491 us, 1244 vs 1249)
-#define NT2X_STEP(S, WC, WN)                                                                             \
-      __builtin_amdgcn_s_setprio(1);                                                                     \
-      sub_step_fill(WC, WN, nxt, (uint32_t)cur, (S) + 3 < nk ? (S) + 3 : -1);                            \
-      __builtin_amdgcn_s_setprio(0);
-#else
-#define NT2X_STEP(S, WC, WN)                                                                             \
+  // (round 3, measured at N = 2816, K = 704 and removed: the DMA pieces of a sub-step going out one by one behind the first six
+  // MFMA groups instead of in one run behind the barrier - 1486 vs 1491 us, 1244 vs 1249: this kernel's K loop is not bound there)
+#define NT2X_STEP(S, AC, AN)                                                                             \
       if ((S) + 3 < nk) issue((uint32_t)cur, (S) + 3);                                                   \
       __builtin_amdgcn_s_setprio(1);                                                                     \
-      sub_step(WC, WN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
+      sub_step(AC, AN, nxt);   /* (past the last sub-step: harmless reads of a stale slot) */            \
       __builtin_amdgcn_s_setprio(0);
-#endif
   wait_vmcnt<12>();   // stage 0 (vmcnt retires in order)
   lds_barrier();
 #ifdef NT_PROBE_STAMPS
   const uint64_t st1 = wall_clock64();
 #endif
-  load_w(wf[0], 0);
+  load_a(af[0], 0);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) xf[j] = *reinterpret_cast<const frag *>(xbase + j * 16 * ROWB3);
+  for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const frag *>(bbase + j * 16 * ROWB3);
   int cur = 0;   // LDS offset of sub-step s's slot
   for (int s = 0; s < nk; s += 2) {
     // top of a sub-step: this wave holds the fragments of s (slot s is free once every wave says so) and its
     // share of stage s+1 has landed; behind the barrier stage s+1 is complete and stage s+3 may overwrite s
-#define SUB(S, WC, WN)                                                                                   \
+#define SUB(S, AC, AN)                                                                                   \
     {                                                                                                    \
       const int nxt = cur + SLOT3 == RING3 ? 0 : cur + SLOT3;                                            \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
       if ((S) + 2 < nk) wait_vmcnt<6>(); else wait_vmcnt<0>();                                           \
       lds_barrier();                                                                                   \
-      NT2X_STEP(S, WC, WN)                                                                               \
+      NT2X_STEP(S, AC, AN)                                                                               \
       cur = nxt;                                                                                         \
     }
-    SUB(s, wf[0], wf[1])
-    if (s + 1 < nk) SUB(s + 1, wf[1], wf[0])
+    SUB(s, af[0], af[1])
+    if (s + 1 < nk) SUB(s + 1, af[1], af[0])
     else {   // odd nk: keep the register roles of the loop
 #pragma unroll
-      for (int i = 0; i < 4; ++i) wf[0][i] = wf[1][i];
+      for (int i = 0; i < 4; ++i) af[0][i] = af[1][i];
     }
 #undef SUB
 #undef NT2X_STEP
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  lds_barrier();   // every wave is done with the ring: it becomes the output staging area
+  // (no barrier: the epilogue leaves straight from the accumulators, the ring is not touched again)
 #ifdef NT_PROBE_STAMPS
   const uint64_t st2 = wall_clock64();
   auto stamp_end = [&]() {
@@ -1414,34 +1369,30 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
-  float bv[4][4];
+  float bv[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 64 + i * 16 + fg * 4 + r;
-      bv[i][r] = (bias && n < N) ? bias[(int64_t)e * N + n] : 0.f;
-    }
-#define OUT(RAW, A, D, DST, ...) \
-  nt2x_out<TO, RAW, A, D, ##__VA_ARGS__>(acc, bv, DST, mul_pre, smem, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, tid, wm, wn, frow, fg)
+  for (int j = 0; j < 8; ++j) {
+    const int n = n0 + frow * 8 + j;
+    bv[j] = (bias && n < N) ? bias[(int64_t)e * N + n] : 0.f;
+  }
+#define OUT(MODE, A, D, DST, DST2) \
+  nt2x_epilogue<TO, MODE, A, D>(acc, bv, DST, DST2, mul_pre, row0, rows_valid, n0, cols_valid, N, act, drop_p, seed, keep_scale, thresh16, wave, frow, fg)
   if (save_grad && pre_act) {   // (GELU: launch_nt refuses the flag for other activations)
-    if (drop_p > 0.f)
-      nt2x_out_both<TO, true>(acc, bv, C, pre_act, smem, row0, rows_valid, n0, cols_valid, N, seed, keep_scale, thresh16, tid, wm, wn, frow, fg);
-    else
-      nt2x_out_both<TO, false>(acc, bv, C, pre_act, smem, row0, rows_valid, n0, cols_valid, N, seed, keep_scale, thresh16, tid, wm, wn, frow, fg);
+    if (drop_p > 0.f) OUT(EPI_BOTH, APERTIS_ACT_GELU, true, C, pre_act);
+    else OUT(EPI_BOTH, APERTIS_ACT_GELU, false, C, pre_act);
     stamp_end();
     return;
   }
-  if (pre_act) OUT(true, APERTIS_ACT_NONE, false, pre_act);
+  if (pre_act) OUT(EPI_RAW, APERTIS_ACT_NONE, false, pre_act, nullptr);
   if (mul_pre) {
-    if (mul_saved) OUT(false, APERTIS_ACT_NONE, false, C, 2);
-    else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C, 1);
-    else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C, 1);
-    else OUT(false, -1, false, C, 1);
-  } else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(false, APERTIS_ACT_NONE, false, C);
-  else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(false, APERTIS_ACT_GELU, true, C);
-  else if (act == APERTIS_ACT_GELU) OUT(false, APERTIS_ACT_GELU, false, C);
-  else OUT(false, -1, false, C);
+    if (mul_saved) OUT(EPI_MULSAVED, APERTIS_ACT_NONE, false, C, nullptr);
+    else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(EPI_MULACT, APERTIS_ACT_GELU, true, C, nullptr);
+    else if (act == APERTIS_ACT_GELU) OUT(EPI_MULACT, APERTIS_ACT_GELU, false, C, nullptr);
+    else OUT(EPI_MULACT, -1, false, C, nullptr);
+  } else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(EPI_RAW, APERTIS_ACT_NONE, false, C, nullptr);
+  else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(EPI_ACT, APERTIS_ACT_GELU, true, C, nullptr);
+  else if (act == APERTIS_ACT_GELU) OUT(EPI_ACT, APERTIS_ACT_GELU, false, C, nullptr);
+  else OUT(EPI_ACT, -1, false, C, nullptr);
 #undef OUT
   stamp_end();
 }

@@ -100,6 +100,14 @@ int main(int argc, char **argv) {
       if (getenv("PROBE_ALL")) printf("   rep %d: %.1f us\n", rep, ms * 1e3);
     }
     printf("%-46s best %7.1f us  avg %7.1f us  %6.0f TF (best)\n", name, best * 1e3, sum / n * 1e3, flops / best / 1e9);
+    if (getenv("PROBE_SUM")) {   // checksums of the three output buffers (two builds agree bit for bit <=> the lines agree)
+      unsigned long long *cs; hipMalloc(&cs, 48); hipMemset(cs, 0, 48);
+      checksum_k<<<1024, 256>>>((const uint32_t *)h, (size_t)rows * I / 2, cs);
+      checksum_k<<<1024, 256>>>((const uint32_t *)pre, (size_t)rows * I / 2, cs + 2);
+      checksum_k<<<1024, 256>>>((const uint32_t *)dpre, (size_t)rows * I / 2, cs + 4);
+      unsigned long long hc[6]; hipMemcpy(hc, cs, 48, hipMemcpyDeviceToHost); hipFree(cs);
+      printf("   sums h %016llx %016llx | pre %016llx %016llx | dpre %016llx %016llx\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5]);
+    }
 #ifdef NT_PROBE_STAMPS
     unsigned long long st[8];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(nt2x_stamps), sizeof st);
