@@ -1397,6 +1397,273 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   stamp_end();
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 256 NT kernel, persistent, FOUR-slot ring of 32-deep stages, epilogue straight from the accumulators (round 4).
+// What round 4's stamps of the two-per-CU kernel say: with the staging pass gone its K loop takes what the epilogue gave
+// back (15 -> 18-19 us per 256 x 128 tile at K = 704 whatever the epilogue) - two work-groups with 48 KiB of LDS-DMA in
+// flight each pull ~57 GB/s per CU from L2, which is what the chip's L2 -> LDS path gives (MI355X_MICROARCH.md: 66-73 GB/s per
+// CU for gathers from L2), and a 256 x 128 tile needs 24 KiB per 32-deep sub-step: the K loop is FILL-bound at 0.0117 B/flop.
+// The persistent kernels above have the better tile (0.0078 B/flop) but ONE 64-76 KiB stage in flight per CU (~35 GB/s).
+// Here: one work-group of 8 waves per CU, tile 256 x 256, wave tile 64 rows x 128 columns (4 x 2 waves; X on the MFMA A
+// operand, W rows permuted per 128-column half as nt2x_epilogue wants them), the two-per-CU kernel's LDS image (64-byte rows,
+// chunk position c ^ F[(r >> 2) & 3]) in 32 KiB stages, FOUR slots = three stages (96 KiB) in flight behind the one being
+// read, a wave's four DMA pieces of a stage going out one by one behind the first four MFMA groups (round 3: a wave sits in
+// each buffer_load ... lds until the address unit has taken it).  The ring runs THROUGH tile boundaries: the stream of
+// (tile, sub-step) stages is filled four ahead of the one being multiplied, so the next tile's first stages land under the
+// current tile's last sub-steps and its epilogue; the epilogue needs no LDS and no barrier, and the in-order vmcnt is
+// accounted for by hand (the epilogue's S stores are younger than the next tile's stages 0..3 and older than its stage 4).
+// ------------------------------------------------------------------------------------------
+constexpr int NT4 = 512, BM4 = 256, BN4 = 256, ROWB4 = 64;
+constexpr int SLOT4 = (BM4 + BN4) * ROWB4;   // 32 KiB: X rows, then W rows
+constexpr int RING4 = 4 * SLOT4;
+
+struct Tile4 { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
+
+#ifdef NT_PROBE_STAMPS
+__device__ unsigned long long nt4r_stamps[8];   // [0] K loops [1] epilogues [2] tiles
+#endif
+template <typename TO, bool RAGGED = false>
+__global__ void __launch_bounds__(NT4)
+grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                    const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
+                    const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int total_tiles, int act_flags,
+                    float drop_p, uint64_t seed, int walk_g, int walk_nb) {
+  typedef bf16x8 frag;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool save_grad = (act_flags & APERTIS_ACT_SAVE_GRAD) != 0, mul_saved = (act_flags & APERTIS_ACT_MUL_SAVED) != 0;
+  const int act = act_flags & 0xff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fg = lane >> 4;
+  const int nk = (K + 31) / 32;   // >= 5 (launcher): the fill pointer enters the next tile four sub-steps before this one ends
+  const int ldb = K * 2, ldwb = ldw * 2;
+  const int G = gridDim.x;
+  // stores a wave leaves per tile (16 rows x one 16-byte piece per output): what the hand-kept vmcnt must let pass
+  const int S = pre_act ? 32 : 16;   // (two outputs, or a pre-activation pass and the activation pass)
+
+  // virtual tile index -> tile (the two-per-CU kernel's order: an XCD takes a contiguous run, n-panel-stationary inside)
+  auto decode = [&](int v) -> Tile4 {
+    Tile4 t; t.valid = 0; t.e = 0; t.rows_valid = 0; t.n0 = 0; t.cols_valid = 0; t.row0 = 0;
+    const int tile = xcd_remap(v, total_tiles);
+    int mt, ntile;
+    tile_walk(tile, total_tiles / n_tiles, n_tiles, walk_g, walk_nb, mt, ntile);
+    int accm = 0;
+    for (int g = 0; g < E; ++g) {
+      const int r0 = offsets[g], r1 = offsets[g + 1];
+      const int nt = (r1 - r0 + BM4 - 1) / BM4;
+      if (mt < accm + nt) {
+        const int m0 = (mt - accm) * BM4;
+        t.valid = 1; t.e = g; t.row0 = r0 + m0; t.rows_valid = min(BM4, r1 - r0 - m0);
+        break;
+      }
+      accm += nt;
+    }
+    t.e = __builtin_amdgcn_readfirstlane(t.e);
+    t.valid = __builtin_amdgcn_readfirstlane(t.valid);
+    t.rows_valid = __builtin_amdgcn_readfirstlane(t.rows_valid);
+    t.row0 = (int64_t)__builtin_amdgcn_readfirstlane((int)t.row0);
+    t.n0 = ntile * BN4; t.cols_valid = min(BN4, N - t.n0);
+    return t;
+  };
+  int vnext = blockIdx.x;
+  auto next_valid = [&]() -> Tile4 {
+    Tile4 t; t.valid = 0; t.e = 0; t.rows_valid = 0; t.n0 = 0; t.cols_valid = 0; t.row0 = 0;
+    while (vnext < total_tiles) {
+      t = decode(vnext);
+      vnext += G;
+      if (t.valid) break;
+    }
+    return t;
+  };
+
+  Tile4 cur = next_valid();
+  if (!cur.valid) return;
+
+  // ---- the fill pointer: (tile, sub-step) of the next stage to issue, and that tile's descriptors.  Past the last tile the
+  // descriptors are EMPTY (every lane out of range: zeros into a slot nobody reads, no memory traffic), so every sub-step of
+  // the stream issues its four pieces and the in-order vmcnt bookkeeping is the same constant everywhere. ----
+  const int fsw = (4 - ((lane >> 4) & 3)) & 3;                       // F[(row >> 2) & 3] for row = lane >> 2
+  const uint32_t vx0 = (uint32_t)((wave * 32 + (lane >> 2)) * ldb + (((lane & 3) ^ fsw) << 4));
+  // W piece p (16 LDS rows p*16 + c, c = lane >> 2): half = p >> 3, j = p & 7 hold W rows half*128 + c*8 + j
+  const uint32_t vw0 = (uint32_t)((lane >> 2) * 8 * ldwb + (((lane & 3) ^ fsw) << 4));
+  const uint32_t wp0 = (uint32_t)((((wave * 2) >> 3) * 128 + ((wave * 2) & 7)) * ldwb);       // this wave's W pieces 2w, 2w+1
+  const uint32_t lds0 = lds_addr_of(smem);
+  v4i fxrs, fwrs, fbrs;
+  int fs = 0, fvalid = 1;
+  auto set_fill = [&](const Tile4 &t) {
+    fxrs = raw_buffer_rsrc(X + t.row0 * K, t.valid ? (uint32_t)t.rows_valid * (uint32_t)ldb : 0u);
+    fwrs = raw_buffer_rsrc(W + ((int64_t)t.e * N + t.n0) * ldw, t.valid ? (uint32_t)t.cols_valid * (uint32_t)ldwb : 0u);
+    if (bias) fbrs = raw_buffer_rsrc(bias + (int64_t)t.e * N + t.n0, t.valid ? (uint32_t)t.cols_valid * 4u : 0u);
+    fvalid = t.valid;
+  };
+  set_fill(cur);
+  // The tile's bias segment (256 floats, zeros past the last column) comes in as ONE more piece in front of the tile's stage 0,
+  // into a 1 KiB area of the issuing wave's own (no barrier: a wave reads only what it fetched): a compiler-tracked global load
+  // in the epilogue would be waited for with vmcnt(0) - the compiler does not count the hand-issued pieces - i.e. until the
+  // next tile's stages have all landed.  It is older than stage 0's pieces (landed when they are) and makes the hand-kept
+  // counts one short where stage 0 of the next tile is among the younger ones: the waits there are one operation stronger.
+  const uint32_t bias_lds = lds0 + RING4 + wave * 1024;
+  auto issue_bias = [&]() { lds_dma16(fbrs, bias_lds, (uint32_t)lane * 16u); };
+  // piece q of this wave's share of the fill stage: q = 0,1 its X pieces (rows wave*32 + q*16 ..), q = 2,3 its W pieces
+  auto issue_piece = [&](uint32_t slot_off, int q) {
+    const uint32_t kb = (uint32_t)fs * ROWB4, base = lds0 + slot_off;
+    const uint32_t kv = RAGGED ? kb : 0u, ks = RAGGED ? 0u : kb;
+    if (q < 2) lds_dma16s(fxrs, base + (wave * 2 + q) * 1024, vx0 + (uint32_t)(q * 16 * ldb) + kv, ks);
+    else lds_dma16s(fwrs, base + BM4 * ROWB4 + (wave * 2 + (q - 2)) * 1024, vw0 + wp0 + (uint32_t)((q - 2) * ldwb) + kv, ks);
+  };
+  Tile4 nxt;   // the tile after cur (decoded at the top of cur, entered by the fill pointer four sub-steps before cur ends)
+  nxt.valid = 0; nxt.e = 0; nxt.rows_valid = 0; nxt.n0 = 0; nxt.cols_valid = 0; nxt.row0 = 0;
+
+  f32x4 acc[4][8];
+  const int frd = frow * ROWB4 + ((fg ^ ((4 - ((frow >> 2) & 3)) & 3)) << 4);
+  const char *abase = smem + wm * 64 * ROWB4 + frd, *bbase = smem + (BM4 + wn * 128) * ROWB4 + frd;
+  frag af[2][4], bfr[8];
+
+  // 32 MFMAs on (acur, bfr) while the fragments of the stream's next sub-step are read under them (W in place once its four
+  // MFMAs have issued, X into the other set - past a tile's last sub-step they are the next tile's first) and the four pieces
+  // of the fill stage go out behind the first four MFMA groups (round 3: a wave sits in each `buffer_load ... lds` until the
+  // address unit has taken it).  Straight-line on purpose: a uniform branch inside the run joins control flow, and hipcc then
+  // waits for the LDS reads in flight at every join (lgkmcnt(0) in front of the next MFMA group).
+  // LATE: the pieces behind the LAST four groups - waves 4-7, so that the two waves of a SIMD (w and w + 4, which run this
+  // code in lock-step behind the barrier) are not both parked in the address unit's queue while the matrix pipe idles.
+  auto sub_step = [&](const frag (&acur)[4], frag (&anxt)[4], int nxt_off, uint32_t fill_off, bool late) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#ifndef NT4R_PROBE_NOREAD   // tools/probes only: the run without its fragment reads (MFMAs on whatever the registers hold)
+      if (j == 0) { anxt[0] = *reinterpret_cast<const frag *>(abase + nxt_off); anxt[1] = *reinterpret_cast<const frag *>(abase + nxt_off + 16 * ROWB4); }
+      if (j == 1) { anxt[2] = *reinterpret_cast<const frag *>(abase + nxt_off + 32 * ROWB4); anxt[3] = *reinterpret_cast<const frag *>(abase + nxt_off + 48 * ROWB4); }
+#else
+      if (j < 4) asm volatile("" : "+v"(anxt[j]));
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mma(acc[i][j], acur[i], bfr[j]);
+#ifndef NT4R_PROBE_NOREAD
+      bfr[j] = *reinterpret_cast<const frag *>(bbase + nxt_off + j * 16 * ROWB4);
+#else
+      asm volatile("" : "+v"(bfr[j]));
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef NT4R_PROBE_NODMA    // tools/probes only: the run without its fills (stale LDS)
+      // (a wave-uniform branch around the hand-issued piece only: nothing the compiler tracks is pending differently on its
+      // two sides, so the join costs no wait)
+      if (late == (j >= 4)) issue_piece(fill_off, j & 3);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+#ifndef NT4R_STAGGER   // measured (B = 44, K = 704): 1037-1045 us with the stagger, 1013 without; priorities move time between the
+#define NT4R_STAGGER 0 // K loop and the epilogue, not the sum (profiles/r4_probe_nt4r_stagger.log)
+#endif
+#ifdef NT4R_PROBE_NOBAR     // tools/probes only: the K loop without its barriers (wrong results)
+#define NT4R_BARRIER
+#else
+#define NT4R_BARRIER lds_barrier();
+#endif
+#ifndef NT4R_PRIO      // 0: every wave at priority 1 inside the MFMA run; 1: waves 4-7 at priority 1 throughout, waves 0-3 at 0
+#define NT4R_PRIO 0
+#endif
+  // (a per-wave branch between an EARLY and a LATE copy of the whole run made hipcc spill the accumulators: 528 B of scratch)
+  const bool late = NT4R_STAGGER && wave >= 4;
+  if (NT4R_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+  // prologue: the first four stages (nk >= 5: all of cur), stage 0's fragments
+  if (bias) issue_bias();
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_piece((uint32_t)(k * SLOT4), q);
+    ++fs;   // (< nk)
+  }
+  wait_vmcnt<12>();
+  lds_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const frag *>(abase + i * 16 * ROWB4);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const frag *>(bbase + j * 16 * ROWB4);
+  int cur_off = 0;      // LDS offset of the slot of the sub-step about to be multiplied
+  int prev_stores = 0;  // S once an epilogue has run
+
+  const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+  for (;;) {
+    nxt = next_valid();
+#ifdef NT_PROBE_STAMPS
+    const uint64_t st1 = wall_clock64();
+#endif
+    // this tile's bias: the piece in front of its stage 0 has landed (the wait that preceded the read of stage 0's fragments)
+    float bv[8];
+    {
+      const float4 b0 = bias ? *reinterpret_cast<const float4 *>(smem + RING4 + wave * 1024 + (wn * 128 + frow * 8) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b1 = bias ? *reinterpret_cast<const float4 *>(smem + RING4 + wave * 1024 + (wn * 128 + frow * 8) * 4 + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // top of sub-step s: this wave holds the fragments of s; stage s+1 of the stream must have landed - two stages are younger
+    // (8 pieces), and through the first three sub-steps behind an epilogue so are its S stores; behind the barrier stage s+1 is
+    // complete everywhere and every wave has read s, so the fill stage (s + 4 of the stream) may overwrite slot(s)
+#define SUB4(S_, AC, AN)                                                                                       \
+    {                                                                                                          \
+      const int nxt_off = cur_off + SLOT4 == RING4 ? 0 : cur_off + SLOT4;                                      \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+      const int stores_behind = (S_) < 3 ? prev_stores : 0;                                                    \
+      if (stores_behind == 0) wait_vmcnt<8>(); else if (stores_behind == 16) wait_vmcnt<24>(); else wait_vmcnt<40>(); \
+      NT4R_BARRIER                                                                                             \
+      if (fs == 0 && bias && fvalid) issue_bias();                                                             \
+      if (NT4R_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                       \
+      sub_step(AC, AN, nxt_off, (uint32_t)cur_off, late);                                                      \
+      if (NT4R_PRIO == 0) __builtin_amdgcn_s_setprio(0);                                                       \
+      if (++fs == nk) { fs = 0; set_fill(nxt); }                                                               \
+      cur_off = nxt_off;                                                                                       \
+    }
+    for (int s = 0; s < nk; s += 2) {
+      SUB4(s, af[0], af[1])
+      if (s + 1 < nk) SUB4(s + 1, af[1], af[0])
+      else {   // odd nk: keep the register roles of the loop
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[0][i] = af[1][i];
+      }
+    }
+#undef SUB4
+#ifdef NT_PROBE_STAMPS
+    const uint64_t st2 = wall_clock64();
+#endif
+    {
+      const int n0w = cur.n0 + wn * 128, cvw = cur.cols_valid - wn * 128;
+#define OUT(MODE, A, D, DST, DST2) \
+  nt2x_epilogue<TO, MODE, A, D>(acc, bv, DST, DST2, mul_pre, cur.row0, cur.rows_valid, n0w, cvw, N, act, drop_p, seed, keep_scale, thresh16, wm, frow, fg)
+      if (save_grad && pre_act) {   // (GELU: launch_nt refuses the flag for other activations)
+        if (drop_p > 0.f) OUT(EPI_BOTH, APERTIS_ACT_GELU, true, C, pre_act);
+        else OUT(EPI_BOTH, APERTIS_ACT_GELU, false, C, pre_act);
+      } else {
+        if (pre_act) OUT(EPI_RAW, APERTIS_ACT_NONE, false, pre_act, nullptr);
+        if (mul_pre) {
+          if (mul_saved) OUT(EPI_MULSAVED, APERTIS_ACT_NONE, false, C, nullptr);
+          else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(EPI_MULACT, APERTIS_ACT_GELU, true, C, nullptr);
+          else if (act == APERTIS_ACT_GELU) OUT(EPI_MULACT, APERTIS_ACT_GELU, false, C, nullptr);
+          else OUT(EPI_MULACT, -1, false, C, nullptr);
+        } else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(EPI_RAW, APERTIS_ACT_NONE, false, C, nullptr);
+        else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(EPI_ACT, APERTIS_ACT_GELU, true, C, nullptr);
+        else if (act == APERTIS_ACT_GELU) OUT(EPI_ACT, APERTIS_ACT_GELU, false, C, nullptr);
+        else OUT(EPI_ACT, -1, false, C, nullptr);
+      }
+#undef OUT
+    }
+#ifdef NT_PROBE_STAMPS
+    if (tid == 0) {
+      atomicAdd(&nt4r_stamps[0], st2 - st1); atomicAdd(&nt4r_stamps[1], wall_clock64() - st2); atomicAdd(&nt4r_stamps[2], 1ull);
+    }
+#endif
+    if (!nxt.valid) break;
+    cur = nxt;
+    prev_stores = S;
+  }
+  // (the empty pieces of the stream's last sub-steps are still in flight: they write zeros into this work-group's own LDS)
+  wait_vmcnt<0>();
+}
+
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
 template <typename T>
 __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict__ pre, T *__restrict__ dpre,
@@ -2512,7 +2779,39 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         return apertis_check_launch();
       }
     }
+    // the persistent 256 x 256 tile on a four-slot ring (grouped_gemm_nt4r_k): every epilogue form of the two-per-CU kernel
     const bool ragged2x = K % 32 != 0;
+    // Taken for the calls with a heavy epilogue on a short K (the expert fc1 forward and the fused fc2 data gradient; the dense
+    // FFN's as one group).  Same box, best of 5 cold runs, two-per-CU kernel -> this one (tools/probes/gemm_probe.hip, PROBE_R4):
+    //   H=704 I=2816 B=32: saved-gradient forward 1195-1200 -> 1096-1105 us, fused data gradient 949-951 -> 792-797
+    //   H=704 I=2816 B=44: 1365 -> 1324-1349, 1116 -> 997-1006 (another box)
+    //   H=256 I=1024 B=16: 193 -> 154-166, 181 -> 108            H=896 I=3584: 820-882 -> 749-757, 715-725 -> 612-628
+    // Plain epilogues stay where they were (N=1024, K=256: 78 us there, 88 here; N=3584, K=896: 565 there, 508 here - not routed).
+    // A caller that passes a tile queue (data-parallel runs: a collective may hold CUs) keeps the non-persistent kernel.
+#ifdef NT_PROBE_FORCE   // tools/probes only: 4 = wherever it applies, otherwise never
+    const bool use4r = NT_PROBE_FORCE == 4;
+#else
+    const bool use4r = (act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512;
+#endif
+    if (use4r && !tile_queue && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 && N >= 128 &&
+        max_rows >= 4096 && E <= 1024) {
+      const int nt4 = (int)ceil_div64(N, BN4);
+      const int64_t grid4 = (ceil_div64(max_rows, BM4) + E) * nt4;
+      if (grid4 < 0x7fffffffLL) {
+        const int gp = (int)std::min<int64_t>(grid4, device_cu_count());   // one persistent work-group per CU
+        auto k4 = ragged2x ? grouped_gemm_nt4r_k<TO, true> : grouped_gemm_nt4r_k<TO, false>;
+        const int lds4 = RING4 + 8 * 1024;   // ring + a bias area per wave
+        hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+        int walk_g = nt4 > 4 ? 8 : 0, walk_nb = 2;
+#ifdef NT_PROBE_WALK
+        if (const char *wv = getenv("NT_WALK4")) sscanf(wv, "%d,%d", &walk_g, &walk_nb);
+#endif
+        hipLaunchKernelGGL(k4, dim3((unsigned)gp), dim3(NT4), lds4, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
+                           (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt4, (int)grid4, act_flags,
+                           drop_p, seed, walk_g, walk_nb);
+        return apertis_check_launch();
+      }
+    }
     if (use2x && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K >= 96 && K % 8 == 0 && N % 8 == 0 && N >= 64 && max_rows >= 4096 && E <= 1024) {
       const int nt3 = (int)ceil_div64(N, BN3);
       const int64_t grid3 = (ceil_div64(max_rows, BM3) + E) * nt3;

@@ -115,6 +115,10 @@ int main(int argc, char **argv) {
                       st[3] / reps, st[0] * 0.01 / st[3], st[1] * 0.01 / st[3], st[2] * 0.01 / st[3], st[4] * 0.01 / st[3]);
     memset(st, 0, sizeof st);
     hipMemcpyToSymbol(HIP_SYMBOL(nt2x_stamps), st, sizeof st);
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(nt4r_stamps), sizeof st);
+    if (st[2]) printf("   four-slot-ring tiles: %llu, per tile: K loop %.2f us, epilogue %.2f us\n", st[2] / reps, st[0] * 0.01 / st[2], st[1] * 0.01 / st[2]);
+    memset(st, 0, sizeof st);
+    hipMemcpyToSymbol(HIP_SYMBOL(nt4r_stamps), st, sizeof st);
 #endif
   };
   if (argc > 4) {   // dense projections of the SSM block (one group): gemm_probe.bin B 704 2816 dense
@@ -170,6 +174,14 @@ int main(int argc, char **argv) {
           return rc ? rc : apertis_grouped_gemm_tn(dpre, x, offs, dw1, db1, rows, I, H, E, ws, wsb, APERTIS_BF16, nullptr); });
       }
     }
+    return 0;
+  }
+  if (getenv("PROBE_R4")) {   // round 4: the four calls that matter for the expert path at K = H
+    fill_k<<<2048, 256>>>(pre, rows * I, 1.f, 9);
+    timeit("fc1 fwd: GELU + dropout + g' out (SAVE_GRAD)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, pre, nullptr, rows, I, H, H, E, APERTIS_ACT_GELU | APERTIS_ACT_SAVE_GRAD, 0.1f, 7, APERTIS_BF16, APERTIS_BF16, nullptr); });
+    timeit("fc2 dgrad * saved g' (MUL_SAVED)", fl, [&] { return apertis_grouped_gemm_nt(y, w2t, nullptr, offs, dpre, nullptr, pre, rows, I, H, H, E, APERTIS_ACT_MUL_SAVED, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+    timeit("fc1 fwd shape, plain (one output)", fl, [&] { return apertis_grouped_gemm_nt(x, w1, b1, offs, h, nullptr, nullptr, rows, I, H, H, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
+    timeit("fc2 fwd (N=H, K=I), plain", fl, [&] { return apertis_grouped_gemm_nt(h, w2t, nullptr, offs, y, nullptr, nullptr, rows, H, I, I, E, APERTIS_ACT_NONE, 0.f, 0, APERTIS_BF16, APERTIS_BF16, nullptr); });
     return 0;
   }
   if (getenv("PROBE_SHORT")) {   // the two plain shapes only (epilogue probes: -DNT_PROBE_FORCE=2 -DNT_PROBE_EPI=1|2)
