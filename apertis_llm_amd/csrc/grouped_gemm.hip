@@ -81,73 +81,97 @@ template <bool FAST> __device__ __forceinline__ float exp_t(float x) {
   else return expf(x);
 }
 
-// gelu(x) = x * Phi(x) with the same 7.1.26 erf, folded: with u = |x|/sqrt2, t = 1/(1 + p*u),
-// erfc(u) = poly(t) * t * exp(-u^2), so gelu = max(x,0) - |x| * (poly/2)(t) * t * exp2(-x^2 * log2e/2)
-// (13 VALU ops, two of them transcendental, instead of ~20)
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * LOG2E_F));
-  return fmaf(-ax, p * t * e, fmaxf(x, 0.f));
+// GELU on the bf16 path (round 4).  gelu(x) = x * Phi(x), gelu'(x) = Phi(x) + x * phi(x), with
+//   Phi(-|x|) = erfc(|x| / sqrt2) / 2 = (a1 t + a2 t^2 + a3 t^3) / 2 * exp(-x^2 / 2),  t = 1 / (1 + p |x| / sqrt2)
+// (Abramowitz-Stegun 7.1.25, three terms, |erf error| <= 2.5e-5; rounds 1-3 used the five-term 7.1.26).  The result is
+// rounded to bf16 (2^-9) and is evaluated on a pre-activation that was itself rounded to bf16, which moves Phi in the tail by
+// x^2 * 2^-9 relative - more than the approximation does anywhere.  exp(-x^2/2) serves phi(x) as well: ONE rcp and ONE exp2
+// per element yield both functions.  The caller's output scale s (1 / (1 - p) of the dropout) is folded into the
+// coefficients, so scaled outputs cost no multiply: q = s * Phi(-|x|), P = s * Phi(x) = x >= 0 ? s - q : q,
+//   s * gelu(x) = x * P,   s * gelu'(x) = P + (x * s / sqrt(2 pi)) * exp(-x^2/2).
+// Every form below performs the same IEEE operations in the same order (scalar, or two elements per v_pk_* instruction):
+// the fused and the stand-alone epilogues agree bit for bit.  (13 -> 10 lane operations for both functions against round
+// 3's, besides the two transcendentals; the epilogue of the saved-gradient forward is VALU-bound.)
+struct GeluK { float c1, c2, c3, s, sphi; };
+__device__ __forceinline__ GeluK gelu_consts(float s) {
+  return {s * (0.5f * 0.3480242f), s * (0.5f * -0.0958798f), s * (0.5f * 0.7478556f), s, s * 0.3989422804014327f};
 }
-
-// d/dx gelu(x) = Phi(x) + x * phi(x) on the same folded 7.1.26 terms: q = Phi(-|x|) = (poly/2)(t) * t * e with
-// e = exp(-x^2/2), which is phi(x) * sqrt(2 pi) as well - one rcp and one exp2 instead of three transcendentals
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * LOG2E_F));
-  const float q = p * t * e;
-  return fmaf(x * 0.3989422804014327f, e, x >= 0.f ? 1.f - q : q);
+#define GELU_TK (0.47047f * 0.70710678118654752f)
+// P = s * Phi(x), e = exp(-x^2 / 2)
+__device__ __forceinline__ void gelu_terms(float x, const GeluK &k, float &P, float &e) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(GELU_TK, fabsf(x), 1.f));
+  float p = fmaf(k.c3, t, k.c2);
+  p = fmaf(p, t, k.c1);
+  e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * LOG2E_F));
+  const float q = (p * t) * e;
+  P = x >= 0.f ? k.s - q : q;
 }
-
-// both at once: the folded terms are the same
-__device__ __forceinline__ void gelu_both_fast(float x, float &g, float &dg) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * LOG2E_F));
-  const float q = p * t * e;
-  g = fmaf(-ax, q, fmaxf(x, 0.f));
-  dg = fmaf(x * 0.3989422804014327f, e, x >= 0.f ? 1.f - q : q);
+__device__ __forceinline__ float gelu_fast(float x, const GeluK &k) {
+  float P, e;
+  gelu_terms(x, k, P, e);
+  return x * P;
 }
-
+__device__ __forceinline__ float gelu_grad_fast(float x, const GeluK &k) {
+  float P, e;
+  gelu_terms(x, k, P, e);
+  return fmaf(x * k.sphi, e, P);
+}
 // the same, two elements per instruction where the packed fp32 pipe has one (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: the same
-// IEEE operation per element, in the same order - bit-identical to gelu_both_fast); rcp, exp2, max and the select stay per element
+// IEEE operation per element, in the same order - bit-identical to the scalar forms); rcp, exp2 and the select stay per element
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f splat2(float v) { return (v2f){v, v}; }
-__device__ __forceinline__ void gelu_both_fast2(v2f x, v2f &g, v2f &dg) {
+__device__ __forceinline__ void gelu_both_fast2(v2f x, const GeluK &k, v2f &g, v2f &dg) {
   const v2f ax = {fabsf(x.x), fabsf(x.y)};
-  const v2f ta = pk_fma(splat2(0.3275911f * 0.70710678118654752f), ax, splat2(1.f));
+  const v2f ta = pk_fma(splat2(GELU_TK), ax, splat2(1.f));
   const v2f t = {__builtin_amdgcn_rcpf(ta.x), __builtin_amdgcn_rcpf(ta.y)};
-  v2f p = pk_fma(splat2(0.5f * 1.061405429f), t, splat2(0.5f * -1.453152027f));
-  p = pk_fma(p, t, splat2(0.5f * 1.421413741f));
-  p = pk_fma(p, t, splat2(0.5f * -0.284496736f));
-  p = pk_fma(p, t, splat2(0.5f * 0.254829592f));
+  v2f p = pk_fma(splat2(k.c3), t, splat2(k.c2));
+  p = pk_fma(p, t, splat2(k.c1));
   const v2f ea = (x * x) * splat2(-0.5f * LOG2E_F);
   const v2f e = {__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)};
   const v2f q = (p * t) * e;
-  g = pk_fma(-ax, q, (v2f){fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)});
-  const v2f omq = splat2(1.f) - q;
-  dg = pk_fma(x * splat2(0.3989422804014327f), e, (v2f){x.x >= 0.f ? omq.x : q.x, x.y >= 0.f ? omq.y : q.y});
+  const v2f smq = splat2(k.s) - q;
+  const v2f P = {x.x >= 0.f ? smq.x : q.x, x.y >= 0.f ? smq.y : q.y};
+  g = x * P;
+  dg = pk_fma(x * splat2(k.sphi), e, P);
+}
+
+// a row piece (four pairs) stage by stage: the four dependent chains side by side in program order - hipcc schedules a single
+// chain at a time otherwise and pads the dependent v_pk_* pairs with s_nop (60 per four rows of the saved-gradient epilogue)
+__device__ __forceinline__ void gelu_both_fast8(const v2f (&x)[4], const GeluK &k, v2f (&g)[4], v2f (&dg)[4]) {
+  v2f t[4], p[4], e[4], q[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) t[w] = pk_fma(splat2(GELU_TK), (v2f){fabsf(x[w].x), fabsf(x[w].y)}, splat2(1.f));
+#pragma unroll
+  for (int w = 0; w < 4; ++w) e[w] = (x[w] * x[w]) * splat2(-0.5f * LOG2E_F);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) t[w] = (v2f){__builtin_amdgcn_rcpf(t[w].x), __builtin_amdgcn_rcpf(t[w].y)};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) e[w] = (v2f){__builtin_amdgcn_exp2f(e[w].x), __builtin_amdgcn_exp2f(e[w].y)};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) p[w] = pk_fma(splat2(k.c3), t[w], splat2(k.c2));
+#pragma unroll
+  for (int w = 0; w < 4; ++w) p[w] = pk_fma(p[w], t[w], splat2(k.c1));
+#pragma unroll
+  for (int w = 0; w < 4; ++w) q[w] = p[w] * t[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) q[w] = q[w] * e[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) p[w] = splat2(k.s) - q[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) p[w] = (v2f){x[w].x >= 0.f ? p[w].x : q[w].x, x[w].y >= 0.f ? p[w].y : q[w].y};
+#pragma unroll
+  for (int w = 0; w < 4; ++w) g[w] = x[w] * p[w];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) t[w] = x[w] * splat2(k.sphi);
+#pragma unroll
+  for (int w = 0; w < 4; ++w) dg[w] = pk_fma(t[w], e[w], p[w]);
 }
 
 template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
-      if constexpr (FAST) return gelu_fast(x);
+      if constexpr (FAST) return gelu_fast(x, gelu_consts(1.f));
       else return 0.5f * x * (1.f + erf_t<FAST>(x * 0.70710678118654752f));
     case APERTIS_ACT_RELU: return x > 0.f ? x : 0.f;
     case APERTIS_ACT_SILU: return x / (1.f + exp_t<FAST>(-x));
@@ -157,7 +181,7 @@ template <bool FAST> __device__ __forceinline__ float act_fwd(float x, int act) 
 template <bool FAST> __device__ __forceinline__ float act_grad(float x, int act) {
   switch (act) {
     case APERTIS_ACT_GELU:
-      if constexpr (FAST) return gelu_grad_fast(x);
+      if constexpr (FAST) return gelu_grad_fast(x, gelu_consts(1.f));
       else return 0.5f * (1.f + erf_t<FAST>(x * 0.70710678118654752f)) + x * 0.3989422804014327f * exp_t<FAST>(-0.5f * x * x);
     case APERTIS_ACT_RELU: return x > 0.f ? 1.f : 0.f;
     case APERTIS_ACT_SILU: { float s = 1.f / (1.f + exp_t<FAST>(-x)); return s * (1.f + x * (1.f - s)); }
@@ -1051,10 +1075,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 // 0xFFFF in each DROPPED half of a hash word: keep <=> r16 >= thresh16 (drop_keep4's rule) <=> clamp(thresh - r, 0) == 0,
 // on the packed 16-bit pipe (three instructions per two elements instead of two extractions, two compares and a select
 // per output)
+// (as inline assembly: from the vector builtins hipcc makes two 16-bit compares, two selects and a byte permute)
 __device__ __forceinline__ uint32_t drop_mask2(uint32_t h, uint32_t thresh16) {
-  const u16x2_t r = __builtin_bit_cast(u16x2_t, h), t = {(unsigned short)thresh16, (unsigned short)thresh16};
-  const u16x2_t d = __builtin_elementwise_sub_sat(t, r), one = {1, 1}, ff = {0xffff, 0xffff};
-  return __builtin_bit_cast(uint32_t, (u16x2_t)(__builtin_elementwise_min(d, one) * ff));
+  const uint32_t t2 = __builtin_amdgcn_readfirstlane((int)(thresh16 | (thresh16 << 16)));
+  uint32_t d;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp\n\tv_pk_min_u16 %0, %0, %3\n\tv_pk_mul_lo_u16 %0, %0, %4"
+      : "=&v"(d) : "s"(t2), "v"(h), "s"(0x00010001u), "s"(0xffffffffu));
+  return d;
 }
 // drop_hash_pair for pair indices below 2^32 (the launcher offers the saved-gradient form only then)
 __device__ __forceinline__ uint32_t drop_hash_pair32(uint64_t seed, uint32_t pair) {
@@ -1119,6 +1146,10 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
     fetch(1);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // GELU constants with the dropout's 1 / (1 - p) folded in (gelu_consts), and the lane's first mask-hash pair index: the
+  // row term of a pair index is wave-uniform (N is even), so a row costs one add
+  [[maybe_unused]] const GeluK gk = gelu_consts(keep_scale);
+  [[maybe_unused]] const uint32_t pair0 = ((uint32_t)(row0 + rl) * (uint32_t)N + (uint32_t)(n0 + frow * 8)) >> 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1130,35 +1161,33 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
       for (int j = 0; j < 8; ++j) v[j] = acc[i][j][q] + bv[j];
       uint32_t o[4];
       if constexpr (MODE == EPI_BOTH) {
-        // mask words: 0xFFFF where the element is dropped (elements 0,1 of a group of four in dm[0], 2,3 in dm[1])
-        uint32_t og[4];
-#pragma unroll
-        for (int h4 = 0; h4 < 2; ++h4) {
-          uint32_t dm[2] = {0u, 0u};
+        // mask words: 0xFFFF where the element is dropped (one hash word per pair of elements)
+        uint32_t og[4], dm[4] = {0u, 0u, 0u, 0u};
 #ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
-          if (DROP) {
-            const uint32_t pair = ((uint32_t)(row0 + rl + r) * (uint32_t)N + (uint32_t)(n0 + frow * 8 + h4 * 4)) >> 1;
-            dm[0] = drop_mask2(drop_hash_pair32(seed, pair), thresh16);
-            dm[1] = drop_mask2(drop_hash_pair32(seed, pair + 1u), thresh16);
-          }
+        if (DROP) {
+          const uint32_t pair = pair0 + (uint32_t)((r * N) >> 1);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) dm[w] = drop_hash_pair32(seed, pair + (uint32_t)w);
+#pragma unroll
+          for (int w = 0; w < 4; ++w) dm[w] = drop_mask2(dm[w], thresh16);
+        }
+#endif
+        v2f x[4], hv[4], gv[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {   // the pre-activation as the other form stores it (rounded to bf16)
+          const uint32_t xpk = pack_bf16x2(v[2 * w], v[2 * w + 1]);
+          x[w] = (v2f){__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
+        }
+#if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { hv[w] = x[w] * splat2(keep_scale); gv[w] = x[w] * splat2(0.5f * keep_scale); }
+#else
+        gelu_both_fast8(x, gk, hv, gv);   // (scaled by 1 / (1 - p) already)
 #endif
 #pragma unroll
-          for (int w = 0; w < 2; ++w) {   // two elements per packed instruction
-            const int j = h4 * 4 + w * 2;
-            // the pre-activation as the other form stores it (rounded to bf16)
-            const uint32_t xpk = pack_bf16x2(v[j], v[j + 1]);
-            const v2f x = {__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
-            v2f hv, gv;
-#if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
-            hv = x * splat2(keep_scale); gv = x * splat2(0.5f * keep_scale);
-#else
-            gelu_both_fast2(x, hv, gv);
-            hv = hv * splat2(keep_scale);
-            gv = gv * splat2(keep_scale);
-#endif
-            o[h4 * 2 + w] = pack_bf16x2(hv.x, hv.y) & ~dm[w];
-            og[h4 * 2 + w] = pack_bf16x2(gv.x, gv.y) & ~dm[w];
-          }
+        for (int w = 0; w < 4; ++w) {
+          o[w] = pack_bf16x2(hv[w].x, hv[w].y) & ~dm[w];
+          og[w] = pack_bf16x2(gv[w].x, gv[w].y) & ~dm[w];
         }
         put(o1, off, o[0], o[1], o[2], o[3]);
         put(o2, off, og[0], og[1], og[2], og[3]);
@@ -1177,8 +1206,13 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (ACT != APERTIS_ACT_NONE) v[j] = act_fwd<true>(to_f32(from_f32<TO>(v[j])), ACT >= 0 ? ACT : act);
-            v[j] = keep[j] ? v[j] * keep_scale : 0.f;   // keep_scale is 1 without dropout
+            if constexpr (ACT == APERTIS_ACT_GELU) {   // the scale folded in: the same operations as EPI_BOTH's, bit for bit
+              v[j] = gelu_fast(to_f32(from_f32<TO>(v[j])), gk);
+              v[j] = keep[j] ? v[j] : 0.f;
+            } else {
+              if (ACT != APERTIS_ACT_NONE) v[j] = act_fwd<true>(to_f32(from_f32<TO>(v[j])), ACT >= 0 ? ACT : act);
+              v[j] = keep[j] ? v[j] * keep_scale : 0.f;   // keep_scale is 1 without dropout
+            }
           }
         }
 #pragma unroll
@@ -1576,10 +1610,6 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   }
   wait_vmcnt<12>();
   lds_barrier();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const frag *>(abase + i * 16 * ROWB4);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const frag *>(bbase + j * 16 * ROWB4);
   int cur_off = 0;      // LDS offset of the slot of the sub-step about to be multiplied
   int prev_stores = 0;  // S once an epilogue has run
 
@@ -1590,7 +1620,15 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #ifdef NT_PROBE_STAMPS
     const uint64_t st1 = wall_clock64();
 #endif
-    // this tile's bias: the piece in front of its stage 0 has landed (the wait that preceded the read of stage 0's fragments)
+    // Stage 0's fragments.  (A tile's last sub-step has read them already, like every sub-step reads its successor's, but
+    // 48 registers held across the epilogue leave its arithmetic no room to interleave: they are read again here - the slot is
+    // not refilled before sub-step 0's barrier - and the stage has landed: the wait + barrier of the prologue resp. of the
+    // previous tile's last sub-step.)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const frag *>(abase + cur_off + i * 16 * ROWB4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const frag *>(bbase + cur_off + j * 16 * ROWB4);
+    // this tile's bias: the piece in front of its stage 0 has landed with it
     float bv[8];
     {
       const float4 b0 = bias ? *reinterpret_cast<const float4 *>(smem + RING4 + wave * 1024 + (wn * 128 + frow * 8) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
