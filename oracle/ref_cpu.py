@@ -18,6 +18,12 @@ import torch
 import torch.nn.functional as F
 
 
+def _up(t):
+    """The reference's `.float()` promotions (core.py:340, :482): low precision -> fp32.  An fp64 run of this oracle (the
+    yardstick the bf16 tests measure both mixed-precision flows against) stays fp64."""
+    return t if t.dtype in (torch.float32, torch.float64) else t.float()
+
+
 # ----------------------------------------------------------------------------------------------
 # S2 — selective scan, sequential recurrence (src/model/core.py:337-353)
 # ----------------------------------------------------------------------------------------------
@@ -115,7 +121,7 @@ def ssm_layer(sd, pre, x, n_heads, d_state, dt_rank, h0=None, return_parts=False
     p = F.linear(xc, sd[pre + "x_param_proj.weight"])                   # :376
     dtf, Bt, C = torch.split(p, [dt_rank, Dn, Dn], dim=-1)               # :377-381
     delta = F.softplus(F.linear(dtf, sd[pre + "dt_proj_head.weight"], sd[pre + "dt_proj_head.bias"]))  # :382-383
-    y, h_last = scan_recurrent(delta.float(), sd[pre + "A_log"].float(), Bt, C, h0)       # :391
+    y, h_last = scan_recurrent(_up(delta), _up(sd[pre + "A_log"]), Bt, C, h0)             # :391
     ys = y + sd[pre + "D"].view(1, 1, -1) * xc                           # :395
     g = ys * F.silu(z)                                                   # :396
     out = F.linear(g, sd[pre + "out_proj.weight"])                       # :397
@@ -137,7 +143,7 @@ def router(sd, pre, x_flat, K, eps, noise=None):
     """x_flat [S,H] -> logits, gates [S,E], idx [S,K], w [S,K].  core.py:481-492,529."""
     H = x_flat.shape[1]
     xn = F.layer_norm(x_flat, (H,), sd[pre + "router_norm.weight"], sd[pre + "router_norm.bias"], eps)  # :481
-    logits = F.linear(xn, sd[pre + "router.weight"], sd[pre + "router.bias"]).float()                  # :482
+    logits = _up(F.linear(xn, sd[pre + "router.weight"], sd[pre + "router.bias"]))                     # :482
     if noise is not None:
         logits = logits + noise                                                                         # :486-488
     gates = F.softmax(logits, dim=-1)                                                                   # :491
@@ -241,7 +247,8 @@ def moe_layer(sd, pre, x, E, K, act, eps, training=False, capacity_factor=1.25,
         tok = torch.from_numpy(row_token[r0:r1]).long()
         kk = torch.from_numpy(row_k[r0:r1]).long()
         ye = expert_mlp(sd, pre, e, xf[tok], act, eps)                 # :593-596
-        contrib[tok, kk] = ye * w[tok, kk].unsqueeze(1).to(ye.dtype)   # :594,:605
+        # (:594,:605: under autocast the expert output is 16-bit and the gate weight fp32 - the product promotes to fp32)
+        contrib[tok, kk] = (ye * w[tok, kk].unsqueeze(1)).to(contrib.dtype)
     for k in range(K):                                                 # k-ascending sum == index_add_ order
         out = out + contrib[:, k]
     return out.reshape(B, L, H), lb, rz, dict(logits=logits, gates=gates, idx=idx, w=w, offsets=offs,
@@ -297,21 +304,22 @@ def vision_encoder(sd, pre, pixel_values, patch, n_layers, n_heads):
 # ----------------------------------------------------------------------------------------------
 # G1/G2 — ApertisModel / ApertisForCausalLM forward, eval mode (core.py:1142-1307, 1361-1472)
 # ----------------------------------------------------------------------------------------------
-def model_forward(sd, cfg, input_ids, pixel_values=None, labels=None, aux_out=None):
+def model_forward(sd, cfg, input_ids, pixel_values=None, labels=None, aux_out=None, inputs_embeds=None):
     """cfg: dict with the ApertisConfig fields.  selective_ssm attention, LayerNorm, dense-FFN or
     MoE feed-forward; eval mode (no dropout / noise / capacity).  Returns (loss, logits).  aux_out: optional list that
-    receives each MoE layer's routing record (gates, idx, ...), for tests that assert a minimum top-k gap."""
+    receives each MoE layer's routing record (gates, idx, ...), for tests that assert a minimum top-k gap.
+    inputs_embeds: used instead of the embedding lookup (core.py:1155-1158) - lets a test take the input gradient."""
     H = cfg["hidden_size"]
     eps = cfg["layer_norm_eps"]
-    x = F.embedding(input_ids, sd["model.token_embeddings.weight"])                     # :1158
+    x = inputs_embeds if inputs_embeds is not None else F.embedding(input_ids, sd["model.token_embeddings.weight"])  # :1158
     if cfg.get("multimodal") and pixel_values is not None:                              # :1207-1212
         img = vision_encoder(sd, "model.multimodal_encoder.", pixel_values, cfg["vision_patch_size"],
                              cfg["vision_layers"], cfg["vision_heads"])
         if cfg["vision_embed_dim"] != H:
             img = F.linear(img, sd["model.vision_projection.weight"], sd["model.vision_projection.bias"])
         x = torch.cat([img, x], dim=1)
-    lb_tot = torch.zeros(())
-    rz_tot = torch.zeros(())
+    lb_tot = torch.zeros((), dtype=x.dtype)
+    rz_tot = torch.zeros((), dtype=x.dtype)
     for i in range(cfg["num_hidden_layers"]):
         lp = f"model.layers.{i}."
         h = F.layer_norm(x, (H,), sd[lp + "attention.pre_norm.weight"], sd[lp + "attention.pre_norm.bias"], eps)  # :695

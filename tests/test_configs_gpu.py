@@ -67,35 +67,150 @@ def test_config2_layer_stack_fp32_L2048(dev):
     assert abs(float(loss) - float(o_loss)) <= 1e-5 * abs(float(o_loss))
 
 
+def _err_vs(ref64, got):
+    """Error of `got` against the fp64 yardstick: (relative RMS, max abs / max|ref|, 99.9th-percentile abs / max|ref|)."""
+    r = ref64.detach().double().cpu().flatten()
+    d = (got.detach().double().cpu().flatten() - r).abs()
+    k = max(1, int(d.numel() * 0.999))
+    return (float(d.pow(2).mean().sqrt() / r.pow(2).mean().sqrt()), float(d.max() / r.abs().max()),
+            float(d.kthvalue(k).values / r.abs().max()))
+
+
+def _bf16_report(name, ref64, hip, cpu_ac, factor=1.5, floor=2e-4):
+    """Two mixed-precision runs of the same arithmetic - the HIP path under CUDA bf16 autocast and the oracle under CPU bf16
+    autocast (the reference's own dtype flow, pipeline.py:533) - each measured against an fp64 run of the oracle on the same
+    bf16-representable weights and inputs.  Held: the HIP path's error is at most `factor` x the CPU flow's own error (plus
+    a floor of `floor` of the tensor's scale for quantities both flows get nearly exact), in RMS and at the 99.9th percentile;
+    two bf16 paths are never compared with each other."""
+    import json
+    import os
+    from conftest import ROOT
+    eh, ec = _err_vs(ref64, hip), _err_vs(ref64, cpu_ac)
+    rec = {"test": name, "dtype": "bf16-autocast", "yardstick": "fp64 oracle on bf16-rounded weights",
+           "hip_rel_rms": eh[0], "hip_max_over_refmax": eh[1], "hip_p999_over_refmax": eh[2],
+           "cpu_autocast_rel_rms": ec[0], "cpu_autocast_max_over_refmax": ec[1], "cpu_autocast_p999_over_refmax": ec[2],
+           "factor": factor, "numel": int(ref64.numel())}
+    print("PARITY " + json.dumps(rec))
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    assert eh[0] <= factor * ec[0] + floor, rec
+    assert eh[2] <= factor * ec[2] + floor, rec
+    return rec
+
+
 def test_config2_ssm_layer_bf16_autocast_L2048(dev):
-    """One SelectiveLinearAttention at config-2 dims under bf16 autocast (the benchmark's dtype) against the oracle
-    run under CPU bf16 autocast - the reference's own mixed-precision flow (Linear / conv outputs bf16, softplus,
-    exp and the state fp32) - forward and input gradient.  Tolerance: bf16 (2^-8) accumulated over the
-    block, stated below; the fp32 1e-4 bar is held by the fp32 test above."""
+    """One SelectiveLinearAttention at config-2 dims (H=896, 14 heads, L=2048) under bf16 autocast - the benchmark's dtype -
+    forward and input gradient.  Yardstick: the oracle in fp64 on the same (bf16-representable) weights and input; the HIP
+    path's error against it must not exceed 1.5 x the error of the oracle under CPU bf16 autocast, which is the reference's
+    own mixed-precision flow (Linear / conv outputs bf16, softplus, exp and the state fp32).  Round 3 compared
+    the two bf16 paths with each other (sig10 5.7e-2, unasserted)."""
     import apertis_llm_amd as A
     from oracle import ref_cpu, seeded
     cfg = _cfg2(A)
     mod = A.SelectiveLinearAttention(cfg)
-    sd = seeded.fill_state_dict(mod.state_dict(), gain=2.0)
+    sd = {k: v.bfloat16().float() for k, v in seeded.fill_state_dict(mod.state_dict(), gain=2.0).items()}
     mod.load_state_dict(sd)
     mod = mod.to(dev).train()
-    x = torch.randn(2, 2048, 896, generator=torch.Generator().manual_seed(4))
+    x = torch.randn(2, 2048, 896, generator=torch.Generator().manual_seed(4)).bfloat16().float()
+    dout = torch.randn(2, 2048, 896, generator=torch.Generator().manual_seed(5)).bfloat16().float()
     xg = x.to(dev).requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = mod(xg)[0]
-    dout = torch.randn(out.shape, generator=torch.Generator().manual_seed(5))
     out.float().backward(dout.to(dev))
     xo = x.clone().requires_grad_(True)
     with torch.autocast("cpu", dtype=torch.bfloat16):
         o = ref_cpu.ssm_layer(sd, "", xo, 14, 16, cfg.ssm_dt_rank)
     o.float().backward(dout)
     assert out.dtype == torch.bfloat16 and o.dtype == torch.bfloat16
-    r1 = rel_error_report("config2_bf16_L2048 ssm out", out.float(), o.float(), rtol=2e-2, check=False)
-    r2 = rel_error_report("config2_bf16_L2048 ssm dx", xg.grad, xo.grad, rtol=2e-2, check=False)
-    # bf16: one rounding is 3.9e-3 relative; the block chains four bf16 GEMMs and a bf16 conv
-    assert r1["max_abs_over_refmax"] <= 2e-2 and r2["max_abs_over_refmax"] <= 2e-2, (r1, r2)
-    # and the mean error must be far below the worst case (no systematic offset)
-    assert float((out.float().cpu() - o.float()).abs().mean()) <= 2e-3 * float(o.float().abs().max())
+    x64 = x.double().requires_grad_(True)
+    o64 = ref_cpu.ssm_layer({k: v.double() for k, v in sd.items()}, "", x64, 14, 16, cfg.ssm_dt_rank)
+    assert o64.dtype == torch.float64
+    o64.backward(dout.double())
+    _bf16_report("config2_bf16_L2048 ssm out", o64, out, o)
+    _bf16_report("config2_bf16_L2048 ssm dx", x64.grad, xg.grad, xo.grad)
+
+
+def test_bench_dtype_whole_model_bf16_autocast(dev):
+    """The dtype the benchmark runs (pipeline.py:533: the reference trains under 16-bit autocast), whole model: 2 layers at the
+    1.5B family's width (H=704, 11 heads, I=2816, 8 experts top-2; core.py:470-607), L=512, B=8, eval (dropout / noise /
+    capacity off).  HIP logits, loss and input-embedding gradient under CUDA bf16 autocast against the fp64 oracle on the same
+    bf16-representable weights, next to the oracle under CPU bf16 autocast (the reference's own flow).
+
+    What bf16 does to such a model (tools/diag_bf16_routing.py): the first layer's gates move by ~1e-3, so tokens whose 2nd and
+    3rd gate are closer than that change expert in EITHER bf16 flow (2-7 of 1024), and a token that changed expert feeds every
+    later token of its sequence through the scan - the second layer then changes expert for gaps up to 0.1, in both flows alike,
+    and the whole-tensor error (6-9 % RMS in both) measures those cascades, not arithmetic.  Held therefore:
+      * first layer: the HIP routing equals the fp64 routing on every token whose 2nd / 3rd gate gap exceeds 1e-3;
+      * every layer: the HIP flow changes expert on at most 1.5 x as many tokens as the CPU flow (+4);
+      * logits on each sequence's CLEAN PREFIX - the tokens before the first token that changed expert in either flow (the
+        model is causal: they depend on nothing that changed) - HIP error <= 1.5 x the CPU flow's, both at bf16 level;
+      * whole tensors (logits, d inputs_embeds, loss): HIP error <= 1.5 x the CPU flow's (+ floor)."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops
+    from oracle import ref_cpu, seeded
+    B, L = 8, 512
+    cfg = A.ApertisConfig(vocab_size=1024, hidden_size=704, num_hidden_layers=2, num_attention_heads=11, intermediate_size=2816,
+                          attention_type="selective_ssm", use_expert_system=True, num_experts=8, experts_per_token=2,
+                          max_position_embeddings=L)
+    model = A.ApertisForCausalLM(cfg)
+    sd = {k: v.bfloat16().float() for k, v in seeded.fill_state_dict(model.state_dict()).items()}
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    ids = torch.randint(4, cfg.vocab_size, (B, L), generator=torch.Generator().manual_seed(31))
+    emb = F.embedding(ids, sd["model.token_embeddings.weight"])
+    cfgd = dict(cfg.to_dict())
+
+    taken, orig = [], ops.moe_gate_topk           # the routing the HIP forward takes, read off the gate op's outputs
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        taken.append(r[1].detach().cpu().long())
+        return r
+    ops.moe_gate_topk = spy
+    try:
+        eg = emb.to(dev).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss, logits = model(inputs_embeds=eg, labels=ids.to(dev), use_cache=False)[:2]
+        loss.float().backward()
+    finally:
+        ops.moe_gate_topk = orig
+    ec = emb.clone().requires_grad_(True)
+    aux_c, aux64 = [], []
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        loss_c, logits_c = ref_cpu.model_forward(sd, cfgd, ids, None, ids, aux_out=aux_c, inputs_embeds=ec)
+    loss_c.float().backward()
+    e64 = emb.double().requires_grad_(True)
+    loss64, logits64 = ref_cpu.model_forward({k: v.double() for k, v in sd.items()}, cfgd, ids, None, ids, aux_out=aux64,
+                                             inputs_embeds=e64)
+    assert logits64.dtype == torch.float64 and len(taken) == len(aux64) == len(aux_c) == 2
+    loss64.backward()
+
+    changed = torch.zeros(B * L, dtype=torch.bool)
+    for li in range(2):
+        ref_idx = aux64[li]["idx"].sort(dim=-1).values
+        same_h = (taken[li].reshape(-1, 2).sort(dim=-1).values == ref_idx).all(dim=-1)
+        same_c = (aux_c[li]["idx"].sort(dim=-1).values == ref_idx).all(dim=-1)
+        top3 = aux64[li]["gates"].topk(3, dim=-1).values
+        gap = top3[:, 1] - top3[:, 2]
+        nh, nc = int((~same_h).sum()), int((~same_c).sum())
+        print("whole_model_bf16 layer %d: tokens that change expert vs fp64: hip %d (largest gap %.2e), cpu-autocast %d (largest gap %.2e) of %d"
+              % (li, nh, float(gap[~same_h].max()) if nh else 0.0, nc, float(gap[~same_c].max()) if nc else 0.0, B * L))
+        if li == 0:
+            assert bool(same_h[gap > 1e-3].all()), ("first layer", int((~same_h & (gap > 1e-3)).sum()))
+        assert nh <= 1.5 * nc + 4, (li, nh, nc)
+        changed |= ~same_h | ~same_c
+    first = torch.where(changed.reshape(B, L).any(dim=1), changed.reshape(B, L).float().argmax(dim=1), torch.full((B,), L))
+    clean = torch.arange(L).unsqueeze(0) < first.unsqueeze(1)            # [B, L]
+    print("whole_model_bf16 clean prefixes:", first.tolist(), "=", int(clean.sum()), "tokens")
+    assert int(clean.sum()) >= 64, first.tolist()
+    r = _bf16_report("whole_model_bf16 logits, clean prefixes", logits64[clean], logits.float().cpu()[clean], logits_c.float()[clean])
+    assert r["hip_rel_rms"] <= 2e-2, r                                   # bf16 level: nothing routed differently in here
+    _bf16_report("whole_model_bf16 logits", logits64, logits.float(), logits_c.float(), floor=5e-3)
+    _bf16_report("whole_model_bf16 d(inputs_embeds)", e64.grad, eg.grad, ec.grad, floor=5e-3)
+    err_h, err_c = abs(float(loss) - float(loss64)), abs(float(loss_c) - float(loss64))
+    print("whole_model_bf16 loss: fp64 %.6f  hip %.6f (err %.2e)  cpu-autocast %.6f (err %.2e)" % (float(loss64), float(loss), err_h, float(loss_c), err_c))
+    assert err_h <= 1.5 * err_c + 1e-3 * abs(float(loss64)), (err_h, err_c)
 
 
 # ------------------------------------------------------------------------------------------------ config 3
