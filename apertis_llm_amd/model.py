@@ -3,10 +3,12 @@
 Same importable names, constructor keywords, config fields, state-dict keys and forward
 contracts as /root/reference/src/model/core.py, so a checkpoint or a `config.json` written by
 either side loads in the other and `apertis train` / `apertis chat` callers need no change.
-What differs is underneath: the selective scan, the depthwise conv, the gate, the whole MoE
-dispatch and the expert GEMMs run as HIP kernels through libapertis_hip.so (apertis_llm_amd.ops);
-stock torch (rocBLAS / hipBLASLt) keeps the plain dense projections, LayerNorm, embeddings and
-the loss.  There is no eager fallback for the kernel paths: off-GPU they raise ApertisHipError.
+What differs is underneath: the selective scan, the depthwise conv, the gate, the SSM block's
+dense projections, LayerNorm and the sub-block boundaries, the whole MoE dispatch, the expert
+GEMMs, the dense FFN, the cross-entropy and the optimizer step run as HIP kernels through
+libapertis_hip.so (apertis_llm_amd.ops); stock torch (hipBLASLt) keeps the embedding, the LM head's
+GEMMs, the ViT body and the `standard_mha` fallback.  There is no eager fallback for the kernel
+paths: off-GPU they raise ApertisHipError.
 """
 import functools
 import inspect
@@ -1039,9 +1041,17 @@ class ApertisForCausalLM(nn.Module):
                  temperature: Optional[float] = 1.0, top_k: Optional[int] = 50, top_p: Optional[float] = 1.0,
                  repetition_penalty: Optional[float] = 1.0, eos_token_id=None, pad_token_id=None,
                  use_cache: bool = True, **kwargs):
-        """Greedy / top-k / top-p / repetition-penalty decoding loop (reference core.py:1520-1644)."""
+        """Greedy / top-k / top-p / repetition-penalty decoding loop (reference core.py:1520-1644).  The prepared copies of
+        the weights (stacked / padded / cast) are reused from token to token inside the call (ops.prep_cache_scope)."""
         if input_ids is None:
             raise ValueError("input_ids must be provided.")
+        with ops.prep_cache_scope():
+            return self._generate(input_ids, attention_mask, position_ids, pixel_values, max_new_tokens, min_new_tokens,
+                                  do_sample, temperature, top_k, top_p, repetition_penalty, eos_token_id, pad_token_id,
+                                  use_cache)
+
+    def _generate(self, input_ids, attention_mask, position_ids, pixel_values, max_new_tokens, min_new_tokens, do_sample,
+                  temperature, top_k, top_p, repetition_penalty, eos_token_id, pad_token_id, use_cache):
         B, prompt_len = input_ids.shape
         temp = max(temperature, 1e-6) if do_sample else 1.0
         eos = self.config.eos_token_id if eos_token_id is None else eos_token_id

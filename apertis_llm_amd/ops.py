@@ -992,8 +992,32 @@ def moe_combine(yr, w, plan, out_dtype=None):
 # was made in: ApertisAdamW bumps the epoch on every step, because its kernels update parameters through raw pointers,
 # which the version counter does not see.  Training never reads the cache (autograd Functions pass cache=False when an
 # input needs a gradient): its compute copies change with every optimizer step anyway.
+# The cache lives only INSIDE a prep_cache_scope() (generate(), the trainer's validation loop): an in-place write through
+# `.data` (weight init, `resize_token_embeddings`, a DDP parameter broadcast, a user's `p.data.copy_(...)`) bumps neither the
+# version counter nor the epoch, so outside a scope - where such writes happen between forwards - every forward prepares
+# its copies afresh, and a scope drops its entries when it closes.
 WEIGHT_EPOCH = 0
 _prep_cache = {}
+_prep_scope_depth = 0
+
+
+class prep_cache_scope:
+    """`with ops.prep_cache_scope():` - the span during which prepared inference copies of the weights may be reused
+    (the weights must not be written inside it except through ApertisAdamW, which invalidates them)."""
+
+    def __enter__(self):
+        global _prep_scope_depth
+        if _prep_scope_depth == 0:
+            _prep_cache.clear()
+        _prep_scope_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _prep_scope_depth
+        _prep_scope_depth -= 1
+        if _prep_scope_depth == 0:
+            _prep_cache.clear()
+        return False
 
 
 def note_weights_changed():
@@ -1015,13 +1039,17 @@ def cached_prep(tag, tensors, make, enable=None):
     inside an autograd Function's forward grad mode is off although the call may belong to a training step) and only
     for stable sources (_stable_source) - otherwise just `make()`."""
     import weakref
+    if _prep_scope_depth == 0:
+        return make()
     if enable is None:
         enable = not torch.is_grad_enabled()
     srcs = [_stable_source(t) for t in tensors] if enable else [None]
     if any(x is None for x in srcs):
         return make()
     key = (tag, tuple(id(x) for x in srcs))
-    state = tuple((t.data_ptr(), x._version, tuple(t.shape), t.dtype) for t, x in zip(tensors, srcs)) + (WEIGHT_EPOCH,)
+    # (strides and offset: `w` and `w.t()` of a square weight share pointer, shape and dtype)
+    state = tuple((t.data_ptr(), x._version, tuple(t.shape), tuple(t.stride()), t.storage_offset(), t.dtype)
+                  for t, x in zip(tensors, srcs)) + (WEIGHT_EPOCH,)
     ent = _prep_cache.get(key)
     if ent is None or ent[0] != state or any(r() is not x for r, x in zip(ent[1], srcs)):
         if len(_prep_cache) > 8192:      # (models come and go in one process: do not keep their copies for ever)

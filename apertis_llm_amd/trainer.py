@@ -220,7 +220,7 @@ class ApertisTrainer:
             return float("inf")
         self.model.eval()
         total, n = 0.0, 0
-        with torch.no_grad():
+        with torch.no_grad(), ops.prep_cache_scope():     # (the weights do not change during a validation pass)
             for batch in self.val_dataloader:
                 if self.stop_event.is_set():
                     return float("inf")

@@ -514,3 +514,42 @@ def test_scan_lookback_timeout_word_rejects_the_step(dev):
         word.zero_()
     assert ops.scan_gate_error(dev) == 0
     assert all(torch.isfinite(b).all() for b in before)
+
+
+def test_prepared_weight_cache_is_scoped_and_never_stale(dev):
+    """prepared inference copies of the weights (stacked in_proj, padded x_param_proj, bf16 casts) are keyed on the
+    parameter's version counter, which an in-place write through `.data` does not bump (weight init, DDP broadcast,
+    `p.data.copy_`).  They are therefore reused only inside ops.prep_cache_scope() - generate(), the trainer's validation
+    loop: two plain no_grad forwards around such a write must see it (fp32 and bf16 autocast), a scope must reuse its
+    entries and drop them when it closes."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops
+    torch.manual_seed(3)
+    cfg = A.ApertisConfig(vocab_size=128, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                          attention_type="selective_ssm", use_expert_system=True, num_experts=4, experts_per_token=2)
+    model = A.ApertisForCausalLM(cfg).to(dev).eval()
+    ids = torch.randint(4, 128, (2, 48), device=dev)
+    ssm = model.model.layers[0].attention.attention_mechanism_impl
+    for autocast in (False, True):
+        def fwd():
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                return model(input_ids=ids, use_cache=False)[1].float().clone()
+        a = fwd()
+        assert len(ops._prep_cache) == 0                       # nothing is kept outside a scope
+        for p in (ssm.in_proj_x.weight, ssm.x_param_proj.weight, ssm.out_proj.weight, model.model.layers[1].feed_forward.ffn.expert_w1):
+            v0 = p._version
+            p.data.mul_(1.5)                                   # behind autograd's back: no version bump
+            assert p._version == v0
+            b = fwd()
+            assert not torch.equal(a, b), "a forward after an in-place .data write served stale prepared weights"
+            p.data.div_(1.5)
+            a = fwd()
+        with ops.prep_cache_scope():
+            c = fwd()
+            n = len(ops._prep_cache)
+            d = fwd()
+            assert n > 0 and len(ops._prep_cache) == n and torch.equal(c, d)
+        assert len(ops._prep_cache) == 0
+    # generate() opens its own scope and leaves nothing behind
+    out = model.generate(input_ids=ids[:, :8], max_new_tokens=4)
+    assert out.shape == (2, 12) and len(ops._prep_cache) == 0
