@@ -69,9 +69,10 @@ __global__ void __launch_bounds__(1024) clip_coef_k(const float *__restrict__ pa
     // turn it into 1 and apply an unclipped step on non-finite gradients)
     const float c = max_norm / (norm + 1e-6f);
     out[1] = (c != c) ? c : fminf(c, 1.f);
-    // a non-zero poison word (the single-pass scan's look-back time-out flag, scan_gate.hip) makes the step as visible as a
-    // non-finite gradient norm: norm and coefficient become NaN and the AdamW pass hands that to every parameter
-    if (poison && *poison != 0) out[0] = out[1] = __builtin_nanf("");
+    // a non-zero poison word (the single-pass scan's look-back time-out flag, scan_gate.hip: the step's activations are
+    // wrong) rejects the step visibly - the norm reads NaN - and WITHOUT destroying the model: the coefficient -1 makes the
+    // AdamW pass a no-op (a transient time-out must not overwrite every parameter and moment with NaN)
+    if (poison && *poison != 0) { out[0] = __builtin_nanf(""); out[1] = -1.f; }
   }
 }
 
@@ -104,6 +105,7 @@ adamw_step_k(const OptTensor *__restrict__ tensors, const int32_t *__restrict__ 
   const int64_t base = (int64_t)chunk_index[blockIdx.x] * OPT_CHUNK;
   const int64_t n = min((int64_t)OPT_CHUNK, t.numel - base);
   const float coef = coef_ptr ? coef_ptr[1] : 1.f;
+  if (coef < 0.f) return;   // (clip_coef's "skip this step": the poison word was set)
   float *p = t.p + base, *m = t.m + base, *v = t.v + base;
   const float *g = t.g + base;
   const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;

@@ -210,19 +210,30 @@ def _scan_gate_ws(lib, B, L, Dn, device):
     """Look-back workspace of the single-pass kernels: one per (device, stream), zero-filled once, and the epoch of the
     next launch on it (incremented by exactly one per launch: the two ticket counters in its head alternate)."""
     need = int(lib.apertis_scan_gate_workspace_bytes(B, L, Dn))
+    device = _indexed(device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ent = _gate_ws.get(key)
     if ent is None or ent[0].numel() < need or ent[1] >= 0xFFFFFFF0:
+        old = ent
         ent = _gate_ws[key] = [torch.zeros(need, device=device, dtype=torch.uint8), 0]
+        if old is not None:
+            ent[0][8:12].copy_(old[0][8:12])     # a larger workspace inherits the sticky error word of the one it replaces
     ent[1] += 1
     return ent[0], ent[1]
+
+
+def _indexed(device):
+    """torch.device with an explicit index ('cuda' -> the current device): the workspace tables are keyed on it."""
+    d = torch.device(device)
+    return torch.device("cuda", torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
 
 
 def scan_gate_error(device=None):
     """Non-zero if a single-pass scan launch hit its bounded-wait timeout on any workspace of `device` (host sync)."""
     bad = 0
+    device = None if device is None else _indexed(device)
     for (dev, _), ent in _gate_ws.items():
-        if device is None or torch.device(dev) == torch.device(device):
+        if device is None or dev == device:
             torch.cuda.synchronize(dev)
             bad |= int(ent[0][8:12].view(torch.int32).item())
     return bad
@@ -232,7 +243,8 @@ def scan_gate_error_word(device):
     """The look-back error word(s) of `device`'s single-pass scan workspaces as ONE device int32 tensor of shape [1]
     (None when no single-pass scan has run there) - no host sync.  `ApertisAdamW.step` hands its address to
     `apertis_clip_coef` as the poison word, `TrainStep` turns the returned loss into NaN with it."""
-    words = [ent[0][8:12].view(torch.int32) for (dev, _), ent in _gate_ws.items() if torch.device(dev) == torch.device(device)]
+    device = _indexed(device)
+    words = [ent[0][8:12].view(torch.int32) for (dev, _), ent in _gate_ws.items() if dev == device]
     if not words:
         return None
     if len(words) == 1:

@@ -145,6 +145,11 @@ class ApertisAdamW(torch.optim.Optimizer):
             for g in T["launches"]:
                 if any(state[p]["step"] is not s for p, s in zip(g["params"], g["steps"])):
                     return False
+                # ... and still COUNT what the kernel's bias correction assumes (an in-place `state['step'].zero_()` keeps
+                # the tensor's identity); host tensors only - reading a device step count would be a sync
+                s0 = g["steps"][0] if g["steps"] else None
+                if s0 is not None and not s0.is_cuda and int(s0.item()) != g["step0"]:
+                    return False
         except KeyError:
             return False
         n_groups = sum(len(g["params"]) for g in self.param_groups)
@@ -155,12 +160,12 @@ class ApertisAdamW(torch.optim.Optimizer):
         from . import _lib
         T = self._tables
         grads = [p.grad for p in T["plist"]]
+        for g, p in zip(grads, T["plist"]):        # (every step: a gradient may change dtype / layout at an unchanged address)
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
+                raise _lib.ApertisHipError("ApertisAdamW needs contiguous fp32 CUDA parameters and gradients")
         gp = [g.data_ptr() for g in grads]
         if gp == T["gp"]:
             return
-        for g, p in zip(grads, T["plist"]):
-            if g.dtype != torch.float32 or not g.is_contiguous() or g.device != p.device:
-                raise _lib.ApertisHipError("ApertisAdamW needs contiguous fp32 CUDA parameters and gradients")
         i = T["turn"] = T["turn"] ^ 1
         if T["pin_ev"][i] is not None:
             T["pin_ev"][i].synchronize()          # the copy issued from this staging buffer two refreshes ago has run
@@ -191,7 +196,7 @@ class ApertisAdamW(torch.optim.Optimizer):
                 for g in T["launches"]:
                     check(lib.apertis_grad_sumsq(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"],
                                                  ptr(T["partials"][g["first"]:]), stream_ptr()), "apertis_grad_sumsq")
-                # the scan's look-back time-out word poisons the coefficient (NaN step, like a non-finite norm): no sync
+                # the scan's look-back time-out word poisons the step (NaN norm, the AdamW pass skipped): no sync
                 poison = ops.scan_gate_error_word(T["partials"].device)
                 check(lib.apertis_clip_coef(ptr(T["partials"]), T["n_total"], float(max_grad_norm), ptr(T["norm_coef"]),
                                             ptr(poison), stream_ptr()), "apertis_clip_coef")

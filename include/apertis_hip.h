@@ -509,13 +509,15 @@ int64_t apertis_opt_chunk_elems(void);
 int apertis_grad_sumsq(const void *tensors, const int32_t *chunk_tensor, const int32_t *chunk_index,
                        int64_t n_chunks, float *partials, void *stream);
 /* norm_coef[0] = sqrt(sum of partials[0..n)) summed in index order, norm_coef[1] = min(1, max_norm/(norm+1e-6)):
- * torch.nn.utils.clip_grad_norm_'s coefficient, left on the device.  `poison` (may be NULL): a device int32 that makes
- * both values NaN when it is non-zero - callers pass the single-pass scan's error word (byte 8 of its workspace), so a
- * look-back time-out rejects the optimizer step as visibly as a non-finite gradient norm does, without a host sync. */
+ * torch.nn.utils.clip_grad_norm_'s coefficient, left on the device.  `poison` (may be NULL): a device int32 that, when
+ * non-zero, makes the norm NaN and the coefficient -1, which apertis_adamw_step reads as "skip this step" - callers pass
+ * the single-pass scan's error word (byte 8 of its workspace), so a look-back time-out rejects the optimizer step
+ * visibly, without a host sync and without overwriting the parameters. */
 int apertis_clip_coef(const float *partials, int64_t n, float max_norm, float *norm_coef, const int32_t *poison,
                       void *stream);
 /* AdamW (torch.optim.AdamW's rule, decoupled decay, bias correction for `step` >= 1) on every chunk, with the gradient
- * scaled by norm_coef[1] when norm_coef != NULL.  p, m, v are updated in place; g is left as it was.  The hyper-
+ * scaled by norm_coef[1] when norm_coef != NULL (a negative coefficient: nothing is updated).  p, m, v are updated in
+ * place; g is left as it was.  The hyper-
  * parameters are doubles: the derived constants (1-beta, 1-lr*wd, lr/bias_correction) are formed in double and rounded
  * once, as the Python optimizer does. */
 int apertis_adamw_step(const void *tensors, const int32_t *chunk_tensor, const int32_t *chunk_index,

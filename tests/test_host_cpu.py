@@ -329,6 +329,10 @@ def test_prepared_weight_cache_is_identity_safe():
         calls[0] += 1
         return w.detach() * 2
     with torch.no_grad():
+        ops.cached_prep("t", (w,), make), ops.cached_prep("t", (w,), make)
+        assert calls[0] == 2 and not ops._prep_cache                     # outside a prep_cache_scope nothing is kept (round 4)
+        calls[0] = 0
+    with torch.no_grad(), ops.prep_cache_scope():
         a, b = ops.cached_prep("t", (w,), make), ops.cached_prep("t", (w,), make)
         assert a is b and calls[0] == 1
         c, d = ops.cached_prep("u", (w.unsqueeze(0),), make), ops.cached_prep("u", (w.unsqueeze(0),), make)
@@ -346,9 +350,11 @@ def test_prepared_weight_cache_is_identity_safe():
             p = torch.nn.Parameter(torch.full((4, 4), float(i)))
             assert float(ops.cached_prep("z", (p,), lambda: p.detach() * 1.0)[0, 0]) == i
             del p
-    before = calls[0]
-    ops.cached_prep("t", (w,), make)
-    assert calls[0] == before + 1                                       # gradients enabled: plain make()
+    assert not ops._prep_cache                                          # the scope dropped its entries
+    with ops.prep_cache_scope():
+        before = calls[0]
+        ops.cached_prep("t", (w,), make)
+        assert calls[0] == before + 1                                   # gradients enabled: plain make()
 
 
 def test_kernel_timer_samples_every_kth_step():
