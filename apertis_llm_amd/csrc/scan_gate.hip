@@ -840,6 +840,325 @@ decode_state_k(const float *__restrict__ dt_logits, const float *__restrict__ A_
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// LEAN forward (round 4; bf16, N = 16).  The kernels above stage tiles through LDS, walk LDS columns, hand y across a
+// transpose and synchronise a 768-thread work-group five times per 64 tokens: ~700 instructions per wave and item, 58 % of a
+// wave's life parked, two work-groups per CU (round 2-3 profiles) - their phases are a latency chain that nothing overlaps,
+// and three restructurings of that design did not move it.  Here NOTHING is staged: a lane owns FOUR consecutive channels
+// (8 bytes of a bf16 row; the Dn/4 lanes of a row cover it as one contiguous run), a wave owns one item of 64 tokens and
+// walks it token by token with the loads of the next tokens in flight (two register batches of U tokens) - every operand
+// (Bt, C, xc, z, out) is touched in its row-major place, there is no LDS, no barrier, no transpose, and a CU holds 11
+// independent waves instead of two work-groups.  The carry between chunks comes from a state pass and a prefix kernel (three
+// launches; Bt and delta are read twice - the second time from the Infinity Cache when they fit):
+//   scan_lean_state_k   per item (P, S) = (prod a, state at the end from zero)       reads delta, Bt    writes agg
+//   scan_lean_prefix_k  per (batch, four channels) the state entering every chunk     reads agg (, h0)   writes h_in
+//   scan_lean_fwd_k     replay from h_in, skip + gate                                 reads delta, Bt, C, xc, z, h_in; writes out
+// The composition order is fixed (token by token; the chunks by a fixed tree): run-to-run identical bits.
+// Measured at B = 44, L = 4096, Dn = 176 (cold caches, rocprofv3): state 19.7 + prefix 6.7 + replay 59.4 us = 90 us end to end
+// against 108-111 us for the single-pass kernel above on the same box (44.9 % against 36.6 % of the HBM peak); config 2 (Dn =
+// 224, L = 2048, B = 32) 49 against 60 us.  What was tried on the way, each measured:
+//   * the (item, four-channel group) pairs as one flat list, 64 consecutive entries per wave - every lane works (44 of 64 do
+//     at Dn = 176), 31 % fewer wave-instructions, and SLOWER (replay 77 vs 72 us, state 24 vs 23): the kernels live on the
+//     number of independent waves per CU (11 against 7.6), not on instruction issue;
+//   * load batches of 2 / 4 / 8 tokens: replay 60.3 / 61.6 / 68.6 us (registers against waves per SIMD);
+//   * the state pass's Bt loads non-temporal: the replay then re-reads Bt from HBM, 72 instead of 60 us;
+//   * the prefix composed inside the replay (every item folds the records in front of it, 31 on average): no prefix launch,
+//     but 125 MB more through L2 and up to eight dependent round trips before an item starts - replay 97 us, 117 end to end;
+//   * a thread per channel walking its 64 records in the prefix kernel: 6.7 us, the same as the wave-parallel scan below - a
+//     small kernel between two big ones costs its launch, one cold round trip and its drain whatever it computes.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef LEAN_U_
+#define LEAN_U_ 4
+#endif
+#ifndef LEAN_US_
+#define LEAN_US_ 4
+#endif
+#ifndef LEAN_NW_
+#define LEAN_NW_ 4
+#endif
+constexpr int LEAN_U = LEAN_U_, LEAN_US = LEAN_US_;   // tokens per load batch (two batches in flight): replay, state pass
+constexpr int LEAN_NW = LEAN_NW_;                     // waves per item in the state pass
+
+// Rows come through raw buffer descriptors over each tensor (slice): a lane's offset is (its item's first token, its four
+// channels) as ONE 32-bit register per tensor and the token's row term rides in the scalar offset - no per-token address
+// arithmetic at all (64-bit pointers cost the first form of these kernels 214 VGPRs).  The launcher takes this path only for
+// tensors below 4 GiB.
+typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const void *p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint2 lean_ld8(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  const lean_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 2);   // (non-temporal: read once)
+  return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ float lean_ld4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+}
+// softplus on the hardware exp2 / log2: max(x, 0) + log1p(exp(-|x|)), the log1p by the u = 1 + e trick (log(u) * e / (u - 1):
+// exact where u - 1 == e, ~1e-7 relative elsewhere) - the library log1pf(expf(x)) is ~50 instructions per (token, head)
+__device__ __forceinline__ float softplus_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(-fabsf(x) * LOG2E_F);
+  const float u = 1.f + e;
+  float r = __builtin_amdgcn_logf(u) * 0.6931471805599453f;
+  const float um1 = u - 1.f;
+  r = um1 > 0.f ? r * (e * __builtin_amdgcn_rcpf(um1)) : e;
+  return fmaxf(x, 0.f) + r;
+}
+
+// A wave takes floor(64 / g) whole items (g = Dn / 4 lanes each; ONE at Dn = 176, where 20 lanes idle - see above).
+struct LeanItem { bool ok; int b, chunk, rows, c0, hh; uint32_t tok0; };
+__device__ __forceinline__ LeanItem lean_item(const ScanDims &d, int g, int64_t items, bool reverse) {
+  LeanItem it;
+  const int ln = (int)threadIdx.x & 63, R = 64 / g, r = ln / g, q = ln - r * g;
+  const int64_t item = (int64_t)blockIdx.x * R + r;
+  it.ok = r < R && item < items;
+  const int64_t bi = it.ok ? item / d.nchunks : 0;
+  it.b = (int)bi;
+  it.chunk = it.ok ? (int)(item - bi * d.nchunks) : 0;
+  if (reverse) it.chunk = d.nchunks - 1 - it.chunk;
+  const int64_t t0 = (int64_t)it.chunk * LTG;
+  it.rows = it.ok ? (int)min((int64_t)LTG, d.L - t0) : 0;
+  it.tok0 = (uint32_t)((int64_t)it.b * d.L + t0);
+  it.c0 = 4 * q;
+  it.hh = it.c0 >> d.log2N;
+  return it;
+}
+__device__ __forceinline__ void unpack4(uint2 v, float (&f)[4]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t lean_pack2(float a, float b) {
+  typedef float f2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+  const f2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2_t));
+}
+struct LeanT { const void *p; uint32_t rs, bytes; };   // tensor (slice): base, row stride in elements, extent in bytes
+
+// delta of FOUR consecutive tokens per wave-instruction: the four lanes of a head (N = 16: a quad) would each run the same
+// softplus for the same token - instead lane i of the quad loads and transforms token t0 + i, and the per-token value is a
+// quad broadcast (one DPP move).
+template <int I> __device__ __forceinline__ float quad_bc(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_bc(float v, int i) {
+  return i == 0 ? quad_bc<0>(v) : i == 1 ? quad_bc<1>(v) : i == 2 ? quad_bc<2>(v) : quad_bc<3>(v);
+}
+
+// State pass.  NW waves share an item (LTG / NW consecutive tokens each); their aggregates meet in LDS and the last wave
+// composes them in order.
+template <int U, int NW>
+__global__ void __launch_bounds__(64 * NW)
+scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *__restrict__ agg, ScanDims d, int g, int64_t items) {
+  static_assert(U % 4 == 0 && (LTG / NW) % (2 * U) == 0, "delta comes in groups of four tokens; whole double batches per wave");
+  constexpr int TW = LTG / NW;                                  // tokens per wave
+  __shared__ float4 part[NW > 1 ? NW - 1 : 1][64][2];
+  const int wv = (int)threadIdx.x >> 6;
+  const LeanItem it = lean_item(d, g, items, false);
+  float A2[4] = {0.f, 0.f, 0.f, 0.f}, S[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
+  if (it.ok) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A2[k] = -expf(A_log[it.c0 + k]) * LOG2E_F;
+    const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rd = lean_rsrc(dl.p, dl.bytes);
+    const int qi = (int)(threadIdx.x & 3);                    // this lane's token inside a group of four
+    const uint32_t tk0 = it.tok0 + (uint32_t)(wv * TW);
+    const int rows = it.rows - wv * TW;                         // (<= 0: this wave's tokens are all past the end)
+    const uint32_t ob = (tk0 * tb_.rs + (uint32_t)it.c0) * 2u, od = ((tk0 + (uint32_t)qi) * dl.rs + (uint32_t)it.hh) * 4u;
+    uint2 vb[2][U];
+    float vd[2][U / 4];
+    const bool ragged = __any(rows < TW);
+    auto ld = [&](int s, int tb) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        // (default cache policy: the replay reads these rows again, from the Infinity Cache where they fit)
+        const lean_u2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)ob, (int)((uint32_t)(tb + u) * tb_.rs * 2u), 0);
+        vb[s][u] = make_uint2(t2[0], t2[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < U / 4; ++j) vd[s][j] = lean_ld4(rd, od, (uint32_t)(tb + 4 * j) * dl.rs * 4u);
+    };
+    auto use = [&](int s, int tb) {
+#pragma unroll
+      for (int j = 0; j < U / 4; ++j) {
+        float sp = d.softplus ? softplus_fast(vd[s][j]) : vd[s][j];
+        if (ragged) sp = tb + 4 * j + qi < rows ? sp : 0.f;       // a token past the item's end: delta 0 -> a = 1 ...
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int u = 4 * j + i;
+          const float dlv = quad_bc(sp, i);
+          float bv[4];
+          unpack4(vb[s][u], bv);
+          const bool v = !ragged || tb + u < rows;                  // ... and Bt 0: the state passes through
+          sumdl += dlv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) S[k] = fmaf(__builtin_amdgcn_exp2f(dlv * A2[k]), S[k], v ? bv[k] : 0.f);
+        }
+      }
+    };
+    ld(0, 0);
+#pragma unroll 1
+    for (int tb = 0; tb < TW; tb += 2 * U) {
+      ld(1, tb + U);
+      use(0, tb);
+      ld(0, tb + 2 * U);
+      use(1, tb + U);
+    }
+  }
+  // prod a_t = exp2(A2 * sum delta_t): one exp2 per channel instead of a multiply per token
+  float P[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) P[k] = __builtin_amdgcn_exp2f(sumdl * A2[k]);
+  if constexpr (NW > 1) {
+    const int ln = (int)threadIdx.x & 63;
+    if (wv < NW - 1) { part[wv][ln][0] = make_float4(P[0], S[0], P[1], S[1]); part[wv][ln][1] = make_float4(P[2], S[2], P[3], S[3]); }
+    __syncthreads();
+    if (wv != NW - 1) return;
+    // (P, S) of the item = the waves' aggregates composed left to right; this (last) wave holds the rightmost
+    float Pa[4] = {1.f, 1.f, 1.f, 1.f}, Sa[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w2 = 0; w2 < NW - 1; ++w2) {
+      const float4 r0 = part[w2][ln][0], r1 = part[w2][ln][1];
+      const float pw[4] = {r0.x, r0.z, r1.x, r1.z}, sw[4] = {r0.y, r0.w, r1.y, r1.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { Sa[k] = fmaf(pw[k], Sa[k], sw[k]); Pa[k] *= pw[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { S[k] = fmaf(P[k], Sa[k], S[k]); P[k] *= Pa[k]; }
+  }
+  if (!it.ok) return;
+  float4 *o = reinterpret_cast<float4 *>(agg + ((int64_t)it.b * d.nchunks + it.chunk) * d.Dn + it.c0);
+  o[0] = make_float4(P[0], S[0], P[1], S[1]);
+  o[1] = make_float4(P[2], S[2], P[3], S[3]);
+}
+
+// State entering every chunk (saved for the backward as well): h_in[b][chunk][c].  One wave per (batch, four-channel group),
+// lane = chunk: the records of (up to) 64 chunks are loaded in one round trip and composed by a log-step scan across the
+// lanes; sequences of more than 64 chunks continue block by block with the carry of the previous block.
+__global__ void __launch_bounds__(64)
+scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in, ScanDims d, int g) {
+  const int64_t b = blockIdx.x / g;
+  const int c0 = 4 * (int)(blockIdx.x - b * g), lane = (int)threadIdx.x;
+  float hc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (h0) {
+    const float4 t = *reinterpret_cast<const float4 *>(h0 + b * d.Dn + c0);
+    hc[0] = t.x; hc[1] = t.y; hc[2] = t.z; hc[3] = t.w;
+  }
+  for (int j0 = 0; j0 < d.nchunks; j0 += 64) {
+    const int j = j0 + lane;
+    const bool ok = j < d.nchunks;
+    float P[4] = {1.f, 1.f, 1.f, 1.f}, S[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+      const float4 *r = reinterpret_cast<const float4 *>(agg + (b * d.nchunks + j) * d.Dn + c0);
+      const float4 r0 = r[0], r1 = r[1];
+      P[0] = r0.x; S[0] = r0.y; P[1] = r0.z; S[1] = r0.w; P[2] = r1.x; S[2] = r1.y; P[3] = r1.z; S[3] = r1.w;
+    }
+    // inclusive scan over the lanes: after the step of distance dd a lane holds the composite of the 2*dd records ending at it
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float pl = __shfl_up(P[k], dd), sl = __shfl_up(S[k], dd);
+        if (lane >= dd) { S[k] = fmaf(P[k], sl, S[k]); P[k] *= pl; }
+      }
+    }
+    // exclusive: the composite of the records before lane's, applied to the carry
+    float hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float pe = __shfl_up(P[k], 1), se = __shfl_up(S[k], 1);
+      hv[k] = lane == 0 ? hc[k] : fmaf(pe, hc[k], se);
+    }
+    if (ok) *reinterpret_cast<float4 *>(h_in + (b * d.nchunks + j) * d.Dn + c0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hc[k] = fmaf(__shfl(P[k], 63), hc[k], __shfl(S[k], 63));
+  }
+}
+
+template <int U>
+__global__ void __launch_bounds__(64)
+scan_lean_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, LeanT tx, LeanT tz, const float *__restrict__ Dv,
+                const float *__restrict__ h_in, float *__restrict__ h_last, LeanT to, ScanDims d, int g, int64_t items) {
+  static_assert(U % 4 == 0, "delta comes in groups of four tokens");
+  const LeanItem it = lean_item(d, g, items, false);
+  if (!it.ok) return;
+  float A2[4], Dk[4], hst[4];
+  {
+    const float4 hv = *reinterpret_cast<const float4 *>(h_in + ((int64_t)it.b * d.nchunks + it.chunk) * d.Dn + it.c0);
+    hst[0] = hv.x; hst[1] = hv.y; hst[2] = hv.z; hst[3] = hv.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { A2[k] = -expf(A_log[it.c0 + k]) * LOG2E_F; Dk[k] = Dv[it.c0 + k]; }
+  const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rc = lean_rsrc(tc.p, tc.bytes), rx = lean_rsrc(tx.p, tx.bytes),
+                               rz = lean_rsrc(tz.p, tz.bytes), rd = lean_rsrc(dl.p, dl.bytes);
+  // (the output through a descriptor as well: a lane past its item's last row stores past the descriptor's end)
+  const __amdgpu_buffer_rsrc_t ro = lean_rsrc(to.p, to.bytes);
+  const int qi = (int)(threadIdx.x & 3);
+  const uint32_t c2 = (uint32_t)it.c0 * 2u;
+  const uint32_t ob = it.tok0 * tb_.rs * 2u + c2, oc = it.tok0 * tc.rs * 2u + c2, ox = it.tok0 * tx.rs * 2u + c2,
+                 oz = it.tok0 * tz.rs * 2u + c2, oo = it.tok0 * to.rs * 2u + c2,
+                 od = ((it.tok0 + (uint32_t)qi) * dl.rs + (uint32_t)it.hh) * 4u;
+  uint2 vb[2][U], vc[2][U], vx[2][U], vz[2][U];
+  float vd[2][U / 4];
+  const bool ragged = __any(it.rows < LTG);
+  auto ld = [&](int s, int tb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t t = (uint32_t)(tb + u);
+      const lean_u2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)ob, (int)(t * tb_.rs * 2u), 0);   // (the state pass left these in the caches)
+      vb[s][u] = make_uint2(t2[0], t2[1]);
+      vc[s][u] = lean_ld8(rc, oc, t * tc.rs * 2u);
+      vx[s][u] = lean_ld8(rx, ox, t * tx.rs * 2u);
+      vz[s][u] = lean_ld8(rz, oz, t * tz.rs * 2u);
+    }
+#pragma unroll
+    for (int j = 0; j < U / 4; ++j) vd[s][j] = lean_ld4(rd, od, (uint32_t)(tb + 4 * j) * dl.rs * 4u);
+  };
+  auto use = [&](int s, int tb) {
+#pragma unroll
+    for (int j = 0; j < U / 4; ++j) {
+      float sp = d.softplus ? softplus_fast(vd[s][j]) : vd[s][j];
+      if (ragged) sp = tb + 4 * j + qi < it.rows ? sp : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int u = 4 * j + i;
+        const float dlv = quad_bc(sp, i);
+        const bool v = !ragged || tb + u < it.rows;
+        float bv[4], cv[4], xv[4], zv[4], o[4];
+        unpack4(vb[s][u], bv); unpack4(vc[s][u], cv); unpack4(vx[s][u], xv); unpack4(vz[s][u], zv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = __builtin_amdgcn_exp2f(dlv * A2[k]);
+          hst[k] = fmaf(a, hst[k], v ? bv[k] : 0.f);
+          const float y = cv[k] * hst[k];
+          const float dx = Dk[k] * xv[k];
+          const float val = y + dx;
+          o[k] = val * silu_g(zv[k]);
+        }
+        const lean_u2 ov = {lean_pack2(o[0], o[1]), lean_pack2(o[2], o[3])};
+        // rows past the item's end: an offset no descriptor covers (the store is dropped)
+        __builtin_amdgcn_raw_buffer_store_b64(ov, ro, (int)(v ? oo : 0xfffffff0u), (int)((uint32_t)(tb + u) * to.rs * 2u), 2);
+      }
+    }
+  };
+  ld(0, 0);
+#pragma unroll 1
+  for (int tb = 0; tb < LTG; tb += 2 * U) {
+    ld(1, tb + U);
+    use(0, tb);
+    ld(0, tb + 2 * U);
+    use(1, tb + U);
+  }
+  if (h_last && it.chunk == d.nchunks - 1)
+    *reinterpret_cast<float4 *>(h_last + (int64_t)it.b * d.Dn + it.c0) = make_float4(hst[0], hst[1], hst[2], hst[3]);
+}
+
+// lanes per item (g); false when the lean kernels do not take the shape
+static inline bool lean_geometry(const ScanDims &d, int &g) {
+  if (d.N != 16 || d.Dn > 256) return false;   // (N = 16: the four lanes of a head are a DPP quad)
+  g = (int)(d.Dn / 4);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // channel groups per work-group: as many as cover Dn (whole rows), bounded by what the LDS tiles allow
 template <typename T> constexpr int cw_max(bool bwd) { return sizeof(T) == 2 ? (bwd ? 3 : 4) : 2; }
 template <typename T> void pick_cw(int64_t Dn, bool bwd, int &cw, int &ncs) {
@@ -991,7 +1310,7 @@ extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const
                                      float *h_in, void *ws, uint32_t epoch, int64_t B, int64_t L, int64_t h, int64_t N,
                                      int dtype, int delta_softplus, int single_pass, void *stream) {
   if (!dlt || !A_log || !Bt || !C || !xc || !z || !D || !out || !h_in) return APERTIS_ERR_ARG;
-  if (single_pass ? (!ws || epoch == 0) : !agg) return APERTIS_ERR_ARG;
+  if (single_pass == 1 ? (!ws || epoch == 0) : !agg) return APERTIS_ERR_ARG;
   FwdArgs a{dlt, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, h0, out, out_rs, h_last, agg, h_in, ws, epoch, {}, single_pass,
             (hipStream_t)stream};
   int rc = make_dims(a.d, B, L, h, N, delta_softplus);
@@ -1000,12 +1319,29 @@ extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const
   const int64_t Dn = a.d.Dn;
   if (bt_rs < Dn || c_rs < Dn || xc_rs < Dn || z_rs < Dn || out_rs < Dn) return APERTIS_ERR_ARG;
   if (dtype == APERTIS_F32) {
+    if (single_pass == 2) a.single_pass = 0;
     const int al = gate_align<float>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, Dn);
     if (al >= 16) return launch_gate_fwd<float, 16>(a);
     if (al >= 8) return launch_gate_fwd<float, 8>(a);
     return launch_gate_fwd<float, 4>(a);
   } else if (dtype == APERTIS_BF16) {
     const int al = gate_align<bf16_t>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, Dn);
+    int lg;
+    const int64_t T = B * L;
+    const bool small = (T * std::max({bt_rs, c_rs, xc_rs, z_rs, out_rs}) + Dn) * 2 < 0xfff00000LL && T * h * 4 < 0xfff00000LL;
+    if (single_pass == 2 && al >= 8 && small && lean_geometry(a.d, lg)) {   // the lean three-launch form (agg as in the two-launch form)
+      const int64_t items = B * a.d.nchunks;
+      const unsigned grid = (unsigned)ceil_div64(items, 64 / lg);
+      auto lt = [&](const void *p, int64_t rs) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + Dn) * 2)}; };
+      const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
+      hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW>), dim3(grid), dim3(64 * LEAN_NW), 0, a.st, tdl, A_log, lt(Bt, bt_rs),
+                         (float2 *)agg, a.d, lg, items);
+      hipLaunchKernelGGL(scan_lean_prefix_k, dim3((unsigned)(B * lg)), dim3(64), 0, a.st, (const float2 *)agg, h0, h_in, a.d, lg);
+      hipLaunchKernelGGL(scan_lean_fwd_k<LEAN_U>, dim3(grid), dim3(64), 0, a.st, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs), lt(xc, xc_rs),
+                         lt(z, z_rs), D, h_in, h_last, lt(out, out_rs), a.d, lg, items);
+      return apertis_check_launch();
+    }
+    if (single_pass == 2) a.single_pass = 0;   // (shapes the lean kernels do not take: the two-launch form, same buffers)
     if (al >= 16) return launch_gate_fwd<bf16_t, 16>(a);
     if (al >= 8) return launch_gate_fwd<bf16_t, 8>(a);
     if (al >= 4) return launch_gate_fwd<bf16_t, 4>(a);

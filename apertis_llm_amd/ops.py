@@ -203,6 +203,10 @@ def selective_scan(dlt, A_log, Bt, C, h0=None, delta_softplus=False, y_dtype=tor
 # ----------------------------------------------------------------------------------------------
 # APERTIS_SCAN_SINGLE_PASS=0 selects the two-launch form of the same kernels (state pass + replay; same bits)
 SCAN_SINGLE_PASS = _os.environ.get("APERTIS_SCAN_SINGLE_PASS", "1") != "0"
+# APERTIS_SCAN_LEAN=1 (round 4): the forward as three lean launches (state pass, chunk prefix, replay: a lane owns four channels
+# of a row, a wave one 64-token item, nothing staged through LDS) for the shapes those kernels take (bf16, N % 4 == 0, 8-byte
+# aligned slices); everything else, and the backward, on the forms above
+SCAN_LEAN = _os.environ.get("APERTIS_SCAN_LEAN", "0") == "1"
 _gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
 
 
@@ -290,7 +294,8 @@ class _ScanGate(torch.autograd.Function):
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
         e = xc.element_size()
         work = B * L * (5 * Dn * e + 4 * h) + 4 * h * N          # algorithmic bytes, fused variant
-        if SCAN_SINGLE_PASS:
+        fwd_mode = 2 if (SCAN_LEAN and xc.dtype == torch.bfloat16) else int(SCAN_SINGLE_PASS)
+        if fwd_mode == 1:
             ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
             agg = None
         else:
@@ -299,7 +304,7 @@ class _ScanGate(torch.autograd.Function):
         _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
                 (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
                  out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(delta_softplus),
-                 int(SCAN_SINGLE_PASS), stream_ptr()), work)
+                 fwd_mode, stream_ptr()), work)
         ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in)
         ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
         ctx.mark_non_differentiable(*([h_last] if return_last else []))
