@@ -203,10 +203,10 @@ def selective_scan(dlt, A_log, Bt, C, h0=None, delta_softplus=False, y_dtype=tor
 # ----------------------------------------------------------------------------------------------
 # APERTIS_SCAN_SINGLE_PASS=0 selects the two-launch form of the same kernels (state pass + replay; same bits)
 SCAN_SINGLE_PASS = _os.environ.get("APERTIS_SCAN_SINGLE_PASS", "1") != "0"
-# APERTIS_SCAN_LEAN=1 (round 4): the forward as three lean launches (state pass, chunk prefix, replay: a lane owns four channels
+# APERTIS_SCAN_LEAN (round 4, default on; 0 = off): the forward as three lean launches (state pass, chunk prefix, replay: a lane owns four channels
 # of a row, a wave one 64-token item, nothing staged through LDS) for the shapes those kernels take (bf16, N % 4 == 0, 8-byte
 # aligned slices); everything else, and the backward, on the forms above
-SCAN_LEAN = _os.environ.get("APERTIS_SCAN_LEAN", "0") == "1"
+SCAN_LEAN = _os.environ.get("APERTIS_SCAN_LEAN", "1") == "1"
 _gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
 
 
