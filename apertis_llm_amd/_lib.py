@@ -49,6 +49,10 @@ SIGNATURES = {
     "apertis_scan_gate_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
                                      _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _i64, _i64,
                                      _i64, _i64, _i32, _i32, _i32, _vp]),
+    "apertis_scan_lean_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                     _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_scan_lean_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
+                                     _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_ssm_decode_conv": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_ssm_decode_state": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
                                         _i32, _vp]),

@@ -131,6 +131,7 @@ __device__ __forceinline__ void stage_delta(float *dl, const float *dlt, int64_t
 struct ScanDims {
   int64_t B, L, h, N, Dn;
   int log2N, HT, nchunks, softplus;
+  int64_t nck;   // rows of the lean forward's checkpoint table per batch: ceil(L / 4)
 };
 
 // Carry entering chunk `chunk` for this lane's channel, composed from the aggregates of the
@@ -208,6 +209,7 @@ int make_dims(ScanDims &d, int64_t B, int64_t L, int64_t h, int64_t N, int softp
   d.log2N = l2; d.HT = (int)(TC / N);
   d.nchunks = (int)ceil_div64(L, LT_DEFAULT);
   d.softplus = softplus;
+  d.nck = ceil_div64(L, 4);
   if (B > 65535 || ceil_div64(d.Dn, TC) > 65535) return APERTIS_ERR_UNSUPPORTED;
   return APERTIS_OK;
 }

@@ -961,20 +961,23 @@ scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *
     const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rd = lean_rsrc(dl.p, dl.bytes);
     const int qi = (int)(threadIdx.x & 3);                    // this lane's token inside a group of four
     const uint32_t tk0 = it.tok0 + (uint32_t)(wv * TW);
-    const int rows = it.rows - wv * TW;                         // (<= 0: this wave's tokens are all past the end)
-    const uint32_t ob = (tk0 * tb_.rs + (uint32_t)it.c0) * 2u, od = ((tk0 + (uint32_t)qi) * dl.rs + (uint32_t)it.hh) * 4u;
+    const int rows = __builtin_amdgcn_readfirstlane(it.rows) - wv * TW;   // (<= 0: this wave's tokens are all past the end)
+    const uint32_t ob = (tk0 * tb_.rs + (uint32_t)it.c0) * 2u, od = (tk0 * dl.rs + (uint32_t)it.hh) * 4u;
     uint2 vb[2][U];
     float vd[2][U / 4];
-    const bool ragged = __any(rows < TW);
+    const bool ragged = rows < TW;
+    const int tlast = rows - 1;                                   // loads past the item's last row re-read that row (never used)
     auto ld = [&](int s, int tb) {
+      if (rows <= 0) return;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         // (default cache policy: the replay reads these rows again, from the Infinity Cache where they fit)
-        const lean_u2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)ob, (int)((uint32_t)(tb + u) * tb_.rs * 2u), 0);
+        const lean_u2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)ob, (int)((uint32_t)min(tb + u, tlast) * tb_.rs * 2u), 0);
         vb[s][u] = make_uint2(t2[0], t2[1]);
       }
 #pragma unroll
-      for (int j = 0; j < U / 4; ++j) vd[s][j] = lean_ld4(rd, od, (uint32_t)(tb + 4 * j) * dl.rs * 4u);
+      for (int j = 0; j < U / 4; ++j)   // (lane qi of a quad takes token tb + 4j + qi: the token rides in the lane offset here)
+        vd[s][j] = lean_ld4(rd, od + (uint32_t)min(tb + 4 * j + qi, tlast) * dl.rs * 4u, 0u);
     };
     auto use = [&](int s, int tb) {
 #pragma unroll
@@ -994,13 +997,15 @@ scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *
         }
       }
     };
-    ld(0, 0);
+    if (rows > 0) {
+      ld(0, 0);
 #pragma unroll 1
-    for (int tb = 0; tb < TW; tb += 2 * U) {
-      ld(1, tb + U);
-      use(0, tb);
-      ld(0, tb + 2 * U);
-      use(1, tb + U);
+      for (int tb = 0; tb < TW; tb += 2 * U) {
+        ld(1, tb + U);
+        use(0, tb);
+        ld(0, tb + 2 * U);
+        use(1, tb + U);
+      }
     }
   }
   // prod a_t = exp2(A2 * sum delta_t): one exp2 per channel instead of a multiply per token
@@ -1033,8 +1038,9 @@ scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *
 // State entering every chunk (saved for the backward as well): h_in[b][chunk][c].  One wave per (batch, four-channel group),
 // lane = chunk: the records of (up to) 64 chunks are loaded in one round trip and composed by a log-step scan across the
 // lanes; sequences of more than 64 chunks continue block by block with the carry of the previous block.
+// `reverse` (backward): the chunks right to left - mu entering a chunk from the right, from the reverse aggregates.
 __global__ void __launch_bounds__(64)
-scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in, ScanDims d, int g) {
+scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in, ScanDims d, int g, int reverse) {
   const int64_t b = blockIdx.x / g;
   const int c0 = 4 * (int)(blockIdx.x - b * g), lane = (int)threadIdx.x;
   float hc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1043,8 +1049,8 @@ scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0,
     hc[0] = t.x; hc[1] = t.y; hc[2] = t.z; hc[3] = t.w;
   }
   for (int j0 = 0; j0 < d.nchunks; j0 += 64) {
-    const int j = j0 + lane;
-    const bool ok = j < d.nchunks;
+    const bool ok = j0 + lane < d.nchunks;
+    const int j = reverse ? d.nchunks - 1 - (j0 + lane) : j0 + lane;
     float P[4] = {1.f, 1.f, 1.f, 1.f}, S[4] = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
       const float4 *r = reinterpret_cast<const float4 *>(agg + (b * d.nchunks + j) * d.Dn + c0);
@@ -1076,7 +1082,8 @@ scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0,
 template <int U>
 __global__ void __launch_bounds__(64)
 scan_lean_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, LeanT tx, LeanT tz, const float *__restrict__ Dv,
-                const float *__restrict__ h_in, float *__restrict__ h_last, LeanT to, ScanDims d, int g, int64_t items) {
+                const float *__restrict__ h_in, float *__restrict__ h_last, float *__restrict__ ckpt, LeanT to, ScanDims d, int g,
+                int64_t items) {
   static_assert(U % 4 == 0, "delta comes in groups of four tokens");
   const LeanItem it = lean_item(d, g, items, false);
   if (!it.ok) return;
@@ -1094,15 +1101,15 @@ scan_lean_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, 
   const int qi = (int)(threadIdx.x & 3);
   const uint32_t c2 = (uint32_t)it.c0 * 2u;
   const uint32_t ob = it.tok0 * tb_.rs * 2u + c2, oc = it.tok0 * tc.rs * 2u + c2, ox = it.tok0 * tx.rs * 2u + c2,
-                 oz = it.tok0 * tz.rs * 2u + c2, oo = it.tok0 * to.rs * 2u + c2,
-                 od = ((it.tok0 + (uint32_t)qi) * dl.rs + (uint32_t)it.hh) * 4u;
+                 oz = it.tok0 * tz.rs * 2u + c2, oo = it.tok0 * to.rs * 2u + c2, od = (it.tok0 * dl.rs + (uint32_t)it.hh) * 4u;
   uint2 vb[2][U], vc[2][U], vx[2][U], vz[2][U];
   float vd[2][U / 4];
-  const bool ragged = __any(it.rows < LTG);
+  const int rows_u = __builtin_amdgcn_readfirstlane(it.rows), tlast = rows_u - 1;
+  const bool ragged = rows_u < LTG;
   auto ld = [&](int s, int tb) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t t = (uint32_t)(tb + u);
+      const uint32_t t = (uint32_t)min(tb + u, tlast);           // (past the item's last row: that row again, never used)
       const lean_u2 t2 = __builtin_amdgcn_raw_buffer_load_b64(rb, (int)ob, (int)(t * tb_.rs * 2u), 0);   // (the state pass left these in the caches)
       vb[s][u] = make_uint2(t2[0], t2[1]);
       vc[s][u] = lean_ld8(rc, oc, t * tc.rs * 2u);
@@ -1110,13 +1117,17 @@ scan_lean_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, 
       vz[s][u] = lean_ld8(rz, oz, t * tz.rs * 2u);
     }
 #pragma unroll
-    for (int j = 0; j < U / 4; ++j) vd[s][j] = lean_ld4(rd, od, (uint32_t)(tb + 4 * j) * dl.rs * 4u);
+    for (int j = 0; j < U / 4; ++j) vd[s][j] = lean_ld4(rd, od + (uint32_t)min(tb + 4 * j + qi, tlast) * dl.rs * 4u, 0u);
   };
   auto use = [&](int s, int tb) {
 #pragma unroll
     for (int j = 0; j < U / 4; ++j) {
       float sp = d.softplus ? softplus_fast(vd[s][j]) : vd[s][j];
       if (ragged) sp = tb + 4 * j + qi < it.rows ? sp : 0.f;
+      // the state entering every fourth token, for the lean backward (which rebuilds four states at a time from it)
+      if (ckpt && tb + 4 * j < it.rows)
+        *reinterpret_cast<float4 *>(ckpt + ((int64_t)it.b * d.nck + (((int64_t)it.chunk * LTG + tb) >> 2) + j) * d.Dn + it.c0) =
+            make_float4(hst[0], hst[1], hst[2], hst[3]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int u = 4 * j + i;
@@ -1151,9 +1162,251 @@ scan_lean_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, 
     *reinterpret_cast<float4 *>(h_last + (int64_t)it.b * d.Dn + it.c0) = make_float4(hst[0], hst[1], hst[2], hst[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LEAN backward: the same geometry (lane = four channels, wave = one 64-token item, no LDS staging), three launches:
+//   scan_lean_bstate_k   per item the reverse aggregate (P, M): mu at the item's first token from zero at its end
+//                        reads delta, C, dout, z                                        writes agg
+//   scan_lean_prefix_k   (reverse) mu entering every chunk from the right               writes mu_in
+//   scan_lean_bwd_k      per item, blocks of four tokens right to left: the four states of a block are rebuilt from the state
+//                        entering it (saved by the lean forward: `ckpt`, every fourth token), then the adjoint
+//                          lambda_t = dv_t C_t + mu_{t+1},  mu_t = a_t lambda_t,   dv = dout silu(z)
+//                        emits dBt = lambda, dC = dv s, dxc = dv D, dz = dout silu'(z) (C s + D xc), d delta = sum over the head of
+//                        lambda s_{t-1} a A, and the item's partial sums of dA_log and dD (folded by colsum_kernel as before)
+//                        reads delta, Bt, C, xc, z, dout, ckpt, mu_in; writes dBt, dC, dxc, dz, d_delta, part
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  return v;
+}
+
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
+scan_lean_bstate_k(LeanT dl, const float *__restrict__ A_log, LeanT tc, LeanT tg, LeanT tz, float2 *__restrict__ agg, ScanDims d,
+                   int g, int64_t items) {
+  constexpr int TW = LTG / NW, U = 4;
+  static_assert(TW % (2 * U) == 0, "whole double batches per wave");
+  __shared__ float4 part[NW > 1 ? NW - 1 : 1][64][2];
+  const int wv = (int)threadIdx.x >> 6;
+  const LeanItem it = lean_item(d, g, items, false);
+  float A2[4] = {0.f, 0.f, 0.f, 0.f}, M[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
+  if (it.ok) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) A2[k] = -expf(A_log[it.c0 + k]) * LOG2E_F;
+    const __amdgpu_buffer_rsrc_t rc = lean_rsrc(tc.p, tc.bytes), rg = lean_rsrc(tg.p, tg.bytes), rz = lean_rsrc(tz.p, tz.bytes),
+                                 rd = lean_rsrc(dl.p, dl.bytes);
+    const int qi = (int)(threadIdx.x & 3);
+    const uint32_t tk0 = it.tok0 + (uint32_t)(wv * TW);
+    const int rows = __builtin_amdgcn_readfirstlane(it.rows) - wv * TW, tlast = rows - 1;
+    const uint32_t c2 = (uint32_t)it.c0 * 2u;
+    const uint32_t oc = tk0 * tc.rs * 2u + c2, og = tk0 * tg.rs * 2u + c2, oz = tk0 * tz.rs * 2u + c2,
+                   od = (tk0 * dl.rs + (uint32_t)it.hh) * 4u;
+    uint2 vc[2][U], vg[2][U], vz[2][U];
+    float vd[2];
+    const bool ragged = rows < TW;
+    auto ld = [&](int s, int tb) {   // tokens tb .. tb+3 (default cache policy: the adjoint pass reads them again)
+      if (tb < 0 || rows <= 0) return;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t t = (uint32_t)min(tb + u, tlast);
+        const lean_u2 a2 = __builtin_amdgcn_raw_buffer_load_b64(rc, (int)oc, (int)(t * tc.rs * 2u), 0);
+        const lean_u2 b2 = __builtin_amdgcn_raw_buffer_load_b64(rg, (int)og, (int)(t * tg.rs * 2u), 0);
+        const lean_u2 c2_ = __builtin_amdgcn_raw_buffer_load_b64(rz, (int)oz, (int)(t * tz.rs * 2u), 0);
+        vc[s][u] = make_uint2(a2[0], a2[1]); vg[s][u] = make_uint2(b2[0], b2[1]); vz[s][u] = make_uint2(c2_[0], c2_[1]);
+      }
+      vd[s] = lean_ld4(rd, od + (uint32_t)min(tb + qi, tlast) * dl.rs * 4u, 0u);
+    };
+    auto use = [&](int s, int tb) {
+      if (tb < 0 || rows <= 0) return;
+      float sp = d.softplus ? softplus_fast(vd[s]) : vd[s];
+      if (ragged) sp = tb + qi < rows ? sp : 0.f;
+#pragma unroll
+      for (int i = 3; i >= 0; --i) {                                 // right to left
+        const float dlv = quad_bc(sp, i);
+        const bool v = !ragged || tb + i < rows;
+        float cv[4], gv[4], zv[4];
+        unpack4(vc[s][i], cv); unpack4(vg[s][i], gv); unpack4(vz[s][i], zv);
+        sumdl += dlv;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float av = __builtin_amdgcn_exp2f(dlv * A2[k]);
+          const float u = v ? (gv[k] * silu_g(zv[k])) * cv[k] : 0.f;
+          M[k] = av * (u + M[k]);
+        }
+      }
+    };
+    ld(0, TW - U);
+#pragma unroll 1
+    for (int tb = TW - U; tb >= 0; tb -= 2 * U) {
+      ld(1, tb - U);
+      use(0, tb);
+      ld(0, tb - 2 * U);
+      use(1, tb - U);
+    }
+  }
+  float P[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) P[k] = __builtin_amdgcn_exp2f(sumdl * A2[k]);
+  if constexpr (NW > 1) {
+    const int ln = (int)threadIdx.x & 63;
+    if (wv > 0) { part[wv - 1][ln][0] = make_float4(P[0], M[0], P[1], M[1]); part[wv - 1][ln][1] = make_float4(P[2], M[2], P[3], M[3]); }
+    __syncthreads();
+    if (wv != 0) return;
+    // the item's (P, M) = the waves' aggregates composed right to left; this (first) wave holds the leftmost
+    float Pa[4] = {1.f, 1.f, 1.f, 1.f}, Ma[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w2 = NW - 1; w2 >= 1; --w2) {
+      const float4 r0 = part[w2 - 1][ln][0], r1 = part[w2 - 1][ln][1];
+      const float pw[4] = {r0.x, r0.z, r1.x, r1.z}, mw[4] = {r0.y, r0.w, r1.y, r1.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { Ma[k] = fmaf(pw[k], Ma[k], mw[k]); Pa[k] *= pw[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { M[k] = fmaf(P[k], Ma[k], M[k]); P[k] *= Pa[k]; }
+  }
+  if (!it.ok) return;
+  float4 *o = reinterpret_cast<float4 *>(agg + ((int64_t)it.b * d.nchunks + it.chunk) * d.Dn + it.c0);
+  o[0] = make_float4(P[0], M[0], P[1], M[1]);
+  o[1] = make_float4(P[2], M[2], P[3], M[3]);
+}
+
+__global__ void __launch_bounds__(64)
+scan_lean_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, LeanT tx, LeanT tz, LeanT tg,
+                const float *__restrict__ Dv, const float *__restrict__ ckpt, const float *__restrict__ mu_in, LeanT ob_, LeanT oc_,
+                int store_w, LeanT ox_, LeanT oz_, float *__restrict__ d_dlt, float *__restrict__ part, ScanDims d, int g,
+                int64_t items) {
+  const LeanItem it = lean_item(d, g, items, false);
+  if (!it.ok) return;
+  float A2[4], Ac[4], Dk[4], mu[4], dA[4] = {0.f, 0.f, 0.f, 0.f}, dD[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { Ac[k] = -expf(A_log[it.c0 + k]); A2[k] = Ac[k] * LOG2E_F; Dk[k] = Dv[it.c0 + k]; }
+  {
+    const float4 m = *reinterpret_cast<const float4 *>(mu_in + ((int64_t)it.b * d.nchunks + it.chunk) * d.Dn + it.c0);
+    mu[0] = m.x; mu[1] = m.y; mu[2] = m.z; mu[3] = m.w;
+  }
+  const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rc = lean_rsrc(tc.p, tc.bytes), rx = lean_rsrc(tx.p, tx.bytes),
+                               rz = lean_rsrc(tz.p, tz.bytes), rg = lean_rsrc(tg.p, tg.bytes), rd = lean_rsrc(dl.p, dl.bytes);
+  const __amdgpu_buffer_rsrc_t wb = lean_rsrc(ob_.p, ob_.bytes), wc = lean_rsrc(oc_.p, oc_.bytes), wx = lean_rsrc(ox_.p, ox_.bytes),
+                               wz = lean_rsrc(oz_.p, oz_.bytes);
+  const int qi = (int)(threadIdx.x & 3);
+  const uint32_t c2 = (uint32_t)it.c0 * 2u;
+  const uint32_t fb = it.tok0 * tb_.rs * 2u + c2, fc = it.tok0 * tc.rs * 2u + c2, fx = it.tok0 * tx.rs * 2u + c2,
+                 fz = it.tok0 * tz.rs * 2u + c2, fg = it.tok0 * tg.rs * 2u + c2, fd = (it.tok0 * dl.rs + (uint32_t)it.hh) * 4u;
+  const uint32_t sb = it.tok0 * ob_.rs * 2u + c2, sc = it.tok0 * oc_.rs * 2u + c2, sx = it.tok0 * ox_.rs * 2u + c2,
+                 sz = it.tok0 * oz_.rs * 2u + c2;
+  // the pad columns [Dn, store_w) of dBt / dC receive zeros (the padded slices of the projection output's gradient): the
+  // first (store_w - Dn) / 4 lanes of the item write them
+  const int npad = (store_w - (int)d.Dn) >> 2, q = it.c0 >> 2;
+  const uint32_t pz = (uint32_t)(d.Dn + 4 * q) * 2u;
+  const float *ck = ckpt + ((int64_t)it.b * d.nck + (((int64_t)it.chunk * LTG) >> 2)) * d.Dn + it.c0;
+  float *ddp = d_dlt + ((int64_t)it.tok0 + qi) * d.h + it.hh;   // (+ tb * h per block)
+  const int rows_u = __builtin_amdgcn_readfirstlane(it.rows), tlast = rows_u - 1;
+  const bool ragged = rows_u < LTG;
+  constexpr int U = 4;
+  uint2 vb[2][U], vc[2][U], vx[2][U], vz[2][U], vg[2][U];
+  float vd[2];
+  float4 vk[2];
+  auto ld = [&](int s, int tb) {
+    if (tb < 0 || tb >= rows_u) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t t = (uint32_t)min(tb + u, tlast);
+      vb[s][u] = lean_ld8(rb, fb, t * tb_.rs * 2u);
+      vc[s][u] = lean_ld8(rc, fc, t * tc.rs * 2u);
+      vx[s][u] = lean_ld8(rx, fx, t * tx.rs * 2u);
+      vz[s][u] = lean_ld8(rz, fz, t * tz.rs * 2u);
+      vg[s][u] = lean_ld8(rg, fg, t * tg.rs * 2u);
+    }
+    vd[s] = lean_ld4(rd, fd + (uint32_t)min(tb + qi, tlast) * dl.rs * 4u, 0u);
+    vk[s] = *reinterpret_cast<const float4 *>(ck + (int64_t)(tb >> 2) * d.Dn);
+  };
+  auto use = [&](int s, int tb) {
+    if (tb < 0 || tb >= rows_u) return;
+    const float spx = d.softplus ? softplus_fast(vd[s]) : vd[s];
+    const float sp = (ragged && tb + qi >= it.rows) ? 0.f : spx;
+    // the four states of the block from the state entering it
+    float hs[4][4], hin[4] = {vk[s].x, vk[s].y, vk[s].z, vk[s].w}, dlv[4];
+    {
+      float hc[4] = {hin[0], hin[1], hin[2], hin[3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dlv[i] = quad_bc(sp, i);
+        float bv[4];
+        unpack4(vb[s][i], bv);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hc[k] = fmaf(__builtin_amdgcn_exp2f(dlv[i] * A2[k]), hc[k], bv[k]); hs[i][k] = hc[k]; }
+      }
+    }
+    float ddl_keep = 0.f;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      const bool v = !ragged || tb + i < it.rows;
+      float cv[4], xv[4], zv[4], gv[4], oB[4], oC[4], oX[4], oZ[4];
+      unpack4(vc[s][i], cv); unpack4(vx[s][i], xv); unpack4(vz[s][i], zv); unpack4(vg[s][i], gv);
+      float qs = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float av = __builtin_amdgcn_exp2f(dlv[i] * A2[k]);
+        float f, df;
+        silu_both(zv[k], f, df);
+        const float dv = gv[k] * f;
+        const float lam = fmaf(dv, cv[k], mu[k]);
+        const float hprev = i > 0 ? hs[i - 1][k] : hin[k];
+        const float qq = lam * hprev * av * Ac[k];                 // da_t * a_t * A
+        const float y = cv[k] * hs[i][k];
+        const float dx = Dk[k] * xv[k];
+        const float val = y + dx;
+        oB[k] = lam;
+        oC[k] = dv * hs[i][k];
+        oX[k] = dv * Dk[k];
+        oZ[k] = gv[k] * df * val;
+        if (v) {
+          dA[k] = fmaf(qq, dlv[i], dA[k]);
+          dD[k] = fmaf(dv, xv[k], dD[k]);
+          qs += qq;
+          mu[k] = av * lam;
+        }
+      }
+      const uint32_t t = (uint32_t)(tb + i);
+      const uint32_t bad = 0xfffffff0u;
+      const lean_u2 wB = {lean_pack2(oB[0], oB[1]), lean_pack2(oB[2], oB[3])}, wC = {lean_pack2(oC[0], oC[1]), lean_pack2(oC[2], oC[3])},
+                    wX = {lean_pack2(oX[0], oX[1]), lean_pack2(oX[2], oX[3])}, wZ = {lean_pack2(oZ[0], oZ[1]), lean_pack2(oZ[2], oZ[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(wB, wb, (int)(v ? sb : bad), (int)(t * ob_.rs * 2u), 2);
+      __builtin_amdgcn_raw_buffer_store_b64(wC, wc, (int)(v ? sc : bad), (int)(t * oc_.rs * 2u), 2);
+      __builtin_amdgcn_raw_buffer_store_b64(wX, wx, (int)(v ? sx : bad), (int)(t * ox_.rs * 2u), 2);
+      __builtin_amdgcn_raw_buffer_store_b64(wZ, wz, (int)(v ? sz : bad), (int)(t * oz_.rs * 2u), 2);
+      if (q < npad) {
+        const lean_u2 zz = {0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b64(zz, wb, (int)(v ? it.tok0 * ob_.rs * 2u + pz : bad), (int)(t * ob_.rs * 2u), 2);
+        __builtin_amdgcn_raw_buffer_store_b64(zz, wc, (int)(v ? it.tok0 * oc_.rs * 2u + pz : bad), (int)(t * oc_.rs * 2u), 2);
+      }
+      // d delta of the head: the quad's 16 channels; token tb+i's value parks in lane i of the quad, one store per block
+      float dq = quad_sum(qs);
+      if (d.softplus) dq *= 1.f - __builtin_amdgcn_exp2f(-dlv[i] * LOG2E_F);      // sigmoid(x) = 1 - exp(-softplus(x))
+      if (qi == i) ddl_keep = dq;
+    }
+    if (tb + qi < it.rows) ddp[(int64_t)tb * d.h] = ddl_keep;
+  };
+  ld(0, LTG - U);
+#pragma unroll 1
+  for (int tb = LTG - U; tb >= 0; tb -= 2 * U) {
+    ld(1, tb - U);
+    use(0, tb);
+    ld(0, tb - 2 * U);
+    use(1, tb - U);
+  }
+  float4 *po = reinterpret_cast<float4 *>(part + (((int64_t)it.b * d.nchunks + it.chunk) * 2) * d.Dn + it.c0);
+  po[0] = make_float4(dA[0], dA[1], dA[2], dA[3]);
+  *reinterpret_cast<float4 *>(part + (((int64_t)it.b * d.nchunks + it.chunk) * 2 + 1) * d.Dn + it.c0) = make_float4(dD[0], dD[1], dD[2], dD[3]);
+}
+
 // lanes per item (g); false when the lean kernels do not take the shape
 static inline bool lean_geometry(const ScanDims &d, int &g) {
-  if (d.N != 16 || d.Dn > 256) return false;   // (N = 16: the four lanes of a head are a DPP quad)
+  // N = 16: the four lanes of a head are a DPP quad.  128 < Dn <= 256: ONE item per wave, so the item's row count is
+  // wave-uniform and the token index of a load can be clamped to the item's last row in a scalar register (the hardware range
+  // check covers a lane's offset, not the scalar row term: an unclamped prefetch past the tensor's last row would read
+  // unowned memory).  Narrower models (Dn = 64) stay on the staged kernels, which are faster there anyway (32 vs 35 us).
+  if (d.N != 16 || d.Dn > 256 || d.Dn <= 128) return false;
   g = (int)(d.Dn / 4);
   return true;
 }
@@ -1310,7 +1563,7 @@ extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const
                                      float *h_in, void *ws, uint32_t epoch, int64_t B, int64_t L, int64_t h, int64_t N,
                                      int dtype, int delta_softplus, int single_pass, void *stream) {
   if (!dlt || !A_log || !Bt || !C || !xc || !z || !D || !out || !h_in) return APERTIS_ERR_ARG;
-  if (single_pass == 1 ? (!ws || epoch == 0) : !agg) return APERTIS_ERR_ARG;
+  if (single_pass ? (!ws || epoch == 0) : !agg) return APERTIS_ERR_ARG;
   FwdArgs a{dlt, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, h0, out, out_rs, h_last, agg, h_in, ws, epoch, {}, single_pass,
             (hipStream_t)stream};
   int rc = make_dims(a.d, B, L, h, N, delta_softplus);
@@ -1319,29 +1572,12 @@ extern "C" int apertis_scan_gate_fwd(const float *dlt, const float *A_log, const
   const int64_t Dn = a.d.Dn;
   if (bt_rs < Dn || c_rs < Dn || xc_rs < Dn || z_rs < Dn || out_rs < Dn) return APERTIS_ERR_ARG;
   if (dtype == APERTIS_F32) {
-    if (single_pass == 2) a.single_pass = 0;
     const int al = gate_align<float>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, Dn);
     if (al >= 16) return launch_gate_fwd<float, 16>(a);
     if (al >= 8) return launch_gate_fwd<float, 8>(a);
     return launch_gate_fwd<float, 4>(a);
   } else if (dtype == APERTIS_BF16) {
     const int al = gate_align<bf16_t>({{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, Dn);
-    int lg;
-    const int64_t T = B * L;
-    const bool small = (T * std::max({bt_rs, c_rs, xc_rs, z_rs, out_rs}) + Dn) * 2 < 0xfff00000LL && T * h * 4 < 0xfff00000LL;
-    if (single_pass == 2 && al >= 8 && small && lean_geometry(a.d, lg)) {   // the lean three-launch form (agg as in the two-launch form)
-      const int64_t items = B * a.d.nchunks;
-      const unsigned grid = (unsigned)ceil_div64(items, 64 / lg);
-      auto lt = [&](const void *p, int64_t rs) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + Dn) * 2)}; };
-      const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
-      hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW>), dim3(grid), dim3(64 * LEAN_NW), 0, a.st, tdl, A_log, lt(Bt, bt_rs),
-                         (float2 *)agg, a.d, lg, items);
-      hipLaunchKernelGGL(scan_lean_prefix_k, dim3((unsigned)(B * lg)), dim3(64), 0, a.st, (const float2 *)agg, h0, h_in, a.d, lg);
-      hipLaunchKernelGGL(scan_lean_fwd_k<LEAN_U>, dim3(grid), dim3(64), 0, a.st, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs), lt(xc, xc_rs),
-                         lt(z, z_rs), D, h_in, h_last, lt(out, out_rs), a.d, lg, items);
-      return apertis_check_launch();
-    }
-    if (single_pass == 2) a.single_pass = 0;   // (shapes the lean kernels do not take: the two-launch form, same buffers)
     if (al >= 16) return launch_gate_fwd<bf16_t, 16>(a);
     if (al >= 8) return launch_gate_fwd<bf16_t, 8>(a);
     if (al >= 4) return launch_gate_fwd<bf16_t, 4>(a);
@@ -1385,6 +1621,91 @@ extern "C" int apertis_scan_gate_bwd(const float *dlt, const float *A_log, const
     return launch_gate_bwd<bf16_t, 2>(a);
   }
   return APERTIS_ERR_UNSUPPORTED;
+}
+
+// ---- lean forms (bf16, N = 16, 128 < Dn <= 256, 8-byte aligned slices, tensors below 4 GiB): APERTIS_ERR_UNSUPPORTED otherwise,
+// the caller then takes apertis_scan_gate_fwd / _bwd ----
+namespace {
+struct LeanShape { ScanDims d; int g; int64_t T, items; };
+int lean_shape(LeanShape &s, int64_t B, int64_t L, int64_t h, int64_t N, int softplus,
+               std::initializer_list<std::pair<const void *, int64_t>> slices, int64_t width_max) {
+  int rc = make_dims(s.d, B, L, h, N, softplus);
+  if (rc) return rc;
+  s.d.nchunks = (int)ceil_div64(L, LTG);
+  if (!lean_geometry(s.d, s.g)) return APERTIS_ERR_UNSUPPORTED;
+  s.T = B * L;
+  s.items = B * s.d.nchunks;
+  int64_t rs_max = 0;
+  for (auto &sl : slices) {
+    if (sl.second < s.d.Dn) return APERTIS_ERR_ARG;
+    if ((((uintptr_t)sl.first) | (uint64_t)(sl.second * 2)) & 7) return APERTIS_ERR_UNSUPPORTED;
+    rs_max = std::max(rs_max, sl.second);
+  }
+  if ((s.T * rs_max + width_max) * 2 >= 0xfff00000LL || s.T * h * 4 >= 0xfff00000LL) return APERTIS_ERR_UNSUPPORTED;
+  return APERTIS_OK;
+}
+}  // namespace
+
+extern "C" int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                                     const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
+                                     void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B,
+                                     int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream) {
+  if (!dlt || !A_log || !Bt || !C || !xc || !z || !D || !out || !h_in || !agg) return APERTIS_ERR_ARG;
+  LeanShape s;
+  int rc = lean_shape(s, B, L, h, N, delta_softplus, {{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, h * N);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t Dn = s.d.Dn, T = s.T;
+  auto lt = [&](const void *p, int64_t rs) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + Dn) * 2)}; };
+  const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
+  const unsigned grid = (unsigned)s.items;
+  hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW>), dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, lt(Bt, bt_rs),
+                     (float2 *)agg, s.d, s.g, s.items);
+  hipLaunchKernelGGL(scan_lean_prefix_k, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, h0, h_in, s.d, s.g, 0);
+  hipLaunchKernelGGL(scan_lean_fwd_k<LEAN_U>, dim3(grid), dim3(64), 0, st, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs), lt(xc, xc_rs),
+                     lt(z, z_rs), D, h_in, h_last, ckpt, lt(out, out_rs), s.d, s.g, s.items);
+  return apertis_check_launch();
+}
+
+extern "C" int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                                     const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const void *dout,
+                                     int64_t dout_rs, const float *ckpt, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs,
+                                     int64_t store_w, void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD,
+                                     float *agg, float *mu_in, float *fold, float *part, int64_t B, int64_t L, int64_t h, int64_t N,
+                                     int delta_softplus, void *stream) {
+  if (!dlt || !A_log || !Bt || !C || !xc || !z || !D || !dout || !ckpt || !dBt || !dC || !dxc || !dz || !d_dlt || !dA_dD || !agg ||
+      !mu_in || !fold || !part)
+    return APERTIS_ERR_ARG;
+  LeanShape s;
+  int rc = lean_shape(s, B, L, h, N, delta_softplus,
+                      {{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {dout, dout_rs}, {dxc, dxc_rs}, {dz, dz_rs}, {dBt, dbt_rs}, {dC, dc_rs}},
+                      store_w);
+  if (rc) return rc;
+  const int64_t Dn = s.d.Dn, T = s.T;
+  if (store_w < Dn || store_w > ceil_div64(Dn, TC) * TC || store_w % 4 || dbt_rs < store_w || dc_rs < store_w) return APERTIS_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  auto lt = [&](const void *p, int64_t rs, int64_t w) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + w) * 2)}; };
+  const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
+  const unsigned grid = (unsigned)s.items;
+  hipLaunchKernelGGL(scan_lean_bstate_k<LEAN_NW>, dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, lt(C, c_rs, Dn), lt(dout, dout_rs, Dn),
+                     lt(z, z_rs, Dn), (float2 *)agg, s.d, s.g, s.items);
+  hipLaunchKernelGGL(scan_lean_prefix_k, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, (const float *)nullptr, mu_in,
+                     s.d, s.g, 1);
+  hipLaunchKernelGGL(scan_lean_bwd_k, dim3(grid), dim3(64), 0, st, tdl, A_log, lt(Bt, bt_rs, Dn), lt(C, c_rs, Dn), lt(xc, xc_rs, Dn),
+                     lt(z, z_rs, Dn), lt(dout, dout_rs, Dn), D, ckpt, mu_in, lt(dBt, dbt_rs, store_w), lt(dC, dc_rs, store_w), (int)store_w,
+                     lt(dxc, dxc_rs, Dn), lt(dz, dz_rs, Dn), d_dlt, part, s.d, s.g, s.items);
+  // fold the per-chunk partials [rows][2*Dn] (dA_log | dD) in a fixed order, two levels (as apertis_scan_gate_bwd does)
+  const int64_t rows = s.d.B * s.d.nchunks, cols = 2 * Dn;
+  const unsigned ctl = (unsigned)ceil_div64(cols, TC);
+  if (rows <= 128) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctl), dim3(1024), 0, st, part, dA_dD, rows, cols, rows);
+  } else {
+    const int64_t groups = std::min<int64_t>(64, ceil_div64(rows, 64)), rpg = ceil_div64(rows, groups);
+    const int64_t ng = ceil_div64(rows, rpg);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctl, (unsigned)ng), dim3(1024), 0, st, part, fold, rows, cols, rpg);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ctl), dim3(1024), 0, st, fold, dA_dD, ng, cols, ng);
+  }
+  return apertis_check_launch();
 }
 
 extern "C" int apertis_ssm_decode_conv(const void *xp, int64_t xp_rs, const void *conv_state, void *conv_state_out,

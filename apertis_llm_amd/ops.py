@@ -203,10 +203,11 @@ def selective_scan(dlt, A_log, Bt, C, h0=None, delta_softplus=False, y_dtype=tor
 # ----------------------------------------------------------------------------------------------
 # APERTIS_SCAN_SINGLE_PASS=0 selects the two-launch form of the same kernels (state pass + replay; same bits)
 SCAN_SINGLE_PASS = _os.environ.get("APERTIS_SCAN_SINGLE_PASS", "1") != "0"
-# APERTIS_SCAN_LEAN (round 4, default on; 0 = off): the forward as three lean launches (state pass, chunk prefix, replay: a lane owns four channels
-# of a row, a wave one 64-token item, nothing staged through LDS) for the shapes those kernels take (bf16, N % 4 == 0, 8-byte
-# aligned slices); everything else, and the backward, on the forms above
+# APERTIS_SCAN_LEAN (round 4, default on; 0 = off): three lean launches per direction (state pass, chunk prefix, replay: a lane
+# owns four channels of a row, a wave one 64-token item, nothing staged through LDS) for the shapes those kernels take (bf16,
+# N = 16, 128 < Dn <= 256, 8-byte aligned slices); everything else on the forms above
 SCAN_LEAN = _os.environ.get("APERTIS_SCAN_LEAN", "1") == "1"
+SCAN_LEAN_BWD = _os.environ.get("APERTIS_SCAN_LEAN_BWD", "1") == "1"   # ... and the backward, from the lean forward's checkpoints
 _gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
 
 
@@ -294,18 +295,30 @@ class _ScanGate(torch.autograd.Function):
         h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
         e = xc.element_size()
         work = B * L * (5 * Dn * e + 4 * h) + 4 * h * N          # algorithmic bytes, fused variant
-        fwd_mode = 2 if (SCAN_LEAN and xc.dtype == torch.bfloat16) else int(SCAN_SINGLE_PASS)
-        if fwd_mode == 1:
-            ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
-            agg = None
-        else:
-            ws, epoch = None, 0
+        # the lean form where it takes the shape (bf16, N = 16, 128 < Dn <= 256): timed under the same name - the same op
+        ckpt, lean = None, False
+        if SCAN_LEAN and xc.dtype == torch.bfloat16 and N == 16 and 128 < Dn <= 256:
             agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
-        _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
-                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
-                 out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(delta_softplus),
-                 fwd_mode, stream_ptr()), work)
-        ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in)
+            need_grad = any(ctx.needs_input_grad[:7])
+            ckpt = torch.empty(B, -(-L // 4), Dn, device=dev, dtype=torch.float32) if need_grad else None
+            rc = []
+            _launch("apertis_scan_gate_fwd", lambda *a: rc.append(lib.apertis_scan_lean_fwd(*a)) or (0 if rc[-1] == -2 else rc[-1]),
+                    (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
+                     out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ckpt), B, L, h, N, int(delta_softplus), stream_ptr()), work)
+            lean = rc[-1] == 0                       # (-2 = APERTIS_ERR_UNSUPPORTED: alignment / size - the staged kernels below)
+        if not lean:
+            ckpt = None
+            if SCAN_SINGLE_PASS:
+                ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
+                agg = None
+            else:
+                ws, epoch = None, 0
+                agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+            _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
+                    (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
+                     out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc),
+                     int(delta_softplus), int(SCAN_SINGLE_PASS), stream_ptr()), work)
+        ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt)
         ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
         ctx.mark_non_differentiable(*([h_last] if return_last else []))
         return (out, h_last) if return_last else out
@@ -313,7 +326,7 @@ class _ScanGate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         lib = _lib.load()
-        dlt, A_log, Bt, C, xc, z, Df, h_in = ctx.saved_tensors
+        dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt = ctx.saved_tensors
         B, L, h, N, sp, wB, Ddt = ctx.cfg
         Dn = h * N
         dev = dlt.device
@@ -329,6 +342,16 @@ class _ScanGate(torch.autograd.Function):
         fold = torch.empty(64, 2 * Dn, device=dev, dtype=torch.float32)
         e = xc.element_size()
         work = B * L * (9 * Dn * e + 8 * h) + 8 * h * N          # algorithmic bytes, fused variant
+        if ckpt is not None and SCAN_LEAN_BWD:       # the lean forward left its checkpoints: the lean backward
+            agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+            mu_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
+            rc = []
+            _launch("apertis_scan_gate_bwd", lambda *a: rc.append(lib.apertis_scan_lean_bwd(*a)) or (0 if rc[-1] == -2 else rc[-1]),
+                    (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
+                     ptr(Df), ptr(dout), do_rs, ptr(ckpt), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
+                     ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(mu_in), ptr(fold), ptr(part), B, L, h, N, int(sp), stream_ptr()), work)
+            if rc[-1] == 0:
+                return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt), None, None, None
         if SCAN_SINGLE_PASS:
             ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
             agg = None

@@ -155,6 +155,22 @@ int apertis_scan_gate_bwd(const float *dlt, const float *A_log, const void *Bt, 
                           float *agg, float *fold, float *part, void *ws, uint32_t epoch, int64_t B, int64_t L, int64_t h,
                           int64_t N, int dtype, int delta_softplus, int single_pass, void *stream);
 
+/* Lean forms of the fused scan + gate (round 4; reference core.py:337-353,394-397; csrc/scan_gate.hip "LEAN"): a lane owns four
+ * channels of a row, a wave one 64-token item, nothing is staged through LDS; state pass + chunk prefix + replay as three
+ * launches per direction.  Shapes taken: bf16, N = 16, 128 < h*N <= 256, row strides and pointers multiples of 8 bytes, every
+ * tensor below 4 GiB - APERTIS_ERR_UNSUPPORTED otherwise (the caller then uses apertis_scan_gate_fwd / _bwd, whose buffers
+ * `h_in` / `h_last` mean the same).  Scratch is the caller's: agg [B, nchunks, h*N, 2] fp32 and, backward, mu_in [B, nchunks,
+ * h*N] fp32, fold / part as for apertis_scan_gate_bwd.  `ckpt` [B, ceil(L/4), h*N] fp32 (forward: may be NULL) receives the
+ * state entering every fourth token; the lean backward rebuilds its states from it and REQUIRES the one its forward wrote. */
+int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                          const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0, void *out,
+                          int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B, int64_t L, int64_t h,
+                          int64_t N, int delta_softplus, void *stream);
+int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                          const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const void *dout,
+                          int64_t dout_rs, const float *ckpt, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs, int64_t store_w,
+                          void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD, float *agg, float *mu_in,
+                          float *fold, float *part, int64_t B, int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream);
 /* Single-token decode step of the SSM block (core.py:364-400 with L = 1 and a cache, called from generate()
  * core.py:1578-1603), two kernels around the caller's x_param_proj / dt projections:
  *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the
