@@ -1387,6 +1387,10 @@ scan_lean_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, 
     }
     if (tb + qi < it.rows) ddp[(int64_t)tb * d.h] = ddl_keep;
   };
+#ifndef LEAN_BWD_DB
+#define LEAN_BWD_DB 0
+#endif
+#if LEAN_BWD_DB   // two blocks' loads in flight: 209 VGPRs = two waves per SIMD = 8 of a CU's 11 items resident (measured: 133 us)
   ld(0, LTG - U);
 #pragma unroll 1
   for (int tb = LTG - U; tb >= 0; tb -= 2 * U) {
@@ -1395,6 +1399,13 @@ scan_lean_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, 
     ld(0, tb - 2 * U);
     use(1, tb - U);
   }
+#else             // one block at a time, three waves per SIMD: every item of a CU resident at once, the waves cover each other
+#pragma unroll 1
+  for (int tb = LTG - U; tb >= 0; tb -= U) {
+    ld(0, tb);
+    use(0, tb);
+  }
+#endif
   float4 *po = reinterpret_cast<float4 *>(part + (((int64_t)it.b * d.nchunks + it.chunk) * 2) * d.Dn + it.c0);
   po[0] = make_float4(dA[0], dA[1], dA[2], dA[3]);
   *reinterpret_cast<float4 *>(part + (((int64_t)it.b * d.nchunks + it.chunk) * 2 + 1) * d.Dn + it.c0) = make_float4(dD[0], dD[1], dD[2], dD[3]);
