@@ -1038,9 +1038,12 @@ scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *
 // State entering every chunk (saved for the backward as well): h_in[b][chunk][c].  One wave per (batch, four-channel group),
 // lane = chunk: the records of (up to) 64 chunks are loaded in one round trip and composed by a log-step scan across the
 // lanes; sequences of more than 64 chunks continue block by block with the carry of the previous block.
-// `reverse` (backward): the chunks right to left - mu entering a chunk from the right, from the reverse aggregates.
+// REVERSE (backward): the chunks right to left - mu entering a chunk from the right, from the reverse aggregates.  (A template
+// parameter so that the two uses have two kernel names in a trace.)
+template <bool REVERSE>
 __global__ void __launch_bounds__(64)
-scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in, ScanDims d, int g, int reverse) {
+scan_lean_prefix_k(const float2 *__restrict__ agg, const float *__restrict__ h0, float *__restrict__ h_in, ScanDims d, int g) {
+  constexpr bool reverse = REVERSE;
   const int64_t b = blockIdx.x / g;
   const int c0 = 4 * (int)(blockIdx.x - b * g), lane = (int)threadIdx.x;
   float hc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1672,7 +1675,7 @@ extern "C" int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const
   const unsigned grid = (unsigned)s.items;
   hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW>), dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, lt(Bt, bt_rs),
                      (float2 *)agg, s.d, s.g, s.items);
-  hipLaunchKernelGGL(scan_lean_prefix_k, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, h0, h_in, s.d, s.g, 0);
+  hipLaunchKernelGGL(scan_lean_prefix_k<false>, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, h0, h_in, s.d, s.g);
   hipLaunchKernelGGL(scan_lean_fwd_k<LEAN_U>, dim3(grid), dim3(64), 0, st, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs), lt(xc, xc_rs),
                      lt(z, z_rs), D, h_in, h_last, ckpt, lt(out, out_rs), s.d, s.g, s.items);
   return apertis_check_launch();
@@ -1700,8 +1703,8 @@ extern "C" int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const
   const unsigned grid = (unsigned)s.items;
   hipLaunchKernelGGL(scan_lean_bstate_k<LEAN_NW>, dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, lt(C, c_rs, Dn), lt(dout, dout_rs, Dn),
                      lt(z, z_rs, Dn), (float2 *)agg, s.d, s.g, s.items);
-  hipLaunchKernelGGL(scan_lean_prefix_k, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, (const float *)nullptr, mu_in,
-                     s.d, s.g, 1);
+  hipLaunchKernelGGL(scan_lean_prefix_k<true>, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, (const float *)nullptr,
+                     mu_in, s.d, s.g);
   hipLaunchKernelGGL(scan_lean_bwd_k, dim3(grid), dim3(64), 0, st, tdl, A_log, lt(Bt, bt_rs, Dn), lt(C, c_rs, Dn), lt(xc, xc_rs, Dn),
                      lt(z, z_rs, Dn), lt(dout, dout_rs, Dn), D, ckpt, mu_in, lt(dBt, dbt_rs, store_w), lt(dC, dc_rs, store_w), (int)store_w,
                      lt(dxc, dxc_rs, Dn), lt(dz, dz_rs, Dn), d_dlt, part, s.d, s.g, s.items);

@@ -341,12 +341,30 @@ def main():
         # HBM traffic per call from the committed rocprofv3 --pmc passes of the same launches
         # (tools/run_pmc.sh benchmix -> profiles/r2_pmc_traffic_*.json); only valid for the workload
         # those passes were taken on, else null
-        traffic = {}
-        tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic_{args.config}_b{B}.json") for r in (3, 2, 1))
+        traffic, traffic_source = {}, None
+        tf = next((f for f in (os.path.join(ROOT, "profiles", f"r{r}_pmc_traffic_{args.config}_b{B}.json") for r in (6, 5, 4, 3, 2, 1))
                    if os.path.exists(f)), "")
         if os.path.exists(tf):
+            import hashlib
             with open(tf) as fh:
-                traffic = {k: v.get("traffic_bytes_per_call") for k, v in json.load(fh).items()}
+                tj = json.load(fh)
+            # the counters were taken on particular kernel sources (tools/pmc_traffic.py records their hashes): with other
+            # sources in the tree the field is null - a number from an older kernel is not this run's traffic
+            want = (tj.get("_source") or {}).get("kernel_source_sha16") or {}
+            have = {}
+            for f in want:
+                try:
+                    with open(os.path.join(ROOT, "apertis_llm_amd", "csrc", f), "rb") as fh:
+                        have[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
+                except OSError:
+                    have[f] = None
+            if want and want == have:
+                traffic = {k: v.get("traffic_bytes_per_call") for k, v in tj.items() if not k.startswith("_")}
+                traffic_source = {"file": os.path.relpath(tf, ROOT), "kernel_source_sha16": want}
+            else:
+                traffic_source = {"file": os.path.relpath(tf, ROOT), "stale": True,
+                                  "note": "taken on other kernel sources than this tree's: traffic is null"}
+        result["traffic_source"] = traffic_source
         for name, d in summ.items():
             if not d["launches"]:
                 continue
@@ -362,6 +380,21 @@ def main():
                 rl[name] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(name), "launches": d["launches"], "avg_ms": avg_ms,
                             "total_ms": d["ms"]}
+        # The expert GEMMs ALSO priced on their bytes (on the H = 256 family they are byte-bound - 114 flop per byte
+        # against the chip's 312 - and the MFMA fraction alone says little there).  Algorithmic bytes per routed row over the four
+        # NT calls of a layer: fc1 forward reads X and writes h and g' (2(H + 2I)), fc2 forward 2(I + H), the fused fc2 data
+        # gradient reads dy and g' and writes dpre (2(H + 2I)), fc1 data gradient 2(I + H); + the bf16 weights once per call.
+        # The weight-gradient pair reads dy, h, dpre, X once (2(2H + 2I) per row) and writes both fp32 gradients.
+        if moe:
+            H_, I_, E_ = cfg.hidden_size, cfg.intermediate_size, cfg.num_experts
+            for name, per_row, fixed, flop_row in (("apertis_grouped_gemm_nt", 2.0 * (4 * H_ + 6 * I_) / 4, 2.0 * E_ * I_ * H_, 2.0 * I_ * H_),
+                                                   ("apertis_grouped_gemm_tn", 2.0 * (2 * H_ + 2 * I_), 8.0 * E_ * I_ * H_, 4.0 * I_ * H_)):
+                if name in rl and rl[name]["launches"]:
+                    rows = summ[name]["work"] / summ[name]["launches"] / flop_row          # routed rows per launch (from the flops)
+                    nbytes = rows * per_row + fixed
+                    gbps = nbytes / (rl[name]["avg_ms"] * 1e-3) / 1e9
+                    rl[name]["hbm_bound"] = {"bytes_per_launch": nbytes, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": gbps / HBM_PEAK_GBS, "flop_per_byte": flop_row * rows / nbytes}
         # the SSM block's dense projections are narrow (N, K <= 704: 88 - 235 flop per byte against the chip's 312): their
         # bound is HBM, so each shape is ALSO priced on its algorithmic bytes (X once, Y once, W once; weight gradient: both
         # operands once + the split-K partials)

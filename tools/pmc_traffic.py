@@ -14,12 +14,17 @@ ENTRY = {  # kernel-name fragment -> C-ABI entry point
     "grouped_gemm_nt256p_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_nt352p_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_nt2x_k": "apertis_grouped_gemm_nt",
+    "grouped_gemm_nt4r_k": "apertis_grouped_gemm_nt",
     "grouped_gemm_tn3_k": "apertis_grouped_gemm_tn", "tn3_fold_k": "apertis_grouped_gemm_tn",
     "grouped_gemm_tn5_k": "apertis_grouped_gemm_tn", "tn5_fold_k": "apertis_grouped_gemm_tn",
     "grouped_gemm_tn2_k": "apertis_grouped_gemm_tn",
     "scan_fwd_state": "apertis_selective_scan_fwd", "scan_fwd_replay": "apertis_selective_scan_fwd",
     "scan_bwd_state": "apertis_selective_scan_bwd", "scan_bwd_replay": "apertis_selective_scan_bwd",
     "scan_gate_fwd_k": "apertis_scan_gate_fwd", "scan_gate_bwd_k": "apertis_scan_gate_bwd",
+    "scan_lean_state_k": "apertis_scan_gate_fwd", "scan_lean_prefix_k<false>": "apertis_scan_gate_fwd",
+    "scan_lean_prefix_k<(bool)0>": "apertis_scan_gate_fwd", "scan_lean_fwd_k": "apertis_scan_gate_fwd",
+    "scan_lean_bstate_k": "apertis_scan_gate_bwd", "scan_lean_prefix_k<true>": "apertis_scan_gate_bwd",
+    "scan_lean_prefix_k<(bool)1>": "apertis_scan_gate_bwd", "scan_lean_bwd_k": "apertis_scan_gate_bwd",
     "colsum_kernel": "apertis_scan_gate_bwd",
 }
 CALLS_PER_REP = {"apertis_grouped_gemm_nt": 4, "apertis_grouped_gemm_tn": 1, "apertis_selective_scan_fwd": 1,
@@ -68,6 +73,14 @@ for tag, v in entry.items():
                 "traffic_bytes_per_call": (2 * v["fetch_kib"] + v["write_kib"]) * 1024 / n_calls,
                 "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes; FETCH_SIZE doubled per "
                         "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B)"}
+# what the numbers were taken on: bench.py reports them only while the kernel sources are the ones measured
+import hashlib, os, subprocess
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = {}
+for f in ("grouped_gemm.hip", "scan_gate.hip"):
+    with open(os.path.join(root, "apertis_llm_amd", "csrc", f), "rb") as fh:
+        src[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
+res["_source"] = {"kernel_source_sha16": src}
 open(out + "/summary.txt", "w").write("\n".join(lines) + "\n")
 json.dump(res, open(out + "/traffic.json", "w"), indent=1)
 print("\n".join(lines[:60]))
