@@ -2829,7 +2829,13 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
 #ifdef NT_PROBE_FORCE   // tools/probes only: 4 = wherever it applies, otherwise never
     const bool use4r = NT_PROBE_FORCE == 4;
 #else
-    const bool use4r = (act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512;
+    const bool use4r = ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
+                       // ... and for the SSM block's dense projections (one group, short K: byte- and latency-bound - the stage
+                       // stream through tile boundaries hides a tile's prologue and epilogue, and 256-wide n-tiles read X half as
+                       // often).  Same box, B = 44 (`gemm_probe 44 704 2816 dense`), two-per-CU -> this kernel: N=704 K=176 121 ->
+                       // 102 us, N=704 K=352 162 -> 141, N=448 K=176 83 -> 74, N=176 K=448 63-67 -> 60, N=176 K=704 85-92 -> 83;
+                       // N=352 K=704 stays on the 352-wide tile (107-110 there, 111 here)
+                       (E == 1 && K <= 1024 && N >= 128 && !(N == BN5 && K % 64 == 0 && ldw == K));
 #endif
     if (use4r && !tile_queue && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 && N >= 128 &&
         max_rows >= 4096 && E <= 1024) {
