@@ -51,6 +51,8 @@ SIGNATURES = {
                                      _i64, _i64, _i32, _i32, _i32, _vp]),
     "apertis_scan_lean_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
                                      _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_scan_lean_fwd_dt": (_i32, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                                        _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_scan_lean_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
                                      _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_ssm_decode_conv": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),

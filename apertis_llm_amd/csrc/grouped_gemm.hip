@@ -1129,8 +1129,15 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t sv = __builtin_amdgcn_make_buffer_rsrc(const_cast<TO *>(MODE >= EPI_MULACT ? saved + tile0 : dst + tile0), 0, tile_bytes, 0x00020000);
   auto row_off = [&](int r) { return voff + (uint32_t)(r * N) * 2u; };
   // (non-temporal, like out_store16: the outputs are far larger than the caches and would only displace the operands)
+#ifndef NT_EPI_AUX   // tools/probes only: the stores' cache policy bits
+#define NT_EPI_AUX 2
+#endif
   auto put = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    __builtin_amdgcn_raw_buffer_store_b128((u4_t){a, b, c, d}, rs, (int)off, 0, 2);
+#ifdef NT_PROBE_NOSTORE   // tools/probes only: the epilogue's arithmetic without its stores (the values stay live)
+    asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(off));
+#else
+    __builtin_amdgcn_raw_buffer_store_b128((u4_t){a, b, c, d}, rs, (int)off, 0, NT_EPI_AUX);
+#endif
   };
   // the saved tensor's pieces: two batches of four rows in flight ahead of the arithmetic
   [[maybe_unused]] uint4 pc[2][4];
@@ -1600,6 +1607,12 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const bool late = NT4R_STAGGER && wave >= 4;
   if (NT4R_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
+#ifdef NT4R_PHASES   // tools/probes only: the work-groups start in NT4R_PHASES phases, NT4R_PHASE_TICKS (10 ns) apart
+  {
+    const uint64_t t0 = wall_clock64(), dly = (uint64_t)((blockIdx.x >> 3) % NT4R_PHASES) * NT4R_PHASE_TICKS;   // (blockIdx & 7 = the XCD)
+    while (wall_clock64() - t0 < dly) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   // prologue: the first four stages (nk >= 5: all of cur), stage 0's fragments
   if (bias) issue_bias();
 #pragma unroll 1
@@ -1615,6 +1628,9 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
+#ifdef NT_PROBE_STAMPS
+  unsigned long long stk[3] = {0, 0, 0}, stw[3] = {0, 0, 0};
+#endif
   for (;;) {
     nxt = next_valid();
 #ifdef NT_PROBE_STAMPS
@@ -1642,13 +1658,22 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     // top of sub-step s: this wave holds the fragments of s; stage s+1 of the stream must have landed - two stages are younger
     // (8 pieces), and through the first three sub-steps behind an epilogue so are its S stores; behind the barrier stage s+1 is
     // complete everywhere and every wave has read s, so the fill stage (s + 4 of the stream) may overwrite slot(s)
+#ifdef NT_PROBE_STAMPS   // [3] waits + barriers of sub-steps 0..2 (stores behind), [4] of sub-step 3 (the stores retired), [5] the rest
+#define NT4R_STAMP_A const uint64_t sw0 = wall_clock64();
+#define NT4R_STAMP_B(S_) stw[(S_) < 3 ? 0 : (S_) == 3 ? 1 : 2] += wall_clock64() - sw0;   // (no memory operation here: the vmcnt is kept by hand)
+#else
+#define NT4R_STAMP_A
+#define NT4R_STAMP_B(S_)
+#endif
 #define SUB4(S_, AC, AN)                                                                                       \
     {                                                                                                          \
       const int nxt_off = cur_off + SLOT4 == RING4 ? 0 : cur_off + SLOT4;                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
       const int stores_behind = (S_) < 3 ? prev_stores : 0;                                                    \
+      NT4R_STAMP_A                                                                                             \
       if (stores_behind == 0) wait_vmcnt<8>(); else if (stores_behind == 16) wait_vmcnt<24>(); else wait_vmcnt<40>(); \
       NT4R_BARRIER                                                                                             \
+      NT4R_STAMP_B(S_)                                                                                         \
       if (fs == 0 && bias && fvalid) issue_bias();                                                             \
       if (NT4R_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                       \
       sub_step(AC, AN, nxt_off, (uint32_t)cur_off, late);                                                      \
@@ -1690,9 +1715,7 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #undef OUT
     }
 #ifdef NT_PROBE_STAMPS
-    if (tid == 0) {
-      atomicAdd(&nt4r_stamps[0], st2 - st1); atomicAdd(&nt4r_stamps[1], wall_clock64() - st2); atomicAdd(&nt4r_stamps[2], 1ull);
-    }
+    stk[0] += st2 - st1; stk[1] += wall_clock64() - st2; stk[2] += 1;
 #endif
     if (!nxt.valid) break;
     cur = nxt;
@@ -1700,6 +1723,11 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   }
   // (the empty pieces of the stream's last sub-steps are still in flight: they write zeros into this work-group's own LDS)
   wait_vmcnt<0>();
+#ifdef NT_PROBE_STAMPS
+  if (tid == 0) {
+    for (int i = 0; i < 3; ++i) { atomicAdd(&nt4r_stamps[i], stk[i]); atomicAdd(&nt4r_stamps[3 + i], stw[i]); }
+  }
+#endif
 }
 
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])

@@ -946,15 +946,31 @@ __device__ __forceinline__ float quad_bc(float v, int i) {
 
 // State pass.  NW waves share an item (LTG / NW consecutive tokens each); their aggregates meet in LDS and the last wave
 // composes them in order.
-template <int U, int NW>
+// R8 > 0 (N4, round 4): dt_proj_head inside the pass - the delta logits are not read but formed from the dt columns of the
+// projection output p (R <= 8 * R8 bf16 per token, the same padded row the pass streams Bt from: [Bt | 0 | C | 0 | dt | 0]) and
+// the [h, R] weight + bias, and WRITTEN to dl for the replay and the backward: lane i of a head's quad takes token t0 + i as it
+// does for the softplus, the weight rows sit in LDS (zero-padded to 8 * R8 columns, read four at a time, a quad shares its
+// address) and the accumulation is apertis_tiny_linear_fwd's chain (bias first, then r = 0, 1, ... in order: the same bits).
+template <int U, int NW, int R8 = 0>
 __global__ void __launch_bounds__(64 * NW)
-scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *__restrict__ agg, ScanDims d, int g, int64_t items) {
+scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *__restrict__ agg, ScanDims d, int g, int64_t items,
+                  LeanT tdt = LeanT{nullptr, 0u, 0u}, const float *__restrict__ Wdt = nullptr, const float *__restrict__ bdt = nullptr,
+                  int R = 0) {
   static_assert(U % 4 == 0 && (LTG / NW) % (2 * U) == 0, "delta comes in groups of four tokens; whole double batches per wave");
   constexpr int TW = LTG / NW;                                  // tokens per wave
   __shared__ float4 part[NW > 1 ? NW - 1 : 1][64][2];
+  __shared__ __attribute__((aligned(16))) float sW[R8 > 0 ? 16 * (8 * R8 + 4) : 4];   // [head][8*R8 weights, bias, 3 pad]
   const int wv = (int)threadIdx.x >> 6;
   const LeanItem it = lean_item(d, g, items, false);
   float A2[4] = {0.f, 0.f, 0.f, 0.f}, S[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
+  if constexpr (R8 > 0) {
+    constexpr int WP = 8 * R8 + 4;
+    for (int i = (int)threadIdx.x; i < 16 * WP; i += 64 * NW) {
+      const int j = i / WP, r = i - j * WP;
+      sW[i] = j < d.h ? (r < R ? Wdt[j * R + r] : (r == 8 * R8 && bdt) ? bdt[j] : 0.f) : 0.f;
+    }
+    __syncthreads();
+  }
   if (it.ok) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) A2[k] = -expf(A_log[it.c0 + k]) * LOG2E_F;
@@ -965,6 +981,11 @@ scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *
     const uint32_t ob = (tk0 * tb_.rs + (uint32_t)it.c0) * 2u, od = (tk0 * dl.rs + (uint32_t)it.hh) * 4u;
     uint2 vb[2][U];
     float vd[2][U / 4];
+    typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
+    [[maybe_unused]] lean_u4 vt[2][U / 4][R8 > 0 ? R8 : 1];
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rt = lean_rsrc(R8 > 0 ? tdt.p : dl.p, R8 > 0 ? tdt.bytes : 0u);
+    [[maybe_unused]] const uint32_t ot = tk0 * tdt.rs * 2u;      // (the dt row of this wave's first token; the token rides in the lane offset)
+    [[maybe_unused]] const float *swh = sW + it.hh * (8 * R8 + 4);
     const bool ragged = rows < TW;
     const int tlast = rows - 1;                                   // loads past the item's last row re-read that row (never used)
     auto ld = [&](int s, int tb) {
@@ -976,12 +997,39 @@ scan_lean_state_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, float2 *
         vb[s][u] = make_uint2(t2[0], t2[1]);
       }
 #pragma unroll
-      for (int j = 0; j < U / 4; ++j)   // (lane qi of a quad takes token tb + 4j + qi: the token rides in the lane offset here)
-        vd[s][j] = lean_ld4(rd, od + (uint32_t)min(tb + 4 * j + qi, tlast) * dl.rs * 4u, 0u);
+      for (int j = 0; j < U / 4; ++j) {  // (lane qi of a quad takes token tb + 4j + qi: the token rides in the lane offset here)
+        if constexpr (R8 > 0) {
+          const uint32_t o = ot + (uint32_t)min(tb + 4 * j + qi, tlast) * tdt.rs * 2u;
+#pragma unroll
+          for (int c = 0; c < R8; ++c) vt[s][j][c] = __builtin_amdgcn_raw_buffer_load_b128(rt, (int)(o + 16u * c), 0, 0);
+        } else {
+          vd[s][j] = lean_ld4(rd, od + (uint32_t)min(tb + 4 * j + qi, tlast) * dl.rs * 4u, 0u);
+        }
+      }
     };
     auto use = [&](int s, int tb) {
 #pragma unroll
       for (int j = 0; j < U / 4; ++j) {
+        if constexpr (R8 > 0) {
+          float a = swh[8 * R8];
+#pragma unroll
+          for (int c = 0; c < R8; ++c) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(swh + 8 * c), w1 = *reinterpret_cast<const float4 *>(swh + 8 * c + 4);
+            const lean_u4 x = vt[s][j][c];
+            if (8 * c < R) {      // (whole chunks of four, like the stand-alone kernel: pad entries are zeros on both sides)
+              a = fmaf(__uint_as_float(x[0] << 16), w0.x, a); a = fmaf(__uint_as_float(x[0] & 0xffff0000u), w0.y, a);
+              a = fmaf(__uint_as_float(x[1] << 16), w0.z, a); a = fmaf(__uint_as_float(x[1] & 0xffff0000u), w0.w, a);
+            }
+            if (8 * c + 4 < R) {
+              a = fmaf(__uint_as_float(x[2] << 16), w1.x, a); a = fmaf(__uint_as_float(x[2] & 0xffff0000u), w1.y, a);
+              a = fmaf(__uint_as_float(x[3] << 16), w1.z, a); a = fmaf(__uint_as_float(x[3] & 0xffff0000u), w1.w, a);
+            }
+          }
+          vd[s][j] = a;
+          // the logits for the replay and the backward (tokens past the item's end: an offset the descriptor drops)
+          const int t = tb + 4 * j + qi;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a), rd, (int)(t < rows ? od + (uint32_t)t * dl.rs * 4u : 0xfffffff0u), 0, 0);
+        }
         float sp = d.softplus ? softplus_fast(vd[s][j]) : vd[s][j];
         if (ragged) sp = tb + 4 * j + qi < rows ? sp : 0.f;       // a token past the item's end: delta 0 -> a = 1 ...
 #pragma unroll
@@ -1660,10 +1708,11 @@ int lean_shape(LeanShape &s, int64_t B, int64_t L, int64_t h, int64_t N, int sof
 }
 }  // namespace
 
-extern "C" int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
-                                     const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
-                                     void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B,
-                                     int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream) {
+static int lean_fwd_impl(const float *dlt, const void *dt_in, int64_t dt_rs, const float *W_dt, const float *b_dt, int64_t R,
+                         const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                         const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
+                         void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B,
+                         int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream) {
   if (!dlt || !A_log || !Bt || !C || !xc || !z || !D || !out || !h_in || !agg) return APERTIS_ERR_ARG;
   LeanShape s;
   int rc = lean_shape(s, B, L, h, N, delta_softplus, {{Bt, bt_rs}, {C, c_rs}, {xc, xc_rs}, {z, z_rs}, {out, out_rs}}, h * N);
@@ -1673,12 +1722,44 @@ extern "C" int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const
   auto lt = [&](const void *p, int64_t rs) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + Dn) * 2)}; };
   const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
   const unsigned grid = (unsigned)s.items;
-  hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW>), dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, lt(Bt, bt_rs),
-                     (float2 *)agg, s.d, s.g, s.items);
+  if (dt_in) {
+    // dt_proj_head inside the state pass: whole 16-byte chunks of the dt columns (the caller's pad columns behind R are zeros
+    // or at least finite: their weights are zeros here), at most 16 heads, the row reachable through a 32-bit descriptor
+    const int64_t r8 = (R + 7) / 8;
+    if (!W_dt || R < 1 || R > 64 || h > 16) return APERTIS_ERR_ARG;
+    if (((uintptr_t)dt_in & 15) || dt_rs % 8 || dt_rs < 8 * r8 || ((T - 1) * dt_rs + 8 * r8) * 2 >= 0xFFFFFFF0LL) return APERTIS_ERR_UNSUPPORTED;
+    const LeanT tdt{dt_in, (uint32_t)dt_rs, (uint32_t)(((T - 1) * dt_rs + 8 * r8) * 2)};
+#define GO_DT(R8) hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW, R8>), dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, \
+                                     lt(Bt, bt_rs), (float2 *)agg, s.d, s.g, s.items, tdt, W_dt, b_dt, (int)R)
+    switch (r8) {
+      case 1: GO_DT(1); break; case 2: GO_DT(2); break; case 3: GO_DT(3); break; case 4: GO_DT(4); break;
+      case 5: GO_DT(5); break; case 6: GO_DT(6); break; case 7: GO_DT(7); break; default: GO_DT(8); break;
+    }
+#undef GO_DT
+  } else {
+    hipLaunchKernelGGL((scan_lean_state_k<LEAN_US, LEAN_NW>), dim3(grid), dim3(64 * LEAN_NW), 0, st, tdl, A_log, lt(Bt, bt_rs),
+                       (float2 *)agg, s.d, s.g, s.items, LeanT{nullptr, 0u, 0u}, (const float *)nullptr, (const float *)nullptr, 0);
+  }
   hipLaunchKernelGGL(scan_lean_prefix_k<false>, dim3((unsigned)(B * s.g)), dim3(64), 0, st, (const float2 *)agg, h0, h_in, s.d, s.g);
   hipLaunchKernelGGL(scan_lean_fwd_k<LEAN_U>, dim3(grid), dim3(64), 0, st, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs), lt(xc, xc_rs),
                      lt(z, z_rs), D, h_in, h_last, ckpt, lt(out, out_rs), s.d, s.g, s.items);
   return apertis_check_launch();
+}
+extern "C" int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                                     const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
+                                     void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B,
+                                     int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream) {
+  return lean_fwd_impl(dlt, nullptr, 0, nullptr, nullptr, 0, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, h0, out, out_rs, h_last,
+                       agg, h_in, ckpt, B, L, h, N, delta_softplus, stream);
+}
+extern "C" int apertis_scan_lean_fwd_dt(const void *dt_in, int64_t dt_rs, const float *W_dt, const float *b_dt, int64_t R, float *dlt,
+                                        const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                                        const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
+                                        void *out, int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B,
+                                        int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream) {
+  if (!dt_in) return APERTIS_ERR_ARG;
+  return lean_fwd_impl(dlt, dt_in, dt_rs, W_dt, b_dt, R, A_log, Bt, bt_rs, C, c_rs, xc, xc_rs, z, z_rs, D, h0, out, out_rs, h_last,
+                       agg, h_in, ckpt, B, L, h, N, delta_softplus, stream);
 }
 
 extern "C" int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,

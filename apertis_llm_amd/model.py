@@ -396,13 +396,24 @@ class SelectiveLinearAttention(nn.Module):
         p = _mfma_linear(xc, wp)                                             # x_param_proj (core.py:376), padded layout
         # Bt / C / dt are column slices of p taken in place (core.py:382-385); the Bt and C slices keep their zero pad
         Btp, Cp, dt_in = ops.split_cols(p, (Wb, Wb, R, Wr - R))[:3]
-        if ops.tiny_linear_supported(dt_in, R, self.num_heads):
+        h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None
+        two_op = output_attentions or not hidden_states.is_cuda
+        tiny = ops.tiny_linear_supported(dt_in, R, self.num_heads)
+        if tiny and not two_op:
+            # dt_proj_head, softplus, recurrence, skip and gate as ONE op (core.py:382-396): the logits come from the
+            # stand-alone kernel or - APERTIS_SCAN_DT_FUSED=1 - from inside the scan's state pass (the same bits)
+            res = ops.scan_gate_dt(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias, self.A_log, Btp, Cp, xc, z, self.D,
+                                   h0=h0, delta_softplus=True, return_last=use_cache)
+            (gated, h_last), y = (res if use_cache else (res, None)), None
+            out = _mfma_linear(gated, self.out_proj.weight)                 # core.py:397
+            cache = (conv_state, h_last.reshape(B, self.num_heads, self.d_state)) if use_cache else None
+            return out, None, cache
+        if tiny:
             dt_logits = ops.tiny_linear(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias)   # [B,L,h] fp32
         else:
             dt_logits = self.dt_proj_head(dt_in).float()
-        h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None
         # softplus (core.py:383) is applied inside the scan kernel
-        if output_attentions or not hidden_states.is_cuda:
+        if two_op:
             # the caller wants y_ssm itself (core.py:401): scan and gate as two ops, y in fp32
             res = ops.selective_scan(dt_logits, self.A_log, Btp[..., :Dn], Cp[..., :Dn], h0=h0,
                                      delta_softplus=True, y_dtype=torch.float32, return_last=use_cache)

@@ -266,104 +266,185 @@ def scan_gate_raise_on_error(device=None):
                               "are invalid - rerun with APERTIS_SCAN_SINGLE_PASS=0 (two-launch form, same bits)")
 
 
+# APERTIS_SCAN_DT_FUSED=1 (round 4, N4's prologue; default OFF): dt_proj_head inside the lean forward's state pass
+# (ops.scan_gate_dt -> apertis_scan_lean_fwd_dt) instead of its own launch.  Same bits; measured in the 1.5B step at B = 44
+# (profiles/r4_dtproj_fused_ab.txt): the state pass grows by 28.6 us per layer (its 44-term dot per (token, head) costs
+# registers: 134 VGPRs, three waves per SIMD instead of eight) against the 19 us launch it replaces - scan forward 89.9 -> 118.5 us,
+# the step within noise (455.0 / 452.5 ms fused, 455.7 / 455.3 ms two launches): not taken.
+SCAN_DT_FUSED = _os.environ.get("APERTIS_SCAN_DT_FUSED", "0") == "1"
+
+
 class _ScanGate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last):
-        _require_gpu(dlt, A_log, Bt, C, xc, z, D, h0)
-        lib = _lib.load()
-        B, L, h = dlt.shape
-        N = A_log.shape[1]
-        Dn = h * N
-        wB, wC = Bt.shape[-1], C.shape[-1]          # >= Dn: zero-padded slices of the projection output
-        if (tuple(Bt.shape[:2]) != (B, L) or tuple(C.shape[:2]) != (B, L) or wB < Dn or wC != wB or A_log.shape[0] != h or
-                tuple(xc.shape) != (B, L, Dn) or tuple(z.shape) != (B, L, Dn) or wB > -(-Dn // 64) * 64):
-            raise ApertisHipError(f"scan_gate shapes: dlt {tuple(dlt.shape)} A_log {tuple(A_log.shape)} Bt {tuple(Bt.shape)} "
-                                  f"C {tuple(C.shape)} xc {tuple(xc.shape)} z {tuple(z.shape)}")
-        if not (Bt.dtype == C.dtype == xc.dtype == z.dtype):
-            raise ApertisHipError("Bt, C, xc and z must share a dtype")
-        dlt = dlt.float().contiguous()
-        A_log = A_log.float().contiguous()
-        Df = D.detach().float().contiguous()
-        if h0 is not None:
-            h0 = h0.float().reshape(B, Dn).contiguous()
-        ctx.slots = (_slot_of(Bt), _slot_of(C), _slot_of(z), _slot_of(xc))
-        (Bt, bt_rs), (C, c_rs), (xc, xc_rs), (z, z_rs) = _rows(Bt, wB), _rows(C, wC), _rows(xc, Dn), _rows(z, Dn)
-        nch = -(-L // int(lib.apertis_scan_gate_chunk_len()))
-        dev = dlt.device
-        out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
-        h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
-        h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
-        e = xc.element_size()
-        work = B * L * (5 * Dn * e + 4 * h) + 4 * h * N          # algorithmic bytes, fused variant
-        # the lean form where it takes the shape (bf16, N = 16, 128 < Dn <= 256): timed under the same name - the same op
-        ckpt, lean = None, False
-        if SCAN_LEAN and xc.dtype == torch.bfloat16 and N == 16 and 128 < Dn <= 256:
-            agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
-            need_grad = any(ctx.needs_input_grad[:7])
-            ckpt = torch.empty(B, -(-L // 4), Dn, device=dev, dtype=torch.float32) if need_grad else None
-            rc = []
-            _launch("apertis_scan_gate_fwd", lambda *a: rc.append(lib.apertis_scan_lean_fwd(*a)) or (0 if rc[-1] == -2 else rc[-1]),
-                    (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
-                     out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ckpt), B, L, h, N, int(delta_softplus), stream_ptr()), work)
-            lean = rc[-1] == 0                       # (-2 = APERTIS_ERR_UNSUPPORTED: alignment / size - the staged kernels below)
-        if not lean:
-            ckpt = None
-            if SCAN_SINGLE_PASS:
-                ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
-                agg = None
-            else:
-                ws, epoch = None, 0
-                agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
-            _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
-                    (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
-                     out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc),
-                     int(delta_softplus), int(SCAN_SINGLE_PASS), stream_ptr()), work)
-        ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt)
-        ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
-        ctx.mark_non_differentiable(*([h_last] if return_last else []))
-        return (out, h_last) if return_last else out
+        return _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last,
+                                  any(ctx.needs_input_grad[:7]), None)
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        return _scan_gate_backward(ctx, dout) + (None, None, None)
+
+
+class _ScanGateDt(torch.autograd.Function):
+    """scan_gate with the delta logits formed inside it: dlt = dt_in @ W_dt.T + b_dt (core.py:382) is computed by the lean
+    forward's state pass where that kernel takes the shape, by the stand-alone kernel otherwise - the same bits either way."""
+
+    @staticmethod
+    def forward(ctx, dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last):
+        _require_gpu(dt_in, W_dt, b_dt)
+        R, h = dt_in.shape[-1], W_dt.shape[0]
+        ctx.dt_slot = _slot_of(dt_in)
+        xr, ldx = _rows(dt_in, R)
+        w = W_dt.detach().float().contiguous()
+        b = None if b_dt is None else b_dt.detach().float().contiguous()
+        ctx.dt_cfg = (ldx, tuple(dt_in.shape), W_dt.dtype, None if b_dt is None else b_dt.dtype)
+        dlt = torch.empty(*dt_in.shape[:-1], h, device=dt_in.device, dtype=torch.float32)
+        res = _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last,
+                                 any(ctx.needs_input_grad[:9]), (xr, ldx, w, b, R))
+        ctx.dt_saved = (xr, w)
+        return res
 
     @staticmethod
     def backward(ctx, dout, *_unused):
         lib = _lib.load()
-        dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt = ctx.saved_tensors
-        B, L, h, N, sp, wB, Ddt = ctx.cfg
-        Dn = h * N
-        dev = dlt.device
-        dout, do_rs = _rows(dout.to(xc.dtype), Dn)
-        nch = h_in.shape[1]
-        dBt, dbt_rs = _grad_out(ctx.slots[0], (B, L), wB, Bt.dtype, dev)
-        dC, dc_rs = _grad_out(ctx.slots[1], (B, L), wB, C.dtype, dev)
-        dz, dz_rs = _grad_out(ctx.slots[2], (B, L), Dn, z.dtype, dev)
-        dxc, dxc_rs = _grad_out(ctx.slots[3], (B, L), Dn, xc.dtype, dev)
-        d_dlt = torch.empty(B, L, h, device=dev, dtype=torch.float32)
-        dA_dD = torch.empty(2, Dn, device=dev, dtype=torch.float32)
-        part = torch.empty(B * nch, 2 * Dn, device=dev, dtype=torch.float32)
-        fold = torch.empty(64, 2 * Dn, device=dev, dtype=torch.float32)
-        e = xc.element_size()
-        work = B * L * (9 * Dn * e + 8 * h) + 8 * h * N          # algorithmic bytes, fused variant
-        if ckpt is not None and SCAN_LEAN_BWD:       # the lean forward left its checkpoints: the lean backward
-            agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
-            mu_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
-            rc = []
-            _launch("apertis_scan_gate_bwd", lambda *a: rc.append(lib.apertis_scan_lean_bwd(*a)) or (0 if rc[-1] == -2 else rc[-1]),
-                    (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
-                     ptr(Df), ptr(dout), do_rs, ptr(ckpt), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
-                     ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(mu_in), ptr(fold), ptr(part), B, L, h, N, int(sp), stream_ptr()), work)
-            if rc[-1] == 0:
-                return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt), None, None, None
+        d_dlt, dA, dBt, dC, dxc, dz, dD = _scan_gate_backward(ctx, dout)
+        xr, w = ctx.dt_saved
+        ldx, xshape, wdt, bdt = ctx.dt_cfg
+        N, K = w.shape
+        if ctx.dt_slot is not None and ctx.dt_slot[0].widths[ctx.dt_slot[1]] == K:
+            dx, Kp = ctx.dt_slot[0].out(ctx.dt_slot[1], xshape[:-1], xr.dtype, xr.device)
+            dxp = dx
+        else:
+            Kp = -(-K // 8) * 8
+            dxp = torch.empty(*xshape[:-1], Kp, device=xr.device, dtype=xr.dtype)
+            dx = dxp[..., :K]
+        T = d_dlt.numel() // N
+        nblk = lib.apertis_tiny_linear_bwd_blocks(T)
+        part = torch.empty(nblk, N * K + N, device=xr.device, dtype=torch.float32)
+        out = torch.empty(N * K + N, device=xr.device, dtype=torch.float32)
+        check(lib.apertis_tiny_linear_bwd(ptr(xr), ldx, ptr(w), ptr(d_dlt), ptr(dxp), Kp, ptr(part), ptr(out), T, K, N,
+                                          dtype_code(xr), stream_ptr()), "apertis_tiny_linear_bwd")
+        return (dx, out[:N * K].reshape(N, K).to(wdt), (out[N * K:].to(bdt) if bdt is not None else None),
+                dA, dBt, dC, dxc, dz, dD, None, None, None)
+
+
+def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last, need_grad, dtp):
+    """Body of the two Functions above.  dtp = (dt rows, row stride, W fp32, b fp32 | None, R): `dlt` is an empty buffer
+    that the launch (or, where the fused kernel does not take the shape, apertis_tiny_linear_fwd) fills."""
+    _require_gpu(dlt, A_log, Bt, C, xc, z, D, h0)
+    lib = _lib.load()
+    B, L, h = dlt.shape
+    N = A_log.shape[1]
+    Dn = h * N
+    wB, wC = Bt.shape[-1], C.shape[-1]          # >= Dn: zero-padded slices of the projection output
+    if (tuple(Bt.shape[:2]) != (B, L) or tuple(C.shape[:2]) != (B, L) or wB < Dn or wC != wB or A_log.shape[0] != h or
+            tuple(xc.shape) != (B, L, Dn) or tuple(z.shape) != (B, L, Dn) or wB > -(-Dn // 64) * 64):
+        raise ApertisHipError(f"scan_gate shapes: dlt {tuple(dlt.shape)} A_log {tuple(A_log.shape)} Bt {tuple(Bt.shape)} "
+                              f"C {tuple(C.shape)} xc {tuple(xc.shape)} z {tuple(z.shape)}")
+    if not (Bt.dtype == C.dtype == xc.dtype == z.dtype):
+        raise ApertisHipError("Bt, C, xc and z must share a dtype")
+    dlt = dlt.float().contiguous()
+    A_log = A_log.float().contiguous()
+    Df = D.detach().float().contiguous()
+    if h0 is not None:
+        h0 = h0.float().reshape(B, Dn).contiguous()
+    ctx.slots = (_slot_of(Bt), _slot_of(C), _slot_of(z), _slot_of(xc))
+    (Bt, bt_rs), (C, c_rs), (xc, xc_rs), (z, z_rs) = _rows(Bt, wB), _rows(C, wC), _rows(xc, Dn), _rows(z, Dn)
+    nch = -(-L // int(lib.apertis_scan_gate_chunk_len()))
+    dev = dlt.device
+    out = torch.empty(B, L, Dn, device=dev, dtype=xc.dtype)
+    h_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
+    h_last = torch.empty(B, Dn, device=dev, dtype=torch.float32) if return_last else None
+    e = xc.element_size()
+    work = B * L * (5 * Dn * e + 4 * h) + 4 * h * N          # algorithmic bytes, fused variant (SURVEY 8d)
+    # the lean form where it takes the shape (bf16, N = 16, 128 < Dn <= 256): timed under the same name - the same op
+    ckpt, lean = None, False
+    dt_done = dtp is None
+    if SCAN_LEAN and xc.dtype == torch.bfloat16 and N == 16 and 128 < Dn <= 256:
+        agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+        ckpt = torch.empty(B, -(-L // 4), Dn, device=dev, dtype=torch.float32) if need_grad else None
+        rc = []
+        tail = (ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
+                out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ckpt), B, L, h, N, int(delta_softplus), stream_ptr())
+        if dtp is not None and SCAN_DT_FUSED and dtp[0].dtype == torch.bfloat16:
+            xr, ldx, w, b, R = dtp
+            _launch("apertis_scan_gate_fwd", lambda *a: rc.append(lib.apertis_scan_lean_fwd_dt(*a)) or (0 if rc[-1] == -2 else rc[-1]),
+                    (ptr(xr), ldx, ptr(w), ptr(b), R, ptr(dlt)) + tail, work + B * L * (2 * R + 4 * h))
+            dt_done = lean = rc[-1] == 0
+        if not lean:
+            if not dt_done:
+                _tiny_linear_into(lib, dtp, dlt)
+                dt_done = True
+            _launch("apertis_scan_gate_fwd", lambda *a: rc.append(lib.apertis_scan_lean_fwd(*a)) or (0 if rc[-1] == -2 else rc[-1]),
+                    (ptr(dlt),) + tail, work)
+            lean = rc[-1] == 0                   # (-2 = APERTIS_ERR_UNSUPPORTED: alignment / size - the staged kernels below)
+    if not dt_done:
+        _tiny_linear_into(lib, dtp, dlt)
+    if not lean:
+        ckpt = None
         if SCAN_SINGLE_PASS:
             ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
             agg = None
         else:
             ws, epoch = None, 0
             agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
-        _launch("apertis_scan_gate_bwd", lib.apertis_scan_gate_bwd,
+        _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
+                (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
+                 out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc),
+                 int(delta_softplus), int(SCAN_SINGLE_PASS), stream_ptr()), work)
+    ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt)
+    ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
+    ctx.mark_non_differentiable(*([h_last] if return_last else []))
+    return (out, h_last) if return_last else out
+
+
+def _tiny_linear_into(lib, dtp, dlt):
+    xr, ldx, w, b, R = dtp
+    check(lib.apertis_tiny_linear_fwd(ptr(xr), ldx, ptr(w), ptr(b), ptr(dlt), dlt.numel() // dlt.shape[-1], R, dlt.shape[-1],
+                                      dtype_code(xr), stream_ptr()), "apertis_tiny_linear_fwd")
+
+
+def _scan_gate_backward(ctx, dout):
+    """-> (d_dlt, dA_log, dBt, dC, dxc, dz, dD)"""
+    lib = _lib.load()
+    dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt = ctx.saved_tensors
+    B, L, h, N, sp, wB, Ddt = ctx.cfg
+    Dn = h * N
+    dev = dlt.device
+    dout, do_rs = _rows(dout.to(xc.dtype), Dn)
+    nch = h_in.shape[1]
+    dBt, dbt_rs = _grad_out(ctx.slots[0], (B, L), wB, Bt.dtype, dev)
+    dC, dc_rs = _grad_out(ctx.slots[1], (B, L), wB, C.dtype, dev)
+    dz, dz_rs = _grad_out(ctx.slots[2], (B, L), Dn, z.dtype, dev)
+    dxc, dxc_rs = _grad_out(ctx.slots[3], (B, L), Dn, xc.dtype, dev)
+    d_dlt = torch.empty(B, L, h, device=dev, dtype=torch.float32)
+    dA_dD = torch.empty(2, Dn, device=dev, dtype=torch.float32)
+    part = torch.empty(B * nch, 2 * Dn, device=dev, dtype=torch.float32)
+    fold = torch.empty(64, 2 * Dn, device=dev, dtype=torch.float32)
+    e = xc.element_size()
+    work = B * L * (9 * Dn * e + 8 * h) + 8 * h * N          # algorithmic bytes, fused variant
+    if ckpt is not None and SCAN_LEAN_BWD:       # the lean forward left its checkpoints: the lean backward
+        agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+        mu_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
+        rc = []
+        _launch("apertis_scan_gate_bwd", lambda *a: rc.append(lib.apertis_scan_lean_bwd(*a)) or (0 if rc[-1] == -2 else rc[-1]),
                 (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
-                 ptr(Df), ptr(dout), do_rs, ptr(h_in), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
-                 ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(sp),
-                 int(SCAN_SINGLE_PASS), stream_ptr()), work)
-        return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt), None, None, None
+                 ptr(Df), ptr(dout), do_rs, ptr(ckpt), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
+                 ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(mu_in), ptr(fold), ptr(part), B, L, h, N, int(sp), stream_ptr()), work)
+        if rc[-1] == 0:
+            return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt)
+    if SCAN_SINGLE_PASS:
+        ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
+        agg = None
+    else:
+        ws, epoch = None, 0
+        agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
+    _launch("apertis_scan_gate_bwd", lib.apertis_scan_gate_bwd,
+            (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
+             ptr(Df), ptr(dout), do_rs, ptr(h_in), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
+             ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(sp),
+             int(SCAN_SINGLE_PASS), stream_ptr()), work)
+    return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt)
 
 
 def scan_gate(dlt, A_log, Bt, C, xc, z, D, h0=None, delta_softplus=False, return_last=False):
@@ -375,6 +456,15 @@ def scan_gate(dlt, A_log, Bt, C, xc, z, D, h0=None, delta_softplus=False, return
     of which the first h*N columns are used; their gradients come back [B,L,w] with zeros in the pad.
     Returns out [B,L,h*N] in the activations' dtype (and the final state [B,h*N] fp32 when return_last)."""
     return _ScanGate.apply(dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
+
+
+def scan_gate_dt(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0=None, delta_softplus=True, return_last=False):
+    """scan_gate(tiny_linear(dt_in, W_dt, b_dt), ...) as ONE op (reference core.py:382-396).  With APERTIS_SCAN_DT_FUSED=1
+    dt_proj_head runs inside the lean forward's state pass where that kernel takes the shape (N4's pre-scan prologue; off by
+    default - measured slower than the launch it replaces, see SCAN_DT_FUSED); otherwise the stand-alone kernel fills the
+    logits.  The logits, outputs and gradients are the two-op form's bit for bit either way.  dt_in [B, L, R] (a column slice
+    of the projection output is read in place), W_dt [h, R], b_dt [h] or None."""
+    return _ScanGateDt.apply(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
 
 
 def ssm_decode_step(xp, conv_state, conv_w, conv_b):

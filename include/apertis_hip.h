@@ -166,6 +166,17 @@ int apertis_scan_lean_fwd(const float *dlt, const float *A_log, const void *Bt, 
                           const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0, void *out,
                           int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B, int64_t L, int64_t h,
                           int64_t N, int delta_softplus, void *stream);
+/* The same forward with dt_proj_head inside its state pass (N4's pre-scan prologue; core.py:382-383 - replaces a
+ * apertis_tiny_linear_fwd launch): the delta logits are formed from the dt columns of the projection output (`dt_in`:
+ * [B*L rows, R bf16] at row stride dt_rs elements, 16-byte aligned, dt_rs % 8 == 0, whole 16-byte chunks readable - the
+ * columns behind R up to the next multiple of 8 must hold finite values) with W_dt [h, R] fp32 and b_dt [h] fp32 (may be
+ * NULL), in apertis_tiny_linear_fwd's accumulation order (the same bits), and are WRITTEN to dlt [B, L, h] for the backward
+ * (apertis_scan_lean_bwd / apertis_tiny_linear_bwd take them from there).  R <= 64, h <= 16. */
+int apertis_scan_lean_fwd_dt(const void *dt_in, int64_t dt_rs, const float *W_dt, const float *b_dt, int64_t R, float *dlt,
+                             const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs, const void *xc,
+                             int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0, void *out,
+                             int64_t out_rs, float *h_last, float *agg, float *h_in, float *ckpt, int64_t B, int64_t L,
+                             int64_t h, int64_t N, int delta_softplus, void *stream);
 int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
                           const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const void *dout,
                           int64_t dout_rs, const float *ckpt, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs, int64_t store_w,

@@ -249,3 +249,62 @@ def test_decode_kernels_match_the_chunk_path(dev):
         _close(out_a, out_b, f"step {t} out", rtol=1e-5)
         _close(cache_a[0], cache_b[0], f"step {t} conv_state", rtol=0, atol_scale=0)
         _close(cache_a[1], cache_b[1], f"step {t} ssm_state", rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,L,h,N,R", [(3, 257, 11, 16, 44), (2, 700, 14, 16, 56), (2, 130, 12, 16, 48), (1, 200, 11, 16, 20)])
+def test_scan_gate_dt_fused_equals_tiny_linear_then_scan_gate(dev, monkeypatch, B, L, h, N, R):
+    """N4's pre-scan prologue: ops.scan_gate_dt (dt_proj_head inside the lean forward's state pass, core.py:382-396) against
+    ops.tiny_linear followed by ops.scan_gate on the same padded projection output: logits, outputs, final state and every
+    gradient (incl. dt_proj_head's weight / bias and the dt columns of p) must be the same BITS; and the fused kernel must be
+    the one that ran (the call count of the stand-alone kernel's entry point does not move)."""
+    from apertis_llm_amd import ops, _lib
+    torch.manual_seed(5)
+    Dn = h * N
+    Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
+    p0 = torch.randn(B, L, 2 * Wb + Wr, device=dev)
+    p0[..., Dn:Wb] = 0
+    p0[..., Wb + Dn:2 * Wb] = 0
+    p0[..., 2 * Wb + R:] = 0
+    W = (0.3 * torch.randn(h, R, device=dev)).requires_grad_(True)
+    bias = (torch.randn(h, device=dev) - 4.0).requires_grad_(True)
+    A_log = torch.empty(h, N, device=dev).uniform_(math.log(0.5), math.log(0.99)).requires_grad_(True)
+    D = (1.0 + 0.2 * torch.randn(Dn, device=dev)).requires_grad_(True)
+    xz0, xc0 = torch.randn(B, L, 2 * Dn, device=dev), torch.randn(B, L, Dn, device=dev)
+    dout = torch.randn(B, L, Dn, device=dev).bfloat16()
+    h0 = torch.randn(B, Dn, device=dev)
+    res = {}
+    lib = _lib.load()
+    calls = {"n": 0}
+    real = lib.apertis_tiny_linear_fwd
+
+    def counting(*a):
+        calls["n"] += 1
+        return real(*a)
+
+    monkeypatch.setattr(ops, "SCAN_DT_FUSED", True)      # (off by default: measured slower than the launch it replaces)
+    for mode in ("two_op", "fused"):
+        p, xz, xc = (t.bfloat16().requires_grad_(True) for t in (p0, xz0, xc0))
+        for t in (W, bias, A_log, D):
+            t.grad = None
+        Btp, Cp, dt_in = ops.split_cols(p, (Wb, Wb, R, Wr - R))[:3]
+        _, z = ops.split_cols(xz, (Dn, Dn))
+        lib.apertis_tiny_linear_fwd = counting
+        try:
+            n0 = calls["n"]
+            if mode == "two_op":
+                out, hl = ops.scan_gate(ops.tiny_linear(dt_in, W, bias), A_log, Btp, Cp, xc, z, D, h0=h0, delta_softplus=True,
+                                        return_last=True)
+            else:
+                out, hl = ops.scan_gate_dt(dt_in, W, bias, A_log, Btp, Cp, xc, z, D, h0=h0, delta_softplus=True, return_last=True)
+            ran_standalone = calls["n"] - n0
+        finally:
+            lib.apertis_tiny_linear_fwd = real
+        out.backward(dout)
+        res[mode] = dict(out=out.detach(), hl=hl.detach(), p=p.grad, xz=xz.grad, xc=xc.grad, W=W.grad.clone(), b=bias.grad.clone(),
+                         A=A_log.grad.clone(), D=D.grad.clone(), standalone=ran_standalone)
+    assert res["two_op"]["standalone"] == 1
+    lean_shape = 128 < Dn <= 256
+    assert res["fused"]["standalone"] == (0 if lean_shape and ops.SCAN_LEAN and ops.SCAN_DT_FUSED else 1)
+    for k in ("out", "hl", "p", "xz", "xc", "W", "b", "A", "D"):
+        assert torch.equal(res["two_op"][k], res["fused"][k]), f"{k}: fused dt_proj differs from the two-op form " \
+            f"(max abs diff {float((res['two_op'][k].float() - res['fused'][k].float()).abs().max()):.3e})"

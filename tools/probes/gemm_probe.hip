@@ -116,7 +116,8 @@ int main(int argc, char **argv) {
     memset(st, 0, sizeof st);
     hipMemcpyToSymbol(HIP_SYMBOL(nt2x_stamps), st, sizeof st);
     hipMemcpyFromSymbol(st, HIP_SYMBOL(nt4r_stamps), sizeof st);
-    if (st[2]) printf("   four-slot-ring tiles: %llu, per tile: K loop %.2f us, epilogue %.2f us\n", st[2] / reps, st[0] * 0.01 / st[2], st[1] * 0.01 / st[2]);
+    if (st[2]) printf("   four-slot-ring tiles: %llu, per tile: K loop %.2f us, epilogue %.2f us; waits + barriers: sub-steps 0-2 %.2f us, sub-step 3 %.2f us, the rest %.2f us\n",
+                      st[2] / reps, st[0] * 0.01 / st[2], st[1] * 0.01 / st[2], st[3] * 0.01 / st[2], st[4] * 0.01 / st[2], st[5] * 0.01 / st[2]);
     memset(st, 0, sizeof st);
     hipMemcpyToSymbol(HIP_SYMBOL(nt4r_stamps), st, sizeof st);
 #endif
