@@ -91,6 +91,7 @@ SIGNATURES = {
     "apertis_grouped_gemm_nt_q": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _f32, _u64,
                                          _i32, _i32, _vp, _vp]),
     "apertis_grouped_gemm_tn_workspace_bytes": (_i64, [_i64, _i32]),
+    "apertis_grouped_gemm_tn_dense_variant": (_i32, [_i64, _i64]),
     "apertis_grouped_gemm_tn_pair": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,
                                             _vp, _i64, _i32, _vp]),
     "apertis_grouped_gemm_tn_pair_q": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64,

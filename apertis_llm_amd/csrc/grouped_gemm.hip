@@ -2747,10 +2747,13 @@ int tn5_variant(int64_t M, int64_t N) {
 }
 
 // returns APERTIS_ERR_UNSUPPORTED when the shapes do not suit v5 (the caller falls back to v3)
-int launch_tn5(Tn3Problem q0, Tn3Problem q1, int64_t E, int64_t max_rows, const int32_t *offsets, float *ws, int64_t ws_bytes,
-               bool item_queue, hipStream_t st) {
-  const int v0 = tn5_variant(q0.M, q0.N), v1 = tn5_variant(q1.M, q1.N);
-  const int64_t groups = 2 * E;
+// (q1p == nullptr: one problem - its groups get all the CUs; with E = 1 that is a dense weight gradient as a row-split GEMM)
+int launch_tn5(Tn3Problem q0, const Tn3Problem *q1p, int64_t E, int64_t max_rows, const int32_t *offsets, float *ws, int64_t ws_bytes,
+               bool item_queue, hipStream_t st, int force_v0 = -1) {
+  Tn3Problem q1 = q1p ? *q1p : q0;
+  const int nprob = q1p ? 2 : 1;
+  const int v0 = force_v0 >= 0 ? force_v0 : tn5_variant(q0.M, q0.N), v1 = q1p ? tn5_variant(q1.M, q1.N) : v0;
+  const int64_t groups = nprob * E;
   const int ncu = device_cu_count();
   if (!ws || v0 < 0 || v1 < 0 || groups > ncu) return APERTIS_ERR_UNSUPPORTED;
   const int cpg = (int)(ncu / groups);
@@ -2763,14 +2766,14 @@ int launch_tn5(Tn3Problem q0, Tn3Problem q1, int64_t E, int64_t max_rows, const 
   q1.m_tiles = (int)ceil_div64(q1.M, v1 ? 352 : 256); q1.n_tiles = (int)ceil_div64(q1.N, v1 ? 256 : 352);
   Tn5Args a;
   a.p0 = q0; a.p1 = q1; a.wide_m0 = v0; a.wide_m1 = v1;
-  a.nprob = 2; a.E = (int)E; a.cpg = cpg; a.ws = ws;
+  a.nprob = nprob; a.E = (int)E; a.cpg = cpg; a.ws = ws;
   a.ctr = item_queue ? reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + slots_bytes) : nullptr;
   if (a.ctr && hipMemsetAsync(a.ctr, 0, (size_t)groups * TN3_CTR_STRIDE * sizeof(int), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
   const size_t lds = 3 * TN5_STAGE + 16;
   hipFuncSetAttribute((const void *)grouped_gemm_tn5_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(grouped_gemm_tn5_k, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
   bool split = false;
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < nprob; ++q) {
     const Tn3Problem &pp = q ? a.p1 : a.p0;
     const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, cpg);
     split |= sc.rem && sc.s > 1;
@@ -2991,6 +2994,27 @@ extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_prob
   return (ncu / groups) * groups * (int64_t)std::max(TN3_SLOT, TN5_SLOT) * (int64_t)sizeof(float) + TN3_CTR_BYTES;
 }
 
+// Which v5 tile a ONE-group [M, N] weight gradient takes through apertis_grouped_gemm_tn (1 = 352 x 256, 0 = 256 x 352), or -1:
+// the caller then cuts the rows into pseudo-groups for the 128 x 128 kernel and folds the partial sums itself (ops.py).
+// Measured at 180 224 rows (tools/dense_wgrad_check.py; 128 x 128 kernel + fold -> this path): dW [704, 2816] 1141 -> 697 us
+// (626 -> 1026 TF), [768, 768] 331 -> 345, [896, 224] 157 -> 229, [352, 704] 191 -> 234, [704, 176] 133 -> 245: every CU
+// writes a whole 352 x 256 fp32 slice (93 MB of partial tiles + their fold per call, whatever the shape) and the row slices
+// of a tile's column share no operand reads - it pays from about a dozen tiles on.  The SSM block's projections stay on
+// the pseudo-group path.
+#ifndef TN_DENSE_MIN_FILL
+#define TN_DENSE_MIN_FILL 60
+#endif
+#ifndef TN_DENSE_MIN_AREA
+#define TN_DENSE_MIN_AREA (1 << 20)
+#endif
+extern "C" int apertis_grouped_gemm_tn_dense_variant(int64_t M, int64_t N) {
+  if (M < 128 || N < 128 || M % 8 || N % 8 || M * N < TN_DENSE_MIN_AREA) return -1;
+  auto area = [&](int64_t tm, int64_t tn) { return ceil_div64(M, tm) * ceil_div64(N, tn) * tm * tn; };
+  const int64_t aw = area(352, 256), an = area(256, 352), best = std::min(aw, an);
+  if (M * N * 100 < best * TN_DENSE_MIN_FILL) return -1;     // (more than 40 % of the MFMA work on zeros)
+  return aw <= an ? 1 : 0;
+}
+
 extern "C" int apertis_grouped_gemm_tn_q(const void *A, const void *Bm, const int32_t *offsets, float *dW,
                                          float *dbias, int64_t max_rows, int64_t M, int64_t N, int64_t E, void *ws,
                                          int64_t ws_bytes, int dtype, int item_queue, void *stream) {
@@ -3005,6 +3029,13 @@ extern "C" int apertis_grouped_gemm_tn_q(const void *A, const void *Bm, const in
     if (ws) {
       Tn3Problem q{(const bf16_t *)A, (const bf16_t *)Bm, dW, dbias, (int)M, (int)N, (int)ceil_div64(M, 256),
                    (int)ceil_div64(N, 256)};
+      // One group (a dense layer's weight gradient: the reduction runs over ALL rows) with enough tiles: the 352-wide tiles of
+      // v5, the rows of every tile split over the CUs and folded in slice order (apertis_grouped_gemm_tn_dense_variant).
+      const int dv = apertis_grouped_gemm_tn_dense_variant(M, N);
+      if (E == 1 && dv >= 0) {
+        const int rc5 = launch_tn5(q, nullptr, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, st, dv);
+        if (rc5 != APERTIS_ERR_UNSUPPORTED) return rc5;
+      }
       const int rc = launch_tn3(q, nullptr, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, st);
       if (rc != APERTIS_ERR_UNSUPPORTED) return rc;
     }
@@ -3071,7 +3102,7 @@ extern "C" int apertis_grouped_gemm_tn_pair_q(const void *A0, const void *B0, fl
     if (const char *ev = getenv("TN_V5")) v5 = atoi(ev) != 0;
 #endif
     if (v5) {   // the 704-wide family: 256 x 352 / 352 x 256 tiles
-      const int rc5 = launch_tn5(p0, p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);
+      const int rc5 = launch_tn5(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);
       if (rc5 != APERTIS_ERR_UNSUPPORTED) return rc5;
     }
     const int rc = launch_tn3(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);

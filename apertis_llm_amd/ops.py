@@ -1226,6 +1226,8 @@ def _cast_transpose(w, dtype, want_plain=True, want_transposed=True):
 
 _SPLITK_ROWS = 1024
 _splitk_cache = {}
+# APERTIS_DENSE_WGRAD_WIDE=0: every dense weight gradient on the 128 x 128 kernel over pseudo-groups (the round-1..3 form)
+DENSE_WGRAD_WIDE = _os.environ.get("APERTIS_DENSE_WGRAD_WIDE", "1") == "1"
 
 
 def _splitk_depth(N, K):
@@ -1377,7 +1379,18 @@ class _GroupedLinear(torch.autograd.Function):
                      0.0, 0, code, code, stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K), dpre.device,
                     *_dense_tag(E, max_rows, K, N, x.element_size()))
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            if E == 1 and max_rows >= 4 * _SPLITK_ROWS:
+            if (E == 1 and max_rows >= 4 * _SPLITK_ROWS and DENSE_WGRAD_WIDE and x.dtype == torch.bfloat16 and not has_bias
+                    and lib.apertis_grouped_gemm_tn_dense_variant(N, K) >= 0):
+                # a WIDE dense layer (from about a dozen 352 x 256 tiles on: dW [704, 2816] 1141 -> 697 us) on the wide-tile
+                # kernel: the library splits the rows of every tile over the CUs and folds the slices in order; the SSM
+                # block's narrow projections lose there (234 vs 191 us for dW [352, 704]) and stay below
+                dw = torch.empty(1, N, K, device=x.device, dtype=torch.float32)
+                ws, ws_bytes = _tn_workspace(1, 1, x.device, max_rows)
+                _launch("apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,
+                        (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), None, max_rows, N, K, 1, ptr(ws), ws_bytes, code, stream_ptr()),
+                        2.0 * max_rows * N * K, f"rows={max_rows} M={N} N={K}", float(max_rows) * (N + K) * x.element_size())
+                db = None
+            elif E == 1 and max_rows >= 4 * _SPLITK_ROWS:
                 # dense layer: the K dimension of the weight gradient is ALL rows; cut it into
                 # pseudo-groups of _SPLITK_ROWS rows so the grid fills the chip, then fold the
                 # partials in a fixed order (deterministic split-K, no atomics).  The dense layers of

@@ -463,6 +463,12 @@ int apertis_grouped_gemm_nt_q(const void *A, const void *W, const float *bias,
  * without zero columns where 256x256 tiles would waste >= 5 % (the 704-wide family: [2816, 704] and [704, 2816]); the
  * workspace size covers either kernel. */
 int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems);
+/* >= 0 when apertis_grouped_gemm_tn takes a ONE-group (E = 1) bf16 [M, N] weight gradient - a dense layer's, core.py:366-397:
+ * the reduction runs over all rows - on its wide-tile kernel, splitting the rows over the CUs and folding the slices itself
+ * (pass the workspace of apertis_grouped_gemm_tn_workspace_bytes(1, 1)); -1 when the caller should cut the rows into
+ * pseudo-groups (offsets every 1024-2048 rows, E = their count, dW = [E, M, N] partial sums) and fold them with
+ * apertis_colsum_f32, as the narrow shapes still do. */
+int apertis_grouped_gemm_tn_dense_variant(int64_t M, int64_t N);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
                             int64_t E, void *ws, int64_t ws_bytes, int dtype, void *stream);

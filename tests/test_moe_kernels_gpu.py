@@ -291,6 +291,39 @@ def test_linear_mfma_splitk_wgrad(dev, rows, N, K, dt):
     _close(bd.grad, br.grad, "db", **tol)
 
 
+@pytest.mark.parametrize("rows,N,K", [(8192, 704, 2816), (9000, 1408, 768)])
+def test_linear_mfma_wide_dense_wgrad(dev, rows, N, K):
+    """A wide bias-free dense layer (M * N >= 2^20): its weight gradient goes through apertis_grouped_gemm_tn as ONE group -
+    the library splits the rows of its 352-wide tiles over the CUs and folds the slices itself (no pseudo-groups, no
+    apertis_colsum_f32 from the caller); values against fp64 on the bf16 operands, bits reproducible."""
+    from apertis_llm_amd import ops, _lib
+    lib = _lib.load()
+    assert lib.apertis_grouped_gemm_tn_dense_variant(N, K) >= 0 and lib.apertis_grouped_gemm_tn_dense_variant(352, 704) < 0
+    torch.manual_seed(rows)
+    x, W = torch.randn(rows, K).bfloat16(), torch.randn(N, K) / K ** 0.5
+    dout = torch.randn(rows, N).bfloat16()
+    xd, Wd = x.to(dev), W.to(dev).requires_grad_(True)
+    folds = {"n": 0}
+    real = lib.apertis_colsum_f32
+
+    def counting(*a):
+        folds["n"] += 1
+        return real(*a)
+
+    lib.apertis_colsum_f32 = counting
+    try:
+        ops.linear_mfma(xd, Wd, None, compute_dtype=torch.bfloat16).backward(dout.to(dev))
+        g1 = Wd.grad.clone()
+        Wd.grad = None
+        ops.linear_mfma(xd, Wd, None, compute_dtype=torch.bfloat16).backward(dout.to(dev))
+    finally:
+        lib.apertis_colsum_f32 = real
+    assert folds["n"] == 0, "the wide path folds inside the library"
+    assert torch.equal(g1, Wd.grad), "slice fold must be bitwise reproducible"
+    ref = dout.double().t() @ x.double()
+    _close(Wd.grad, ref, "dW", rtol=1e-4, atol_scale=2e-6)
+
+
 @pytest.mark.parametrize("T,H,dt_in,dt_out", [(1000, 704, torch.float32, torch.float32), (333, 32, torch.float32, torch.float32),
                                               (4100, 256, torch.float32, torch.bfloat16), (77, 1028, torch.float32, torch.float32)])
 def test_layer_norm_kernels(dev, T, H, dt_in, dt_out):
