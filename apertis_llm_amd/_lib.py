@@ -98,6 +98,8 @@ SIGNATURES = {
                                               _vp, _i64, _i32, _i32, _vp]),
     "apertis_grouped_gemm_tn_q": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp]),
     "apertis_cast_transpose": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_weight_prep_entry_bytes": (_i64, []),
+    "apertis_weight_prep": (_i32, [_vp, _i64, _i64, _vp]),
     "apertis_grouped_gemm_tn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i32, _vp]),
     "apertis_moe_gate_topk_aux_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp]),
     "apertis_moe_gate_topk_aux_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _i64, _i64, _i64, _vp]),

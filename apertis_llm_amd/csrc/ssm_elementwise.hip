@@ -515,6 +515,54 @@ cast_transpose4_k(const float *__restrict__ src, TO *__restrict__ dst, TO *__res
   }
 }
 
+// The same for MANY weights in one launch (round 4; the training step's compute copies, prepared once per step): a table of
+// matrices [R, C] fp32 -> bf16 copy (rows at `rowmap[r]` if given, pitch ld_plain) and bf16 transposed copy (pitch ld_tr), a
+// work-group per 64 x 64 tile found by bisection over the entries' first-tile indices.  Pad rows / columns of the
+// destinations are never written (the caller zero-fills them once).  The conversion is apertis_cast_transpose's (RNE).
+struct WPEntry {
+  const float *src; bf16_t *plain; bf16_t *tr; const int32_t *rowmap;
+  int32_t R, C, ld_plain, ld_tr, tiles_c, tile0, pad0, pad1;
+};
+__global__ void __launch_bounds__(256)
+weight_prep_k(const WPEntry *__restrict__ tab, int n_entries) {
+  __shared__ float tile[64][65];
+  const int t = (int)blockIdx.x;
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {                       // the last entry whose first tile is <= t
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile0 <= t) lo = mid; else hi = mid - 1;
+  }
+  const WPEntry en = tab[lo];
+  const int lt = t - en.tile0, tr_ = lt / en.tiles_c, r0 = tr_ * 64, c0 = (lt - tr_ * en.tiles_c) * 64;
+  const int R = en.R, C = en.C;
+  const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = g + 16 * i, r = r0 + rl, c = c0 + q * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R && c < C) {
+      v = *reinterpret_cast<const float4 *>(en.src + (int64_t)r * C + c);
+      if (en.plain) out4<bf16_t>::store(en.plain + (int64_t)(en.rowmap ? en.rowmap[r] : r) * en.ld_plain + c, v.x, v.y, v.z, v.w);
+    }
+    tile[rl][q * 4 + 0] = v.x; tile[rl][q * 4 + 1] = v.y; tile[rl][q * 4 + 2] = v.z; tile[rl][q * 4 + 3] = v.w;
+  }
+  __syncthreads();
+  if (en.tr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cl = g + 16 * i, c = c0 + cl, r = r0 + q * 4;
+      if (c >= C || r >= R) continue;
+      bf16_t *row = en.tr + (int64_t)c * en.ld_tr;
+      if (!en.rowmap && r + 3 < R) {
+        out4<bf16_t>::store(row + r, tile[q * 4 + 0][cl], tile[q * 4 + 1][cl], tile[q * 4 + 2][cl], tile[q * 4 + 3][cl]);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (r + k < R) row[en.rowmap ? en.rowmap[r + k] : r + k] = (bf16_t)tile[q * 4 + k][cl];
+      }
+    }
+  }
+}
+
 int gate_blocks(int64_t T, int64_t Dn) {
   Geo g = make_geo(Dn);
   int64_t nb = ceil_div64(T, (int64_t)g.RP * 8);
@@ -657,6 +705,14 @@ extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, i
     return APERTIS_ERR_ARG;
   }
 #undef CT_GO
+  return apertis_check_launch();
+}
+
+extern "C" int64_t apertis_weight_prep_entry_bytes(void) { return (int64_t)sizeof(WPEntry); }
+extern "C" int apertis_weight_prep(const void *table, int64_t n_entries, int64_t total_tiles, void *stream) {
+  if (!table || n_entries <= 0 || total_tiles <= 0 || n_entries > 0x7fffffff || total_tiles > 0x7fffffff) return APERTIS_ERR_ARG;
+  hipLaunchKernelGGL(weight_prep_k, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, (const WPEntry *)table,
+                     (int)n_entries);
   return apertis_check_launch();
 }
 

@@ -332,6 +332,26 @@ class SelectiveLinearAttention(nn.Module):
         self.use_cache = False
         self._pad_idx = None
 
+    def _pad_index(self, device):
+        """Destination row of every row of x_param_proj.weight ([dt | Bt | C]) in the padded layout [Bt | 0 | C | 0 | dt | 0]."""
+        Dn, R = self.d_inner, self.dt_rank
+        Wb = -(-Dn // 64) * 64
+        idx = self._pad_idx
+        if idx is None or idx.device != device:
+            i = torch.arange(R + 2 * Dn)
+            dst = torch.where(i < R, 2 * Wb + i, torch.where(i < R + Dn, i - R, Wb + i - R - Dn))
+            idx = self._pad_idx = dst.to(device)
+        return idx
+
+    def register_train_prep(self, prep):
+        """This block's GEMM weights into a TrainPrep (ops.py): stacked in_proj, padded x_param_proj, out_proj."""
+        Dn, R = self.d_inner, self.dt_rank
+        Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
+        prep.add_stack(("in_proj_xz", id(self)), (self.in_proj_x.weight, self.in_proj_z.weight))
+        prep.add_rowmap(("x_param_padded", id(self)), self.x_param_proj.weight, self._pad_index(self.x_param_proj.weight.device),
+                        2 * Wb + Wr)
+        prep.add_plain(self.out_proj.weight)
+
     def _padded_param_weight(self):
         """x_param_proj.weight with its output columns re-ordered and zero-padded so that, in the GEMM output p, the Bt
         and C column blocks each start on a 128-byte boundary and every row does too (core.py:376-381 reads them as
@@ -341,13 +361,8 @@ class SelectiveLinearAttention(nn.Module):
         w, Dn, R = self.x_param_proj.weight, self.d_inner, self.dt_rank
         Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
         if w.is_cuda:
-            idx = self._pad_idx
-            if idx is None or idx.device != w.device:
-                # source row i of [dt | Bt | C] lands at: dt -> 2*Wb + i, Bt -> i - R, C -> Wb + i - R - Dn
-                i = torch.arange(R + 2 * Dn)
-                dst = torch.where(i < R, 2 * Wb + i, torch.where(i < R + Dn, i - R, Wb + i - R - Dn))
-                idx = self._pad_idx = dst.to(w.device)
-            return ops.scatter_rows(w, idx, 2 * Wb + Wr), Wb, Wr
+            # source row i of [dt | Bt | C] lands at: dt -> 2*Wb + i, Bt -> i - R, C -> Wb + i - R - Dn
+            return ops.scatter_rows(w, self._pad_index(w.device), 2 * Wb + Wr), Wb, Wr
         zb = w.new_zeros(Wb - Dn, Dn)
         zr = w.new_zeros(Wr - R, Dn)
         return torch.cat([w[R:R + Dn], zb, w[R + Dn:], zb, w[:R], zr], dim=0), Wb, Wr
@@ -365,10 +380,17 @@ class SelectiveLinearAttention(nn.Module):
         # in_proj_x and in_proj_z share their input: one GEMM with the stacked weight, outputs are
         # column views (core.py:366-367)
         # (under no_grad - generate() - the stacked and the padded weight are prepared once, not per token)
-        w_xz = ops.cached_prep("in_proj_xz", (self.in_proj_x.weight, self.in_proj_z.weight),
-                               lambda: torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
+        # (inside a training step the stacked and the padded weight come prepared - ops.TrainPrep: one launch per step for the
+        # whole model - and these are placeholders that carry shape and gradient route only)
+        w_xz = ops.prepared_weight(("in_proj_xz", id(self)), (self.in_proj_x.weight, self.in_proj_z.weight))
+        if w_xz is None:
+            w_xz = ops.cached_prep("in_proj_xz", (self.in_proj_x.weight, self.in_proj_z.weight),
+                                   lambda: torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
         xz = _mfma_linear(hidden_states, w_xz)
-        wp, Wb, Wr = ops.cached_prep("x_param_padded", (self.x_param_proj.weight,), self._padded_param_weight)
+        Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
+        wp = ops.prepared_weight(("x_param_padded", id(self)), (self.x_param_proj.weight,))
+        if wp is None:
+            wp, Wb, Wr = ops.cached_prep("x_param_padded", (self.x_param_proj.weight,), self._padded_param_weight)
         if (L == 1 and have_window and ssm_prev is not None and not output_attentions and not torch.is_grad_enabled()
                 and hidden_states.is_cuda and kw > 1):
             # single-token decode step (generate(), core.py:1578-1603): two small kernels around the projections
@@ -452,6 +474,11 @@ class AdaptiveExpertSystem(nn.Module):
 
     _STACKED = (("0.weight", "expert_ln_weight"), ("0.bias", "expert_ln_bias"), ("1.weight", "expert_w1"),
                 ("1.bias", "expert_b1"), ("4.weight", "expert_w2"), ("4.bias", "expert_b2"))
+
+    def register_train_prep(self, prep):
+        """The stacked expert weights into a TrainPrep (ops.py): bf16 and transposed bf16 copies, one launch per step."""
+        prep.add_plain(self.expert_w1)
+        prep.add_plain(self.expert_w2)
 
     def __init__(self, config: ApertisConfig, activation_function_override: Optional[str] = None):
         super().__init__()
@@ -714,6 +741,12 @@ class ApertisFeedForward(nn.Module):
                                      _activation_module(config.hidden_act), nn.Dropout(config.hidden_dropout_prob),
                                      nn.Linear(config.intermediate_size, config.hidden_size))
         self.output_dropout = nn.Dropout(config.hidden_dropout_prob)
+
+    def register_train_prep(self, prep):
+        """The plain dense FFN's two weights into a TrainPrep (the expert system registers its own)."""
+        if isinstance(self.ffn, nn.Sequential):
+            prep.add_plain(self.ffn[0].weight)
+            prep.add_plain(self.ffn[3].weight)
 
     def _dense_ffn(self, x):
         """Linear -> act -> Dropout -> Linear (core.py:861-866).  On the GPU the plain (non-MoE, non-SwiGLU) FFN runs on the

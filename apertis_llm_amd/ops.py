@@ -1192,12 +1192,204 @@ def cached_prep(tag, tensors, make, enable=None):
     return ent[2]
 
 
+# ----------------------------------------------------------------------------------------------
+# Training-step weight preparation in ONE launch (round 4).  A training forward needs, per GEMM weight, a bf16 copy (K zero-
+# padded to 64) and - for the data gradient - a transposed bf16 copy; the SSM block additionally stacks in_proj_x | in_proj_z
+# and permutes / pads x_param_proj's rows.  Done per call that was 7 launches per layer and step (cat, scatter, five
+# casts).  A TrainPrep holds persistent destination buffers for every registered weight of a model and a device table of
+# them; `refresh()` - called by training.TrainStep at the START of every step, so a write to the weights between steps,
+# through whatever door, is always seen - fills all of them with one apertis_weight_prep launch, and inside
+# `with prep.active():` cast_transpose() / prepared_weight() hand out those buffers instead of making copies.
+# Only bf16 compute copies; anything not registered (or another dtype) takes the per-call path as before.
+# ----------------------------------------------------------------------------------------------
+_ACTIVE_TRAIN_PREP = None
+TRAIN_PREP = _os.environ.get("APERTIS_TRAIN_PREP", "1") == "1"
+
+
+class _PrepEntry:
+    __slots__ = ("sources", "rows", "cols", "plain", "tr", "kind", "rowmap", "rows_out")
+
+
+class TrainPrep:
+    def __init__(self, device):
+        self.device = _indexed(device)
+        self.entries = []
+        self.by_param = {}        # id(parameter) -> entry (plain weights: the parameter itself is what the op receives)
+        self.by_key = {}          # (tag, id(module)) -> entry (stacked / row-mapped weights: the op receives a placeholder)
+        self.table = None
+        self.total_tiles = 0
+        self._records = []
+
+    @staticmethod
+    def _ok(*ws):
+        return all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.shape[-1] % 4 == 0 and w.data_ptr() % 16 == 0
+                   for w in ws)
+
+    def _alloc(self, E, rows, cols):
+        Cp, Rp = -(-cols // 64) * 64, -(-rows // 64) * 64
+        return (torch.zeros(E, rows, Cp, device=self.device, dtype=torch.bfloat16),
+                torch.zeros(E, cols, Rp, device=self.device, dtype=torch.bfloat16))
+
+    def add_plain(self, param):
+        """[R, C] or [E, R, C] parameter -> copies shaped as cast_transpose's ([E, R, C'], [E, C, R'])."""
+        w = param if param.dim() == 3 else param.unsqueeze(0)
+        if param.dim() not in (2, 3) or not self._ok(param) or id(param) in self.by_param:
+            return False
+        E, R, C = w.shape
+        en = _PrepEntry()
+        en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rows_out = (param,), R, C, "plain", None, R
+        en.plain, en.tr = self._alloc(E, R, C)
+        for e in range(E):
+            self._records.append((param, e * R * C * 4, en.plain[e], en.tr[e], None, R, C, 0))
+        self.entries.append(en)
+        self.by_param[id(param)] = en
+        return True
+
+    def add_stack(self, key, params):
+        """Row-stacked [sum R_i, C] weight of several [R_i, C] parameters (in_proj_x | in_proj_z)."""
+        if key in self.by_key or not self._ok(*params) or len({p.shape[1] for p in params}) != 1:
+            return False
+        C, R = params[0].shape[1], sum(p.shape[0] for p in params)
+        en = _PrepEntry()
+        en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rows_out = tuple(params), R, C, "stack", None, R
+        en.plain, en.tr = self._alloc(1, R, C)
+        r0 = 0
+        for p_ in params:
+            self._records.append((p_, 0, en.plain[0], en.tr[0], None, p_.shape[0], C, r0))
+            r0 += p_.shape[0]
+        self.entries.append(en)
+        self.by_key[key] = en
+        return True
+
+    def add_rowmap(self, key, param, dst_idx, rows_out):
+        """[R, C] parameter whose row r lands in row dst_idx[r] of a [rows_out, C] weight, the other rows zero (x_param_proj in
+        the scan's padded layout)."""
+        if key in self.by_key or not self._ok(param):
+            return False
+        R, C = param.shape
+        en = _PrepEntry()
+        en.sources, en.rows, en.cols, en.kind, en.rows_out = (param,), R, C, "rowmap", rows_out
+        en.rowmap = dst_idx.to(device=self.device, dtype=torch.int32).contiguous()
+        en.plain, en.tr = self._alloc(1, rows_out, C)
+        self._records.append((param, 0, en.plain[0], en.tr[0], en.rowmap, R, C, 0))
+        self.entries.append(en)
+        self.by_key[key] = en
+        return True
+
+    def finalize(self):
+        """Builds the device table (sources' addresses are read here: the parameters must stay where they are)."""
+        import struct
+        lib = _lib.load()
+        assert lib.apertis_weight_prep_entry_bytes() == 64
+        blob, tile0 = bytearray(), 0
+        self._addr = []
+        for (src, off, plain, tr, rowmap, R, C, r0) in self._records:
+            tiles_c = -(-C // 64)
+            ldp, ldt = plain.shape[-1], tr.shape[-1]
+            # a stacked source's rows start at row r0 of the destination: plain base + r0 rows, transposed base + r0 columns
+            blob += struct.pack("<QQQQiiiiiiii", src.data_ptr() + off, plain.data_ptr() + r0 * ldp * 2, tr.data_ptr() + r0 * 2,
+                                0 if rowmap is None else rowmap.data_ptr(), R, C, ldp, ldt, tiles_c, tile0, 0, 0)
+            tile0 += -(-R // 64) * tiles_c
+            self._addr.append((src, src.data_ptr()))
+        self.total_tiles = tile0
+        self.n_records = len(self._records)
+        if self.n_records:
+            self.table = torch.frombuffer(blob, dtype=torch.uint8).to(self.device)      # (bytearray: writable)
+        return self
+
+    def refresh(self):
+        """All copies from the parameters' current values: one launch."""
+        if not self.n_records:
+            return
+        for src, addr in self._addr:
+            if src.data_ptr() != addr:
+                raise ApertisHipError("TrainPrep: a registered parameter moved (model.to(...) after the first step?): build a new "
+                                      "TrainStep / TrainPrep")
+        check(_lib.load().apertis_weight_prep(ptr(self.table), self.n_records, self.total_tiles, stream_ptr()), "apertis_weight_prep")
+
+    def active(self):
+        return _TrainPrepScope(self)
+
+
+class _TrainPrepScope:
+    def __init__(self, prep):
+        self.prep = prep
+
+    def __enter__(self):
+        global _ACTIVE_TRAIN_PREP
+        self.prev, _ACTIVE_TRAIN_PREP = _ACTIVE_TRAIN_PREP, self.prep
+        return self.prep
+
+    def __exit__(self, *exc):
+        global _ACTIVE_TRAIN_PREP
+        _ACTIVE_TRAIN_PREP = self.prev
+        return False
+
+
+class _PreparedWeight(torch.autograd.Function):
+    """Stand-in for a stacked / row-mapped fp32 weight whose compute copies a TrainPrep holds: an UNINITIALISED [rows, C]
+    tensor that only carries shape, dtype and the gradient route - the GEMM ops find the copies on it (`_apertis_prep`) and
+    never read its values.  backward: the weight's gradient back to the source parameters' layouts."""
+
+    @staticmethod
+    def forward(ctx, en, *sources):
+        ctx.en = en
+        return torch.empty(en.rows_out, en.cols, device=sources[0].device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dw):
+        en = ctx.en
+        if en.kind == "stack":
+            outs, r0 = [], 0
+            for p_ in en.sources:
+                outs.append(dw[r0:r0 + p_.shape[0]])
+                r0 += p_.shape[0]
+            return (None, *outs)
+        return None, dw.index_select(0, en.rowmap.long())
+
+
+def prepared_weight(key, sources):
+    """The placeholder of a registered stacked / row-mapped weight inside an active TrainPrep scope under bf16 autocast, else
+    None (the caller then builds the weight itself)."""
+    tp = _ACTIVE_TRAIN_PREP
+    if tp is None or not torch.is_autocast_enabled() or torch.get_autocast_dtype("cuda") != torch.bfloat16:
+        return None
+    en = tp.by_key.get(key)
+    if en is None or len(en.sources) != len(sources) or any(a is not b for a, b in zip(en.sources, sources)):
+        return None
+    w = _PreparedWeight.apply(en, *sources)
+    w._apertis_prep = en
+    return w
+
+
+def _train_prep_lookup(w, dtype):
+    tp = _ACTIVE_TRAIN_PREP
+    if tp is None or dtype != torch.bfloat16:
+        return None
+    base = w._base if w._base is not None else w
+    en = getattr(base, "_apertis_prep", None)
+    if en is None:
+        en = tp.by_param.get(id(base))
+        if en is not None and en.sources[0] is not base:
+            en = None
+    if en is None:
+        return None
+    E, R, C = w.shape
+    if (E, R, C) != (en.plain.shape[0], en.rows_out, en.cols):
+        return None
+    return en.plain, en.tr
+
+
 def cast_transpose(w, dtype, want_plain=True, want_transposed=True, cache=False):
     """Compute copies of an fp32 master weight [E,R,C]: ([E,R,C'], [E,C,R']) in `dtype`.  In bf16 the
     last dimension is zero-padded to a multiple of 64 (C', R'): the GEMM's W operand then has whole
     64-wide K steps whatever K is; pass `.shape[-1]` as its row pitch (ldw).  cache=True (inference: no input of the
     calling op needs a gradient): the result is kept per weight (cached_prep), and an fp32 plain copy of an fp32 weight
     is the weight itself."""
+    if _ACTIVE_TRAIN_PREP is not None and w.is_cuda and w.dim() == 3:
+        hit = _train_prep_lookup(w, dtype)
+        if hit is not None:
+            return hit
     if cache and w.is_cuda:
         if dtype == torch.float32 and w.dtype == torch.float32 and want_plain and not want_transposed and w.is_contiguous():
             return w.detach(), None

@@ -214,6 +214,42 @@ class ApertisAdamW(torch.optim.Optimizer):
         return loss
 
 
+def build_train_prep(model):
+    """ops.TrainPrep over every module of `model` that offers `register_train_prep` (SSM blocks, expert systems, dense FFNs), or
+    None (CPU model, APERTIS_TRAIN_PREP=0, nothing to register)."""
+    from . import ops
+    p0 = next((p for p in model.parameters()), None)
+    if not ops.TRAIN_PREP or p0 is None or not p0.is_cuda:
+        return None
+    prep = ops.TrainPrep(p0.device)
+    for m in model.modules():
+        reg = getattr(m, "register_train_prep", None)
+        if callable(reg):
+            reg(prep)
+    prep.finalize()
+    return prep if prep.n_records else None
+
+
+class prepared_step:
+    """`with prepared_step(prep):` around a training micro-step's forward + backward: refreshes the prepared weight copies (one
+    launch) and makes them visible to the ops; a no-op for prep = None."""
+
+    def __init__(self, prep):
+        self.prep, self.scope = prep, None
+
+    def __enter__(self):
+        if self.prep is not None:
+            self.prep.refresh()
+            self.scope = self.prep.active()
+            self.scope.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.scope is not None:
+            self.scope.__exit__(*exc)
+        return False
+
+
 class TrainStep:
     """loss = model(**batch)[0]; backward; (all-reduce); clip; AdamW; OneCycleLR."""
 
@@ -238,13 +274,14 @@ class TrainStep:
         self.accum = max(1, gradient_accumulation_steps)
         self._micro = 0
         self._params = [p for p in model.parameters() if p.requires_grad]
+        self.prep = build_train_prep(model) if bf16 else None     # (bf16 compute copies only)
 
     def __call__(self, **batch):
         """One micro-batch.  Returns the detached loss tensor (no host sync)."""
         self._micro += 1
         last = self._micro % self.accum == 0
         ctx = self.dp.no_sync() if (self.dp is not None and not last) else _null()
-        with ctx:
+        with ctx, prepared_step(self.prep):
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
                 loss = self.model(**batch)[0]
             (loss / self.accum).backward()

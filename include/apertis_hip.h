@@ -499,6 +499,18 @@ int apertis_grouped_gemm_tn_pair_q(const void *A0, const void *B0, float *dW0, f
  * are written as zero - the form apertis_grouped_gemm_nt wants for K % 64 != 0. */
 int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R,
                            int64_t C, int64_t ld_dst, int64_t ld_dstT, int dtype_out, void *stream);
+/* The compute copies of MANY weights in ONE launch (the training step prepares every layer's stacked / padded / cast /
+ * transposed weights once, at its start: core.py:366-397,437-440 read them).  `table`: device array of n_entries records of
+ * apertis_weight_prep_entry_bytes() = 64 bytes each, in order of `tile0`:
+ *   { const float *src;      fp32 [R, C], contiguous, 16-byte aligned, C % 4 == 0
+ *     bf16 *plain;           or NULL: row r of src -> row (rowmap ? rowmap[r] : r), pitch ld_plain (% 4 == 0), 16-byte aligned
+ *     bf16 *tr;              or NULL: the transposed copy, column index mapped the same way, pitch ld_tr (% 4 == 0)
+ *     const int32_t *rowmap; or NULL
+ *     int32_t R, C, ld_plain, ld_tr, tiles_c (= ceil(C / 64)), tile0 (first 64 x 64 tile of this entry in the launch), 0, 0 }
+ * total_tiles = sum of ceil(R/64) * ceil(C/64).  Pad rows / columns of the destinations are not written (zero them once).
+ * The conversion is apertis_cast_transpose's: the copies are bit-identical to its outputs. */
+int64_t apertis_weight_prep_entry_bytes(void);
+int apertis_weight_prep(const void *table, int64_t n_entries, int64_t total_tiles, void *stream);
 /* out[c] = sum_r in[r,c] over a row-major fp32 [rows, cols] matrix, fixed summation order
  * (folds split-K partial weight gradients and per-block partial sums deterministically). */
 int apertis_colsum_f32(const float *in, float *out, int64_t rows, int64_t cols, void *stream);

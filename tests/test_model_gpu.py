@@ -554,3 +554,71 @@ def test_prepared_weight_cache_is_scoped_and_never_stale(dev):
     # generate() opens its own scope and leaves nothing behind
     out = model.generate(input_ids=ids[:, :8], max_new_tokens=4)
     assert out.shape == (2, 12) and len(ops._prep_cache) == 0
+
+
+@pytest.mark.parametrize("experts", [0, 4])
+def test_train_prep_one_launch_equals_per_call_preparation(dev, experts):
+    """training.TrainStep prepares every GEMM weight's compute copies (stacked in_proj, padded x_param_proj, bf16 and transposed
+    bf16 of the projections / experts / dense FFN) in ONE apertis_weight_prep launch at the start of a step.  Three steps with
+    it against three steps with the per-call preparation (cat / scatter / apertis_cast_transpose per layer): losses and every
+    parameter bit-identical; no per-call cast inside a prepared step; and a write to a weight BETWEEN steps - through `.data`,
+    which no version counter sees - is picked up (the refresh runs at the start of every step)."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops, _lib
+    from apertis_llm_amd.training import TrainStep
+    cfg = dict(vocab_size=512, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+               attention_type="selective_ssm", use_expert_system=experts > 0, num_experts=experts, experts_per_token=2)
+    torch.manual_seed(3)
+    init = A.ApertisForCausalLM(A.ApertisConfig(**cfg)).state_dict()
+    lib = _lib.load()
+    counts = {"cast": 0, "prep": 0}
+    real_cast, real_prep = lib.apertis_cast_transpose, lib.apertis_weight_prep
+
+    def cast(*a):
+        counts["cast"] += 1
+        return real_cast(*a)
+
+    def prep(*a):
+        counts["prep"] += 1
+        return real_prep(*a)
+
+    def run(on, monkey_between):
+        ops.TRAIN_PREP = on
+        torch.manual_seed(5)          # (the dropout / router-noise seeds are drawn from the global CPU generator)
+        m = A.ApertisForCausalLM(A.ApertisConfig(**cfg))
+        m.load_state_dict(init)
+        m = m.to(dev).train()
+        step = TrainStep(m, lr=1e-3, total_steps=10, bf16=True)
+        assert (step.prep is not None) == on
+        g = torch.Generator().manual_seed(11)
+        losses = []
+        counts["cast"] = counts["prep"] = 0
+        lib.apertis_cast_transpose, lib.apertis_weight_prep = cast, prep
+        try:
+            for i in range(3):
+                ids = torch.randint(4, 512, (4, 1024), generator=g).to(dev)
+                losses.append(step(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids))
+                if monkey_between and i == 0:      # a write behind torch's back between two steps
+                    blk = m.model.layers[0].attention.attention_mechanism_impl
+                    blk.in_proj_z.weight.data.mul_(0.5)
+                    blk.x_param_proj.weight.data.add_(0.01)
+                    blk.out_proj.weight.data.mul_(1.5)
+        finally:
+            lib.apertis_cast_transpose, lib.apertis_weight_prep = real_cast, real_prep
+        torch.cuda.synchronize()
+        return [float(x) for x in losses], [p.detach().clone() for p in m.parameters()], dict(counts)
+
+    try:
+        for monkey in (False, True):
+            l0, p0, c0 = run(False, monkey)
+            l1, p1, c1 = run(True, monkey)
+            assert c0["prep"] == 0 and c0["cast"] > 0
+            assert c1["prep"] == 3, c1
+            # what is left to the per-call path inside a prepared step: the LM head's pieces (not registered), nothing per layer
+            assert c1["cast"] <= c0["cast"] // 4, (c0, c1)
+            assert l0 == l1, (monkey, l0, l1)
+            assert all(torch.equal(a, b) for a, b in zip(p0, p1)), f"parameters differ after three steps (write between steps: {monkey})"
+            assert all(x == x for x in l0)
+        assert ops.scan_gate_error(dev) == 0
+    finally:
+        ops.TRAIN_PREP = True
