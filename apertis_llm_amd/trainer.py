@@ -37,7 +37,7 @@ from . import ops
 from .data import ApertisFineTuneDataset, ApertisPretrainDataset, load_vocabulary
 from .model import ApertisConfig, ApertisForCausalLM, create_apertis_model
 from .parallel import BucketedDataParallel
-from .training import build_optimizer, clip_and_step
+from .training import build_optimizer, build_train_prep, clip_and_step, prepared_step
 
 logger = logging.getLogger(__name__)
 
@@ -130,6 +130,13 @@ class ApertisTrainer:
             self.val_dataloader = DataLoader(self.val_dataset, batch_size=self.batch_size, shuffle=False, sampler=vs,
                                              num_workers=self._num_workers, pin_memory=pin, drop_last=False)
 
+    def _train_prep(self):
+        """The one-launch weight preparation of a training micro-step (ops.TrainPrep): built at the first step, bf16 autocast on
+        the GPU only."""
+        if not hasattr(self, "_prep"):
+            self._prep = build_train_prep(self.model) if (self.fp16 and self.device.type == "cuda") else None
+        return self._prep
+
     def _loss(self, batch):
         batch = {k: v.to(self.device, non_blocking=True) for k, v in batch.items()}
         with torch.autocast(self.device.type, dtype=torch.bfloat16, enabled=self.fp16):
@@ -167,7 +174,7 @@ class ApertisTrainer:
                 try:
                     boundary = (step + 1) % accum == 0 or (step + 1) == n_batches
                     sync = self.dp.no_sync() if (self.dp is not None and not boundary) else _nullcontext()
-                    with sync:
+                    with sync, prepared_step(self._train_prep()):
                         loss = self._loss(batch)
                         if loss is None:
                             continue
