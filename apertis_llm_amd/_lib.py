@@ -28,6 +28,7 @@ _vp, _i64, _i32, _f32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 _f64 = ctypes.c_double
 
 # name -> (restype, argtypes).  Order and meaning mirror include/apertis_hip.h exactly.
+ABI_VERSION = (4 << 16) | 3      # = APERTIS_ABI_VERSION of include/apertis_hip.h (tests/test_host_cpu.py compares them)
 SIGNATURES = {
     "apertis_abi_version": (ctypes.c_int, []),
     "apertis_arch": (ctypes.c_char_p, []),
@@ -158,7 +159,17 @@ def load():
             raise ApertisHipError(
                 f"{LIB_PATH} not found: build it with `python -m apertis_llm_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU or eager fallback.")
-        _lib = _Lib(ctypes.CDLL(LIB_PATH))
+        cdll = ctypes.CDLL(LIB_PATH)
+        # the binding below is written against ONE version of include/apertis_hip.h: another build of the library (a stale
+        # in-tree .so, or APERTIS_HIP_LIB pointing at an older one) would be called with the wrong argument lists
+        try:
+            got = int(cdll.apertis_abi_version())
+        except AttributeError:
+            got = -1
+        if got != ABI_VERSION:
+            raise ApertisHipError(f"{LIB_PATH} has ABI version {got >> 16}.{got & 0xffff} but this binding needs "
+                                  f"{ABI_VERSION >> 16}.{ABI_VERSION & 0xffff}: rebuild with `python -m apertis_llm_amd.build --force`")
+        _lib = _Lib(cdll)
     return _lib
 
 

@@ -1,7 +1,7 @@
 // Version / error-string entry points of libapertis_hip.so.
 #include "common.h"
 
-extern "C" int apertis_abi_version(void) { return (1 << 16) | 0; }
+extern "C" int apertis_abi_version(void) { return APERTIS_ABI_VERSION; }
 extern "C" const char *apertis_arch(void) { return "gfx950"; }
 extern "C" const char *apertis_strerror(int code) {
   switch (code) {

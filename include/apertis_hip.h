@@ -45,7 +45,10 @@ extern "C" {
 #define APERTIS_ACT_SAVE_GRAD 0x100
 #define APERTIS_ACT_MUL_SAVED 0x200
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes. */
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 4: 4.3 - lean scan
+ * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep).  A host binding should
+ * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
+#define APERTIS_ABI_VERSION ((4 << 16) | 3)
 int apertis_abi_version(void);
 /* Name of the code-object architecture this library was compiled for ("gfx950"). */
 const char *apertis_arch(void);

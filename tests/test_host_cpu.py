@@ -215,7 +215,10 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(cdll, name), name
     lib = _lib.load()
-    assert lib.apertis_abi_version() >> 16 == 1 and lib.apertis_arch() == b"gfx950"
+    # the binding, the header and the library agree on ONE ABI version (_lib.load() refuses any other build of the library)
+    hv = re.search(r"#define APERTIS_ABI_VERSION \(\((\d+) << 16\) \| (\d+)\)", hdr)
+    assert hv and (int(hv.group(1)) << 16 | int(hv.group(2))) == _lib.ABI_VERSION == lib.apertis_abi_version()
+    assert lib.apertis_arch() == b"gfx950"
     assert b"invalid" in lib.apertis_strerror(-1) and lib.apertis_scan_chunk_len(1, 4096, 176) == 64
     assert lib.apertis_scan_num_chunks(1, 4097, 176) == 65
     # argument validation happens before any launch, so it can be exercised without a GPU
