@@ -140,8 +140,13 @@ __device__ __forceinline__ void gelu_both_fast2(v2f x, const GeluK &k, v2f &g, v
 // chain at a time otherwise and pads the dependent v_pk_* pairs with s_nop (60 per four rows of the saved-gradient epilogue)
 __device__ __forceinline__ void gelu_both_fast8(const v2f (&x)[4], const GeluK &k, v2f (&g)[4], v2f (&dg)[4]) {
   v2f t[4], p[4], e[4], q[4];
+  // (1 + k |x| per element with the |.| as a source modifier: from the packed form hipcc makes two v_and and a v_pk_fma_f32)
+  const float tk = GELU_TK;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) t[w] = pk_fma(splat2(GELU_TK), (v2f){fabsf(x[w].x), fabsf(x[w].y)}, splat2(1.f));
+  for (int w = 0; w < 4; ++w) {
+    asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(t[w].x) : "v"(x[w].x), "s"(tk));
+    asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(t[w].y) : "v"(x[w].y), "s"(tk));
+  }
 #pragma unroll
   for (int w = 0; w < 4; ++w) e[w] = (x[w] * x[w]) * splat2(-0.5f * LOG2E_F);
 #pragma unroll
@@ -1164,8 +1169,15 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
       const int r = i * 16 + q;
       const uint32_t off = row_off(r);
       float v[8];
+      if constexpr (MODE == EPI_BOTH) {
+        // (one v_add_f32 per element: the eight addends of a row sit in eight different accumulator quads, and for a
+        // v_pk_add_f32 hipcc first copies each pair into adjacent registers - three instructions for two sums)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = acc[i][j][q] + bv[j];
+        for (int j = 0; j < 8; ++j) asm("v_add_f32 %0, %1, %2" : "=v"(v[j]) : "v"(acc[i][j][q]), "v"(bv[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = acc[i][j][q] + bv[j];
+      }
       uint32_t o[4];
       if constexpr (MODE == EPI_BOTH) {
         // mask words: 0xFFFF where the element is dropped (one hash word per pair of elements)
