@@ -80,12 +80,12 @@ template <int MODE> float run(float *out, int iters, int m, int v) {
 int main() {
   float *out; hipMalloc(&out, 64);
   const int iters = 4000;
-  // per loop trip and MFMA wave: 16 x 16x16x32 = 8 x 32x32x16 = 262144 MACs; VALU wave: 8 element pairs
+  // per loop trip and MFMA wave: 16 x 16x16x32 = 8 x 32x32x16 = 131072 MACs; VALU wave: 8 element pairs
   for (int mode = 0; mode < 2; ++mode) {
     float tm = mode ? run<1>(out, iters, 1, 0) : run<0>(out, iters, 1, 0);
     float tv = mode ? run<1>(out, iters, 0, 1) : run<0>(out, iters, 0, 1);
     float tb = mode ? run<1>(out, iters, 1, 1) : run<0>(out, iters, 1, 1);
-    const double tf = 2.0 * 262144.0 * iters * 4 * 256 / (tm * 1e-6) / 1e12;
+    const double tf = 2.0 * 131072.0 * iters * 4 * 256 / (tm * 1e-6) / 1e12;
     printf("%s: MFMA waves alone %8.1f us (%6.0f TF chip-wide), VALU waves alone %8.1f us, both %8.1f us  (sum %8.1f, max %8.1f)\n",
            mode ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_16x16x32_bf16", tm, tf, tv, tb, tm + tv, tm > tv ? tm : tv);
   }
