@@ -1207,7 +1207,7 @@ TRAIN_PREP = _os.environ.get("APERTIS_TRAIN_PREP", "1") == "1"
 
 
 class _PrepEntry:
-    __slots__ = ("sources", "rows", "cols", "plain", "tr", "kind", "rowmap", "rows_out")
+    __slots__ = ("sources", "rows", "cols", "plain", "tr", "kind", "rowmap", "rowmap64", "rows_out")
 
 
 class TrainPrep:
@@ -1237,7 +1237,7 @@ class TrainPrep:
             return False
         E, R, C = w.shape
         en = _PrepEntry()
-        en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rows_out = (param,), R, C, "plain", None, R
+        en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rowmap64, en.rows_out = (param,), R, C, "plain", None, None, R
         en.plain, en.tr = self._alloc(E, R, C)
         for e in range(E):
             self._records.append((param, e * R * C * 4, en.plain[e], en.tr[e], None, R, C, 0))
@@ -1251,7 +1251,7 @@ class TrainPrep:
             return False
         C, R = params[0].shape[1], sum(p.shape[0] for p in params)
         en = _PrepEntry()
-        en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rows_out = tuple(params), R, C, "stack", None, R
+        en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rowmap64, en.rows_out = tuple(params), R, C, "stack", None, None, R
         en.plain, en.tr = self._alloc(1, R, C)
         r0 = 0
         for p_ in params:
@@ -1270,6 +1270,7 @@ class TrainPrep:
         en = _PrepEntry()
         en.sources, en.rows, en.cols, en.kind, en.rows_out = (param,), R, C, "rowmap", rows_out
         en.rowmap = dst_idx.to(device=self.device, dtype=torch.int32).contiguous()
+        en.rowmap64 = en.rowmap.long()            # (for the backward's index_select: not converted per step)
         en.plain, en.tr = self._alloc(1, rows_out, C)
         self._records.append((param, 0, en.plain[0], en.tr[0], en.rowmap, R, C, 0))
         self.entries.append(en)
@@ -1345,7 +1346,7 @@ class _PreparedWeight(torch.autograd.Function):
                 outs.append(dw[r0:r0 + p_.shape[0]])
                 r0 += p_.shape[0]
             return (None, *outs)
-        return None, dw.index_select(0, en.rowmap.long())
+        return None, dw.index_select(0, en.rowmap64)
 
 
 def prepared_weight(key, sources):
