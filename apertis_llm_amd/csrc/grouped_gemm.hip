@@ -2180,10 +2180,19 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
   //  caller's choice.  Which work-group computes an item changes neither its arithmetic nor where it lands: bit-identical.
   int *s_next = reinterpret_cast<int *>(smem + 4 * OPB);
   const int n_full = sc.full * a.cpg, n_items = n_full + (sc.rem ? sc.rem * sc.s : 0);
-  int item = j;   // first item: the work-group's own index
+  int item = j;   // first item: the work-group's own index ...
+  if (a.ctr) {
+    // ... unless the items come from the group's queue: then the FIRST one does too.  A work-group whose CU another kernel
+    // holds (an RCCL collective) starts when some other work-group has exited, i.e. when the queue is empty - with a
+    // statically assigned first item it then ran a whole tile alone behind everyone else (tools/probes/hog_probe.hip, 32 of
+    // 256 CUs held: 1900 us against 1670 for 224 CUs' worth of work; now it finds nothing and leaves)
+    if (tid == 0) s_next[0] = atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(s_next[0]);   // (slot 0 is next written two barriers from here)
+  }
   for (int par = 1; item < n_items; par ^= 1) {
     int nxt = 0;
-    if (a.ctr && tid == 0) nxt = a.cpg + atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);   // returns under the K loop
+    if (a.ctr && tid == 0) nxt = atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);   // returns under the K loop
     int tile, s0 = 0, s1 = nsteps, slot = 0;
     bool partial = false;
     if (item < n_full) {
@@ -2488,9 +2497,14 @@ __device__ __forceinline__ void tn5_body(const Tn5Args &a, const int32_t *__rest
   int *s_next = reinterpret_cast<int *>(smem + 3 * TN5_STAGE);
   const int n_full = sc.full * a.cpg, n_items = n_full + (sc.rem ? sc.rem * sc.s : 0);
   int item = j;
+  if (a.ctr) {   // (queue mode: the first item from the group's counter too - see grouped_gemm_tn3_k)
+    if (tid == 0) s_next[0] = atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);
+    __syncthreads();
+    item = __builtin_amdgcn_readfirstlane(s_next[0]);
+  }
   for (int par = 1; item < n_items; par ^= 1) {
     int nxt = 0;
-    if (a.ctr && tid == 0) nxt = a.cpg + atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);
+    if (a.ctr && tid == 0) nxt = atomicAdd(a.ctr + g * TN3_CTR_STRIDE, 1);
     int tile, s0 = 0, s1 = nsteps, slot = 0;
     bool partial = false;
     if (item < n_full) {

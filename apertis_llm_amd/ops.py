@@ -1470,6 +1470,13 @@ class _RowsWork:
 # tools/probes/hog_probe.hip: 32 of 256 CUs held -> NT 1109 us static / 762 queue / 702 alone, TN 2400 / 1900 / 1460).
 # Off on one GPU: the queues cost 3 % there.
 GEMM_DYNAMIC_QUEUE = False
+# ... and whether the WEIGHT-GRADIENT kernels follow it.  Off (round 4): with the 352-wide tiles a (problem, expert) group has
+# 22 tiles on 16 CUs, and a queue of such coarse items quantises badly when CUs are missing - measured at B = 44 with 32 of 256
+# CUs held (tools/probes/hog_probe.hip, profiles/r4_probe_cu_hog_32.log): static shares 2130-2210 us, item queue 2620-2750 us
+# (1700-1790 / 1680-1730 alone; 224 CUs' worth of work would be 1940).  The work-groups that start late on a freed CU run
+# their static share on an otherwise idle chip, which costs less than the queue's last round.  The NT tile queue keeps its gain
+# (903 against 1254 us under the same hog; 867 against 780 alone).
+TN_DYNAMIC_QUEUE = _os.environ.get("APERTIS_TN_QUEUE", "0") == "1"
 _NT_QUEUE = {}
 
 
@@ -1610,7 +1617,7 @@ class _GroupedLinear(torch.autograd.Function):
                 ws, ws_bytes = _tn_workspace(E, 1, x.device, max_rows)
                 _launch("apertis_grouped_gemm_tn" if E > 1 else "apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn_q,
                         (ptr(dpre), ptr(x), ptr(offsets), ptr(dw), ptr(db), max_rows, N, K, E, ptr(ws), ws_bytes, code,
-                         int(GEMM_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
+                         int(GEMM_DYNAMIC_QUEUE and TN_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 2.0 * N * K))
             dw = dw.to(wdtype)
         return dx, dw, db, None, None, None, None, None, None
 
@@ -1956,10 +1963,11 @@ class _ExpertMLP(torch.autograd.Function):
         dw1 = grad_destination(ctx.wparams[0], (E, I, H), dev)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
         ws, ws_bytes = _tn_workspace(E, 2, dev, max_rows)
-        # (item queue of the 256x256 kernel: on when the step overlaps RCCL kernels, see GEMM_DYNAMIC_QUEUE)
+        # (item queue of the weight-gradient kernels: only with TN_DYNAMIC_QUEUE on top of GEMM_DYNAMIC_QUEUE - measured slower
+        # than static shares under a CU hog with the 352-wide tiles)
         _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair_q,
                 (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
-                 max_rows, E, ptr(ws), ws_bytes, code, int(GEMM_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
+                 max_rows, E, ptr(ws), ws_bytes, code, int(GEMM_DYNAMIC_QUEUE and TN_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
         return dxg, dw1.to(w1dt), db1, dw2.to(w2dt), db2, None, None, None, None, None, None
 
 

@@ -163,6 +163,7 @@ def _nccl_worker(port, out):
         def three_steps(force):
             os.environ["APERTIS_FORCE_DP"] = "1" if force else "0"
             ops.GEMM_DYNAMIC_QUEUE = bool(force)          # what BucketedDataParallel switches on when world_size > 1
+            ops.TN_DYNAMIC_QUEUE = bool(force)            # (opt-in since round 4: exercised here so that the path stays tested)
             m = A.ApertisForCausalLM(A.ApertisConfig(**big))
             m.load_state_dict(init2)
             m = m.to(dev).train()
@@ -181,6 +182,7 @@ def _nccl_worker(port, out):
             l_dp, p_dp, nb2 = three_steps(True)
         finally:
             ops.GEMM_DYNAMIC_QUEUE = False
+            ops.TN_DYNAMIC_QUEUE = False
             os.environ["APERTIS_FORCE_DP"] = "1"
         same = l_plain == l_dp and all(torch.equal(a, b) for a, b in zip(p_plain, p_dp))
         out.put(res + (same, l_plain, l_dp, nb2, int(ops.scan_gate_error(dev))))
