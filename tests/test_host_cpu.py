@@ -228,6 +228,42 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.apertis_moe_plan_workspace_bytes(4096, 8, 2) > 0
 
 
+def test_round4_entry_points_validate_before_any_launch():
+    """The entry points added in round 4 refuse bad arguments / report their routing without touching a GPU: the dense
+    weight-gradient routing rule, the one-launch weight preparation, the lean scan forms."""
+    from apertis_llm_amd import _lib
+    lib = _lib.load()
+    # one-group weight gradients: wide-tile kernel from 2^20 output elements on, never for the SSM block's narrow projections
+    assert lib.apertis_grouped_gemm_tn_dense_variant(704, 2816) == 1 and lib.apertis_grouped_gemm_tn_dense_variant(2816, 704) >= 0
+    for m, n in [(352, 704), (704, 176), (448, 176), (768, 768), (64, 1 << 20), (1 << 20, 6)]:
+        assert lib.apertis_grouped_gemm_tn_dense_variant(m, n) == -1, (m, n)
+    assert lib.apertis_weight_prep_entry_bytes() == 64
+    assert lib.apertis_weight_prep(None, 1, 1, None) == -1 and lib.apertis_weight_prep(1, 0, 1, None) == -1
+    # lean scan: NULL operands are an argument error, a shape it does not take (N = 8) is "unsupported" - both before any launch
+    assert lib.apertis_scan_lean_fwd(None, None, None, 0, None, 0, None, 0, None, 0, None, None, None, 0, None, None, None, None,
+                                     1, 64, 11, 16, 1, None) == -1
+    assert lib.apertis_scan_lean_fwd_dt(None, 0, None, None, 44, None, None, None, 0, None, 0, None, 0, None, 0, None, None, None,
+                                        0, None, None, None, None, 1, 64, 11, 16, 1, None) == -1
+    assert lib.apertis_scan_lean_fwd(8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, None, 8, 8, None, 8, 8, None, 1, 64, 11, 8, 1, None) == -2
+
+
+def test_train_prep_is_gpu_only_and_optional():
+    """training.build_train_prep gives None for a CPU model (the per-call preparation path), TrainStep carries it as `prep`
+    and prepared_step(None) is a no-op scope; ops.prepared_weight outside an active scope is None."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops
+    from apertis_llm_amd.training import TrainStep, build_train_prep, prepared_step
+    cfg = A.ApertisConfig(vocab_size=64, hidden_size=32, num_hidden_layers=1, num_attention_heads=2, intermediate_size=64,
+                          attention_type="selective_ssm")
+    m = A.ApertisForCausalLM(cfg)
+    assert build_train_prep(m) is None
+    blk = m.model.layers[0].attention.attention_mechanism_impl
+    assert ops.prepared_weight(("in_proj_xz", id(blk)), (blk.in_proj_x.weight, blk.in_proj_z.weight)) is None
+    with prepared_step(None):
+        pass
+    assert TrainStep(m, total_steps=4, bf16=False).prep is None
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No eager/CPU fallback: the kernel paths raise instead of silently computing elsewhere."""
     import apertis_llm_amd as A
