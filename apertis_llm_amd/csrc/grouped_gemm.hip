@@ -2447,6 +2447,7 @@ constexpr int TN5_SLOT = 256 * 352 + 352;           // floats per partial tile (
 struct Tn5Args {
   Tn3Problem p0, p1;   // (m_tiles / n_tiles in units of this kernel's tiles)
   int wide_m0, wide_m1;
+  int slice_major;
   int nprob, E, cpg;
   float *ws;
   int *ctr;
@@ -2510,13 +2511,19 @@ __device__ __forceinline__ void tn5_body(const Tn5Args &a, const int32_t *__rest
     if (item < n_full) {
       tile = item;
     } else {
-      const int r = item - n_full, ri = r / sc.s;
-      const int sl = r - ri * sc.s, per = (nsteps + sc.s - 1) / sc.s;
+      const int r = item - n_full;
+      // which (tile, row slice) item r is.  Several groups: tile-major (a tile's slices on neighbouring work-groups).  ONE group
+      // holding all the CUs (a dense layer: slice_major): slice-major - the work-groups that share a row slice, and with it
+      // one operand's rows, are neighbours, i.e. on one XCD and its L2 (tile-major they sat cpg / rem apart: every tile's
+      // column of slices fetched that operand from HBM again)
+      int ri, sl;
+      if (a.slice_major) { sl = r / sc.rem; ri = r - sl * sc.rem; } else { ri = r / sc.s; sl = r - ri * sc.s; }
+      const int per = (nsteps + sc.s - 1) / sc.s;
       tile = n_full + ri;
       s0 = min(sl * per, nsteps);
       s1 = min(s0 + per, nsteps);
       partial = sc.s > 1;
-      slot = g * a.cpg + r;
+      slot = g * a.cpg + ri * sc.s + sl;
     }
     int mt, nt;
     tn3_tile_coord(tile, m_tiles, n_tiles, mt, nt);
@@ -2676,8 +2683,10 @@ grouped_gemm_tn5_k(Tn5Args a, const int32_t *__restrict__ offsets) {
   else tn5_body<false>(a, offsets, smem, g, j, second);
 }
 
-// sums the row-slices of the split tiles in slice order.  grid = (groups * max(1, cpg/2), 22)
-__global__ void __launch_bounds__(256) tn5_fold_k(Tn5Args a) {
+// sums the row-slices of the split tiles in slice order.  grid = (groups * max(1, cpg/2), 88 / cpb): cpb chunks of 1024 floats
+// per work-group - four where a tile has a few slices (the expert groups: two), ONE where it has many (a single group holding
+// all the CUs: 85 slices per tile and only `rem` tiles - with four chunks each that fold ran on 66 work-groups)
+__global__ void __launch_bounds__(256) tn5_fold_k(Tn5Args a, int cpb) {
   const int half = max(1, a.cpg / 2);
   const int g = blockIdx.x / half, ri = blockIdx.x - g * half;
   const bool second = g >= a.E;
@@ -2693,12 +2702,12 @@ __global__ void __launch_bounds__(256) tn5_fold_k(Tn5Args a) {
   const int m0 = mt * TMx, n0 = nt * TNx;
   const float *src = a.ws + (int64_t)(g * a.cpg + ri * sc.s) * TN5_SLOT;
   float *out = pp.dW + (int64_t)e * pp.M * pp.N;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = (blockIdx.y * 1024 + q * 256 + threadIdx.x) * 4;   // < 256 * 352 = 22 * 4096
+  for (int q = 0; q < cpb; ++q) {
+    const int idx = ((blockIdx.y * cpb + q) * 256 + threadIdx.x) * 4;   // < 256 * 352 = 88 * 1024
     const int m = idx / TNx, n = idx - m * TNx;
     if (m0 + m >= pp.M || n0 + n >= pp.N) continue;
     float4 sum = *reinterpret_cast<const float4 *>(src + idx);
+#pragma unroll 4
     for (int sl = 1; sl < sc.s; ++sl) {
       const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)sl * TN5_SLOT + idx);
       sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
@@ -2793,6 +2802,7 @@ int launch_tn5(Tn3Problem q0, const Tn3Problem *q1p, int64_t E, int64_t max_rows
   Tn5Args a;
   a.p0 = q0; a.p1 = q1; a.wide_m0 = v0; a.wide_m1 = v1;
   a.nprob = nprob; a.E = (int)E; a.cpg = cpg; a.ws = ws;
+  a.slice_major = groups == 1;
   a.ctr = item_queue ? reinterpret_cast<int *>(reinterpret_cast<char *>(ws) + slots_bytes) : nullptr;
   if (a.ctr && hipMemsetAsync(a.ctr, 0, (size_t)groups * TN3_CTR_STRIDE * sizeof(int), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
   const size_t lds = 3 * TN5_STAGE + 16;
@@ -2804,7 +2814,10 @@ int launch_tn5(Tn3Problem q0, const Tn3Problem *q1p, int64_t E, int64_t max_rows
     const Tn3Sched sc = tn3_sched(pp.m_tiles, pp.n_tiles, cpg);
     split |= sc.rem && sc.s > 1;
   }
-  if (split) hipLaunchKernelGGL(tn5_fold_k, dim3((unsigned)(groups * std::max(1, cpg / 2)), 22), dim3(256), 0, st, a);
+  if (split) {
+    const int cpb = groups == 1 ? 1 : 4;
+    hipLaunchKernelGGL(tn5_fold_k, dim3((unsigned)(groups * std::max(1, cpg / 2)), 88 / cpb), dim3(256), 0, st, a, cpb);
+  }
   return apertis_check_launch();
 }
 
@@ -3022,16 +3035,17 @@ extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_prob
 
 // Which v5 tile a ONE-group [M, N] weight gradient takes through apertis_grouped_gemm_tn (1 = 352 x 256, 0 = 256 x 352), or -1:
 // the caller then cuts the rows into pseudo-groups for the 128 x 128 kernel and folds the partial sums itself (ops.py).
-// Measured at 180 224 rows (tools/dense_wgrad_check.py; 128 x 128 kernel + fold -> this path): dW [704, 2816] 1141 -> 697 us
-// (626 -> 1026 TF), [768, 768] 331 -> 345, [896, 224] 157 -> 229, [352, 704] 191 -> 234, [704, 176] 133 -> 245: every CU
-// writes a whole 352 x 256 fp32 slice (93 MB of partial tiles + their fold per call, whatever the shape) and the row slices
-// of a tile's column share no operand reads - it pays from about a dozen tiles on.  The SSM block's projections stay on
-// the pseudo-group path.
+// Measured at 180 224 rows (tools/dense_wgrad_check.py; 128 x 128 kernel over pseudo-groups + fold -> this path): dW [704, 2816]
+// 1105 -> 637 us (647 -> 1122 TF), [768, 768] 328 -> 279, [352, 704] 191 -> 166, [896, 224] 156 -> 160, [704, 176] 133 -> 141:
+// every CU writes a whole 352 x 256 fp32 slice (93 MB of partial tiles + their fold per call, whatever the shape), so it pays
+// from about a quarter of a million output elements on.  (Its first form lost everywhere below a dozen tiles - 234 us for
+// dW [352, 704]: the fold of a single group's 85 slices per tile ran on 66 work-groups; it now takes one 1024-float chunk per
+// work-group, and the work-groups that share a row slice are neighbours on one XCD.)
 #ifndef TN_DENSE_MIN_FILL
 #define TN_DENSE_MIN_FILL 60
 #endif
 #ifndef TN_DENSE_MIN_AREA
-#define TN_DENSE_MIN_AREA (1 << 20)
+#define TN_DENSE_MIN_AREA 240000
 #endif
 extern "C" int apertis_grouped_gemm_tn_dense_variant(int64_t M, int64_t N) {
   if (M < 128 || N < 128 || M % 8 || N % 8 || M * N < TN_DENSE_MIN_AREA) return -1;

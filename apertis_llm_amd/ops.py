@@ -1581,9 +1581,9 @@ class _GroupedLinear(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             if (E == 1 and max_rows >= 4 * _SPLITK_ROWS and DENSE_WGRAD_WIDE and x.dtype == torch.bfloat16 and not has_bias
                     and lib.apertis_grouped_gemm_tn_dense_variant(N, K) >= 0):
-                # a WIDE dense layer (from about a dozen 352 x 256 tiles on: dW [704, 2816] 1141 -> 697 us) on the wide-tile
-                # kernel: the library splits the rows of every tile over the CUs and folds the slices in order; the SSM
-                # block's narrow projections lose there (234 vs 191 us for dW [352, 704]) and stay below
+                # a dense layer with enough output (from ~240 000 elements: dW [352, 704] 191 -> 166 us, [704, 2816] 1105 ->
+                # 637 us) on the wide-tile kernel: the library splits the rows of every 352-wide tile over the CUs and folds
+                # the slices in order; narrower projections (dW [704, 176]: 133 vs 141 us) stay on the pseudo-groups below
                 dw = torch.empty(1, N, K, device=x.device, dtype=torch.float32)
                 ws, ws_bytes = _tn_workspace(1, 1, x.device, max_rows)
                 _launch("apertis_grouped_gemm_tn[dense]", lib.apertis_grouped_gemm_tn,

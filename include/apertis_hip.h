@@ -470,7 +470,7 @@ int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems);
  * the reduction runs over all rows - on its wide-tile kernel, splitting the rows over the CUs and folding the slices itself
  * (pass the workspace of apertis_grouped_gemm_tn_workspace_bytes(1, 1)); -1 when the caller should cut the rows into
  * pseudo-groups (offsets every 1024-2048 rows, E = their count, dW = [E, M, N] partial sums) and fold them with
- * apertis_colsum_f32, as the narrow shapes still do. */
+ * apertis_colsum_f32, as the narrow shapes (under about 240 000 output elements, or tiles mostly padding) still do. */
 int apertis_grouped_gemm_tn_dense_variant(int64_t M, int64_t N);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,

@@ -233,9 +233,12 @@ def test_round4_entry_points_validate_before_any_launch():
     weight-gradient routing rule, the one-launch weight preparation, the lean scan forms."""
     from apertis_llm_amd import _lib
     lib = _lib.load()
-    # one-group weight gradients: wide-tile kernel from 2^20 output elements on, never for the SSM block's narrow projections
+    # one-group weight gradients: the wide-tile kernel from ~240 000 output elements on (in_proj's dW [352, 704]), not for the
+    # SSM block's narrower projections or tiles that would be mostly padding
     assert lib.apertis_grouped_gemm_tn_dense_variant(704, 2816) == 1 and lib.apertis_grouped_gemm_tn_dense_variant(2816, 704) >= 0
-    for m, n in [(352, 704), (704, 176), (448, 176), (768, 768), (64, 1 << 20), (1 << 20, 6)]:
+    assert lib.apertis_grouped_gemm_tn_dense_variant(352, 704) == 1 and lib.apertis_grouped_gemm_tn_dense_variant(768, 768) >= 0
+    assert lib.apertis_grouped_gemm_tn_dense_variant(448, 896) == 0          # (256 x 352 tiles: 2 x 3, 74 % filled)
+    for m, n in [(704, 176), (448, 176), (896, 224), (64, 1 << 20), (1 << 20, 6)]:
         assert lib.apertis_grouped_gemm_tn_dense_variant(m, n) == -1, (m, n)
     assert lib.apertis_weight_prep_entry_bytes() == 64
     assert lib.apertis_weight_prep(None, 1, 1, None) == -1 and lib.apertis_weight_prep(1, 0, 1, None) == -1

@@ -291,14 +291,15 @@ def test_linear_mfma_splitk_wgrad(dev, rows, N, K, dt):
     _close(bd.grad, br.grad, "db", **tol)
 
 
-@pytest.mark.parametrize("rows,N,K", [(8192, 704, 2816), (9000, 1408, 768)])
+@pytest.mark.parametrize("rows,N,K", [(8192, 704, 2816), (9000, 1408, 768), (20000, 352, 704), (4200, 768, 768),
+                                      (9000, 448, 896)])     # (the last: 256 x 352 tiles with a ragged edge on both sides)
 def test_linear_mfma_wide_dense_wgrad(dev, rows, N, K):
-    """A wide bias-free dense layer (M * N >= 2^20): its weight gradient goes through apertis_grouped_gemm_tn as ONE group -
+    """A bias-free dense layer with enough output (M * N >= 240 000): its weight gradient goes through apertis_grouped_gemm_tn as ONE group -
     the library splits the rows of its 352-wide tiles over the CUs and folds the slices itself (no pseudo-groups, no
     apertis_colsum_f32 from the caller); values against fp64 on the bf16 operands, bits reproducible."""
     from apertis_llm_amd import ops, _lib
     lib = _lib.load()
-    assert lib.apertis_grouped_gemm_tn_dense_variant(N, K) >= 0 and lib.apertis_grouped_gemm_tn_dense_variant(352, 704) < 0
+    assert lib.apertis_grouped_gemm_tn_dense_variant(N, K) >= 0 and lib.apertis_grouped_gemm_tn_dense_variant(704, 176) < 0
     torch.manual_seed(rows)
     x, W = torch.randn(rows, K).bfloat16(), torch.randn(N, K) / K ** 0.5
     dout = torch.randn(rows, N).bfloat16()

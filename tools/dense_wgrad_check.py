@@ -13,7 +13,7 @@ lib = _lib.load()
 T = B * 4096
 flush = torch.empty(1 << 28, device=dev, dtype=torch.float32)
 code = _lib.BF16 if hasattr(_lib, "BF16") else 1
-shapes = [(352, 704), (448, 176), (704, 176), (704, 2816), (768, 768), (448, 224), (896, 224)]
+shapes = [(352, 704), (448, 176), (704, 176), (704, 2816), (768, 768), (448, 224), (896, 224), (448, 896), (896, 448)]
 
 
 def timed(fn, reps=5):
