@@ -252,6 +252,12 @@ def _dropout_add(drop: nn.Dropout, out, residual):
     return drop(out) + residual
 
 
+# generate(): from this many remaining greedy tokens on, the single-token steps of an SSM model are replayed from a captured HIP
+# graph (APERTIS_DECODE_GRAPH=0: always eager).  Capture costs about three eager steps.
+DECODE_GRAPH = os.environ.get("APERTIS_DECODE_GRAPH", "1") == "1"
+DECODE_GRAPH_MIN_STEPS = 24
+
+
 def _mfma_linear(x, weight, bias=None):
     """x @ W.T (+b) on the MFMA GEMM tile when the shapes allow 16-byte rows, else stock F.linear
     (both run on the GPU; this is a provider choice, not a fallback to the host)."""
@@ -1153,7 +1159,83 @@ class ApertisForCausalLM(nn.Module):
                     alive = alive.masked_fill((nxt == e_) & (alive == 1), 0)
             if alive.max() == 0 and tokens.shape[1] - prompt_len >= min_new_tokens:
                 break
+            left = max_new_tokens - (tokens.shape[1] - prompt_len)
+            if past is not None and left >= DECODE_GRAPH_MIN_STEPS and self._decode_graph_ok(tokens, do_sample, repetition_penalty):
+                # the remaining single-token steps as ONE captured HIP graph replayed `left` times (same kernels, same tokens)
+                return self._generate_graph_tail(tokens, past, alive, left, prompt_len, min_new_tokens, eos, pad)
         return tokens
+
+    def _decode_graph_ok(self, tokens, do_sample, repetition_penalty):
+        cfg = self.config
+        return (DECODE_GRAPH and tokens.is_cuda and not do_sample and repetition_penalty == 1.0 and not torch.is_grad_enabled()
+                and cfg.attention_type != "standard_mha" and cfg.position_embedding_type != "absolute" and not self.training)
+
+    def _generate_graph_tail(self, tokens, past, alive, left, prompt_len, min_new_tokens, eos, pad):
+        """Greedy decoding of `left` more tokens through a captured HIP graph of the single-token step (reference
+        core.py:1578-1644: the same forward through the cache, argmax, eos / pad bookkeeping - attention mask and position ids
+        do not enter an SSM model's step).  An eager token step is ~2 600 small launches, 18 ms of mostly host time at 44
+        layers; the replay is 10 ms (tools/decode_graph_try.py).  Token, cache, alive flags, the step counter and the outputs
+        live in static buffers that the graph updates in place; the host looks at the alive flags every 16 steps only."""
+        B, dev = tokens.shape[0], tokens.device
+        s_tok = tokens[:, -1:].clone()
+        s_past = [(c.clone(), st.clone()) for (c, st) in past]
+        s_alive = alive.clone()
+        s_idx = torch.zeros(1, dtype=torch.long, device=dev)
+        s_out = torch.full((B, left), pad, dtype=tokens.dtype, device=dev)
+        s_any = torch.ones(left, dtype=alive.dtype, device=dev)          # max over the batch of `alive` after each step
+
+        def body():
+            out = self(input_ids=s_tok, past_key_values=s_past, use_cache=True)
+            nxt = torch.argmax(out[1][:, -1, :].float(), dim=-1)
+            nxt = nxt * s_alive + pad * (1 - s_alive)
+            s_out.scatter_(1, s_idx.expand(B, 1), nxt.unsqueeze(1).to(s_out.dtype))
+            al = s_alive
+            for e_ in eos:
+                if e_ is not None:
+                    al = al.masked_fill((nxt == e_) & (al == 1), 0)
+            s_alive.copy_(al)
+            s_any.scatter_(0, s_idx, al.max().reshape(1))
+            s_idx.add_(1)
+            s_tok.copy_(nxt.unsqueeze(1))
+            for (sc, ss), (nc, ns) in zip(s_past, out[4]):
+                sc.copy_(nc)
+                ss.copy_(ns)
+
+        # warm-up on a side stream (lazy bindings, prepared-weight cache, allocator), then restore the state it advanced
+        keep = (s_tok.clone(), [(c.clone(), st.clone()) for (c, st) in s_past], s_alive.clone())
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+        def restore():
+            s_tok.copy_(keep[0])
+            for (sc, ss), (c, st) in zip(s_past, keep[1]):
+                sc.copy_(c)
+                ss.copy_(st)
+            s_alive.copy_(keep[2])
+            s_idx.zero_()
+            s_out.fill_(pad)
+            s_any.fill_(1)
+
+        restore()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            body()
+        restore()
+        done = left
+        for i in range(left):
+            graph.replay()
+            if (i + 1) % 16 == 0 or i + 1 == left:
+                flags = s_any[:i + 1].tolist()                         # the only host sync: every 16 steps
+                stop = next((j for j, a in enumerate(flags)
+                             if a == 0 and tokens.shape[1] - prompt_len + j + 1 >= min_new_tokens), None)
+                if stop is not None:
+                    done = stop + 1
+                    break
+        return torch.cat([tokens, s_out[:, :done]], dim=-1)
 
 
 # ----------------------------------------------------------------------------------------------

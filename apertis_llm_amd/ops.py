@@ -128,6 +128,7 @@ def _rows(t, width):
 # selective scan
 # ----------------------------------------------------------------------------------------------
 import os as _os
+import threading
 
 class _SelectiveScan(torch.autograd.Function):
     @staticmethod
@@ -266,6 +267,26 @@ def scan_gate_raise_on_error(device=None):
                               "are invalid - rerun with APERTIS_SCAN_SINGLE_PASS=0 (two-launch form, same bits)")
 
 
+# Whether the CALLER of an op runs under autograd.  Inside Function.forward grad mode is always off, and
+# ctx.needs_input_grad only says whether an input is a tensor that requires grad - a Parameter does, under torch.no_grad() too.
+# Ops that decide in their forward what to keep for a backward (transposed weight copies, the pre-activation / saved-gradient
+# output of the expert MLP, scan checkpoints) read the mode their public wrapper recorded: under no_grad (generate(), eval)
+# they used to prepare for a backward that never comes - every token step of a decode re-cast the expert weights.
+_tls = threading.local()
+
+
+def _apply(fn, *args):
+    _tls.grad = torch.is_grad_enabled()
+    try:
+        return fn.apply(*args)
+    finally:
+        _tls.grad = True          # (a direct Function.apply keeps the conservative default)
+
+
+def _grad_wanted(ctx, n):
+    return getattr(_tls, "grad", True) and any(ctx.needs_input_grad[:n])
+
+
 # APERTIS_SCAN_DT_FUSED=1 (round 4, N4's prologue; default OFF): dt_proj_head inside the lean forward's state pass
 # (ops.scan_gate_dt -> apertis_scan_lean_fwd_dt) instead of its own launch.  Same bits; measured in the 1.5B step at B = 44
 # (profiles/r4_dtproj_fused_ab.txt): the state pass grows by 28.6 us per layer (its 44-term dot per (token, head) costs
@@ -278,7 +299,7 @@ class _ScanGate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last):
         return _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last,
-                                  any(ctx.needs_input_grad[:7]), None)
+                                  _grad_wanted(ctx, 7), None)
 
     @staticmethod
     def backward(ctx, dout, *_unused):
@@ -300,7 +321,7 @@ class _ScanGateDt(torch.autograd.Function):
         ctx.dt_cfg = (ldx, tuple(dt_in.shape), W_dt.dtype, None if b_dt is None else b_dt.dtype)
         dlt = torch.empty(*dt_in.shape[:-1], h, device=dt_in.device, dtype=torch.float32)
         res = _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last,
-                                 any(ctx.needs_input_grad[:9]), (xr, ldx, w, b, R))
+                                 _grad_wanted(ctx, 9), (xr, ldx, w, b, R))
         ctx.dt_saved = (xr, w)
         return res
 
@@ -455,7 +476,7 @@ def scan_gate(dlt, A_log, Bt, C, xc, z, D, h0=None, delta_softplus=False, return
     Bt / C [B,L,w] with h*N <= w <= ceil(h*N/64)*64: the (possibly zero-padded) column slices of the projection output,
     of which the first h*N columns are used; their gradients come back [B,L,w] with zeros in the pad.
     Returns out [B,L,h*N] in the activations' dtype (and the final state [B,h*N] fp32 when return_last)."""
-    return _ScanGate.apply(dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
+    return _apply(_ScanGate, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
 
 
 def scan_gate_dt(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0=None, delta_softplus=True, return_last=False):
@@ -464,7 +485,7 @@ def scan_gate_dt(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0=None, delta_softp
     default - measured slower than the launch it replaces, see SCAN_DT_FUSED); otherwise the stand-alone kernel fills the
     logits.  The logits, outputs and gradients are the two-op form's bit for bit either way.  dt_in [B, L, R] (a column slice
     of the projection output is read in place), W_dt [h, R], b_dt [h] or None."""
-    return _ScanGateDt.apply(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
+    return _apply(_ScanGateDt, dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
 
 
 def ssm_decode_step(xp, conv_state, conv_w, conv_b):
@@ -1539,7 +1560,7 @@ class _GroupedLinear(torch.autograd.Function):
         x = x.contiguous()
         if x.shape[1] != K:
             raise ApertisHipError(f"grouped_linear: x {tuple(x.shape)} vs weight {tuple(weight.shape)}")
-        need_grad = any(ctx.needs_input_grad[:3])
+        need_grad = _grad_wanted(ctx, 3)
         if compute_dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous():
             wc = weight.detach()
             wt = cast_transpose(weight, compute_dtype, want_plain=False)[1] if need_grad else None
@@ -1627,7 +1648,7 @@ def grouped_linear(x, weight, bias, offsets, max_rows, act=None, drop_p=0.0, see
     x [R,K] rows sorted by group, weight [E,N,K] (nn.Linear layout, fp32 master), bias [E,N],
     offsets [E+1] int32 device tensor.  Rows >= offsets[E] are neither read nor written.
     (reference: expert Linear/activation/Dropout/Linear, core.py:437-440)"""
-    return _GroupedLinear.apply(x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype or x.dtype)
+    return _apply(_GroupedLinear, x, weight, bias, offsets, max_rows, act, drop_p, seed, compute_dtype or x.dtype)
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -1894,7 +1915,7 @@ class _ExpertMLP(torch.autograd.Function):
         lib = _lib.load()
         E, I, H = w1.shape
         xg = xg.to(cd).contiguous()
-        need = any(ctx.needs_input_grad[:5])
+        need = _grad_wanted(ctx, 5)
         w1c, w1t = cast_transpose(w1, cd, want_transposed=need, cache=not need)
         w2c, w2t = cast_transpose(w2, cd, want_transposed=need, cache=not need)
         b1f, b2f = b1.detach().float().contiguous(), b2.detach().float().contiguous()
@@ -1974,7 +1995,7 @@ class _ExpertMLP(torch.autograd.Function):
 def expert_mlp(xg, w1, b1, w2, b2, offsets, max_rows, act="gelu", drop_p=0.0, seed=0, compute_dtype=None):
     """Grouped expert MLP (reference core.py:437-440): Linear(H->I) -> act -> Dropout -> Linear(I->H) for
     expert-sorted rows xg [R,H]; w1 [E,I,H], b1 [E,I], w2 [E,H,I], b2 [E,H] (fp32 masters)."""
-    return _ExpertMLP.apply(xg, w1, b1, w2, b2, offsets, max_rows, act, drop_p, seed, compute_dtype or xg.dtype)
+    return _apply(_ExpertMLP, xg, w1, b1, w2, b2, offsets, max_rows, act, drop_p, seed, compute_dtype or xg.dtype)
 
 
 class _ShiftedCrossEntropy(torch.autograd.Function):
@@ -2047,7 +2068,7 @@ class _LinearCrossEntropy(torch.autograd.Function):
         V = weight.shape[0]
         labels = labels.contiguous()
         n_pos = min(L, labels.shape[1]) - 1
-        need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need = _grad_wanted(ctx, 2)
         x = hidden.to(compute_dtype).contiguous()
         w = weight.detach().to(compute_dtype)
         tgt = labels[:, 1:n_pos + 1]
@@ -2101,7 +2122,7 @@ def linear_cross_entropy(hidden, weight, labels, ignore_index=-100, compute_dtyp
     """mean over valid (b, l) of CE((hidden @ weight.T)[b, l], labels[b, l + 1]): the LM head (reference core.py:1412) and
     the shifted cross entropy (core.py:1417-1450) as one op that never holds more than one sequence of logits.
     hidden [B, L, H], weight [V, H] (the tied embedding), labels [B, >= L] int64."""
-    return _LinearCrossEntropy.apply(hidden, weight, labels, ignore_index, compute_dtype or hidden.dtype)
+    return _apply(_LinearCrossEntropy, hidden, weight, labels, ignore_index, compute_dtype or hidden.dtype)
 
 
 class _ScatterRows(torch.autograd.Function):
