@@ -1451,6 +1451,69 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Skinny NT kernel (round 4): a handful of rows per call - the single-token decode step (reference core.py:1578-1603: B <= 16
+// rows through every projection and through the experts a token chose).  The 128 x 128 kernel below spent 21.5 us per call
+// there (one 128-row tile per group for 1-16 rows, N / 128 work-groups, operands through LDS): 5 calls per layer = over half
+// of a captured token step.  Here a WAVE owns 16 output columns of one group: W rows stream straight from global memory
+// into the MFMA A operand (16 B per lane and 32-deep step, eight steps in flight), the rows of X are the B operand, nothing
+// goes through LDS, N / 16 waves per group fill the chip, and a lane ends up with four consecutive outputs of one row (one
+// 8-byte store).  The k order and the epilogue arithmetic are the 128 x 128 kernel's.  bf16, no dropout / second output.
+// ------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void __launch_bounds__(64)
+grouped_gemm_nt_skinny_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
+                         const int32_t *__restrict__ offsets, TO *__restrict__ C, int N, int K, int ldw, int act, int max_rows) {
+  typedef bf16x8 frag;
+  constexpr int U = 8;
+  const int e = blockIdx.y, n0 = blockIdx.x * 16, lane = threadIdx.x;
+  const int r0 = offsets[e], rows = min(offsets[e + 1], max_rows) - r0;     // (rows >= max_rows are neither read nor written)
+  if (rows <= 0) return;
+  const int l15 = lane & 15, fg = lane >> 4, kc = fg * 8;
+  const int wcol = n0 + l15;                                     // this lane's W row (= output column) as the A operand's row
+  const bf16_t *wrow = W + ((int64_t)e * N + min(wcol, N - 1)) * ldw;
+  const bool w_ok = wcol < N;
+  const int nq = n0 + fg * 4;                                    // the four output columns this lane ends up with
+  float bq[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bq[q] = nq + q < N ? bias[(int64_t)e * N + nq + q] : 0.f;
+  }
+  const frag zero = {};
+  for (int rb = 0; rb < rows; rb += 16) {
+    const int xr = rb + l15;                                     // this lane's X row as the B operand's column
+    const bool x_ok = xr < rows;
+    const bf16_t *xrow = X + (int64_t)(r0 + min(xr, rows - 1)) * K;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32 * U) {
+      frag a[U], b[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = k0 + u * 32 + kc;                          // (K % 8 == 0: a chunk is inside the row or wholly past it)
+        const bool ok = k < K;
+        a[u] = (ok && w_ok) ? *reinterpret_cast<const frag *>(wrow + k) : zero;
+        b[u] = (ok && x_ok) ? *reinterpret_cast<const frag *>(xrow + k) : zero;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) mma(acc, a[u], b[u]);
+    }
+    // D rows = output columns nq + q, D column = X row l15
+    if (x_ok && nq < N) {
+      TO o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = acc[q] + bq[q];
+        v = to_f32(from_f32<TO>(v));
+        v = act_fwd<true>(v, act);
+        o[q] = from_f32<TO>(v);
+      }
+      TO *dst = C + (int64_t)(r0 + xr) * N + nq;
+      if (nq + 3 < N) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
+      else for (int q = 0; q < 4 && nq + q < N; ++q) dst[q] = o[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // 256 x 256 NT kernel, persistent, FOUR-slot ring of 32-deep stages, epilogue straight from the accumulators (round 4).
 // What round 4's stamps of the two-per-CU kernel say: with the staging pass gone its K loop takes what the epilogue gave
 // back (15 -> 18-19 us per 256 x 128 tile at K = 704 whatever the epilogue) - two work-groups with 48 KiB of LDS-DMA in
@@ -2843,6 +2906,13 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
   const int64_t grid = m_tiles * n_tiles;
   if (grid > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   if constexpr (sizeof(T) == 2 && sizeof(TO) == 2) {
+    // a handful of rows (the decode step): a wave per 16 output columns, operands straight from global memory
+    if (max_rows <= 64 && !flagged && !pre_act && !mul_pre && drop_p <= 0.f && K % 8 == 0 && N % 4 == 0 && ldw % 8 == 0 && E <= 65535 &&
+        ceil_div64(N, 16) <= 0x7fffffff) {
+      hipLaunchKernelGGL(grouped_gemm_nt_skinny_k<TO>, dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(64), 0, st,
+                         (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
+      return apertis_check_launch();
+    }
     // the 256x256 kernel steps K in 64s: K itself may be ragged when W's rows are zero-padded to the step.
     // One group (dense projection) takes it at any width: narrow outputs are HBM-bound and the
     // persistent kernel's cross-tile prefetch matters more than the MFMA work a partial n-tile wastes

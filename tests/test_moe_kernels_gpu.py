@@ -291,6 +291,37 @@ def test_linear_mfma_splitk_wgrad(dev, rows, N, K, dt):
     _close(bd.grad, br.grad, "db", **tol)
 
 
+@pytest.mark.parametrize("counts,N,K,act,use_bias", [
+    ([1], 352, 704, None, False), ([16], 704, 176, None, False), ([3], 448, 176, None, True),
+    ([0, 2, 0, 1, 0, 0, 5, 0], 2816, 704, "gelu", True), ([4, 4, 4, 4, 4, 4, 4, 4], 704, 2816, None, True),
+    ([17, 0, 33, 1], 104, 104, "gelu", True), ([7, 9], 40, 40, "relu", False)])
+def test_grouped_linear_skinny_rows(dev, counts, N, K, act, use_bias):
+    """The decode step's shapes: a handful of rows per call (<= 64 in all) go to the skinny NT kernel - a wave per 16 output
+    columns, W straight from global memory into the MFMA operand.  Values against fp64 on the bf16 operands (bf16 rounding of
+    the pre-activation and of the output as in the tiled kernels), empty groups, groups of more than 16 rows, widths that are
+    not multiples of 16 / 32; rows past the last group untouched."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(sum(counts) + N)
+    E, rows = len(counts), sum(counts)
+    offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0).tolist()), dtype=torch.int32, device=dev)
+    x = torch.randn(rows + 3, K).bfloat16()
+    W = (torch.randn(E, N, K) / K ** 0.5)
+    b = torch.randn(E, N) if use_bias else None
+    xd = x.to(dev)
+    out = ops.grouped_linear(xd, W.to(dev), None if b is None else b.to(dev), offs, rows, act=act, compute_dtype=torch.bfloat16)
+    assert out.shape == (rows + 3, N) or out.shape[0] >= rows
+    Wq = W.bfloat16().double()
+    r0 = 0
+    for e, c in enumerate(counts):
+        if c == 0:
+            continue
+        pre = x[r0:r0 + c].double() @ Wq[e].t() + (b[e].double() if b is not None else 0.0)
+        pre = pre.float().bfloat16().double()                     # the activation sees the pre-activation as stored
+        ref = {None: pre, "gelu": F.gelu(pre), "relu": F.relu(pre)}[act]
+        _close(out[r0:r0 + c], ref, f"group {e}", rtol=2e-2, atol_scale=1e-2)
+        r0 += c
+
+
 @pytest.mark.parametrize("rows,N,K", [(8192, 704, 2816), (9000, 1408, 768), (20000, 352, 704), (4200, 768, 768),
                                       (9000, 448, 896)])     # (the last: 256 x 352 tiles with a ragged edge on both sides)
 def test_linear_mfma_wide_dense_wgrad(dev, rows, N, K):
