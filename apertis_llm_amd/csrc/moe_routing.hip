@@ -1944,6 +1944,24 @@ tiny_linear_fwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
   }
 }
 
+// The same for a handful of rows (the decode step: T <= 64): a thread per (row, output) with W straight from global memory -
+// the kernel above stages a 16 x 64 table in LDS and then has ONE thread walk all N outputs of a row (13 us for one token).
+// Same accumulation chain per output (bias first, then r = 0, 1, ...): the same bits.
+template <typename TX>
+__global__ void __launch_bounds__(256)
+tiny_linear_fwd_small_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ b,
+                        float *__restrict__ y, int64_t T, int K, int N) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * N) return;
+  const int64_t t = i / N;
+  const int j = (int)(i - t * N);
+  const TX *row = x + t * ldx;
+  const float *w = W + (int64_t)j * K;
+  float a = b ? b[j] : 0.f;
+  for (int r = 0; r < K; ++r) a = fmaf(to_f32(row[r]), w[r], a);
+  y[i] = a;
+}
+
 // Backward.  dx per row (W four at a time from LDS, as above).  dW/db as per-block partial sums over the row tile
 // staged in LDS: thread p owns the 2 x 4 block dW[2*(p/16) + {0,1}][4*(p%16) + {0..3}] (and db of its two rows when
 // p%16 == 0) and reads one 8-byte dy pair and one 16-byte x chunk per row for eight FMAs; rows are walked in order and
@@ -2330,6 +2348,12 @@ extern "C" int apertis_tiny_linear_fwd(const void *x, int64_t ldx, const float *
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)std::min<int64_t>(ceil_div64(T, TL_ROWS), 4096)), block(TL_ROWS);
   if (dtype_x != APERTIS_BF16 && dtype_x != APERTIS_F32) return APERTIS_ERR_ARG;
+  if (T <= 64) {   // the decode step
+    const dim3 gs((unsigned)ceil_div64(T * N, 256)), bs(256);
+    if (dtype_x == APERTIS_BF16) hipLaunchKernelGGL(tiny_linear_fwd_small_k<bf16_t>, gs, bs, 0, st, (const bf16_t *)x, ldx, W, b, y, T, (int)K, (int)N);
+    else hipLaunchKernelGGL(tiny_linear_fwd_small_k<float>, gs, bs, 0, st, (const float *)x, ldx, W, b, y, T, (int)K, (int)N);
+    return apertis_check_launch();
+  }
   const int64_t esz = dtype_x == APERTIS_BF16 ? 2 : 4, epc = 16 / esz;
   const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx * esz) % 16 == 0 && ceil_div64(K, epc) * epc <= ldx;
 #define GO(TX, V) hipLaunchKernelGGL((tiny_linear_fwd_k<TX, V>), grid, block, 0, st, (const TX *)x, ldx, W, b, y, T, (int)K, (int)N)
