@@ -442,6 +442,82 @@ __global__ void plan_assign_k(PlanWs w, const int32_t *__restrict__ idx, const f
   }
 }
 
+// The whole plan in ONE launch for a handful of tokens (S <= 64, E * K <= 16: the single-token decode step, reference
+// core.py:1578-1603 - the five launches above were a fifth of a captured token step).  One wave per (expert, k) slot,
+// lane = token.  Same semantics: candidates idx[s, k] == e; per expert the capacity is consumed k-major; an overflowing
+// slot keeps its `keep` largest gate weights (compared as bits, as the radix select does), ties at the threshold in token
+// order; the kept rows of a slot sit in token order, the slots expert-major then k.
+__global__ void __launch_bounds__(1024)
+plan_small_k(const int32_t *__restrict__ idx, const float *__restrict__ wk, const uint8_t *__restrict__ active, int64_t capacity,
+             int32_t *__restrict__ offsets, int32_t *__restrict__ row_token, int32_t *__restrict__ row_k,
+             int32_t *__restrict__ slot_of, int S, int E, int K) {
+  __shared__ int32_t s_tot[16], s_keep[16], s_start[16];
+  const int P = E * K, p = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int e = p / K, k = p - e * K;
+  int es = -1;
+  uint32_t bits = 0;
+  if (p < P && lane < S) {
+    es = idx[lane * K + k];
+    bits = __float_as_uint(wk[lane * K + k]);
+  }
+  const bool cand = p < P && es == e;
+  const unsigned long long cm = __ballot(cand);
+  if (p < P && lane == 0) s_tot[p] = __popcll(cm);
+  __syncthreads();
+  if ((int)threadIdx.x < E) {
+    const int ee = threadIdx.x;
+    const bool on = active ? active[ee] != 0 : true;
+    int64_t load = 0;
+    for (int kk = 0; kk < K; ++kk) {
+      const int tot = s_tot[ee * K + kk];
+      int64_t keep = tot;
+      if (!on) keep = 0;
+      else if (capacity > 0) {
+        const int64_t rem = capacity - load;
+        keep = rem <= 0 ? 0 : (tot < rem ? tot : rem);
+      }
+      s_keep[ee * K + kk] = (int)keep;
+      load += keep;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int ee = 0; ee < E; ++ee) {
+      offsets[ee] = run;
+      for (int kk = 0; kk < K; ++kk) { s_start[ee * K + kk] = run; run += s_keep[ee * K + kk]; }
+    }
+    offsets[E] = run;
+  }
+  __syncthreads();
+  if (p >= P) return;
+  const int keep = s_keep[p], tot = s_tot[p];
+  bool kept = cand && keep > 0;
+  if (keep > 0 && keep < tot) {      // overflow: rank among the slot's candidates by (weight descending, token ascending)
+    int pos = 0;
+    for (int j = 0; j < S; ++j) {
+      const uint32_t bj = (uint32_t)__shfl((int)bits, j);
+      if ((cm >> j) & 1ull) pos += (bj > bits) || (bj == bits && j < lane);
+    }
+    kept = cand && pos < keep;
+  }
+  const unsigned long long km = __ballot(kept);
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  if (lane < S) {
+    if (cand) {
+      int slot = -1;
+      if (kept) {
+        slot = s_start[p] + __popcll(km & lt);
+        row_token[slot] = lane;
+        row_k[slot] = k;
+      }
+      slot_of[lane * K + k] = slot;
+    } else if (e == 0 && (es < 0 || es >= E)) {
+      slot_of[lane * K + k] = -1;     // an index outside [0, E): no expert's wave claims the pair
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // row helpers: a wave owns one row of H elements, lane handles 4-element chunks lane+64*i
 // ------------------------------------------------------------------------------------------
@@ -2125,6 +2201,11 @@ extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_
   if (E < 1 || E > MAXE || K < 1 || K > MAXK) return APERTIS_ERR_UNSUPPORTED;
   if (S * K > 0x7fffffffLL) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (S > 0 && S <= 64 && E * K <= 16) {   // a handful of tokens: the whole plan in one launch
+    hipLaunchKernelGGL(plan_small_k, dim3(1), dim3(64 * (unsigned)(E * K)), 0, st, idx, w, active, capacity, expert_offsets,
+                       row_token, row_k, slot_of, (int)S, (int)E, (int)K);
+    return apertis_check_launch();
+  }
   PlanWs pw = carve_ws(ws, S > 0 ? S : 1, E, K);
   int nhist = 0;
   if (S > 0) {

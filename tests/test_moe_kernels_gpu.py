@@ -97,6 +97,14 @@ def test_plan_ties_and_dropped_experts(dev):
     _plan_case(dev, 2000, 8, 2, 100, seed=5, skew=1.0, ties=True)
     _plan_case(dev, 900, 8, 2, 150, seed=6, active=[1, 0, 1, 1, 0, 1, 1, 1])
     _plan_case(dev, 900, 8, 2, None, seed=7, active=[0, 1, 1, 1, 1, 1, 1, 1])
+    # a handful of tokens (the decode step's one-launch plan: S <= 64, E * K <= 16): ties at the capacity threshold, dropped
+    # experts, a capacity of one row, every token on one expert
+    _plan_case(dev, 60, 8, 2, 9, seed=8, skew=1.0, ties=True)
+    _plan_case(dev, 64, 8, 2, 5, seed=9, skew=3.0, ties=True)
+    _plan_case(dev, 48, 8, 2, 10, seed=10, active=[1, 0, 1, 1, 0, 1, 1, 1])
+    _plan_case(dev, 16, 8, 2, None, seed=11, active=[0, 1, 1, 1, 1, 1, 1, 0])
+    _plan_case(dev, 33, 4, 2, 1, seed=12, skew=5.0)
+    _plan_case(dev, 2, 8, 2, None, seed=13)
 
 
 def test_plan_golden_kept_rows(dev):
