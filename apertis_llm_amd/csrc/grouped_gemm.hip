@@ -1457,15 +1457,20 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 // of a captured token step.  Here a WAVE owns 16 output columns of one group: W rows stream straight from global memory
 // into the MFMA A operand (16 B per lane and 32-deep step, eight steps in flight), the rows of X are the B operand, nothing
 // goes through LDS, N / 16 waves per group fill the chip, and a lane ends up with four consecutive outputs of one row (one
-// 8-byte store).  The k order and the epilogue arithmetic are the 128 x 128 kernel's.  bf16, no dropout / second output.
+// 8-byte store).  The k order (for K < 1024) and the epilogue arithmetic are the 128 x 128 kernel's.  bf16, no dropout / second output.
 // ------------------------------------------------------------------------------------------
-template <typename TO>
-__global__ void __launch_bounds__(64)
+// KS > 1 (long K: the experts' second GEMM, K = I): KS waves of a work-group split the K range, their partial sums meet in LDS
+// and wave 0 adds them in wave order - a wave alone walked 88 dependent load -> MFMA batches' worth of K = 2816.
+template <typename TO, int KS>
+__global__ void __launch_bounds__(64 * KS)
 grouped_gemm_nt_skinny_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                          const int32_t *__restrict__ offsets, TO *__restrict__ C, int N, int K, int ldw, int act, int max_rows) {
   typedef bf16x8 frag;
   constexpr int U = 8;
-  const int e = blockIdx.y, n0 = blockIdx.x * 16, lane = threadIdx.x;
+  __shared__ f32x4 s_part[KS > 1 ? KS - 1 : 1][64];
+  const int e = blockIdx.y, n0 = blockIdx.x * 16, lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int kq = KS > 1 ? ((K + KS * 32 - 1) / (KS * 32)) * 32 : K;        // this wave's K range: [ks * kq, min(K, ks * kq + kq))
+  const int kbeg = ks * kq, kend = min(K, kbeg + kq);
   const int r0 = offsets[e], rows = min(offsets[e + 1], max_rows) - r0;     // (rows >= max_rows are neither read nor written)
   if (rows <= 0) return;
   const int l15 = lane & 15, fg = lane >> 4, kc = fg * 8;
@@ -1484,20 +1489,29 @@ grouped_gemm_nt_skinny_k(const bf16_t *__restrict__ X, const bf16_t *__restrict_
     const bool x_ok = xr < rows;
     const bf16_t *xrow = X + (int64_t)(r0 + min(xr, rows - 1)) * K;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 32 * U) {
+    for (int k0 = kbeg; k0 < kend; k0 += 32 * U) {
       frag a[U], b[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = k0 + u * 32 + kc;                          // (K % 8 == 0: a chunk is inside the row or wholly past it)
-        const bool ok = k < K;
+        const bool ok = k < kend;
         a[u] = (ok && w_ok) ? *reinterpret_cast<const frag *>(wrow + k) : zero;
         b[u] = (ok && x_ok) ? *reinterpret_cast<const frag *>(xrow + k) : zero;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) mma(acc, a[u], b[u]);
     }
+    if constexpr (KS > 1) {
+      if (rb > 0) __syncthreads();                               // (the previous row block's partials have been read)
+      if (ks > 0) s_part[ks - 1][lane] = acc;
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int w2 = 0; w2 < KS - 1; ++w2) { const f32x4 t = s_part[w2][lane]; acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3]; }
+      }
+    }
     // D rows = output columns nq + q, D column = X row l15
-    if (x_ok && nq < N) {
+    if (ks == 0 && x_ok && nq < N) {
       TO o[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -2909,8 +2923,12 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // a handful of rows (the decode step): a wave per 16 output columns, operands straight from global memory
     if (max_rows <= 64 && !flagged && !pre_act && !mul_pre && drop_p <= 0.f && K % 8 == 0 && N % 4 == 0 && ldw % 8 == 0 && E <= 65535 &&
         ceil_div64(N, 16) <= 0x7fffffff) {
-      hipLaunchKernelGGL(grouped_gemm_nt_skinny_k<TO>, dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(64), 0, st,
-                         (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
+      if (K >= 1024)
+        hipLaunchKernelGGL((grouped_gemm_nt_skinny_k<TO, 4>), dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(256), 0, st,
+                           (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
+      else
+        hipLaunchKernelGGL((grouped_gemm_nt_skinny_k<TO, 1>), dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(64), 0, st,
+                           (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
       return apertis_check_launch();
     }
     // the 256x256 kernel steps K in 64s: K itself may be ragged when W's rows are zero-padded to the step.
