@@ -822,12 +822,24 @@ __global__ void __launch_bounds__(256)
 decode_state_k(const float *__restrict__ dt_logits, const float *__restrict__ A_log, const T *__restrict__ Bt, int64_t bt_rs,
                const T *__restrict__ C, int64_t c_rs, const T *__restrict__ xc, const T *__restrict__ z, int64_t z_rs,
                const float *__restrict__ Dv, float *__restrict__ state, T *__restrict__ out, int64_t B, int64_t h, int64_t N,
-               int softplus) {
+               int softplus, const T *__restrict__ dt_in = nullptr, int64_t dt_rs = 0, const float *__restrict__ Wdt = nullptr,
+               const float *__restrict__ bdt = nullptr, int R = 0) {
   const int64_t Dn = h * N;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B * Dn) return;
   const int64_t b = i / Dn, c = i - b * Dn;
-  float dlv = dt_logits[b * h + c / N];
+  float dlv;
+  if (dt_in) {
+    // dt_proj_head here (core.py:382; one launch less per layer of a token step): every channel of a head forms the head's
+    // logit itself - apertis_tiny_linear_fwd's chain (bias first, then r = 0, 1, ...), the same bits
+    const int64_t hd = c / N;
+    const T *xr = dt_in + b * dt_rs;
+    const float *w = Wdt + hd * R;
+    dlv = bdt ? bdt[hd] : 0.f;
+    for (int r = 0; r < R; ++r) dlv = fmaf(to_f32(xr[r]), w[r], dlv);
+  } else {
+    dlv = dt_logits[b * h + c / N];
+  }
   if (softplus) dlv = softplus_f(dlv);
   const float av = __builtin_amdgcn_exp2f(dlv * (-expf(A_log[c]) * LOG2E_F));
   const float s = fmaf(av, state[b * Dn + c], to_f32(Bt[b * bt_rs + c]));
@@ -1821,11 +1833,13 @@ extern "C" int apertis_ssm_decode_conv(const void *xp, int64_t xp_rs, const void
   return apertis_check_launch();
 }
 
-extern "C" int apertis_ssm_decode_state(const float *dt_logits, const float *A_log, const void *Bt, int64_t bt_rs,
-                                        const void *C, int64_t c_rs, const void *xc, const void *z, int64_t z_rs,
-                                        const float *D, float *state, void *out, int64_t B, int64_t h, int64_t N, int dtype,
-                                        int delta_softplus, void *stream) {
-  if (!dt_logits || !A_log || !Bt || !C || !xc || !z || !D || !state || !out || B <= 0 || h <= 0 || N <= 0) return APERTIS_ERR_ARG;
+static int decode_state_impl(const float *dt_logits, const void *dt_in, int64_t dt_rs, const float *W_dt, const float *b_dt, int64_t R,
+                             const float *A_log, const void *Bt, int64_t bt_rs,
+                             const void *C, int64_t c_rs, const void *xc, const void *z, int64_t z_rs,
+                             const float *D, float *state, void *out, int64_t B, int64_t h, int64_t N, int dtype,
+                             int delta_softplus, void *stream) {
+  if ((!dt_logits && !dt_in) || !A_log || !Bt || !C || !xc || !z || !D || !state || !out || B <= 0 || h <= 0 || N <= 0) return APERTIS_ERR_ARG;
+  if (dt_in && (!W_dt || R < 1 || R > 4096 || dt_rs < R)) return APERTIS_ERR_ARG;
   const int64_t Dn = h * N;
   if (bt_rs < Dn || c_rs < Dn || z_rs < Dn) return APERTIS_ERR_ARG;
   const unsigned grid = (unsigned)ceil_div64(B * Dn, 256);
@@ -1833,12 +1847,28 @@ extern "C" int apertis_ssm_decode_state(const float *dt_logits, const float *A_l
   if (dtype == APERTIS_F32)
     hipLaunchKernelGGL(decode_state_k<float>, dim3(grid), dim3(256), 0, st, dt_logits, A_log, (const float *)Bt, bt_rs,
                        (const float *)C, c_rs, (const float *)xc, (const float *)z, z_rs, D, state, (float *)out, B, h, N,
-                       delta_softplus);
+                       delta_softplus, (const float *)dt_in, dt_rs, W_dt, b_dt, (int)R);
   else if (dtype == APERTIS_BF16)
     hipLaunchKernelGGL(decode_state_k<bf16_t>, dim3(grid), dim3(256), 0, st, dt_logits, A_log, (const bf16_t *)Bt, bt_rs,
                        (const bf16_t *)C, c_rs, (const bf16_t *)xc, (const bf16_t *)z, z_rs, D, state, (bf16_t *)out, B, h, N,
-                       delta_softplus);
+                       delta_softplus, (const bf16_t *)dt_in, dt_rs, W_dt, b_dt, (int)R);
   else
     return APERTIS_ERR_UNSUPPORTED;
   return apertis_check_launch();
+}
+extern "C" int apertis_ssm_decode_state(const float *dt_logits, const float *A_log, const void *Bt, int64_t bt_rs,
+                                        const void *C, int64_t c_rs, const void *xc, const void *z, int64_t z_rs,
+                                        const float *D, float *state, void *out, int64_t B, int64_t h, int64_t N, int dtype,
+                                        int delta_softplus, void *stream) {
+  if (!dt_logits) return APERTIS_ERR_ARG;
+  return decode_state_impl(dt_logits, nullptr, 0, nullptr, nullptr, 0, A_log, Bt, bt_rs, C, c_rs, xc, z, z_rs, D, state, out, B, h, N,
+                           dtype, delta_softplus, stream);
+}
+extern "C" int apertis_ssm_decode_state_dt(const void *dt_in, int64_t dt_rs, const float *W_dt, const float *b_dt, int64_t R,
+                                           const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                                           const void *xc, const void *z, int64_t z_rs, const float *D, float *state, void *out,
+                                           int64_t B, int64_t h, int64_t N, int dtype, int delta_softplus, void *stream) {
+  if (!dt_in) return APERTIS_ERR_ARG;
+  return decode_state_impl(nullptr, dt_in, dt_rs, W_dt, b_dt, R, A_log, Bt, bt_rs, C, c_rs, xc, z, z_rs, D, state, out, B, h, N,
+                           dtype, delta_softplus, stream);
 }

@@ -337,6 +337,7 @@ class SelectiveLinearAttention(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, self.hidden_size, bias=False)
         self.use_cache = False
         self._pad_idx = None
+        self._inplace_cache = False     # generate()'s graph replay: the single-token step updates the SSM state it is handed
 
     def _pad_index(self, device):
         """Destination row of every row of x_param_proj.weight ([dt | Bt | C]) in the padded layout [Bt | 0 | C | 0 | dt | 0]."""
@@ -405,12 +406,16 @@ class SelectiveLinearAttention(nn.Module):
             xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias)
             p = _mfma_linear(xc, wp)                                                   # [B, 2*Wb + Wr]
             dt_in = p[:, 2 * Wb:2 * Wb + R]
+            state = ssm_prev.reshape(B, Dn).float()
+            if not (self._inplace_cache and state.data_ptr() == ssm_prev.data_ptr()):
+                state = state.clone()            # (the captured decode graph owns its cache buffers and updates them in place)
             if ops.tiny_linear_supported(dt_in, R, self.num_heads):
-                dt_logits = ops.tiny_linear(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias)
+                # dt_proj_head inside the state kernel (one launch less per layer of a token step; the same bits)
+                gated = ops.ssm_decode_state_dt(dt_in, self.dt_proj_head.weight, self.dt_proj_head.bias, self.A_log, p[:, :Dn],
+                                                p[:, Wb:Wb + Dn], xc, xz2[:, Dn:], self.D, state)
             else:
                 dt_logits = self.dt_proj_head(dt_in).float()
-            state = ssm_prev.reshape(B, Dn).float().clone()
-            gated = ops.ssm_decode_state(dt_logits, self.A_log, p[:, :Dn], p[:, Wb:Wb + Dn], xc, xz2[:, Dn:], self.D, state)
+                gated = ops.ssm_decode_state(dt_logits, self.A_log, p[:, :Dn], p[:, Wb:Wb + Dn], xc, xz2[:, Dn:], self.D, state)
             out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight)
             return out, None, (conv_state, state.reshape(B, self.num_heads, self.d_state))
         xp, z = ops.split_cols(xz, (Dn, Dn))
@@ -1199,8 +1204,20 @@ class ApertisForCausalLM(nn.Module):
             s_tok.copy_(nxt.unsqueeze(1))
             for (sc, ss), (nc, ns) in zip(s_past, out[4]):
                 sc.copy_(nc)
-                ss.copy_(ns)
+                if ns.data_ptr() != ss.data_ptr():     # (updated in place by the step: _inplace_cache)
+                    ss.copy_(ns)
 
+        ssm_blocks = [m for m in self.modules() if isinstance(m, SelectiveLinearAttention)]
+        for m in ssm_blocks:
+            m._inplace_cache = True
+        try:
+            return self._generate_graph_run(body, tokens, s_tok, s_past, s_alive, s_idx, s_out, s_any, left, prompt_len, min_new_tokens, pad)
+        finally:
+            for m in ssm_blocks:
+                m._inplace_cache = False
+
+    def _generate_graph_run(self, body, tokens, s_tok, s_past, s_alive, s_idx, s_out, s_any, left, prompt_len, min_new_tokens, pad):
+        dev = tokens.device
         # warm-up on a side stream (lazy bindings, prepared-weight cache, allocator), then restore the state it advanced
         keep = (s_tok.clone(), [(c.clone(), st.clone()) for (c, st) in s_past], s_alive.clone())
         side = torch.cuda.Stream(device=dev)

@@ -528,6 +528,28 @@ def ssm_decode_state(dt_logits, A_log, Bt, C, xc, z, D, state, delta_softplus=Tr
     return out
 
 
+def ssm_decode_state_dt(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, state, delta_softplus=True):
+    """ssm_decode_state(tiny_linear(dt_in, W_dt, b_dt), ...) as one launch (dt_proj_head inside the state kernel; the same
+    bits).  dt_in [B, R]: the dt columns of the x_param_proj output, read in place."""
+    _require_gpu(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, state)
+    lib = _lib.load()
+    B, R = dt_in.shape
+    h, N = A_log.shape
+    Dn = h * N
+    fix = lambda t: t if t.stride(-1) == 1 else t.contiguous()
+    dt_in, Bt, C, z = fix(dt_in), fix(Bt), fix(C), fix(z)
+    xc = xc.contiguous()
+    if not (dt_in.dtype == Bt.dtype == C.dtype == xc.dtype == z.dtype) or state.dtype != torch.float32 or not state.is_contiguous():
+        raise ApertisHipError("ssm_decode_state_dt: dt_in, Bt, C, xc, z share a dtype; state is contiguous fp32")
+    out = torch.empty(B, Dn, device=xc.device, dtype=xc.dtype)
+    check(lib.apertis_ssm_decode_state_dt(ptr(dt_in), dt_in.stride(0), ptr(W_dt.detach().float().contiguous()),
+                                          ptr(None if b_dt is None else b_dt.detach().float().contiguous()), R,
+                                          ptr(A_log.detach().float().contiguous()), ptr(Bt), Bt.stride(0), ptr(C), C.stride(0),
+                                          ptr(xc), ptr(z), z.stride(0), ptr(D.detach().float().contiguous()), ptr(state), ptr(out),
+                                          B, h, N, dtype_code(xc), int(delta_softplus), stream_ptr()), "apertis_ssm_decode_state_dt")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # SSM companions: depthwise causal conv + SiLU, post-scan gate
 # ----------------------------------------------------------------------------------------------

@@ -45,10 +45,10 @@ extern "C" {
 #define APERTIS_ACT_SAVE_GRAD 0x100
 #define APERTIS_ACT_MUL_SAVED 0x200
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 4: 4.3 - lean scan
- * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep).  A host binding should
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 4: 4.4 - lean scan
+ * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
-#define APERTIS_ABI_VERSION ((4 << 16) | 3)
+#define APERTIS_ABI_VERSION ((4 << 16) | 4)
 int apertis_abi_version(void);
 /* Name of the code-object architecture this library was compiled for ("gfx950"). */
 const char *apertis_arch(void);
@@ -198,6 +198,13 @@ int apertis_ssm_decode_conv(const void *xp, int64_t xp_rs, const void *conv_stat
 int apertis_ssm_decode_state(const float *dt_logits, const float *A_log, const void *Bt, int64_t bt_rs, const void *C,
                              int64_t c_rs, const void *xc, const void *z, int64_t z_rs, const float *D, float *state,
                              void *out, int64_t B, int64_t h, int64_t N, int dtype, int delta_softplus, void *stream);
+/* The same with dt_proj_head inside (core.py:382: one launch less per layer of a token step): the delta logits are formed from
+ * dt_in [B, R] (the dt columns of the x_param_proj output, dtype as the other operands, row stride dt_rs elements), W_dt [h, R]
+ * and b_dt [h] (may be NULL) fp32, in apertis_tiny_linear_fwd's accumulation order - the same bits. */
+int apertis_ssm_decode_state_dt(const void *dt_in, int64_t dt_rs, const float *W_dt, const float *b_dt, int64_t R,
+                                const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs, const void *xc,
+                                const void *z, int64_t z_rs, const float *D, float *state, void *out, int64_t B, int64_t h,
+                                int64_t N, int dtype, int delta_softplus, void *stream);
 
 /* Residual + dropout of every sub-block (core.py:836-837, 918-919): y = res + keep/(1-p) * x over
  * n elements (n % 4 == 0); mask = counter hash of (seed, element index).  Backward: dx = keep/(1-p)*g
