@@ -1457,7 +1457,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 // of a captured token step.  Here a WAVE owns 16 output columns of one group: W rows stream straight from global memory
 // into the MFMA A operand (16 B per lane and 32-deep step, eight steps in flight), the rows of X are the B operand, nothing
 // goes through LDS, N / 16 waves per group fill the chip, and a lane ends up with four consecutive outputs of one row (one
-// 8-byte store).  The k order (for K < 1024) and the epilogue arithmetic are the 128 x 128 kernel's.  bf16, no dropout / second output.
+// 8-byte store).  The k order (for K < 512) and the epilogue arithmetic are the 128 x 128 kernel's.  bf16, no dropout / second output.
 // ------------------------------------------------------------------------------------------
 // KS > 1 (long K: the experts' second GEMM, K = I): KS waves of a work-group split the K range, their partial sums meet in LDS
 // and wave 0 adds them in wave order - a wave alone walked 88 dependent load -> MFMA batches' worth of K = 2816.
@@ -2923,7 +2923,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // a handful of rows (the decode step): a wave per 16 output columns, operands straight from global memory
     if (max_rows <= 64 && !flagged && !pre_act && !mul_pre && drop_p <= 0.f && K % 8 == 0 && N % 4 == 0 && ldw % 8 == 0 && E <= 65535 &&
         ceil_div64(N, 16) <= 0x7fffffff) {
-      if (K >= 1024)
+      if (K >= 512)   // (a wave's share is then one batch of eight 32-deep steps or a few: the K walk is a chain of round trips)
         hipLaunchKernelGGL((grouped_gemm_nt_skinny_k<TO, 4>), dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(256), 0, st,
                            (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
       else

@@ -800,7 +800,7 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
 // Two kernels around the x_param_proj GEMM the caller runs: decode_conv_k (B x Dn threads) and decode_state_k.
 template <typename T>
 __global__ void __launch_bounds__(256)
-decode_conv_k(const T *__restrict__ xp, int64_t xp_rs, const T *__restrict__ conv_state, T *__restrict__ conv_state_out,
+decode_conv_k(const T *__restrict__ xp, int64_t xp_rs, const T *conv_state, T *conv_state_out,
               const float *__restrict__ w, const float *__restrict__ bias, T *__restrict__ xc, int64_t B, int64_t Dn, int k) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B * Dn) return;
@@ -811,10 +811,17 @@ decode_conv_k(const T *__restrict__ xp, int64_t xp_rs, const T *__restrict__ con
   const float first = k > 1 ? to_f32(cs[0]) : to_f32(xp[b * xp_rs + c]);
   const float acc = w[c * k + (k - 1)] * first + bias[c];
   xc[b * Dn + c] = from_f32<T>(acc / (1.f + expf(-acc)));
-  // new cache = the last k-1 tokens of the window
+  // new cache = the last k-1 tokens of the window (conv_state_out MAY be conv_state itself: a thread reads its channel's
+  // window into registers before it writes - the captured decode graph updates its cache in place)
   T *co = conv_state_out + (b * Dn + c) * (k - 1);
-  for (int j = 0; j + 1 < k - 1; ++j) co[j] = cs[j + 1];
-  if (k > 1) co[k - 2] = xp[b * xp_rs + c];
+  T keep[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) keep[j] = j + 1 < k - 1 ? cs[j + 1] : T(0);
+  const T last = xp[b * xp_rs + c];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (j + 1 < k - 1) co[j] = keep[j];
+  if (k > 1) co[k - 2] = last;
 }
 
 template <typename T>

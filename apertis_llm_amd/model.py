@@ -403,7 +403,8 @@ class SelectiveLinearAttention(nn.Module):
             # single-token decode step (generate(), core.py:1578-1603): two small kernels around the projections
             # instead of the chunk machinery
             xz2 = xz.reshape(B, 2 * Dn)
-            xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias)
+            xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias,
+                                                 inplace=self._inplace_cache)
             p = _mfma_linear(xc, wp)                                                   # [B, 2*Wb + Wr]
             dt_in = p[:, 2 * Wb:2 * Wb + R]
             state = ssm_prev.reshape(B, Dn).float()
@@ -1203,8 +1204,9 @@ class ApertisForCausalLM(nn.Module):
             s_idx.add_(1)
             s_tok.copy_(nxt.unsqueeze(1))
             for (sc, ss), (nc, ns) in zip(s_past, out[4]):
-                sc.copy_(nc)
-                if ns.data_ptr() != ss.data_ptr():     # (updated in place by the step: _inplace_cache)
+                if nc.data_ptr() != sc.data_ptr():     # (both updated in place by the step: _inplace_cache)
+                    sc.copy_(nc)
+                if ns.data_ptr() != ss.data_ptr():
                     ss.copy_(ns)
 
         ssm_blocks = [m for m in self.modules() if isinstance(m, SelectiveLinearAttention)]

@@ -488,7 +488,7 @@ def scan_gate_dt(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0=None, delta_softp
     return _apply(_ScanGateDt, dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last)
 
 
-def ssm_decode_step(xp, conv_state, conv_w, conv_b):
+def ssm_decode_step(xp, conv_state, conv_w, conv_b, inplace=False):
     """First half of the single-token SSM step (reference core.py:368-375 with a cached window): returns
     (xc [B,Dn], new conv_state [B,Dn,k-1]).  xp [B,Dn] (a row-strided view is fine), conv_state [B,Dn,k-1]."""
     _require_gpu(xp, conv_state, conv_w, conv_b)
@@ -501,7 +501,7 @@ def ssm_decode_step(xp, conv_state, conv_w, conv_b):
     w2 = conv_w.detach().float().reshape(Dn, k).contiguous()
     b2 = conv_b.detach().float().contiguous()
     xc = torch.empty(B, Dn, device=xp.device, dtype=xp.dtype)
-    cs_out = torch.empty_like(cs)
+    cs_out = cs if (inplace and cs.data_ptr() == conv_state.data_ptr()) else torch.empty_like(cs)   # (in place: the decode graph's cache)
     check(lib.apertis_ssm_decode_conv(ptr(xp), xp.stride(0), ptr(cs), ptr(cs_out), ptr(w2), ptr(b2), ptr(xc), B, Dn, k,
                                       dtype_code(xp), stream_ptr()), "apertis_ssm_decode_conv")
     return xc, cs_out

@@ -190,7 +190,7 @@ int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const void *Bt, 
  *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the
  *     reference keeps the FIRST output of the padded conv over that window (core.py:369-373), reproduced as is;
  *     conv_state_out = the last k-1 tokens of the window.  xp [B,Dn] (row stride xp_rs), conv_state / conv_state_out
- *     [B,Dn,k-1] (may not alias), w [Dn,k] fp32, bias [Dn] fp32, xc [B,Dn] contiguous.
+ *     [B,Dn,k-1] (may be the same buffer), w [Dn,k] fp32, bias [Dn] fp32, xc [B,Dn] contiguous.
  *   apertis_ssm_decode_state: s = exp(delta*A)*s + Bt (state [B,Dn] fp32, updated IN PLACE), out = (C*s + D*xc)*silu(z);
  *     dt_logits [B,h] fp32, Bt / C / z [B,Dn] with row strides, xc / out [B,Dn] contiguous. */
 int apertis_ssm_decode_conv(const void *xp, int64_t xp_rs, const void *conv_state, void *conv_state_out, const float *w,
