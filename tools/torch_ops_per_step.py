@@ -28,12 +28,13 @@ for ev in prof.events():
     kids = [k for k in ev.cpu_children if k.name.startswith("aten::")]
     if not ev.kernels or kids and any(k.kernels for k in kids):
         continue          # count the innermost aten op that launches
-    src = next((s for s in (ev.stack or []) if "apertis_llm_amd" in s or "bench.py" in s), "?")
-    src = src.split("apertis_llm_amd/")[-1][:80]
+    st = [s for s in (ev.stack or []) if "torch/" not in s and "<built-in" not in s and "runpy" not in s]
+    src = " < ".join(x.split("/")[-1][:44] for x in st[:3]) if st else "?"
+
     ops[ev.name] += len(ev.kernels)
     where[ev.name][(src, str(ev.input_shapes)[:60])] += len(ev.kernels)
 print("torch ops that launch kernels in one step of a 4-layer model (kernel launches):")
 for name, n in ops.most_common(25):
     print(f"  {name:34s} {n:5d}")
-    for (src, shp), c in where[name].most_common(6):
-        print(f"        {c:4d}  {src}  {shp}")
+    for (src, shp), c in where[name].most_common(10):
+        print(f"        {c:4d}  {shp:40s} {src}")
