@@ -891,14 +891,17 @@ class _SplitCols(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slot):
         ctx.slot = slot
-        return tuple(x[..., a:a + n] for a, n in zip(slot.offsets, slot.widths))
+        ctx.set_materialize_grads(False)     # an unused piece (the pad columns) arrives as None: zeroed in place below, not
+        return tuple(x[..., a:a + n] for a, n in zip(slot.offsets, slot.widths))   # as a materialised zero tensor + a copy
 
     @staticmethod
     def backward(ctx, *grads):
         slot = ctx.slot
         buf, slot.buf = slot.buf, None
         if buf is None:
-            ref = next(g for g in grads if g is not None)
+            ref = next((g for g in grads if g is not None), None)
+            if ref is None:
+                return None, None
             parts = [g if g is not None else ref.new_zeros(*ref.shape[:-1], n) for g, n in zip(grads, slot.widths)]
             return torch.cat(parts, dim=-1), None
         es = buf.element_size()
