@@ -89,6 +89,12 @@ class ApertisAdamW(torch.optim.Optimizer):
             for p in ps:
                 by_step.setdefault(int(self.state[p]["step"].item()), []).append(p)
             for step0, sub in sorted(by_step.items()):
+                # the step counts of a launch's parameters as views of ONE host tensor: a step is one add (a
+                # `torch._foreach_add_` over the 1 300 separate host tensors of the 76-layer configuration was 1.4 ms of host
+                # time per group and step); `optimizer.state[p]["step"]` stays current and 0-dim as torch's AdamW keeps it
+                steps_all = torch.full((len(sub),), float(step0))
+                for i, p in enumerate(sub):
+                    self.state[p]["step"] = steps_all[i]
                 rec = np.zeros((len(sub), 5), dtype=np.int64)
                 ct, ci = [], []
                 for i, p in enumerate(sub):
@@ -98,7 +104,7 @@ class ApertisAdamW(torch.optim.Optimizer):
                     ct.append(np.full(nc, i, dtype=np.int32))
                     ci.append(np.arange(nc, dtype=np.int32))
                 ct, ci = np.concatenate(ct), np.concatenate(ci)
-                launches.append(dict(group=gi, params=sub, steps=[self.state[p]["step"] for p in sub], step0=step0,
+                launches.append(dict(group=gi, params=sub, steps=[self.state[p]["step"] for p in sub], steps_all=steps_all, step0=step0,
                                      n=len(ct), first=n_total, row0=len(plist), chunk0=sum(len(c) for c in cts)))
                 recs.append(rec), cts.append(ct), cis.append(ci)
                 plist.extend(sub)
@@ -205,7 +211,7 @@ class ApertisAdamW(torch.optim.Optimizer):
             for g in T["launches"]:
                 group = self.param_groups[g["group"]]
                 g["step0"] += 1
-                torch._foreach_add_(g["steps"], 1)           # the per-parameter `step` tensors of torch.optim.AdamW's state
+                g["steps_all"].add_(1)                       # the per-parameter `step` tensors of torch.optim.AdamW's state: views
                 b1, b2 = group["betas"]
                 check(lib.apertis_adamw_step(ptr(g["rec"]), ptr(g["ct"]), ptr(g["ci"]), g["n"], float(group["lr"]), float(b1),
                                              float(b2), float(group["eps"]), float(group["weight_decay"]), g["step0"], ptr(coef),
