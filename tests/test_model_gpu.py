@@ -673,3 +673,32 @@ def test_generate_graph_replay_equals_eager_decoding(dev, monkeypatch, experts, 
     finally:
         model.forward = fwd
     assert calls["n"] <= 6, calls
+
+
+def test_train_step_overfits_one_batch(dev):
+    """End to end through everything the bench step uses (bf16 autocast, one-launch weight preparation, lean scan, expert
+    kernels with dropout and capacity, fused LM head + loss, clip + AdamW kernels, OneCycleLR): eighty steps on ONE batch
+    drive the loss of a small 8-expert SSM model from ln(V) to well under half of it, monotonically on the whole, with a
+    finite gradient norm and a clean look-back error word throughout."""
+    import math
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops
+    from apertis_llm_amd.training import TrainStep
+    torch.manual_seed(21)
+    cfg = A.ApertisConfig(vocab_size=512, hidden_size=704, num_hidden_layers=2, num_attention_heads=11, intermediate_size=1408,
+                          attention_type="selective_ssm", use_expert_system=True, num_experts=8, experts_per_token=2)
+    model = A.ApertisForCausalLM(cfg).to(dev).train()
+    step = TrainStep(model, lr=3e-3, total_steps=100)
+    assert step.prep is not None
+    ids = torch.randint(4, 512, (4, 512), device=dev)
+    losses = []
+    for i in range(80):
+        losses.append(step(input_ids=ids, labels=ids))
+        if i % 20 == 19:
+            assert torch.isfinite(step.optimizer.last_grad_norm)
+    losses = [float(x) for x in losses]
+    assert all(math.isfinite(x) for x in losses)
+    assert 5.5 < losses[0] < 7.5, losses[0]                       # ~ ln(512) = 6.24 (+ the auxiliary losses)
+    assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
+    assert sum(losses[60:]) / 20 < sum(losses[20:40]) / 20 < sum(losses[:20]) / 20
+    assert ops.scan_gate_error(dev) == 0
