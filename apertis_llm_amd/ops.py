@@ -2084,7 +2084,7 @@ def shifted_cross_entropy(logits, labels, ignore_index=-100):
 # rows of logits held at a time by linear_cross_entropy (16384 x 32000 bf16 = 1 GiB): with one 4096-token sequence per
 # chunk the 32 weight-gradient partial GEMMs and their fp32 accumulation cost 4 ms of the 440 ms step, with four per chunk
 # the step time equals the logits path's and the peak is still 14 GiB lower at batch 32
-_LCE_CHUNK_ROWS = 16384
+_LCE_CHUNK_ROWS = int(_os.environ.get("APERTIS_LCE_CHUNK_ROWS", "16384"))
 
 
 class _LinearCrossEntropy(torch.autograd.Function):
