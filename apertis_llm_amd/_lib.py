@@ -28,7 +28,7 @@ _vp, _i64, _i32, _f32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 _f64 = ctypes.c_double
 
 # name -> (restype, argtypes).  Order and meaning mirror include/apertis_hip.h exactly.
-ABI_VERSION = (4 << 16) | 4      # = APERTIS_ABI_VERSION of include/apertis_hip.h (tests/test_host_cpu.py compares them)
+ABI_VERSION = (4 << 16) | 5      # = APERTIS_ABI_VERSION of include/apertis_hip.h (tests/test_host_cpu.py compares them)
 SIGNATURES = {
     "apertis_abi_version": (ctypes.c_int, []),
     "apertis_arch": (ctypes.c_char_p, []),
@@ -56,6 +56,12 @@ SIGNATURES = {
                                         _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_scan_lean_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
                                      _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_scan_lookback_workspace_bytes": (_i64, [_i64, _i64, _i64]),
+    "apertis_scan_lookback_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp,
+                                         ctypes.c_uint32, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_scan_lookback_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+                                         _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, ctypes.c_uint32, _i64, _i64, _i64,
+                                         _i64, _i32, _vp]),
     "apertis_ssm_decode_conv": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_ssm_decode_state": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32,
                                         _i32, _vp]),

@@ -77,6 +77,25 @@ def _launch(name, fn, args, work=0.0, detail=None, nbytes=0.0):
     t.records.append((name, s, e, work, detail, nbytes))
 
 
+def _try_launch(name, fn, args, work=0.0):
+    """_launch for an entry point that may decline the shape: returns False on APERTIS_ERR_UNSUPPORTED (-2) WITHOUT recording
+    a timed launch (the caller then takes another form, which records its own), True when the launch went out."""
+    t = _TIMER
+    timed = t is not None and t.on and name in t.names
+    if timed:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    rc = fn(*args)
+    if rc == -2:
+        return False
+    if timed:
+        e.record()
+    check(rc, name.split("[")[0])
+    if timed:
+        t.records.append((name, s, e, work, None, 0.0))
+    return True
+
+
 def _require_gpu(*ts):
     """Every tensor of a call lives on ONE ROCm device and that device is the current one: the library launches on the
     current HIP device and on torch's current stream of it (`_lib.stream_ptr`), so a tensor elsewhere would be touched
@@ -218,13 +237,17 @@ SCAN_SINGLE_PASS = _os.environ.get("APERTIS_SCAN_SINGLE_PASS", "1") != "0"
 # N = 16, 128 < Dn <= 256, 8-byte aligned slices); everything else on the forms above
 SCAN_LEAN = _os.environ.get("APERTIS_SCAN_LEAN", "1") == "1"
 SCAN_LEAN_BWD = _os.environ.get("APERTIS_SCAN_LEAN_BWD", "1") == "1"   # ... and the backward, from the lean forward's checkpoints
+# APERTIS_SCAN_LOOKBACK (round 5, default on; 0 = off): ONE launch per direction in the lean layout - a work-group per 64-token
+# chunk, 16 tokens per wave held in registers, chunk carries by a decoupled look-back through the workspace below (every operand
+# row read once; csrc/scan_lookback.hip) - for bf16, N = 16, Dn <= 256; takes precedence over the three-launch lean form
+SCAN_LOOKBACK = _os.environ.get("APERTIS_SCAN_LOOKBACK", "1") == "1"
 _gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
 
 
 def _scan_gate_ws(lib, B, L, Dn, device):
     """Look-back workspace of the single-pass kernels: one per (device, stream), zero-filled once, and the epoch of the
     next launch on it (incremented by exactly one per launch: the two ticket counters in its head alternate)."""
-    need = int(lib.apertis_scan_gate_workspace_bytes(B, L, Dn))
+    need = max(int(lib.apertis_scan_gate_workspace_bytes(B, L, Dn)), int(lib.apertis_scan_lookback_workspace_bytes(B, L, Dn)))
     device = _indexed(device)
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ent = _gate_ws.get(key)
@@ -235,6 +258,13 @@ def _scan_gate_ws(lib, B, L, Dn, device):
             ent[0][8:12].copy_(old[0][8:12])     # a larger workspace inherits the sticky error word of the one it replaces
     ent[1] += 1
     return ent[0], ent[1]
+
+
+def _scan_gate_ws_unused(device):
+    """The epoch handed out last was not launched with (the entry point declined the shape): take it back - the two ticket
+    counters alternate with the epoch's parity, so an epoch that is skipped would leave the next launch a stale counter."""
+    device = _indexed(device)
+    _gate_ws[(device, torch.cuda.current_stream(device).cuda_stream)][1] -= 1
 
 
 def _indexed(device):
@@ -390,7 +420,26 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
     # the lean form where it takes the shape (bf16, N = 16, 128 < Dn <= 256): timed under the same name - the same op
     ckpt, lean = None, False
     dt_done = dtp is None
-    if SCAN_LEAN and xc.dtype == torch.bfloat16 and N == 16 and 128 < Dn <= 256:
+    kind = "staged"
+    if SCAN_LOOKBACK and xc.dtype == torch.bfloat16 and N == 16 and Dn <= 256:
+        if not dt_done:
+            _tiny_linear_into(lib, dtp, dlt)
+            dt_done = True
+        ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
+        ckpt = torch.empty(B, -(-L // 16), Dn, device=dev, dtype=torch.float32) if need_grad else None
+        lean = _try_launch("apertis_scan_gate_fwd", lib.apertis_scan_lookback_fwd,
+                           (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0),
+                            ptr(out), out.stride(-2), ptr(h_last), ptr(None if need_grad else h_in), ptr(ckpt), ptr(ws), epoch,
+                            B, L, h, N, int(delta_softplus), stream_ptr()), work)
+        if lean:
+            kind = "lookback"
+            if need_grad:
+                h_in = None              # (ckpt16[:, ::4] is the state entering every chunk)
+        else:
+            _scan_gate_ws_unused(dev)
+            ckpt = None
+    if not lean and SCAN_LEAN and xc.dtype == torch.bfloat16 and N == 16 and 128 < Dn <= 256:
+        kind = "lean"
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         ckpt = torch.empty(B, -(-L // 4), Dn, device=dev, dtype=torch.float32) if need_grad else None
         rc = []
@@ -411,7 +460,7 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
     if not dt_done:
         _tiny_linear_into(lib, dtp, dlt)
     if not lean:
-        ckpt = None
+        ckpt, kind = None, "staged"
         if SCAN_SINGLE_PASS:
             ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
             agg = None
@@ -424,6 +473,7 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
                  int(delta_softplus), int(SCAN_SINGLE_PASS), stream_ptr()), work)
     ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt)
     ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
+    ctx.scan_kind = kind
     ctx.mark_non_differentiable(*([h_last] if return_last else []))
     return (out, h_last) if return_last else out
 
@@ -442,7 +492,8 @@ def _scan_gate_backward(ctx, dout):
     Dn = h * N
     dev = dlt.device
     dout, do_rs = _rows(dout.to(xc.dtype), Dn)
-    nch = h_in.shape[1]
+    kind = ctx.scan_kind
+    nch = -(-L // int(lib.apertis_scan_gate_chunk_len()))
     dBt, dbt_rs = _grad_out(ctx.slots[0], (B, L), wB, Bt.dtype, dev)
     dC, dc_rs = _grad_out(ctx.slots[1], (B, L), wB, C.dtype, dev)
     dz, dz_rs = _grad_out(ctx.slots[2], (B, L), Dn, z.dtype, dev)
@@ -453,7 +504,17 @@ def _scan_gate_backward(ctx, dout):
     fold = torch.empty(64, 2 * Dn, device=dev, dtype=torch.float32)
     e = xc.element_size()
     work = B * L * (9 * Dn * e + 8 * h) + 8 * h * N          # algorithmic bytes, fused variant
-    if ckpt is not None and SCAN_LEAN_BWD:       # the lean forward left its checkpoints: the lean backward
+    if kind == "lookback":                       # the look-back forward left the state entering every 16th token
+        ws, epoch = _scan_gate_ws(lib, B, L, Dn, dev)
+        if _try_launch("apertis_scan_gate_bwd", lib.apertis_scan_lookback_bwd,
+                       (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z),
+                        z.stride(-2), ptr(Df), ptr(dout), do_rs, ptr(ckpt), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs,
+                        ptr(dz), dz_rs, ptr(d_dlt), ptr(dA_dD), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, int(sp),
+                        stream_ptr()), work):
+            return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt)
+        _scan_gate_ws_unused(dev)
+        h_in = ckpt[:, ::4].contiguous()         # (declined: the staged kernels below, from the chunk-entry states)
+    if kind == "lean" and ckpt is not None and SCAN_LEAN_BWD:       # the lean forward left its checkpoints: the lean backward
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
         mu_in = torch.empty(B, nch, Dn, device=dev, dtype=torch.float32)
         rc = []

@@ -45,10 +45,10 @@ extern "C" {
 #define APERTIS_ACT_SAVE_GRAD 0x100
 #define APERTIS_ACT_MUL_SAVED 0x200
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 4: 4.4 - lean scan
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
-#define APERTIS_ABI_VERSION ((4 << 16) | 4)
+#define APERTIS_ABI_VERSION ((4 << 16) | 5)
 int apertis_abi_version(void);
 /* Name of the code-object architecture this library was compiled for ("gfx950"). */
 const char *apertis_arch(void);
@@ -185,6 +185,32 @@ int apertis_scan_lean_bwd(const float *dlt, const float *A_log, const void *Bt, 
                           int64_t dout_rs, const float *ckpt, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs, int64_t store_w,
                           void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD, float *agg, float *mu_in,
                           float *fold, float *part, int64_t B, int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream);
+/* The fused scan + gate as ONE launch per direction with a decoupled look-back (round 5; reference core.py:337-353,394-397;
+ * csrc/scan_lookback.hip): the lean layout (a lane owns four channels of a row), a work-group per 64-token chunk with 16 tokens
+ * per wave held in registers, so every operand row is read once; chunk aggregates and, per four chunks, an inclusive state are
+ * published as {epoch, value} granules in `ws` and gathered by later chunks of the same sequence (work-groups take their chunk
+ * from a ticket counter in chunk-major order, so a wait only ever concerns a work-group that has started).  Shapes taken: bf16,
+ * N = 16, h*N <= 256 (several sequences side by side in a wave when h*N <= 128), row strides and pointers multiples of 8 bytes,
+ * every tensor below 4 GiB - APERTIS_ERR_UNSUPPORTED otherwise (the caller then uses the forms above).
+ *   ws     apertis_scan_lookback_workspace_bytes() bytes, 16-byte aligned, zero-filled ONCE by the caller and then only ever
+ *          touched by these two functions and apertis_scan_gate_fwd / _bwd (the head - ticket counters, error word - is shared);
+ *          `epoch` as for those: starts at 1 and grows by exactly one per launch on that workspace.  A look-back wait that
+ *          times out ORs 2 into the error word (int at byte 8 of ws); the launch's outputs are then invalid.
+ *   h_in   [B, nchunks, h*N] fp32 or NULL: the state entering every 64-token chunk (what apertis_scan_gate_bwd consumes)
+ *   ckpt16 [B, ceil(L/16), h*N] fp32 (forward: may be NULL): the state entering every 16th token; apertis_scan_lookback_bwd
+ *          rebuilds its states from it and REQUIRES the one its forward wrote.  (ckpt16[:, 4*j] is h_in[:, j].)
+ *   fold / part, dA_dD, store_w and the gradient slices as for apertis_scan_gate_bwd. */
+int64_t apertis_scan_lookback_workspace_bytes(int64_t B, int64_t L, int64_t Dn);
+int apertis_scan_lookback_fwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                              const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const float *h0,
+                              void *out, int64_t out_rs, float *h_last, float *h_in, float *ckpt16, void *ws, uint32_t epoch,
+                              int64_t B, int64_t L, int64_t h, int64_t N, int delta_softplus, void *stream);
+int apertis_scan_lookback_bwd(const float *dlt, const float *A_log, const void *Bt, int64_t bt_rs, const void *C, int64_t c_rs,
+                              const void *xc, int64_t xc_rs, const void *z, int64_t z_rs, const float *D, const void *dout,
+                              int64_t dout_rs, const float *ckpt16, void *dBt, int64_t dbt_rs, void *dC, int64_t dc_rs,
+                              int64_t store_w, void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD,
+                              float *fold, float *part, void *ws, uint32_t epoch, int64_t B, int64_t L, int64_t h, int64_t N,
+                              int delta_softplus, void *stream);
 /* Single-token decode step of the SSM block (core.py:364-400 with L = 1 and a cache, called from generate()
  * core.py:1578-1603), two kernels around the caller's x_param_proj / dt projections:
  *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the
