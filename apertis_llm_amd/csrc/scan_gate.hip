@@ -795,12 +795,15 @@ decode_conv_k(const T *__restrict__ xp, int64_t xp_rs, const T *conv_state, T *c
   // new cache = the last k-1 tokens of the window (conv_state_out MAY be conv_state itself: a thread reads its channel's
   // window into registers before it writes - the captured decode graph updates its cache in place)
   T *co = conv_state_out + (b * Dn + c) * (k - 1);
-  T keep[3];
+  // (the host accepts k <= 16: k - 2 <= 14 shifted entries.  Round 4 kept three - right for the default k = 4, and for k >= 6
+  //  left co[3 .. k-3] unwritten: stale in place, uninitialised out of place)
+  constexpr int KEEP = 14;
+  T keep[KEEP];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) keep[j] = j + 1 < k - 1 ? cs[j + 1] : T(0);
+  for (int j = 0; j < KEEP; ++j) keep[j] = j + 1 < k - 1 ? cs[j + 1] : T(0);
   const T last = xp[b * xp_rs + c];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < KEEP; ++j)
     if (j + 1 < k - 1) co[j] = keep[j];
   if (k > 1) co[k - 2] = last;
 }

@@ -62,8 +62,19 @@ __device__ __forceinline__ void lb_store16(__amdgpu_buffer_rsrc_t rs, uint32_t o
   const lb_u4 v = {e, __float_as_uint(a), e, __float_as_uint(b)};
   __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 16);     // aux 16 = sc1: write-through
 }
-__device__ __forceinline__ lb_u4 lb_load16(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16);   // sc1: past this CU's L1
+// The poll's loads are inline asm: hipcc hoists __builtin_amdgcn_raw_buffer_load_b128 out of the poll loop (with an empty
+// memory-clobber asm in the loop, and with the builtin's volatile bit as well) and the loop then spins on registers.  The
+// descriptor as four plain words for the "s" operand; the wait names the loaded registers so that their uses stay behind it.
+typedef int lb_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lb_i4 lb_desc(const void *p, uint32_t bytes) {
+  const uint64_t a = (uint64_t)(uintptr_t)p;
+  const lb_i4 r = {(int)(uint32_t)a, (int)(uint32_t)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ lb_u4 lb_load16(lb_i4 rs, uint32_t off) {
+  lb_u4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(v) : "v"(off), "s"(rs) : "memory");   // sc1: past this CU's L1
+  return v;
 }
 // LDS-only barrier: the waves' row loads (and output stores) stay in flight across it
 __device__ __forceinline__ void lb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -95,20 +106,22 @@ __device__ __forceinline__ bool lb_take(GateWsHead *head, uint32_t epoch, int *s
 
 // one record polled by one wave: pieces [0, np) at `off` (+ piece * g * 16), until every granule carries this launch's epoch
 template <int NP>
-__device__ __forceinline__ void lb_poll(__amdgpu_buffer_rsrc_t rw, uint32_t off, uint32_t pstep, uint32_t epoch, bool lane_ok,
+__device__ __forceinline__ void lb_poll(lb_i4 rw, uint32_t off, uint32_t pstep, uint32_t epoch, bool lane_ok,
                                         int *err, float (&S)[4], float &sd) {
+  static_assert(NP == 2 || NP == 3, "an inclusive record or an aggregate");
   lb_u4 p[NP];
   unsigned spins = 0;
   while (true) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) p[i] = lb_load16(rw, off + (uint32_t)i * pstep);
+    for (int i = 0; i < NP; ++i) p[i] = lb_load16(rw, lane_ok ? off + (uint32_t)i * pstep : 0xfffffff0u);   // (select LAST: bad + step wraps)
+    if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : : "memory");
     bool okk = true;
 #pragma unroll
     for (int i = 0; i < NP; ++i) okk = okk && p[i][0] == epoch && p[i][2] == epoch;
     if (__all(okk || !lane_ok)) break;
     if (++spins > LB_SPIN_MAX) { if ((threadIdx.x & 63) == 0) atomicOr(err, 2); break; }
     __builtin_amdgcn_s_sleep(2);
-    asm volatile("" ::: "memory");     // (the next pass re-reads memory)
   }
   S[0] = __uint_as_float(p[0][1]); S[1] = __uint_as_float(p[0][3]); S[2] = __uint_as_float(p[1][1]); S[3] = __uint_as_float(p[1][3]);
   sd = NP > 2 ? __uint_as_float(p[NP - 1][1]) : 0.f;
@@ -145,6 +158,7 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rc = lean_rsrc(tc.p, tc.bytes), rx = lean_rsrc(tx.p, tx.bytes),
                                rz = lean_rsrc(tz.p, tz.bytes), rd = lean_rsrc(dl.p, dl.bytes), ro = lean_rsrc(to.p, to.bytes),
                                rw = lean_rsrc(head, G.wsbytes);
+  const lb_i4 rwp = lb_desc(head, G.wsbytes);
   const uint32_t tok0 = (uint32_t)((int64_t)L.b * d.L + t0), c2 = (uint32_t)L.c0 * 2u;
   const uint32_t ob = L.ok ? tok0 * tb_.rs * 2u + c2 : bad, oc = L.ok ? tok0 * tc.rs * 2u + c2 : bad,
                  ox = L.ok ? tok0 * tx.rs * 2u + c2 : bad, oz = L.ok ? tok0 * tz.rs * 2u + c2 : bad,
@@ -203,13 +217,13 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       for (int k = 0; k < 4; ++k) Sa[k] = fmaf(__builtin_amdgcn_exp2f(sw * A2[k]), Sa[k], sv[k]);
       sda += sw;
     }
-    const uint32_t o = L.ok ? G.offA + ((uint32_t)(L.b * d.nchunks + chunk) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad;
-    lb_store16(rw, o, epoch, Sa[0], Sa[1]);
-    lb_store16(rw, o + pstep, epoch, Sa[2], Sa[3]);
-    lb_store16(rw, o + 2u * pstep, epoch, sda, sda);
+    const uint32_t o = G.offA + ((uint32_t)(L.b * d.nchunks + chunk) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u;
+    lb_store16(rw, L.ok ? o : bad, epoch, Sa[0], Sa[1]);          // (select LAST: bad + pstep would wrap into the table)
+    lb_store16(rw, L.ok ? o + pstep : bad, epoch, Sa[2], Sa[3]);
+    lb_store16(rw, L.ok ? o + 2u * pstep : bad, epoch, sda, sda);
     float hv[4] = {0.f, 0.f, 0.f, 0.f}, unused;
     if (sup > 0) {
-      lb_poll<2>(rw, L.ok ? G.offI + ((uint32_t)(L.b * G.nsup + sup - 1) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad, pstep, epoch,
+      lb_poll<2>(rwp, G.offI + ((uint32_t)(L.b * G.nsup + sup - 1) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u, pstep, epoch,
                  L.ok, &head->err, hv, unused);
     } else if (h0 && L.ok) {
       const float4 t = *reinterpret_cast<const float4 *>(h0 + (int64_t)L.b * d.Dn + L.c0);
@@ -218,7 +232,7 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
     sS[1][0][ln] = make_float4(hv[0], hv[1], hv[2], hv[3]);
   } else if (wv - 1 < sib) {
     float rv[4], rsd;
-    lb_poll<3>(rw, L.ok ? G.offA + ((uint32_t)(L.b * d.nchunks + sup * LB_SUP + wv - 1) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad,
+    lb_poll<3>(rwp, G.offA + ((uint32_t)(L.b * d.nchunks + sup * LB_SUP + wv - 1) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u,
                pstep, epoch, L.ok, &head->err, rv, rsd);
     sS[1][wv][ln] = make_float4(rv[0], rv[1], rv[2], rv[3]);
     sD[1][wv][ln] = rsd;
@@ -240,12 +254,12 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
     }
   if (wv == 0) {
     if (sib == LB_SUP - 1) {      // the inclusive state after this super-chunk: the next one's chunks wait for it
-      const uint32_t o = L.ok ? G.offI + ((uint32_t)(L.b * G.nsup + sup) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad;
+      const uint32_t o = G.offI + ((uint32_t)(L.b * G.nsup + sup) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u;
       float hi[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) hi[k] = fmaf(__builtin_amdgcn_exp2f(sda * A2[k]), hst[k], Sa[k]);
-      lb_store16(rw, o, epoch, hi[0], hi[1]);
-      lb_store16(rw, o + pstep, epoch, hi[2], hi[3]);
+      lb_store16(rw, L.ok ? o : bad, epoch, hi[0], hi[1]);
+      lb_store16(rw, L.ok ? o + pstep : bad, epoch, hi[2], hi[3]);
     }
     if (h_in && L.ok)
       *reinterpret_cast<float4 *>(h_in + ((int64_t)L.b * d.nchunks + chunk) * d.Dn + L.c0) = make_float4(hst[0], hst[1], hst[2], hst[3]);
@@ -336,6 +350,7 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rc = lean_rsrc(tc.p, tc.bytes), rx = lean_rsrc(tx.p, tx.bytes),
                                rz = lean_rsrc(tz.p, tz.bytes), rg = lean_rsrc(tg.p, tg.bytes), rd = lean_rsrc(dl.p, dl.bytes),
                                rw = lean_rsrc(head, G.wsbytes);
+  const lb_i4 rwp = lb_desc(head, G.wsbytes);
   const __amdgpu_buffer_rsrc_t wb = lean_rsrc(ob_.p, ob_.bytes), wc = lean_rsrc(oc_.p, oc_.bytes), wx = lean_rsrc(ox_.p, ox_.bytes),
                                wz = lean_rsrc(oz_.p, oz_.bytes);
   const uint32_t tok0 = (uint32_t)((int64_t)L.b * d.L + t0), c2 = (uint32_t)L.c0 * 2u;
@@ -409,18 +424,18 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       for (int k = 0; k < 4; ++k) Ma[k] = fmaf(__builtin_amdgcn_exp2f(sw * A2[k]), Ma[k], sv[k]);
       sda += sw;
     }
-    const uint32_t o = L.ok ? G.offA + ((uint32_t)(L.b * d.nchunks + kpos) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad;
-    lb_store16(rw, o, epoch, Ma[0], Ma[1]);
-    lb_store16(rw, o + pstep, epoch, Ma[2], Ma[3]);
-    lb_store16(rw, o + 2u * pstep, epoch, sda, sda);
+    const uint32_t o = G.offA + ((uint32_t)(L.b * d.nchunks + kpos) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u;
+    lb_store16(rw, L.ok ? o : bad, epoch, Ma[0], Ma[1]);
+    lb_store16(rw, L.ok ? o + pstep : bad, epoch, Ma[2], Ma[3]);
+    lb_store16(rw, L.ok ? o + 2u * pstep : bad, epoch, sda, sda);
     float mv[4] = {0.f, 0.f, 0.f, 0.f}, unused;
     if (sup > 0)
-      lb_poll<2>(rw, L.ok ? G.offI + ((uint32_t)(L.b * G.nsup + sup - 1) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad, pstep, epoch,
+      lb_poll<2>(rwp, G.offI + ((uint32_t)(L.b * G.nsup + sup - 1) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u, pstep, epoch,
                  L.ok, &head->err, mv, unused);
     sS[1][0][ln] = make_float4(mv[0], mv[1], mv[2], mv[3]);
   } else if (wr - 1 < sib) {
     float rv[4], rsd;
-    lb_poll<3>(rw, L.ok ? G.offA + ((uint32_t)(L.b * d.nchunks + sup * LB_SUP + wr - 1) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad,
+    lb_poll<3>(rwp, G.offA + ((uint32_t)(L.b * d.nchunks + sup * LB_SUP + wr - 1) * 3u * (uint32_t)G.g + (uint32_t)L.q) * 16u,
                pstep, epoch, L.ok, &head->err, rv, rsd);
     sS[1][wr][ln] = make_float4(rv[0], rv[1], rv[2], rv[3]);
     sD[1][wr][ln] = rsd;
@@ -440,12 +455,12 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       for (int k = 0; k < 4; ++k) mu[k] = fmaf(__builtin_amdgcn_exp2f(sw * A2[k]), mu[k], sv[k]);
     }
   if (wr == 0 && sib == LB_SUP - 1) {
-    const uint32_t o = L.ok ? G.offI + ((uint32_t)(L.b * G.nsup + sup) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u : bad;
+    const uint32_t o = G.offI + ((uint32_t)(L.b * G.nsup + sup) * 2u * (uint32_t)G.g + (uint32_t)L.q) * 16u;
     float mi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) mi[k] = fmaf(__builtin_amdgcn_exp2f(sda * A2[k]), mu[k], Ma[k]);
-    lb_store16(rw, o, epoch, mi[0], mi[1]);
-    lb_store16(rw, o + pstep, epoch, mi[2], mi[3]);
+    lb_store16(rw, L.ok ? o : bad, epoch, mi[0], mi[1]);
+    lb_store16(rw, L.ok ? o + pstep : bad, epoch, mi[2], mi[3]);
   }
 #pragma unroll
   for (int w = 0; w < LB_NW - 1; ++w)

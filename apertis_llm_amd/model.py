@@ -264,6 +264,9 @@ def _mfma_linear(x, weight, bias=None):
     K = weight.shape[1]
     if x.is_cuda and K % 8 == 0 and weight.shape[0] % 8 == 0:
         return ops.linear_mfma(x, weight, bias, compute_dtype=_compute_dtype(x))
+    if getattr(weight, "_apertis_prep", None) is not None:
+        # (a TrainPrep placeholder carries shape and gradient route only: its values are uninitialised memory)
+        raise ops.ApertisHipError(f"prepared-weight placeholder {tuple(weight.shape)} on the stock linear path")
     return F.linear(x, weight, bias)
 
 

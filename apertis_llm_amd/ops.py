@@ -1366,6 +1366,8 @@ class TrainPrep:
         if key in self.by_key or not self._ok(*params) or len({p.shape[1] for p in params}) != 1:
             return False
         C, R = params[0].shape[1], sum(p.shape[0] for p in params)
+        if C % 8 or R % 8:         # (model._mfma_linear's predicate: other shapes go to F.linear, which would READ the placeholder)
+            return False
         en = _PrepEntry()
         en.sources, en.rows, en.cols, en.kind, en.rowmap, en.rowmap64, en.rows_out = tuple(params), R, C, "stack", None, None, R
         en.plain, en.tr = self._alloc(1, R, C)
@@ -1380,7 +1382,7 @@ class TrainPrep:
     def add_rowmap(self, key, param, dst_idx, rows_out):
         """[R, C] parameter whose row r lands in row dst_idx[r] of a [rows_out, C] weight, the other rows zero (x_param_proj in
         the scan's padded layout)."""
-        if key in self.by_key or not self._ok(param):
+        if key in self.by_key or not self._ok(param) or param.shape[1] % 8 or rows_out % 8:   # (as add_stack)
             return False
         R, C = param.shape
         en = _PrepEntry()

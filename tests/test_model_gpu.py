@@ -624,6 +624,41 @@ def test_train_prep_one_launch_equals_per_call_preparation(dev, experts):
         ops.TRAIN_PREP = True
 
 
+def test_train_prep_leaves_shapes_the_mfma_linear_refuses_to_the_per_call_path(dev):
+    """hidden_size % 8 == 4: model._mfma_linear sends the in_proj stack to stock F.linear (K % 8 != 0), which READS its weight -
+    so TrainPrep must not register it (round 4 did: shape[-1] % 4 was its only test, and the step multiplied by the
+    placeholder's uninitialised memory).  Three bf16 steps with and without the one-launch preparation: identical losses."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import ops
+    from apertis_llm_amd.training import TrainStep
+    cfg = dict(vocab_size=256, hidden_size=100, num_hidden_layers=2, num_attention_heads=5, intermediate_size=256,
+               attention_type="selective_ssm", use_expert_system=False)
+    torch.manual_seed(3)
+    init = A.ApertisForCausalLM(A.ApertisConfig(**cfg)).state_dict()
+
+    def run(on):
+        ops.TRAIN_PREP = on
+        torch.manual_seed(5)
+        m = A.ApertisForCausalLM(A.ApertisConfig(**cfg))
+        m.load_state_dict(init)
+        m = m.to(dev).train()
+        step = TrainStep(m, lr=1e-3, total_steps=10, bf16=True)
+        g = torch.Generator().manual_seed(11)
+        out = []
+        for _ in range(3):
+            ids = torch.randint(4, 256, (2, 200), generator=g).to(dev)
+            out.append(float(step(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids)))
+        if on and step.prep is not None:
+            blk = m.model.layers[0].attention.attention_mechanism_impl
+            assert ("in_proj_xz", id(blk)) not in step.prep.by_key      # (K = 100: not the MFMA tile's shape)
+        return out
+    try:
+        l0, l1 = run(False), run(True)
+        assert l0 == l1 and all(x == x for x in l0), (l0, l1)
+    finally:
+        ops.TRAIN_PREP = True
+
+
 @pytest.mark.parametrize("experts,bf16", [(0, False), (4, True)])
 def test_generate_graph_replay_equals_eager_decoding(dev, monkeypatch, experts, bf16):
     """generate(): from 24 remaining greedy tokens on, the single-token steps of an SSM model run as ONE captured HIP graph

@@ -251,6 +251,31 @@ def test_decode_kernels_match_the_chunk_path(dev):
         _close(cache_a[1], cache_b[1], f"step {t} ssm_state", rtol=1e-6)
 
 
+@pytest.mark.parametrize("k", [2, 4, 5, 6, 8, 16])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_decode_conv_window_shift_for_every_accepted_kernel_width(dev, k, dt):
+    """apertis_ssm_decode_conv's cache update (reference core.py:369-373,398-400: the new window is the last k - 1 tokens of
+    [conv_state | xp]) for every ssm_conv_kernel the entry point accepts, out of place and in place (the decode graph's form).
+    Round 4's kernel shifted three entries only: right for the default k = 4, stale / uninitialised from k = 6 on."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(k)
+    B, Dn = 3, 80
+    xp = torch.randn(B, Dn, device=dev).to(dt)
+    cs = torch.randn(B, Dn, max(k - 1, 0), device=dev).to(dt)
+    w = torch.randn(Dn, 1, k, device=dev)
+    bias = torch.randn(Dn, device=dev)
+    win = torch.cat([cs, xp.unsqueeze(-1)], -1).float()                 # [B, Dn, k]
+    acc = w[:, 0, k - 1] * win[..., 0] + bias                            # (the front-slice quirk: only the last tap meets a value)
+    ref_xc, ref_cs = torch.nn.functional.silu(acc), win[..., 1:].to(dt)
+    xc, cs_out = ops.ssm_decode_step(xp, cs, w, bias)
+    assert cs_out.data_ptr() != cs.data_ptr()
+    assert torch.equal(cs_out, ref_cs)
+    _close(xc, ref_xc, "xc", rtol=1e-5 if dt == torch.float32 else 1e-2)
+    cs2 = cs.clone()
+    xc2, cs_in = ops.ssm_decode_step(xp, cs2, w, bias, inplace=True)
+    assert cs_in.data_ptr() == cs2.data_ptr() and torch.equal(cs2, ref_cs) and torch.equal(xc2, xc)
+
+
 @pytest.mark.parametrize("B,L,h,N,R", [(3, 257, 11, 16, 44), (2, 700, 14, 16, 56), (2, 130, 12, 16, 48), (1, 200, 11, 16, 20)])
 def test_scan_gate_dt_fused_equals_tiny_linear_then_scan_gate(dev, monkeypatch, B, L, h, N, R):
     """N4's pre-scan prologue: ops.scan_gate_dt (dt_proj_head inside the lean forward's state pass, core.py:382-396) against
