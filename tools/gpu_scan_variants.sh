@@ -8,15 +8,15 @@ for v in "$@"; do
   rm -rf gpurun_out/sv_trace
   echo "== variant $v" >> $L
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sv_trace -- python3 tools/scan_lean_check.py 44 4096 11 16 > gpurun_out/sv.out 2> gpurun_out/sv.err || { tail -5 gpurun_out/sv.err; exit 1; }
-  grep -v amdgpu.ids gpurun_out/sv.out | grep "lean\|out:\|grad" >> $L
+  grep -v amdgpu.ids gpurun_out/sv.out | grep "best\|!!" >> $L
   f=$(ls gpurun_out/sv_trace/*/*kernel_stats.csv 2>/dev/null | head -1)
   [ -n "$f" ] || { echo "no kernel_stats.csv" >> $L; cat $L; exit 1; }
   python3 - "$f" >> $L <<'PY'
 import csv, re, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if "scan_lean" in n or "scan_gate" in n:
-        m = re.search(r"(scan_[a-z_]+_k(<[^>]*>)?)", n)
+    if "scan_lean" in n or "scan_gate" in n or "scan_lb" in n or "colsum" in n:
+        m = re.search(r"((scan_[a-z_]+_k|colsum_kernel)(<[^>]*>)?)", n)
         print("   %-34s calls %4s  avg %9.1f us" % (m.group(1) if m else n[:34], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
