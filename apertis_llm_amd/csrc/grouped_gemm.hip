@@ -34,6 +34,44 @@ constexpr int NT = 256;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
 
+// ---- Dropout mask of the expert MLP's activation (reference core.py:439: Dropout(p) between the two Linears; every kernel of
+// this file, forward and backward, draws it from here).  16 random bits per element; elements (row, 2c) and (row, 2c + 1) of an
+// [*, N] tensor take the low / high half of
+//     h(row, c) = fin(rowmix(row) ^ colmix(c)),   fin(x) = x * 0x2C1B3C6D, x ^= x >> 15
+// - FACTORISED (round 5): rowmix and colmix are full murmur3 finalisers of (seed, row) resp. (seed, column pair), computed once
+// per row resp. once per lane and tile by the epilogues that walk whole tiles; what is left per element pair is one xor, one
+// multiply and one xor-shift.  (Rounds 1-4: one full finaliser - two multiplies, three xor-shifts - of the linear pair index per
+// element pair: 63 of the 182 VALU instructions of the saved-gradient epilogue's row piece.)  The multiply between the xor of
+// the two halves and the output breaks the xor-linearity h(r1,c1)^h(r1,c2)^h(r2,c1)^h(r2,c2) = 0 of the bare xor;
+// tests/test_moe_kernels_gpu.py checks keep fraction and row / column correlations of the recovered mask.
+__device__ __forceinline__ uint32_t gd_fmix(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t gd_rowmix(uint64_t seed, uint64_t row) {
+  return gd_fmix((uint32_t)row * 0x9E3779B9u + (uint32_t)(row >> 32) * 0x7F4A7C15u + (uint32_t)seed);
+}
+__device__ __forceinline__ uint32_t gd_colmix(uint64_t seed, uint32_t cpair) {
+  return gd_fmix(cpair * 0x85EBCA77u ^ (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ uint32_t gd_pair(uint32_t rowmix, uint32_t colmix) {
+  uint32_t x = rowmix ^ colmix;
+  x *= 0x2C1B3C6Du;
+  x ^= x >> 15;
+  return x;
+}
+__device__ __forceinline__ bool gd_keep(uint64_t seed, int64_t row, int64_t col, uint32_t thresh16) {
+  const uint32_t h = gd_pair(gd_rowmix(seed, (uint64_t)row), gd_colmix(seed, (uint32_t)(col >> 1)));
+  return ((col & 1) ? (h >> 16) : (h & 0xffffu)) >= thresh16;
+}
+// four consecutive elements from a column that is a multiple of 4
+__device__ __forceinline__ void gd_keep4(uint64_t seed, int64_t row, int64_t col0, uint32_t thresh16, bool (&keep)[4]) {
+  const uint32_t rm = gd_rowmix(seed, (uint64_t)row), c = (uint32_t)(col0 >> 1);
+  const uint32_t h0 = gd_pair(rm, gd_colmix(seed, c)), h1 = gd_pair(rm, gd_colmix(seed, c + 1u));
+  keep[0] = (h0 & 0xffffu) >= thresh16; keep[1] = (h0 >> 16) >= thresh16;
+  keep[2] = (h1 & 0xffffu) >= thresh16; keep[3] = (h1 >> 16) >= thresh16;
+}
+
 template <typename T> struct frag_t;
 template <> struct frag_t<bf16_t> { typedef bf16x8 type; };
 template <> struct frag_t<float> { typedef f32x4 type; };
@@ -290,7 +328,7 @@ __device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       bool keep[4] = {true, true, true, true};
-      if (drop_p > 0.f) drop_keep4(seed, (uint64_t)row * (uint64_t)N + (uint64_t)(col0 + 4 * h), thresh16, keep);
+      if (drop_p > 0.f) gd_keep4(seed, row, col0 + 4 * h, thresh16, keep);
 #pragma unroll
       for (int w = 0; w < 2; ++w) {
         const uint32_t aw = a[2 * h + w], bw = b[2 * h + w];
@@ -306,7 +344,7 @@ __device__ __forceinline__ uint4 actbwd_chunk(uint4 dhc, uint4 prec, int64_t row
     union { uint4 u; TO e[NE]; } a, b, o;
     a.u = dhc; b.u = prec;
     bool keep[4] = {true, true, true, true};
-    if (drop_p > 0.f) drop_keep4(seed, (uint64_t)row * (uint64_t)N + (uint64_t)col0, thresh16, keep);
+    if (drop_p > 0.f) gd_keep4(seed, row, col0, thresh16, keep);
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
       const float g = to_f32(a.e[j]) * act_grad<FAST>(to_f32(b.e[j]), act);
@@ -444,7 +482,7 @@ grouped_gemm_nt_k(const T *__restrict__ X, const T *__restrict__ W, const float 
           v = to_f32(from_f32<TO>(v));  // the activation sees the pre-activation as stored (bf16-rounded under bf16)
           v = act_fwd<sizeof(T) == 2>(v, act);
           if (drop_p > 0.f)
-            v = drop_keep(seed, tc.row0 + m, n0 + n + r, N, thresh16) ? v * keep_scale : 0.f;
+            v = gd_keep(seed, tc.row0 + m, n0 + n + r, thresh16) ? v * keep_scale : 0.f;
         }
         p[r] = from_f32<TO>(v);
       }
@@ -564,7 +602,7 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
         uint32_t o[4];
         bool keep[4] = {true, true, true, true};
         if (!raw && (ACT >= 0 ? DROP : (!mul_pre && drop_p > 0.f)))
-          drop_keep4(seed, (uint64_t)(cur.row0 + m) * (uint64_t)N + (uint64_t)(cur.n0 + wn * 64 + i * 16 + fg * 4), thresh16, keep);
+          gd_keep4(seed, cur.row0 + m, cur.n0 + wn * 64 + i * 16 + fg * 4, thresh16, keep);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float a = acc[i][j][q];
@@ -1088,13 +1126,6 @@ __device__ __forceinline__ uint32_t drop_mask2(uint32_t h, uint32_t thresh16) {
       : "=&v"(d) : "s"(t2), "v"(h), "s"(0x00010001u), "s"(0xffffffffu));
   return d;
 }
-// drop_hash_pair for pair indices below 2^32 (the launcher offers the saved-gradient form only then)
-__device__ __forceinline__ uint32_t drop_hash_pair32(uint64_t seed, uint32_t pair) {
-  uint32_t h = pair ^ (uint32_t)seed;
-  h += (uint32_t)(seed >> 32);
-  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-  return h;
-}
 
 // Epilogue of the two-per-CU kernel, STRAIGHT FROM THE ACCUMULATORS (round 4).  In this kernel the ACTIVATION tile feeds the
 // MFMA A operand and the WEIGHT tile the B operand (the reverse of the other kernels here), the four waves split the tile's
@@ -1158,10 +1189,14 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
     fetch(1);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // GELU constants with the dropout's 1 / (1 - p) folded in (gelu_consts), and the lane's first mask-hash pair index: the
-  // row term of a pair index is wave-uniform (N is even), so a row costs one add
+  // GELU constants with the dropout's 1 / (1 - p) folded in (gelu_consts), and the column halves of the lane's four mask
+  // hashes (gd_colmix: once per tile; a row then costs one gd_rowmix and its pairs one xor-multiply-xorshift each)
   [[maybe_unused]] const GeluK gk = gelu_consts(keep_scale);
-  [[maybe_unused]] const uint32_t pair0 = ((uint32_t)(row0 + rl) * (uint32_t)N + (uint32_t)(n0 + frow * 8)) >> 1;
+  [[maybe_unused]] uint32_t cmix[4] = {0u, 0u, 0u, 0u};
+  if constexpr (MODE == EPI_BOTH && DROP) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) cmix[w] = gd_colmix(seed, (uint32_t)((n0 + frow * 8) >> 1) + (uint32_t)w);
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1184,9 +1219,9 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
         uint32_t og[4], dm[4] = {0u, 0u, 0u, 0u};
 #ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
         if (DROP) {
-          const uint32_t pair = pair0 + (uint32_t)((r * N) >> 1);
+          const uint32_t rmix = gd_rowmix(seed, (uint64_t)(row0 + rl + r));
 #pragma unroll
-          for (int w = 0; w < 4; ++w) dm[w] = drop_hash_pair32(seed, pair + (uint32_t)w);
+          for (int w = 0; w < 4; ++w) dm[w] = gd_pair(rmix, cmix[w]);
 #pragma unroll
           for (int w = 0; w < 4; ++w) dm[w] = drop_mask2(dm[w], thresh16);
         }
@@ -1214,12 +1249,11 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
         if constexpr (MODE == EPI_ACT) {
           bool keep[8] = {true, true, true, true, true, true, true, true};
           if (ACT >= 0 ? DROP : drop_p > 0.f) {
-            const uint64_t lin = (uint64_t)(row0 + rl + r) * (uint64_t)N + (uint64_t)(n0 + frow * 8);
             bool k4[4];
-            drop_keep4(seed, lin, thresh16, k4);
+            gd_keep4(seed, row0 + rl + r, n0 + frow * 8, thresh16, k4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) keep[j] = k4[j];
-            drop_keep4(seed, lin + 4, thresh16, k4);
+            gd_keep4(seed, row0 + rl + r, n0 + frow * 8 + 4, thresh16, k4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) keep[4 + j] = k4[j];
           }
@@ -1845,7 +1879,7 @@ __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float g = d[j] * act_grad<sizeof(T) == 2>(p[j], act);
-      if (drop_p > 0.f) g = drop_keep(seed, row, col + j, N, thresh16) ? g * keep_scale : 0.f;
+      if (drop_p > 0.f) g = gd_keep(seed, row, col + j, thresh16) ? g * keep_scale : 0.f;
       o[j] = g;
     }
     if constexpr (sizeof(T) == 4) {

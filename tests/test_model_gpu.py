@@ -625,42 +625,34 @@ def test_train_prep_one_launch_equals_per_call_preparation(dev, experts):
 
 
 def test_train_prep_leaves_shapes_the_mfma_linear_refuses_to_the_per_call_path(dev):
-    """hidden_size % 8 == 4: model._mfma_linear sends the in_proj stack to stock F.linear (K % 8 != 0), which READS its weight -
-    so TrainPrep must not register it (round 4 did: shape[-1] % 4 was its only test, and the step multiplied by the
-    placeholder's uninitialised memory).  Three bf16 steps with and without the one-launch preparation: identical losses."""
-    import apertis_llm_amd as A
+    """ops.TrainPrep registers a stacked / row-mapped weight only when model._mfma_linear will take it to the MFMA tile
+    (K % 8 == 0 and rows % 8 == 0): any other shape goes to stock F.linear, which READS its weight - and a registered weight is
+    a placeholder of uninitialised memory (round 4 registered on shape[-1] % 4 == 0 alone: hidden_size 36, 100, 132 ... would
+    have multiplied by garbage in every SSM block).  And _mfma_linear refuses a placeholder on the stock path outright."""
     from apertis_llm_amd import ops
-    from apertis_llm_amd.training import TrainStep
-    cfg = dict(vocab_size=256, hidden_size=100, num_hidden_layers=2, num_attention_heads=5, intermediate_size=256,
-               attention_type="selective_ssm", use_expert_system=False)
-    torch.manual_seed(3)
-    init = A.ApertisForCausalLM(A.ApertisConfig(**cfg)).state_dict()
-
-    def run(on):
-        ops.TRAIN_PREP = on
-        torch.manual_seed(5)
-        m = A.ApertisForCausalLM(A.ApertisConfig(**cfg))
-        m.load_state_dict(init)
-        m = m.to(dev).train()
-        step = TrainStep(m, lr=1e-3, total_steps=10, bf16=True)
-        g = torch.Generator().manual_seed(11)
-        out = []
-        for _ in range(3):
-            ids = torch.randint(4, 256, (2, 200), generator=g).to(dev)
-            out.append(float(step(input_ids=ids, attention_mask=torch.ones_like(ids), labels=ids)))
-        if on and step.prep is not None:
-            blk = m.model.layers[0].attention.attention_mechanism_impl
-            assert ("in_proj_xz", id(blk)) not in step.prep.by_key      # (K = 100: not the MFMA tile's shape)
-        return out
-    try:
-        l0, l1 = run(False), run(True)
-        assert l0 == l1 and all(x == x for x in l0), (l0, l1)
-    finally:
-        ops.TRAIN_PREP = True
+    from apertis_llm_amd import model as M
+    prep = ops.TrainPrep(dev)
+    wx, wz = (torch.nn.Parameter(torch.randn(80, 100, device=dev)) for _ in range(2))          # K = 100: K % 8 == 4
+    assert not prep.add_stack(("in_proj_xz", 1), (wx, wz))
+    wx8, wz8 = (torch.nn.Parameter(torch.randn(80, 104, device=dev)) for _ in range(2))
+    assert prep.add_stack(("in_proj_xz", 2), (wx8, wz8))
+    wo = torch.nn.Parameter(torch.randn(84, 104, device=dev))                                  # 84 rows: rows % 8 == 4
+    assert not prep.add_stack(("odd_rows", 3), (wo,))
+    wp = torch.nn.Parameter(torch.randn(30, 100, device=dev))
+    idx = torch.arange(30, device=dev)
+    assert not prep.add_rowmap(("x_param_padded", 4), wp, idx, 64)                             # K % 8 == 4
+    wp8 = torch.nn.Parameter(torch.randn(30, 104, device=dev))
+    assert not prep.add_rowmap(("x_param_padded", 5), wp8, idx, 60)                            # rows_out % 8 == 4
+    assert prep.add_rowmap(("x_param_padded", 6), wp8, idx, 64)
+    # a placeholder never reaches F.linear
+    ph = torch.empty(12, 100, device=dev)
+    ph._apertis_prep = object()
+    with pytest.raises(ops.ApertisHipError):
+        M._mfma_linear(torch.randn(4, 100, device=dev), ph)
 
 
-@pytest.mark.parametrize("experts,bf16", [(0, False), (4, True)])
-def test_generate_graph_replay_equals_eager_decoding(dev, monkeypatch, experts, bf16):
+@pytest.mark.parametrize("experts,bf16,layers", [(0, False, 3), (4, True, 3), (0, True, 44)])
+def test_generate_graph_replay_equals_eager_decoding(dev, monkeypatch, experts, bf16, layers):
     """generate(): from 24 remaining greedy tokens on, the single-token steps of an SSM model run as ONE captured HIP graph
     replayed per token (static token / cache / alive buffers, the host looks at the alive flags every 16 steps).  The tokens
     must be the eager loop's: without eos, with an eos that finishes the sequences at different steps (pad after it, the
@@ -669,7 +661,8 @@ def test_generate_graph_replay_equals_eager_decoding(dev, monkeypatch, experts, 
     import apertis_llm_amd as A
     from apertis_llm_amd import model as M
     torch.manual_seed(11)
-    cfg = A.ApertisConfig(vocab_size=97, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+    # (layers = 44: the depth at which round 3's capture faulted - cause never found, did not reproduce in round 4; a tripwire)
+    cfg = A.ApertisConfig(vocab_size=97, hidden_size=128, num_hidden_layers=layers, num_attention_heads=2, intermediate_size=256,
                           attention_type="selective_ssm", use_expert_system=experts > 0, num_experts=experts, experts_per_token=2,
                           pad_token_id=0)
     model = A.ApertisForCausalLM(cfg).to(dev).eval()

@@ -1074,6 +1074,20 @@ def test_expert_mlp_full_size_dropout_mask_recovered(dev, batch):
     kf = keep[: 1 << 15].float() - (1 - p)
     for shifted in (kf[:, 1:] * kf[:, :-1], kf[1:] * kf[:-1], kf[:, 4:] * kf[:, :-4]):   # neighbours in a row, a column, a hash group
         assert abs(float(shifted.mean())) < 6 * p * (1 - p) / shifted.numel() ** 0.5
+    # the mask hash is FACTORISED (round 5: fin(rowmix(row) ^ colmix(column pair)), grouped_gemm.hip gd_pair): rows and columns at the
+    # distances its structure repeats on (a lane's rows are 16 apart, its pieces 8 columns wide, a tile 256 x 128) must be as
+    # uncorrelated as neighbours, and so must the four corners of a rectangle - the bare xor of a row half and a column half
+    # would make h(r1,c1) ^ h(r1,c2) ^ h(r2,c1) ^ h(r2,c2) vanish, the multiply behind it is what has to break that
+    for dr in (16, 64, 256, 1024):
+        sh = kf[dr:] * kf[:-dr]
+        assert abs(float(sh.mean())) < 6 * p * (1 - p) / sh.numel() ** 0.5, ("rows", dr)
+    for dc in (2, 8, 128, 1408):
+        sh = kf[:, dc:] * kf[:, :-dc]
+        assert abs(float(sh.mean())) < 6 * p * (1 - p) / sh.numel() ** 0.5, ("columns", dc)
+    for dr, dc in ((1, 1), (1, 2), (16, 2), (4, 8), (64, 352), (256, 128)):
+        quad = kf[:-dr, :-dc] * kf[:-dr, dc:] * kf[dr:, :-dc] * kf[dr:, dc:]
+        assert abs(float(quad.mean())) < 6 * (p * (1 - p)) ** 2 / quad.numel() ** 0.5, ("rectangle", dr, dc)
+    # (and between the two 16-bit halves of one hash word: elements 2c and 2c + 1 of a row are kf[:, 1:] * kf[:, :-1] above)
     # ---- kept elements = dense math, dropped = exact zeros (sampled rows)
     sample = torch.from_numpy(np.random.default_rng(2).choice(rows, 320, replace=False)).to(dev)
     exp_of = (sample // per).long()

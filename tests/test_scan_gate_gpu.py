@@ -59,11 +59,35 @@ def _oracle(i, use_h0):
     return out.detach(), hl.detach(), {k: v.grad for k, v in leaves.items()}
 
 
-def _fused(dev, i, use_h0, single_pass):
+KINDS = {"staged": (False, False), "lean": (True, False), "lookback": (False, True)}      # (SCAN_LEAN, SCAN_LOOKBACK)
+
+
+class _kind:
+    """`with _kind("staged" | "lean" | "lookback"):` pins which form of the fused scan ops.scan_gate takes where the shape
+    allows it (bf16, N = 16: lean for 128 < Dn <= 256, look-back for Dn <= 256; everything else is staged anyway)."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        from apertis_llm_amd import ops
+        self.old = (ops.SCAN_LEAN, ops.SCAN_LEAN_BWD, ops.SCAN_LOOKBACK)
+        lean, lb = KINDS[self.kind]
+        ops.SCAN_LEAN = ops.SCAN_LEAN_BWD = lean
+        ops.SCAN_LOOKBACK = lb
+
+    def __exit__(self, *a):
+        from apertis_llm_amd import ops
+        ops.SCAN_LEAN, ops.SCAN_LEAN_BWD, ops.SCAN_LOOKBACK = self.old
+
+
+def _fused(dev, i, use_h0, single_pass, kind="staged"):
     from apertis_llm_amd import ops
     Dn, Wb = i["Dn"], i["Wb"]
     old = ops.SCAN_SINGLE_PASS
     ops.SCAN_SINGLE_PASS = single_pass
+    pin = _kind(kind)
+    pin.__enter__()
     try:
         lv = {k: i[k].to(dev).requires_grad_(True) for k in ("p", "xz", "xc", "logits", "A_log", "D")}
         Btp, Cp, _dt = ops.split_cols(lv["p"], (Wb, Wb, lv["p"].shape[-1] - 2 * Wb))
@@ -74,6 +98,7 @@ def _fused(dev, i, use_h0, single_pass):
         assert ops.scan_gate_error() == 0
     finally:
         ops.SCAN_SINGLE_PASS = old
+        pin.__exit__()
     return out.detach(), hl.detach(), {k: v.grad for k, v in lv.items()}
 
 
@@ -143,15 +168,17 @@ def test_scan_gate_equals_scan_then_gate(dev, B, L, h, N):
     _close(fg["xz"], tg["xz"], "dxz (dz)", rtol=1e-5)
 
 
-def test_scan_gate_bf16_config4_shape(dev):
-    """bf16 activations at the bench's per-layer shape (B=4 of the 32, L=4096, 11 heads, Dn=176): against the oracle on
-    the SAME bf16-rounded inputs (fp32 state; only the output rounding to bf16 differs), and one launch == two launches."""
+@pytest.mark.parametrize("kind", ["staged", "lean", "lookback"])
+def test_scan_gate_bf16_config4_shape(dev, kind):
+    """bf16 activations at the bench's per-layer shape (B=4 of the 44, L=4096, 11 heads, Dn=176), every form of the kernel
+    (staged single-pass / its two-launch form, lean three-launch, look-back one-launch): against the oracle on the SAME
+    bf16-rounded inputs (fp32 state; only the output rounding to bf16 differs), and the staged form's one launch == its two."""
     i = _inputs(4, 4096, 11, 16, seed=5, dtype=torch.bfloat16)
     Dn, Wb = i["Dn"], i["Wb"]
     o_out, o_hl, og = _oracle(i, False)
     res = {}
     for sp in (False, True):
-        out, hl, g = _fused(dev, i, False, sp)
+        out, hl, g = _fused(dev, i, False, sp, kind)
         res[sp] = (out, hl, g)
         assert out.dtype == torch.bfloat16 and g["p"].dtype == torch.bfloat16
         _close(out.float(), o_out, "out", rtol=8e-3, atol_scale=1e-3)             # one bf16 rounding: 2^-8 = 3.9e-3
@@ -168,15 +195,22 @@ def test_scan_gate_bf16_config4_shape(dev):
         assert torch.equal(res[False][2][k], res[True][2][k]), k
 
 
-@pytest.mark.parametrize("batch", [32, 44])
-def test_scan_gate_single_pass_stress_full_size(dev, batch):
-    """The single-launch form at the bench's full per-GPU size (B=44 - the batch the bench line is quoted on - and the
-    earlier B=32; L=4096, Dn=176: thousands of forward and backward work items, far more than are resident at once) run
-    back to back on one workspace: the ticket order must keep every wait on an already started work-group (no time-out
-    in the error word), the alternating ticket counters must hand over cleanly from launch to launch, and every
-    repetition must give the same bits."""
+@pytest.mark.parametrize("kind,batch,heads", [("staged", 32, 11), ("staged", 44, 11), ("lean", 44, 11), ("lookback", 44, 11),
+                                              ("lookback", 32, 11), ("staged", 16, 4), ("lookback", 16, 4)])
+def test_scan_gate_single_pass_stress_full_size(dev, kind, batch, heads):
+    """Every form of the fused scan at the bench's full per-GPU sizes - config 4 (B=44, the batch the bench line is quoted
+    on, and the earlier B=32; L=4096, Dn=176) and config 3 (B=16, L=4096, Dn=64: four sequences side by side in a wave of the
+    look-back form) - thousands of forward and backward work items, far more than are resident at once, run back to back on
+    one workspace: the ticket order of the staged and look-back forms must keep every wait on an already started
+    work-group (no time-out in the error word), the alternating ticket counters - which the two forms SHARE - must hand over
+    cleanly from launch to launch, and every repetition must give the same bits."""
     from apertis_llm_amd import ops
-    i = _inputs(batch, 4096, 11, 16, seed=9, dtype=torch.bfloat16)
+    with _kind(kind):
+        _stress(dev, ops, batch, heads)
+
+
+def _stress(dev, ops, batch, heads):
+    i = _inputs(batch, 4096, heads, 16, seed=9, dtype=torch.bfloat16)
     Dn, Wb = i["Dn"], i["Wb"]
     lv = {k: i[k].to(dev).requires_grad_(True) for k in ("p", "xz", "xc", "logits", "A_log", "D")}
     dout = i["dout"].to(dev)
@@ -203,6 +237,51 @@ def test_scan_gate_single_pass_stress_full_size(dev, batch):
                           lv["xc"].detach()[:, :half].contiguous(), lv["xz"].detach()[:, :half, Dn:], lv["D"].detach(),
                           delta_softplus=True)
     assert torch.equal(out_h, first[0][:, :half])
+
+
+@pytest.mark.parametrize("kind", ["lean", "lookback"])
+def test_scan_forms_agree_on_gradients(dev, kind):
+    """The lean (three launches) and look-back (one launch) forms against the staged kernels at (4, 4096, 11, 16) bf16: the
+    same recurrence, different chunk-carry compositions - outputs within one bf16 rounding of each other, every gradient
+    within 4e-3 relative RMS (bf16 outputs) resp. 1e-4 (the fp32 ones), pad columns exactly zero.  (Round 4 checked this with
+    tools/scan_lean_check.py only.)"""
+    i = _inputs(4, 4096, 11, 16, seed=13, dtype=torch.bfloat16)
+    Dn, Wb = i["Dn"], i["Wb"]
+    a_out, a_hl, ag = _fused(dev, i, False, True, "staged")
+    b_out, b_hl, bg = _fused(dev, i, False, True, kind)
+    d = (a_out.float() - b_out.float()).abs()
+    assert float(d.max()) <= 2.0 ** -7 * float(a_out.float().abs().max()), float(d.max())
+    _close(b_hl, a_hl, "h_last", rtol=1e-4)
+    for k in ag:
+        ga, gb = ag[k].float(), bg[k].float()
+        rel = float((ga - gb).pow(2).mean().sqrt() / (ga.pow(2).mean().sqrt() + 1e-30))
+        assert rel < (4e-3 if ag[k].dtype == torch.bfloat16 else 1e-4), (k, rel)
+    assert float(bg["p"][..., Dn:Wb].abs().max()) == 0.0 and float(bg["p"][..., Wb + Dn:2 * Wb].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,L,h", [(3, 257, 11), (5, 100, 4), (1, 64, 16), (7, 1000, 2), (3, 130, 1), (2, 2245, 11), (9, 333, 8), (2, 640, 6)])
+@pytest.mark.parametrize("use_h0", [False, True])
+def test_scan_lookback_bf16_vs_oracle_shapes(dev, B, L, h, use_h0):
+    """The look-back form (apertis_scan_lookback_fwd / _bwd) against the oracle on bf16-rounded inputs over the geometries it
+    takes: ragged last chunks and waves past the end, one to sixteen sequences side by side in a wave (Dn = 16 ... 256), a
+    batch that does not fill the last wave, an initial state and the final state (the prefill-with-cache form), Dn = 16 whose
+    backward declines (pad columns wider than the row's lanes) and falls through to the staged kernels from ckpt16[:, ::4]."""
+    from apertis_llm_amd import ops
+    i = _inputs(B, L, h, 16, seed=17 * L + h, dtype=torch.bfloat16)
+    Dn, Wb = i["Dn"], i["Wb"]
+    o_out, o_hl, og = _oracle(i, use_h0)
+    out, hl, g = _fused(dev, i, use_h0, True, "lookback")
+    _close(out.float(), o_out, "out", rtol=8e-3, atol_scale=1e-3)
+    _close(hl, o_hl, "h_last", rtol=1e-4, atol_scale=1e-5)
+    _close(g["logits"], og["logits"], "d_logits", rtol=2e-3, atol_scale=2e-4)
+    _close(g["A_log"], og["A_log"], "dA_log", rtol=2e-3, atol_scale=2e-4)
+    _close(g["D"], og["D"], "dD", rtol=2e-3, atol_scale=2e-4)
+    _close(g["xc"].float(), og["xc"], "dxc", rtol=8e-3, atol_scale=1e-3)
+    _close(g["p"][..., :Dn].float(), og["p"][..., :Dn], "dBt", rtol=8e-3, atol_scale=1e-3)
+    _close(g["p"][..., Wb:Wb + Dn].float(), og["p"][..., Wb:Wb + Dn], "dC", rtol=8e-3, atol_scale=1e-3)
+    _close(g["xz"][..., Dn:].float(), og["xz"][..., Dn:], "dz", rtol=8e-3, atol_scale=1e-3)
+    assert float(g["p"][..., Dn:Wb].abs().max() if Wb > Dn else 0.0) == 0.0
+    assert float(g["p"][..., Wb + Dn:2 * Wb].abs().max() if Wb > Dn else 0.0) == 0.0
 
 
 def test_ssm_layer_golden_through_fused_path(dev):
@@ -307,6 +386,7 @@ def test_scan_gate_dt_fused_equals_tiny_linear_then_scan_gate(dev, monkeypatch, 
         return real(*a)
 
     monkeypatch.setattr(ops, "SCAN_DT_FUSED", True)      # (off by default: measured slower than the launch it replaces)
+    monkeypatch.setattr(ops, "SCAN_LOOKBACK", False)     # (the fused prologue lives in the lean form's state pass)
     for mode in ("two_op", "fused"):
         p, xz, xc = (t.bfloat16().requires_grad_(True) for t in (p0, xz0, xc0))
         for t in (W, bias, A_log, D):
