@@ -73,7 +73,9 @@ __device__ __forceinline__ lb_i4 lb_desc(const void *p, uint32_t bytes) {
 }
 __device__ __forceinline__ lb_u4 lb_load16(lb_i4 rs, uint32_t off) {
   lb_u4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(v) : "v"(off), "s"(rs) : "memory");   // sc1: past this CU's L1
+  // (s_nop 4: hipcc's hazard recogniser does not look inside inline asm - a descriptor word restored from a spill lane by
+  //  v_readlane right in front of this would be read by the load before it has landed: five wait states, gfx9 VALU-SGPR -> VMEM)
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(v) : "v"(off), "s"(rs) : "memory");   // sc1: past this CU's L1
   return v;
 }
 // LDS-only barrier: the waves' row loads (and output stores) stay in flight across it

@@ -25,6 +25,7 @@ ENTRY = {  # kernel-name fragment -> C-ABI entry point
     "scan_lean_prefix_k<(bool)0>": "apertis_scan_gate_fwd", "scan_lean_fwd_k": "apertis_scan_gate_fwd",
     "scan_lean_bstate_k": "apertis_scan_gate_bwd", "scan_lean_prefix_k<true>": "apertis_scan_gate_bwd",
     "scan_lean_prefix_k<(bool)1>": "apertis_scan_gate_bwd", "scan_lean_bwd_k": "apertis_scan_gate_bwd",
+    "scan_lb_fwd_k": "apertis_scan_gate_fwd", "scan_lb_bwd_k": "apertis_scan_gate_bwd",
     "colsum_kernel": "apertis_scan_gate_bwd",
 }
 CALLS_PER_REP = {"apertis_grouped_gemm_nt": 4, "apertis_grouped_gemm_tn": 1, "apertis_selective_scan_fwd": 1,
@@ -77,7 +78,7 @@ for tag, v in entry.items():
 import hashlib, os, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = {}
-for f in ("grouped_gemm.hip", "scan_gate.hip"):
+for f in ("grouped_gemm.hip", "scan_gate.hip", "scan_lookback.hip", "scan_lean.h"):
     with open(os.path.join(root, "apertis_llm_amd", "csrc", f), "rb") as fh:
         src[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
 res["_source"] = {"kernel_source_sha16": src}
