@@ -124,6 +124,7 @@ SIGNATURES = {
     "apertis_router_bwd_blocks": (_i64, [_i64]),
     "apertis_tiny_linear_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_tiny_linear_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_tiny_linear_bwd_pad": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_tiny_linear_bwd_blocks": (_i64, [_i64]),
     "apertis_cross_entropy_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_cross_entropy_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),

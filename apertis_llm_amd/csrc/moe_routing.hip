@@ -2045,7 +2045,7 @@ tiny_linear_fwd_small_k(const TX *__restrict__ x, int64_t ldx, const float *__re
 template <typename TX, bool VEC>
 __global__ void __launch_bounds__(TL_ROWS)
 tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict__ W, const float *__restrict__ dy,
-                  TX *__restrict__ dx, int64_t lddx, float *__restrict__ part, int64_t T, int K, int N) {
+                  TX *__restrict__ dx, int64_t lddx, float *__restrict__ part, int64_t T, int K, int N, int zero_to) {
   static_assert(TL_ROWS == (TL_MAXN / 2) * (TL_MAXK / 4), "one 2 x 4 block of dW per thread");
   __shared__ __attribute__((aligned(16))) float sW[TL_MAXN * TL_MAXK];
   __shared__ __attribute__((aligned(16))) float sx[TL_ROWS][TL_MAXK + 4];
@@ -2106,6 +2106,17 @@ tiny_linear_bwd_k(const TX *__restrict__ x, int64_t ldx, const float *__restrict
           for (int u = 0; u < EPC; ++u)
             if (r0 + u < K) drow[r0 + u] = from_f32<TX>(a[u]);
         }
+      }
+      // the columns [K, zero_to) behind the row receive zeros: the pad of the projection output's gradient (the caller's
+      // split_cols slot next to the dt columns - one strided torch fill per layer otherwise)
+      if (zero_to > K) {
+        int c = K;
+        if (VEC && (K & 3) == 0)
+          for (; c + 4 <= zero_to; c += 4) {
+            if constexpr (sizeof(TX) == 2) *reinterpret_cast<uint2 *>(drow + c) = make_uint2(0u, 0u);
+            else *reinterpret_cast<float4 *>(drow + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+        for (; c < zero_to; ++c) drow[c] = from_f32<TX>(0.f);
       }
     }
     __syncthreads();
@@ -2444,11 +2455,12 @@ extern "C" int apertis_tiny_linear_fwd(const void *x, int64_t ldx, const float *
   return apertis_check_launch();
 }
 
-extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *W, const float *dy, void *dx, int64_t lddx,
-                                       float *part, float *dW_db, int64_t T, int64_t K, int64_t N, int dtype_x,
-                                       void *stream) {
+extern "C" int apertis_tiny_linear_bwd_pad(const void *x, int64_t ldx, const float *W, const float *dy, void *dx, int64_t lddx,
+                                           float *part, float *dW_db, int64_t T, int64_t K, int64_t N, int64_t zero_to, int dtype_x,
+                                           void *stream) {
   // part: workspace [apertis_tiny_linear_bwd_blocks(T)][N*K + N]; dW_db: out [N*K + N] (dW then db)
-  if (!x || !W || !dy || !dx || !part || !dW_db || T < 0 || ldx < K || lddx < K) return APERTIS_ERR_ARG;
+  if (!x || !W || !dy || !dx || !part || !dW_db || T < 0 || ldx < K || lddx < K || zero_to > lddx) return APERTIS_ERR_ARG;
+  if (zero_to < K) zero_to = K;
   if (K < 1 || K > TL_MAXK || N < 1 || N > TL_MAXN) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nblk = apertis_tiny_linear_bwd_blocks(T);
@@ -2457,13 +2469,18 @@ extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *
   const int64_t esz = dtype_x == APERTIS_BF16 ? 2 : 4, epc = 16 / esz;
   const bool vec = (((uintptr_t)x) & 15) == 0 && (ldx * esz) % 16 == 0 && ceil_div64(K, epc) * epc <= ldx &&
                    (((uintptr_t)dx) & 15) == 0 && (lddx * esz) % 16 == 0;
-#define GO(TX, V) hipLaunchKernelGGL((tiny_linear_bwd_k<TX, V>), grid, block, 0, st, (const TX *)x, ldx, W, dy, (TX *)dx, lddx, part, T, (int)K, (int)N)
+#define GO(TX, V) hipLaunchKernelGGL((tiny_linear_bwd_k<TX, V>), grid, block, 0, st, (const TX *)x, ldx, W, dy, (TX *)dx, lddx, part, T, (int)K, (int)N, (int)zero_to)
   if (dtype_x == APERTIS_BF16) { if (vec) GO(bf16_t, true); else GO(bf16_t, false); }
   else { if (vec) GO(float, true); else GO(float, false); }
 #undef GO
   const int64_t cols = N * K + N;
   hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, dW_db, nblk, cols);
   return apertis_check_launch();
+}
+extern "C" int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *W, const float *dy, void *dx, int64_t lddx,
+                                       float *part, float *dW_db, int64_t T, int64_t K, int64_t N, int dtype_x,
+                                       void *stream) {
+  return apertis_tiny_linear_bwd_pad(x, ldx, W, dy, dx, lddx, part, dW_db, T, K, N, K, dtype_x, stream);
 }
 
 extern "C" int64_t apertis_router_bwd_blocks(int64_t T) { return std::min<int64_t>(ceil_div64(T > 0 ? T : 1, 4), 512); }

@@ -342,6 +342,8 @@ class _ScanGate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused):
+        if dout is None:
+            return (None,) * 10
         return _scan_gate_backward(ctx, dout) + (None, None, None)
 
 
@@ -367,13 +369,18 @@ class _ScanGateDt(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         lib = _lib.load()
+        if dout is None:
+            return (None,) * 12
         d_dlt, dA, dBt, dC, dxc, dz, dD = _scan_gate_backward(ctx, dout)
         xr, w = ctx.dt_saved
         ldx, xshape, wdt, bdt = ctx.dt_cfg
         N, K = w.shape
+        zero_to = K
         if ctx.dt_slot is not None and ctx.dt_slot[0].widths[ctx.dt_slot[1]] == K:
             dx, Kp = ctx.dt_slot[0].out(ctx.dt_slot[1], xshape[:-1], xr.dtype, xr.device)
             dxp = dx
+            if dx.data_ptr() == ctx.dt_slot[0].buf.data_ptr() + ctx.dt_slot[0].offsets[ctx.dt_slot[1]] * dx.element_size():
+                zero_to = K + ctx.dt_slot[0].zero_next(ctx.dt_slot[1])    # the pad columns behind dt: zeroed by this kernel
         else:
             Kp = -(-K // 8) * 8
             dxp = torch.empty(*xshape[:-1], Kp, device=xr.device, dtype=xr.dtype)
@@ -382,8 +389,8 @@ class _ScanGateDt(torch.autograd.Function):
         nblk = lib.apertis_tiny_linear_bwd_blocks(T)
         part = torch.empty(nblk, N * K + N, device=xr.device, dtype=torch.float32)
         out = torch.empty(N * K + N, device=xr.device, dtype=torch.float32)
-        check(lib.apertis_tiny_linear_bwd(ptr(xr), ldx, ptr(w), ptr(d_dlt), ptr(dxp), Kp, ptr(part), ptr(out), T, K, N,
-                                          dtype_code(xr), stream_ptr()), "apertis_tiny_linear_bwd")
+        check(lib.apertis_tiny_linear_bwd_pad(ptr(xr), ldx, ptr(w), ptr(d_dlt), ptr(dxp), Kp, ptr(part), ptr(out), T, K, N, zero_to,
+                                              dtype_code(xr), stream_ptr()), "apertis_tiny_linear_bwd")
         return (dx, out[:N * K].reshape(N, K).to(wdt), (out[N * K:].to(bdt) if bdt is not None else None),
                 dA, dBt, dC, dxc, dz, dD, None, None, None)
 
@@ -475,6 +482,7 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
     ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
     ctx.scan_kind = kind
     ctx.mark_non_differentiable(*([h_last] if return_last else []))
+    ctx.set_materialize_grads(False)          # (autograd otherwise zero-fills a [B, Dn] gradient for h_last: one launch per layer)
     return (out, h_last) if return_last else out
 
 
@@ -797,12 +805,15 @@ class _GateTopKAux(torch.autograd.Function):
         ctx.save_for_backward(gates, idx, lse, stats, wn)
         ctx.cfg = (K, float(lb_coef), float(rz_coef), float(alpha), int(seed), None if w_noise is None else w_noise.dtype)
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)      # (autograd otherwise zero-fills an [S, K] gradient for idx: one launch per layer)
         return idx, w, stats[0], stats[1]
 
     @staticmethod
     def backward(ctx, _didx, dw, dlb, drz):
         lib = _lib.load()
         gates, idx, lse, stats, wn = ctx.saved_tensors
+        if dw is None and dlb is None and drz is None:
+            return None, None, None, None, None, None, None
         K, lb_coef, rz_coef, alpha, seed, wdt = ctx.cfg
         S, E = gates.shape
         dw = None if dw is None else dw.float().contiguous()
@@ -925,7 +936,7 @@ class _ColSlot:
     view (`x._apertis_slot = (slot, i)`) write their input gradient straight into columns [off_i, off_i + w_i)
     of `buf` (their kernels take an output row stride), so split_cols' backward is the buffer itself instead of
     a concatenation."""
-    __slots__ = ("widths", "offsets", "total", "buf", "claimed")
+    __slots__ = ("widths", "offsets", "total", "buf", "claimed", "zeroed")
 
     def __init__(self, widths):
         self.widths = tuple(widths)
@@ -933,6 +944,17 @@ class _ColSlot:
         self.total = sum(widths)
         self.buf = None
         self.claimed = set()
+        self.zeroed = set()
+
+    def zero_next(self, i):
+        """The op that wrote view i offers to zero the view behind it in the same kernel (the pad columns of a padded
+        projection output): returns that view's width when nobody has claimed it - the op's kernel then writes zeros there and
+        _SplitCols.backward skips its fill - else 0."""
+        j = i + 1
+        if self.buf is None or j >= len(self.widths) or j in self.claimed or self.widths[j] == 0:
+            return 0
+        self.zeroed.add(j)
+        return self.widths[j]
 
     def out(self, i, lead_shape, dtype, device):
         """(gradient tensor for view i, its row stride in elements).  A view's columns are handed out once per
@@ -940,6 +962,7 @@ class _ColSlot:
         if self.buf is None:
             self.buf = torch.empty(*lead_shape, self.total, device=device, dtype=dtype)
             self.claimed = set()
+            self.zeroed = set()
         if i in self.claimed or self.buf.dtype != dtype or tuple(self.buf.shape[:-1]) != tuple(lead_shape):
             return torch.empty(*lead_shape, self.widths[i], device=device, dtype=dtype), self.widths[i]
         self.claimed.add(i)
@@ -968,6 +991,7 @@ class _SplitCols(torch.autograd.Function):
     def backward(ctx, *grads):
         slot = ctx.slot
         buf, slot.buf = slot.buf, None
+        zeroed, slot.zeroed = slot.zeroed, set()
         if buf is None:
             ref = next((g for g in grads if g is not None), None)
             if ref is None:
@@ -975,12 +999,13 @@ class _SplitCols(torch.autograd.Function):
             parts = [g if g is not None else ref.new_zeros(*ref.shape[:-1], n) for g, n in zip(grads, slot.widths)]
             return torch.cat(parts, dim=-1), None
         es = buf.element_size()
-        for g, off, n in zip(grads, slot.offsets, slot.widths):
+        for j, (g, off, n) in enumerate(zip(grads, slot.offsets, slot.widths)):
             if n == 0:
                 continue
             dst = buf[..., off:off + n]
             if g is None:
-                dst.zero_()
+                if j not in zeroed:          # (else: the neighbouring view's kernel has written the zeros - _ColSlot.zero_next)
+                    dst.zero_()
             elif not (g.data_ptr() == buf.data_ptr() + off * es and g.stride() == dst.stride()):
                 dst.copy_(g)      # produced by an op that does not know the protocol
         return buf, None

@@ -45,7 +45,7 @@ extern "C" {
 #define APERTIS_ACT_SAVE_GRAD 0x100
 #define APERTIS_ACT_MUL_SAVED 0x200
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*; round 4: 4.4 - lean scan
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
 #define APERTIS_ABI_VERSION ((4 << 16) | 5)
@@ -346,6 +346,11 @@ int apertis_tiny_linear_fwd(const void *x, int64_t ldx, const float *W, const fl
 int apertis_tiny_linear_bwd(const void *x, int64_t ldx, const float *W, const float *dy, void *dx,
                             int64_t lddx, float *part, float *dW_db, int64_t T, int64_t K,
                             int64_t N, int dtype_x, void *stream);
+/* ... and with the columns [K, zero_to) of every dx row set to zero (zero_to <= lddx): the pad behind the dt columns in the
+ * padded projection output's gradient, which otherwise costs a strided fill of its own. */
+int apertis_tiny_linear_bwd_pad(const void *x, int64_t ldx, const float *W, const float *dy, void *dx,
+                                int64_t lddx, float *part, float *dW_db, int64_t T, int64_t K,
+                                int64_t N, int64_t zero_to, int dtype_x, void *stream);
 int64_t apertis_tiny_linear_bwd_blocks(int64_t T);
 
 /* ------------------------------------------------------------------------------------------

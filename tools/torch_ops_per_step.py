@@ -29,7 +29,12 @@ for ev in prof.events():
     if not ev.kernels or kids and any(k.kernels for k in kids):
         continue          # count the innermost aten op that launches
     st = [s for s in (ev.stack or []) if "torch/" not in s and "<built-in" not in s and "runpy" not in s]
-    src = " < ".join(x.split("/")[-1][:44] for x in st[:3]) if st else "?"
+    src = " < ".join(x.split("/")[-1][:44] for x in st[:3]) if st else ""
+    if not src:          # backward: no Python stack - name the autograd node the op runs under
+        par = ev.cpu_parent
+        while par is not None and "evaluate_function" not in par.name and "Backward" not in par.name:
+            par = par.cpu_parent
+        src = par.name.replace("autograd::engine::evaluate_function: ", "bwd of ") if par is not None else "?"
 
     ops[ev.name] += len(ev.kernels)
     where[ev.name][(src, str(ev.input_shapes)[:60])] += len(ev.kernels)
