@@ -43,6 +43,9 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_BWD_LAUNDER_DECAY
 #define LB_BWD_LAUNDER_DECAY 1
 #endif
+#ifndef LB_CXZ_AFTER_AGG
+#define LB_CXZ_AFTER_AGG 0
+#endif
 #ifndef LB_SCHED_TOKEN
 #define LB_SCHED_TOKEN 1
 #endif
@@ -209,8 +212,10 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   };
   // (the last LB_LATE tokens' C, xc, z follow group by group inside the replay, into the registers it frees: everything at once
   //  is 173 VGPRs against the 168 of three waves per SIMD)
+#if !LB_CXZ_AFTER_AGG
 #pragma unroll
   for (int u = 0; u < LB_TW - LB_LATE; ++u) ld_late(u);
+#endif
   LB_STAMP(2);
   // ---- aggregate of the 16 tokens: (sum of delta, state from zero) ----
   float sp[4], S[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
@@ -230,6 +235,10 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       for (int k = 0; k < 4; ++k) S[k] = fmaf(__builtin_amdgcn_exp2f(dlv * A2[k]), S[k], bv[k]);
     }
   }
+#if LB_CXZ_AFTER_AGG   // (the aggregate's rows - delta, Bt - first on every wave of the CU; C, xc, z ride under the poll)
+#pragma unroll
+  for (int u = 0; u < LB_TW - LB_LATE; ++u) ld_late(u);
+#endif
   sS[0][wv][ln] = make_float4(S[0], S[1], S[2], S[3]);
   sD[0][wv][ln] = sumdl;
   LB_STAMP(3);
@@ -331,7 +340,7 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
         o[k] = val * silu_g(zv[k]);
       }
       const lean_u2 ov = {lean_pack2(o[0], o[1]), lean_pack2(o[2], o[3])};
-      __builtin_amdgcn_raw_buffer_store_b64(ov, ro, (int)(u < rows ? oo : bad), (int)((uint32_t)u * to.rs * 2u), 2);
+      if (u < rows) __builtin_amdgcn_raw_buffer_store_b64(ov, ro, (int)oo, (int)((uint32_t)u * to.rs * 2u), 2);   // (wave-uniform branch)
 #if LB_SCHED_TOKEN
       __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -351,8 +360,9 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
 // backward: chunks right to left (position k = nchunks - 1 - chunk), waves right to left inside a chunk (rank wr = 3 - wave).
 //   aggregate of 16 tokens: (sum of delta, M) with M = mu at the first token from zero entering at the right end,
 //       mu_t = a_t lambda_t,  lambda_t = dv_t C_t + mu_{t+1},  dv = dout silu(z)
-//   replay: the 16 states are rebuilt from the state entering the wave's first token (the forward's ckpt16), eight at a time
-//   (the right half first: one more pass over the left half's Bt instead of 32 more registers), then the adjoint walk emits
+//   replay: the states are rebuilt from the state entering the wave's first token (the forward's ckpt16) - one pass over Bt for
+//   the entry states of the four blocks of four tokens, then each block's four states right before its adjoint walk (a second
+//   pass over Bt instead of 48 more registers) -, and the adjoint walk emits
 //   dBt = lambda, dC = dv s, dxc = dv D, dz = dout silu'(z) (C s + D xc), d delta = sum over the head of lambda s_{t-1} a A (through
 //   the softplus), and the chunk's partial sums of dA_log and dD (folded by colsum_kernel in a fixed order).
 // ---------------------------------------------------------------------------------------------------------------
@@ -375,11 +385,14 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   const bool ragged = rows < LB_TW;
   const int tlast = max(rows - 1, 0);
   const uint32_t bad = 0xfffffff0u;
-  float A2[4] = {0.f, 0.f, 0.f, 0.f}, Ac[4] = {0.f, 0.f, 0.f, 0.f}, Dk[4] = {0.f, 0.f, 0.f, 0.f};
+  // (A2 = A log2(e) serves the decay exp2(delta A2) AND, with a factor ln 2 applied once per sum, the A of da_t a_t A: no second
+  //  copy of A in registers)
+  float A2[4] = {0.f, 0.f, 0.f, 0.f}, Dk[4] = {0.f, 0.f, 0.f, 0.f};
   if (L.ok) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { Ac[k] = -expf(A_log[L.c0 + k]); A2[k] = Ac[k] * LOG2E_F; Dk[k] = Dv[L.c0 + k]; }
+    for (int k = 0; k < 4; ++k) { A2[k] = -expf(A_log[L.c0 + k]) * LOG2E_F; Dk[k] = Dv[L.c0 + k]; }
   }
+  constexpr float LN2_F = 0.6931471805599453f;
   const __amdgpu_buffer_rsrc_t rb = lean_rsrc(tb_.p, tb_.bytes), rc = lean_rsrc(tc.p, tc.bytes), rx = lean_rsrc(tx.p, tx.bytes),
                                rz = lean_rsrc(tz.p, tz.bytes), rg = lean_rsrc(tg.p, tg.bytes), rd = lean_rsrc(dl.p, dl.bytes),
                                rw = lean_rsrc(head, G.wsbytes);
@@ -389,7 +402,10 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   const uint32_t tok0 = (uint32_t)((int64_t)L.b * d.L + t0), c2 = (uint32_t)L.c0 * 2u;
   const uint32_t fb = L.ok ? tok0 * tb_.rs * 2u + c2 : bad, fc = L.ok ? tok0 * tc.rs * 2u + c2 : bad, fx = L.ok ? tok0 * tx.rs * 2u + c2 : bad,
                  fz = L.ok ? tok0 * tz.rs * 2u + c2 : bad, fg = L.ok ? tok0 * tg.rs * 2u + c2 : bad;
-  const uint32_t sb = tok0 * ob_.rs * 2u + c2, sc = tok0 * oc_.rs * 2u + c2, sx = tok0 * ox_.rs * 2u + c2, sz = tok0 * oz_.rs * 2u + c2;
+  // (store offsets with the lane mask folded in once; a token past the sequence's end skips its stores by a wave-uniform branch -
+  //  a select per token and tensor was hoisted by hipcc into 96 live registers)
+  const uint32_t sb = L.ok ? tok0 * ob_.rs * 2u + c2 : bad, sc = L.ok ? tok0 * oc_.rs * 2u + c2 : bad,
+                 sx = L.ok ? tok0 * ox_.rs * 2u + c2 : bad, sz = L.ok ? tok0 * oz_.rs * 2u + c2 : bad;
   // ---- the rows of this wave's 16 tokens (delta, C, dout, z first: the aggregate needs only them).  A token past the
   // sequence's end re-reads the last row, gets delta = 0 (a = 1) and its dout registers are zeroed where the aggregate pass first
   // meets them: the adjoint passes through it and nothing else in the token loops needs a mask (its stores are dropped) ----
@@ -409,11 +425,12 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   if (L.ok && rows > 0) vk = *reinterpret_cast<const float4 *>(ckpt + ((int64_t)L.b * G.nck16 + (t0 >> 4)) * d.Dn + L.c0);
 #pragma unroll
   for (int u = 0; u < LB_TW; ++u) vb[u] = lean_ld8(rb, fb, (uint32_t)min(u, tlast) * tb_.rs * 2u);
-  // (xc is only met in the adjoint walk: its right half is issued behind the aggregate pass, its left half behind the right
-  //  half's walk - with all 80 rows in flight at once the kernel does not fit 256 VGPRs)
-  auto ld_xc = [&](int half) {
+  // (xc is only met in the adjoint walk, block of four tokens by block: the rightmost block's rows are issued behind the aggregate
+  //  pass, every other block's under the walk of the block to its right - with all 80 rows in flight at once the kernel does not
+  //  fit 256 VGPRs)
+  auto ld_xc = [&](int blk) {
 #pragma unroll
-    for (int u = 8 * half; u < 8 * half + 8; ++u) vx[u] = lean_ld8(rx, fx, (uint32_t)min(u, tlast) * tx.rs * 2u);
+    for (int u = 4 * blk; u < 4 * blk + 4; ++u) vx[u] = lean_ld8(rx, fx, (uint32_t)min(u, tlast) * tx.rs * 2u);
   };
   // ---- reverse aggregate of the 16 tokens ----
   float sp[4], M[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
@@ -441,7 +458,7 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       __builtin_amdgcn_sched_barrier(0);   // (a token at a time: hipcc otherwise gates many tokens ahead of the chain: +75 VGPRs)
     }
   }
-  ld_xc(1);
+  ld_xc(3);
   sS[0][wr][ln] = make_float4(M[0], M[1], M[2], M[3]);
   sD[0][wr][ln] = sumdl;
   lb_barrier();
@@ -503,7 +520,7 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
 #pragma unroll
       for (int k = 0; k < 4; ++k) mu[k] = fmaf(__builtin_amdgcn_exp2f(sw * A2[k]), mu[k], sv[k]);
     }
-  // ---- replay: states eight at a time (right half first), adjoint right to left ----
+  // ---- replay: block of four tokens by block, right to left: the block's four states rebuilt from its entry state, then the adjoint ----
   // (the register copy is laundered through an empty asm between the passes: hipcc otherwise keeps the aggregate pass's unpacked
   //  rows, gates and decay factors alive as common subexpressions and spills)
 #pragma unroll
@@ -515,35 +532,42 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   // first (store_w - Dn) / 4 lanes of the row write them
   const int npad = (store_w - (int)d.Dn) >> 2;
   const uint32_t pz = (uint32_t)(d.Dn + 4 * L.q) * 2u;
+  const bool pad_lane = L.ok && L.q < npad;
+  const uint32_t spb = tok0 * ob_.rs * 2u + pz, spc = tok0 * oc_.rs * 2u + pz;
   float *ddp = d_dlt + ((int64_t)tok0 + qi) * d.h + L.hh;
   const float hin[4] = {vk.x, vk.y, vk.z, vk.w};
-  float h8[4], dA[4] = {0.f, 0.f, 0.f, 0.f}, dD[4] = {0.f, 0.f, 0.f, 0.f};
+  float dA[4] = {0.f, 0.f, 0.f, 0.f}, dD[4] = {0.f, 0.f, 0.f, 0.f};
+  // entry states of the four blocks of four tokens: one pass over the Bt of tokens 0 .. 11
+  float hb[4][4];
   {
     float hc[4] = {hin[0], hin[1], hin[2], hin[3]};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int k = 0; k < 4; ++k) hb[0][k] = hin[k];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
       const float dlv = quad_bc(sp[u >> 2], u & 3);
       float bv[4];
       unpack4(vb[u], bv);
 #pragma unroll
       for (int k = 0; k < 4; ++k) hc[k] = fmaf(__builtin_amdgcn_exp2f(dlv * A2[k]), hc[k], bv[k]);
-    }
+      if ((u & 3) == 3) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) h8[k] = hc[k];
+        for (int k = 0; k < 4; ++k) hb[(u >> 2) + 1][k] = hc[k];
+      }
+    }
   }
 #pragma unroll
-  for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(vb[u].x), "+v"(vb[u].y));
+  for (int u = 0; u < 12; ++u) asm volatile("" : "+v"(vb[u].x), "+v"(vb[u].y));
 #pragma unroll
-  for (int half = 1; half >= 0; --half) {
-    float hs[8][4];
+  for (int j = 3; j >= 0; --j) {          // tokens 4j .. 4j+3, right to left
+    if (j > 0) ld_xc(j - 1);              // (the next block's xc under this block's walk)
+    float hs[4][4];
     {
-      float hc[4];
+      float hc[4] = {hb[j][0], hb[j][1], hb[j][2], hb[j][3]};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) hc[k] = half ? h8[k] : hin[k];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int u = 8 * half + e;
-        const float dlv = quad_bc(sp[u >> 2], u & 3);
+      for (int e = 0; e < 4; ++e) {
+        const int u = 4 * j + e;
+        const float dlv = quad_bc(sp[j], e);
         float bv[4];
         unpack4(vb[u], bv);
 #pragma unroll
@@ -551,67 +575,62 @@ scan_lb_bwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       }
     }
 #if LB_BWD_LAUNDER_DECAY
-#pragma unroll
-    for (int j = 2 * half; j < 2 * half + 2; ++j) asm volatile("" : "+v"(sp[j]));   // (the adjoint recomputes its decay factors)
+    asm volatile("" : "+v"(sp[j]));   // (the adjoint recomputes its decay factors)
 #endif
+    float ddl_keep = 0.f;
 #pragma unroll
-    for (int jj = 1; jj >= 0; --jj) {
-      const int j = 2 * half + jj;          // tokens 4j .. 4j+3
-      float ddl_keep = 0.f;
+    for (int i = 3; i >= 0; --i) {
+      const int u = 4 * j + i;
+      const float dlv = quad_bc(sp[j], i);
+      float cv[4], xv[4], zv[4], gv[4], oB[4], oC[4], oX[4], oZ[4];
+      unpack4(vc[u], cv); unpack4(vx[u], xv); unpack4(vz[u], zv); unpack4(vg[u], gv);
+      float qs = 0.f;
 #pragma unroll
-      for (int i = 3; i >= 0; --i) {
-        const int u = 4 * j + i, e = u - 8 * half;
-        const float dlv = quad_bc(sp[j], i);
-        float cv[4], xv[4], zv[4], gv[4], oB[4], oC[4], oX[4], oZ[4];
-        unpack4(vc[u], cv); unpack4(vx[u], xv); unpack4(vz[u], zv); unpack4(vg[u], gv);
-        float qs = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float av = __builtin_amdgcn_exp2f(dlv * A2[k]);
-          float f, df;
-          silu_both(zv[k], f, df);
-          const float dv = gv[k] * f;
-          const float lam = fmaf(dv, cv[k], mu[k]);
-          const float hprev = e > 0 ? hs[e - 1][k] : (half ? h8[k] : hin[k]);
-          const float qq = lam * hprev * av * Ac[k];                 // da_t * a_t * A
-          const float y = cv[k] * hs[e][k];
-          const float dx = Dk[k] * xv[k];
-          const float val = y + dx;
-          oB[k] = lam;
-          oC[k] = dv * hs[e][k];
-          oX[k] = dv * Dk[k];
-          oZ[k] = gv[k] * df * val;
-          dA[k] = fmaf(qq, dlv, dA[k]);
-          dD[k] = fmaf(dv, xv[k], dD[k]);
-          qs += qq;
-          mu[k] = av * lam;
-        }
-        const uint32_t ts = (uint32_t)u;
-        const bool st = u < rows && L.ok;
-        const lean_u2 wB = {lean_pack2(oB[0], oB[1]), lean_pack2(oB[2], oB[3])}, wC = {lean_pack2(oC[0], oC[1]), lean_pack2(oC[2], oC[3])},
-                      wX = {lean_pack2(oX[0], oX[1]), lean_pack2(oX[2], oX[3])}, wZ = {lean_pack2(oZ[0], oZ[1]), lean_pack2(oZ[2], oZ[3])};
-        __builtin_amdgcn_raw_buffer_store_b64(wB, wb, (int)(st ? sb : bad), (int)(ts * ob_.rs * 2u), 2);
-        __builtin_amdgcn_raw_buffer_store_b64(wC, wc, (int)(st ? sc : bad), (int)(ts * oc_.rs * 2u), 2);
-        __builtin_amdgcn_raw_buffer_store_b64(wX, wx, (int)(st ? sx : bad), (int)(ts * ox_.rs * 2u), 2);
-        __builtin_amdgcn_raw_buffer_store_b64(wZ, wz, (int)(st ? sz : bad), (int)(ts * oz_.rs * 2u), 2);
-        if (L.q < npad) {
-          const lean_u2 zz = {0u, 0u};
-          __builtin_amdgcn_raw_buffer_store_b64(zz, wb, (int)(st ? tok0 * ob_.rs * 2u + pz : bad), (int)(ts * ob_.rs * 2u), 2);
-          __builtin_amdgcn_raw_buffer_store_b64(zz, wc, (int)(st ? tok0 * oc_.rs * 2u + pz : bad), (int)(ts * oc_.rs * 2u), 2);
-        }
-        // d delta of the head: the quad's 16 channels; token 4j+i's value parks in lane i of the quad, one store per four tokens
-        float dq = quad_sum(qs);
-        if (d.softplus) dq *= 1.f - __builtin_amdgcn_exp2f(-dlv * LOG2E_F);      // sigmoid(x) = 1 - exp(-softplus(x))
-        if (qi == i) ddl_keep = dq;
-        __builtin_amdgcn_sched_barrier(0);   // (a token at a time, in this order: the whole walk is one basic block, and hipcc otherwise
-                                             //  starts the gate arithmetic of later tokens early and holds its results: spills)
+      for (int k = 0; k < 4; ++k) {
+        const float av = __builtin_amdgcn_exp2f(dlv * A2[k]);
+        float f, df;
+        silu_both(zv[k], f, df);
+        const float dv = gv[k] * f;
+        const float lam = fmaf(dv, cv[k], mu[k]);
+        const float hprev = i > 0 ? hs[i - 1][k] : hb[j][k];
+        const float qq = lam * hprev * av * A2[k];                 // da_t * a_t * A (x log2 e: taken out below)
+        const float y = cv[k] * hs[i][k];
+        const float dx = Dk[k] * xv[k];
+        const float val = y + dx;
+        oB[k] = lam;
+        oC[k] = dv * hs[i][k];
+        oX[k] = dv * Dk[k];
+        oZ[k] = gv[k] * df * val;
+        dA[k] = fmaf(qq, dlv, dA[k]);
+        dD[k] = fmaf(dv, xv[k], dD[k]);
+        qs += qq;
+        mu[k] = av * lam;
       }
-      if (L.ok && 4 * j + qi < rows) ddp[(int64_t)(4 * j) * d.h] = ddl_keep;
+      const uint32_t ts = (uint32_t)u;
+      const lean_u2 wB = {lean_pack2(oB[0], oB[1]), lean_pack2(oB[2], oB[3])}, wC = {lean_pack2(oC[0], oC[1]), lean_pack2(oC[2], oC[3])},
+                    wX = {lean_pack2(oX[0], oX[1]), lean_pack2(oX[2], oX[3])}, wZ = {lean_pack2(oZ[0], oZ[1]), lean_pack2(oZ[2], oZ[3])};
+      if (u < rows) {
+        __builtin_amdgcn_raw_buffer_store_b64(wB, wb, (int)sb, (int)(ts * ob_.rs * 2u), 2);
+        __builtin_amdgcn_raw_buffer_store_b64(wC, wc, (int)sc, (int)(ts * oc_.rs * 2u), 2);
+        __builtin_amdgcn_raw_buffer_store_b64(wX, wx, (int)sx, (int)(ts * ox_.rs * 2u), 2);
+        __builtin_amdgcn_raw_buffer_store_b64(wZ, wz, (int)sz, (int)(ts * oz_.rs * 2u), 2);
+        if (pad_lane) {
+          const lean_u2 zz = {0u, 0u};
+          __builtin_amdgcn_raw_buffer_store_b64(zz, wb, (int)spb, (int)(ts * ob_.rs * 2u), 2);
+          __builtin_amdgcn_raw_buffer_store_b64(zz, wc, (int)spc, (int)(ts * oc_.rs * 2u), 2);
+        }
+      }
+      // d delta of the head: the quad's 16 channels; token 4j+i's value parks in lane i of the quad, one store per four tokens
+      float dq = quad_sum(qs) * LN2_F;
+      if (d.softplus) dq *= 1.f - __builtin_amdgcn_exp2f(-dlv * LOG2E_F);      // sigmoid(x) = 1 - exp(-softplus(x))
+      if (qi == i) ddl_keep = dq;
+      __builtin_amdgcn_sched_barrier(0);   // (a token at a time, in this order: the whole walk is one basic block, and hipcc otherwise
+                                           //  starts the gate arithmetic of later tokens early and holds its results: spills)
     }
-    if (half) ld_xc(0);
+    if (L.ok && 4 * j + qi < rows) ddp[(int64_t)(4 * j) * d.h] = ddl_keep;
   }
   // ---- the chunk's partial sums of dA_log and dD: the waves' in a fixed order ----
-  sP[0][wv][ln] = make_float4(dA[0], dA[1], dA[2], dA[3]);
+  sP[0][wv][ln] = make_float4(dA[0] * LN2_F, dA[1] * LN2_F, dA[2] * LN2_F, dA[3] * LN2_F);
   sP[1][wv][ln] = make_float4(dD[0], dD[1], dD[2], dD[3]);
   lb_barrier();
   if (wv == 0 && L.ok) {
