@@ -43,6 +43,9 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_BWD_LAUNDER_DECAY
 #define LB_BWD_LAUNDER_DECAY 1
 #endif
+#ifndef LB_BATCH_MAJOR
+#define LB_BATCH_MAJOR 0
+#endif
 #ifndef LB_CXZ_AFTER_AGG
 #define LB_CXZ_AFTER_AGG 0
 #endif
@@ -102,8 +105,13 @@ __device__ __forceinline__ bool lb_take(GateWsHead *head, uint32_t epoch, int *s
   __syncthreads();
   const int item = __builtin_amdgcn_readfirstlane(*s_item);     // (wave-uniform: the rows' token terms ride in scalar offsets)
   if (item >= d.nchunks * G.nbw) return false;
+#if LB_BATCH_MAJOR   // (probe: tickets walk a sequence's chunks before the next sequence's - contiguous memory, a deeper look-back)
+  const int bw = item / d.nchunks, ln = (int)threadIdx.x & 63;
+  k = item - bw * d.nchunks;
+#else
   k = item / G.nbw;
   const int bw = item - k * G.nbw, ln = (int)threadIdx.x & 63;
+#endif
   const int r = ln / G.g;
   ln_.q = ln - r * G.g;
   ln_.b = bw * G.R + r;
@@ -120,6 +128,10 @@ __device__ __forceinline__ void lb_poll(lb_i4 rw, uint32_t off, uint32_t pstep, 
   static_assert(NP == 2 || NP == 3, "an inclusive record or an aggregate");
   lb_u4 p[NP];
   unsigned spins = 0;
+#ifdef LB_PROBE_NOPOLL   // (tools/ probe builds only: what the waits cost - one look, never a second; the results are wrong)
+  spins = LB_SPIN_MAX + 1;
+  (void)err;
+#endif
   while (true) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) p[i] = lb_load16(rw, lane_ok ? off + (uint32_t)i * pstep : 0xfffffff0u);   // (select LAST: bad + step wraps)
@@ -129,6 +141,9 @@ __device__ __forceinline__ void lb_poll(lb_i4 rw, uint32_t off, uint32_t pstep, 
 #pragma unroll
     for (int i = 0; i < NP; ++i) okk = okk && p[i][0] == epoch && p[i][2] == epoch;
     if (__all(okk || !lane_ok)) break;
+#ifdef LB_PROBE_NOPOLL
+    break;
+#endif
     if (++spins > LB_SPIN_MAX) { if ((threadIdx.x & 63) == 0) atomicOr(err, 2); break; }
     __builtin_amdgcn_s_sleep(2);
   }
