@@ -43,8 +43,8 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_BWD_LAUNDER_DECAY
 #define LB_BWD_LAUNDER_DECAY 1
 #endif
-#ifndef LB_BATCH_MAJOR
-#define LB_BATCH_MAJOR 0
+#ifndef LB_ORDER
+#define LB_ORDER 0
 #endif
 #ifndef LB_CXZ_AFTER_AGG
 #define LB_CXZ_AFTER_AGG 0
@@ -104,13 +104,20 @@ __device__ __forceinline__ bool lb_take(GateWsHead *head, uint32_t epoch, int *s
 #endif
   __syncthreads();
   const int item = __builtin_amdgcn_readfirstlane(*s_item);     // (wave-uniform: the rows' token terms ride in scalar offsets)
+  const int ln = (int)threadIdx.x & 63;
+#if LB_ORDER == 1     // (probe: tickets walk a sequence's chunks before the next sequence's - contiguous memory, a deeper look-back)
   if (item >= d.nchunks * G.nbw) return false;
-#if LB_BATCH_MAJOR   // (probe: tickets walk a sequence's chunks before the next sequence's - contiguous memory, a deeper look-back)
-  const int bw = item / d.nchunks, ln = (int)threadIdx.x & 63;
+  const int bw = item / d.nchunks;
   k = item - bw * d.nchunks;
-#else
+#elif LB_ORDER == 2   // super-chunk-major: the four chunks of a super-chunk of one (wave of) sequence(s) hold consecutive tickets
+  if (item >= G.nsup * G.nbw * LB_SUP) return false;
+  const int kg = item / (G.nbw * LB_SUP), rem = item - kg * (G.nbw * LB_SUP), bw = rem / LB_SUP;
+  k = kg * LB_SUP + (rem - bw * LB_SUP);
+  if (k >= d.nchunks) return false;                            // (the last super-chunk may be short; nobody waits for such an item)
+#else                 // chunk-major
+  if (item >= d.nchunks * G.nbw) return false;
   k = item / G.nbw;
-  const int bw = item - k * G.nbw, ln = (int)threadIdx.x & 63;
+  const int bw = item - k * G.nbw;
 #endif
   const int r = ln / G.g;
   ln_.q = ln - r * G.g;
@@ -694,6 +701,11 @@ int lb_shape(LbShape &s, int64_t B, int64_t L, int64_t h, int64_t N, int softplu
   return APERTIS_OK;
 }
 
+// one work-group per ticket (lb_take's orders; LB_ORDER 2 rounds the chunk count up to whole super-chunks)
+int64_t lb_grid(const LbShape &s) {
+  return LB_ORDER == 2 ? (int64_t)s.G.nsup * s.G.nbw * LB_SUP : (int64_t)s.d.nchunks * s.G.nbw;
+}
+
 }  // namespace
 
 #ifdef LB_PROBE
@@ -719,7 +731,7 @@ extern "C" int apertis_scan_lookback_fwd(const float *dlt, const float *A_log, c
   const int64_t Dn = s.d.Dn, T = s.T;
   auto lt = [&](const void *p, int64_t rs) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + Dn) * 2)}; };
   const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
-  const unsigned grid = (unsigned)((int64_t)s.d.nchunks * s.G.nbw);
+  const unsigned grid = (unsigned)lb_grid(s);
   hipLaunchKernelGGL(scan_lb_fwd_k, dim3(grid), dim3(64 * LB_NW), 0, (hipStream_t)stream, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs),
                      lt(xc, xc_rs), lt(z, z_rs), D, h0, h_in, h_last, ckpt16, lt(out, out_rs), (GateWsHead *)ws, epoch, s.d, s.G LB_PROBE_ARG);
   return apertis_check_launch();
@@ -746,7 +758,7 @@ extern "C" int apertis_scan_lookback_bwd(const float *dlt, const float *A_log, c
   hipStream_t st = (hipStream_t)stream;
   auto lt = [&](const void *p, int64_t rs, int64_t w) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + w) * 2)}; };
   const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
-  const unsigned grid = (unsigned)((int64_t)s.d.nchunks * s.G.nbw);
+  const unsigned grid = (unsigned)lb_grid(s);
   hipLaunchKernelGGL(scan_lb_bwd_k, dim3(grid), dim3(64 * LB_NW), 0, st, tdl, A_log, lt(Bt, bt_rs, Dn), lt(C, c_rs, Dn), lt(xc, xc_rs, Dn),
                      lt(z, z_rs, Dn), lt(dout, dout_rs, Dn), D, ckpt16, lt(dBt, dbt_rs, store_w), lt(dC, dc_rs, store_w), (int)store_w,
                      lt(dxc, dxc_rs, Dn), lt(dz, dz_rs, Dn), d_dlt, part, (GateWsHead *)ws, epoch, s.d, s.G);
