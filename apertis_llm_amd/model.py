@@ -1244,7 +1244,7 @@ class ApertisForCausalLM(nn.Module):
 
         restore()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):    # (another thread's GPU work - a trainer thread beside chat - must not fail on this capture)
             body()
         restore()
         done = left

@@ -363,8 +363,8 @@ class _ScanGateDt(torch.autograd.Function):
         dlt = torch.empty(*dt_in.shape[:-1], h, device=dt_in.device, dtype=torch.float32)
         res = _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, return_last,
                                  _grad_wanted(ctx, 9), (xr, ldx, w, b, R))
-        ctx.dt_saved = (xr, w)
-        return res
+        ctx.dt_saved = (xr, w)     # (kept on ctx beside the tensors _scan_gate_forward saved: xr is a view of the projection output that the
+        return res                 #  scan's own saved Bt / C slices keep alive and version-checked; w is an fp32 copy or the parameter itself)
 
     @staticmethod
     def backward(ctx, dout, *_unused):

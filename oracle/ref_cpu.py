@@ -6,7 +6,7 @@ bench.py's cpu_baseline leg may import it.  The product package (apertis_llm_amd
 
 Pinned against the reference itself: tools/gen_golden.py imports /root/reference, runs the
 reference modules on seeded inputs and commits the input/output vectors under tests/golden/;
-tests/test_oracle_golden.py replays them through this file (the reference's own tests hold no
+tests/test_host_cpu.py (test_oracle_* at its top) replays them through this file (the reference's own tests hold no
 numeric vectors for this path — SURVEY.md §4).
 
 Every function cites the reference lines it follows (paths relative to /root/reference).
