@@ -1950,6 +1950,254 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
 }
 
 // ------------------------------------------------------------------------------------------
+// Router backward (dx half) + the boundary's LayerNorm backward in ONE pass over the rows (round 5).  In front of an MoE
+// feed-forward the two kernels run back to back on the same rows: router_bwd3_k<MODE 1> writes the total gradient of the
+// normalised stream xn ([T,H] in the compute dtype) and layernorm_bwd_k reads it straight back as its `dy` - 2 x 253 MB per
+// layer at the bench shape, both kernels at 5-6 TB/s of their own bytes (profiles/r5_probe_row_kernels_nostore.log).  Here a
+// wave forms the row of d xn in registers (the router kernel's arithmetic, rounded to the compute dtype exactly where that
+// kernel stored it) and carries on with the LayerNorm backward of the same row (layernorm_bwd_k's arithmetic): d y and the
+// masked copy d blk are bit-identical to the two-launch form; the four affine-gradient sums are taken in this kernel's row
+// order (wave-strided) and folded in a fixed order.  The router's dW / db stay with router_bwd3_k<MODE 2> (96 accumulator
+// registers that would put this kernel at one wave per SIMD).
+//   y, dres, dx: TX (the residual stream);  xn, grows, dblk: TG (the compute dtype);  no dense gradient term on xn.
+//   part_r: [gridDim.x][NN*H + NN + 2H] (this kernel writes the dgamma_r | dbeta_r columns), part_ln: [gridDim.x][2][H].
+// ------------------------------------------------------------------------------------------
+template <typename TX, typename TG, int IT, int NN>
+__global__ void __launch_bounds__(256, 2)
+boundary_router_bwd_k(const TX *__restrict__ y, const float *__restrict__ gamma, const float *__restrict__ mean_i,
+                      const float *__restrict__ rstd_i, const TX *__restrict__ dres, TX *__restrict__ dx, TG *__restrict__ dblk,
+                      float drop_p, uint64_t seed, const TG *__restrict__ xn, const float *__restrict__ rgamma,
+                      const float *__restrict__ rbeta, const float *__restrict__ rmean_i, const float *__restrict__ rrstd_i,
+                      const float *__restrict__ W, const float *__restrict__ dlogits, const TG *__restrict__ grows,
+                      const int32_t *__restrict__ slot_of, int KS, float *__restrict__ part_r, float *__restrict__ part_ln,
+                      int64_t T, int H) {
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
+  typedef typename raw4<TX>::type rawx_t;
+  typedef typename raw4<TG>::type rawg_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *sW = reinterpret_cast<float4 *>(smem);                 // [NN][H/4]
+  float4 *red = sW + NN * (H / 4);                               // [2][H/4], one wave at a time
+  // the boundary norm's two affine-gradient sums live in LDS, a private [2][H/4] table per wave (with them in registers
+  // the kernel does not fit the 256 VGPRs of two waves per SIMD at H = 704, N = 8: 196 bytes of scratch per lane)
+  float4 *acc = red + 2 * (H / 4) + (size_t)(threadIdx.x >> 6) * 2 * (H / 4);
+  float4 *sG = red + 10 * (H / 4);                               // [2][H/4]: the router norm's gamma, the boundary norm's (as W: read per use)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, Q = H / 4;
+  for (int i = threadIdx.x; i < NN * Q; i += 256) sW[i] = reinterpret_cast<const float4 *>(W)[i];
+  for (int i = threadIdx.x; i < Q; i += 256) {
+    sG[i] = reinterpret_cast<const float4 *>(rgamma)[i];
+    sG[Q + i] = reinterpret_cast<const float4 *>(gamma)[i];
+  }
+  float4 agr[IT], abr[IT];
+#pragma unroll
+  for (int i = 0; i < IT; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    (void)c;
+    agr[i] = make_float4(0, 0, 0, 0); abr[i] = make_float4(0, 0, 0, 0);
+    if (lane + 64 * i < Q) { acc[lane + 64 * i] = make_float4(0, 0, 0, 0); acc[Q + lane + 64 * i] = make_float4(0, 0, 0, 0); }
+  }
+  __syncthreads();
+  const int64_t wave = (int64_t)blockIdx.x * 4 + wv, nw = (int64_t)gridDim.x * 4;
+  rawg_t xc[IT], xn_[IT], gc[2][IT], gn_[2][IT];
+  rawx_t yc[IT], yn_[IT], rc[IT];
+  int sc[2] = {-1, -1}, sn[2] = {-1, -1};
+  const bool gath = grows != nullptr;
+  auto fetch_slots = [&](int64_t r) -> int { return (gath && r < T && lane < KS) ? slot_of[r * KS + lane] : -1; };
+  auto slots_of = [&](int v, int (&so)[2]) {
+    so[0] = __builtin_amdgcn_readlane(v, 0);
+    so[1] = __builtin_amdgcn_readlane(v, 1);
+  };
+  int slv_n = -1, slv_n2 = -1;
+  auto fetch = [&](rawg_t (&xo)[IT], rawg_t (&go)[2][IT], rawx_t (&yo)[IT], const int (&so)[2], int64_t r) {
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      const bool ok = c < H && r < T;
+      xo[i] = ok ? raw_load(xn + r * H + c) : rawg_t{};
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        go[k][i] = (gath && ok && so[k] >= 0) ? raw_load(grows + (int64_t)so[k] * H + c) : rawg_t{};
+      yo[i] = ok ? raw_load(y + r * H + c) : rawx_t{};
+    }
+  };
+  // the row's scalars in ONE register (router_bwd3_k): lanes < NN the logit gradients, then the router norm's mean / rstd,
+  // then the boundary norm's
+  auto fetch_meta = [&](int64_t r) -> float {
+    if (r >= T || lane >= NN + 4) return 0.f;
+    const float *p = lane < NN ? dlogits + r * NN + lane
+                   : lane == NN ? rmean_i + r : lane == NN + 1 ? rrstd_i + r : lane == NN + 2 ? mean_i + r : rstd_i + r;
+    return *p;
+  };
+  auto lane_val = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+  float meta = 0.f, meta_next = 0.f;
+  if (wave < T) {
+    slots_of(fetch_slots(wave), sc);
+    slv_n = fetch_slots(wave + nw);
+    fetch(xc, gc, yc, sc, wave);
+    meta = fetch_meta(wave);
+  }
+  const uint32_t th = (uint32_t)(drop_p * 65536.f);
+  const float ks = 1.f / (1.f - drop_p);
+  for (int64_t r = wave; r < T; r += nw) {
+    slv_n2 = fetch_slots(r + 2 * nw);
+    slots_of(slv_n, sn);
+    // (the residual branch's gradient row is met last, ~700 instructions from here: fetched for THIS row, not a row ahead -
+    //  a second copy does not fit the 256 VGPRs of two waves per SIMD)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      rc[i] = (c < H && dres) ? raw_load(dres + r * H + c) : rawx_t{};
+    }
+    fetch(xn_, gn_, yn_, sn, r + nw);
+    meta_next = fetch_meta(r + nw);
+    float g[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) g[n] = lane_val(meta, n);
+    const float rmean = lane_val(meta, NN), rrstd = lane_val(meta, NN + 1), mean = lane_val(meta, NN + 2), rstd = lane_val(meta, NN + 3);
+    // ---- the router norm + projection, backward (router_bwd3_k<MODE 1>, operation for operation) ----
+    float4 xh[IT], dn[IT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const bool in = lane + 64 * i < Q;
+      const float4 xv = raw_to_f4(xc[i]);
+      const v2f mm = {-rmean, -rmean}, rs = {rrstd, rrstd};
+      v2f xh0 = in ? ((v2f){xv.x, xv.y} + mm) * rs : (v2f){0.f, 0.f}, xh1 = in ? ((v2f){xv.z, xv.w} + mm) * rs : (v2f){0.f, 0.f};
+      xh[i] = make_float4(xh0.x, xh0.y, xh1.x, xh1.y);
+      const float4 gr4 = in ? sG[lane + 64 * i] : make_float4(0, 0, 0, 0);
+      const v2f g0 = {gr4.x, gr4.y}, g1 = {gr4.z, gr4.w};
+      v2f d0 = {0.f, 0.f}, d1 = {0.f, 0.f};   // dxn = dlogits @ W
+#pragma unroll
+      for (int n = 0; n < NN; ++n) {
+        const float4 wn = in ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
+        const v2f gn = {g[n], g[n]};
+        d0 = pk_fma2(gn, (v2f){wn.x, wn.y}, d0); d1 = pk_fma2(gn, (v2f){wn.z, wn.w}, d1);
+      }
+      v2f a0 = pk_fma2(d0, xh0, (v2f){agr[i].x, agr[i].y}), a1 = pk_fma2(d1, xh1, (v2f){agr[i].z, agr[i].w});
+      agr[i] = make_float4(a0.x, a0.y, a1.x, a1.y);
+      const v2f b0 = (v2f){abr[i].x, abr[i].y} + d0, b1 = (v2f){abr[i].z, abr[i].w} + d1;
+      abr[i] = make_float4(b0.x, b0.y, b1.x, b1.y);
+      const v2f dn0 = d0 * g0, dn1 = d1 * g1;
+      dn[i] = make_float4(dn0.x, dn0.y, dn1.x, dn1.y);
+      s1 += (dn[i].x + dn[i].y) + (dn[i].z + dn[i].w);
+      s2 += (dn[i].x * xh[i].x + dn[i].y * xh[i].y) + (dn[i].z * xh[i].z + dn[i].w * xh[i].w);
+      __builtin_amdgcn_sched_barrier(0);   // (a chunk at a time: hipcc otherwise fetches every chunk's W rows from LDS up front and spills)
+    }
+    const float rm1 = wave_sum(s1) * inv_h(H), rm2 = wave_sum(s2) * inv_h(H);
+    float4 dq[IT];     // d xn of this row as router_bwd3_k stores it (rounded to the compute dtype): the LayerNorm backward's dy
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      dq[i] = make_float4(0, 0, 0, 0);
+      if (c < H) {
+        float4 rr = make_float4(0, 0, 0, 0);
+        if (gath) {
+          float4 ga = make_float4(0, 0, 0, 0);
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+            if (sc[k] >= 0) { const float4 gv = raw_to_f4(gc[k][i]); ga.x += gv.x; ga.y += gv.y; ga.z += gv.z; ga.w += gv.w; }
+          rr.x += to_f32(from_f32<TG>(ga.x)); rr.y += to_f32(from_f32<TG>(ga.y));
+          rr.z += to_f32(from_f32<TG>(ga.z)); rr.w += to_f32(from_f32<TG>(ga.w));
+        }
+        dq[i] = make_float4(to_f32(from_f32<TG>(rrstd * (dn[i].x - rm1 - xh[i].x * rm2) + rr.x)),
+                            to_f32(from_f32<TG>(rrstd * (dn[i].y - rm1 - xh[i].y * rm2) + rr.y)),
+                            to_f32(from_f32<TG>(rrstd * (dn[i].z - rm1 - xh[i].z * rm2) + rr.z)),
+                            to_f32(from_f32<TG>(rrstd * (dn[i].w - rm1 - xh[i].w * rm2) + rr.w)));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- the boundary's LayerNorm, backward (layernorm_bwd_k, operation for operation) ----
+    float t1 = 0.f, t2 = 0.f;
+    float4 gd[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      const float4 xq = c < H ? raw_to_f4(yc[i]) : make_float4(0, 0, 0, 0), d4 = dq[i];
+      xh[i] = make_float4((xq.x - mean) * rstd, (xq.y - mean) * rstd, (xq.z - mean) * rstd, (xq.w - mean) * rstd);
+      const float4 g4 = c < H ? sG[Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
+      gd[i] = make_float4(d4.x * g4.x, d4.y * g4.y, d4.z * g4.z, d4.w * g4.w);
+      if (c < H) {
+        float4 ag = acc[lane + 64 * i], ab = acc[Q + lane + 64 * i];
+        ag.x += d4.x * xh[i].x; ag.y += d4.y * xh[i].y; ag.z += d4.z * xh[i].z; ag.w += d4.w * xh[i].w;
+        ab.x += d4.x; ab.y += d4.y; ab.z += d4.z; ab.w += d4.w;
+        acc[lane + 64 * i] = ag; acc[Q + lane + 64 * i] = ab;
+        t1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+        t2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+      }
+    }
+    const float m1 = wave_sum(t1) * inv_h(H), m2 = wave_sum(t2) * inv_h(H);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 rr = raw_to_f4(rc[i]);        // (zeros without dres)
+        const float4 dt = make_float4(rstd * (gd[i].x - m1 - xh[i].x * m2) + rr.x, rstd * (gd[i].y - m1 - xh[i].y * m2) + rr.y,
+                                      rstd * (gd[i].z - m1 - xh[i].z * m2) + rr.z, rstd * (gd[i].w - m1 - xh[i].w * m2) + rr.w);
+        store4<TX>(dx + r * H + c, dt);
+        float e[4] = {dt.x, dt.y, dt.z, dt.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = to_f32(from_f32<TX>(e[j]));
+        if (drop_p > 0.f) {
+          bool keep[4];
+          drop_keep4(seed, (uint64_t)r * (uint64_t)H + (uint64_t)c, th, keep);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
+        }
+        store4<TG>(dblk + r * H + c, make_float4(e[0], e[1], e[2], e[3]));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) { xc[i] = xn_[i]; gc[0][i] = gn_[0][i]; gc[1][i] = gn_[1][i]; yc[i] = yn_[i]; }
+    sc[0] = sn[0]; sc[1] = sn[1];
+    slv_n = slv_n2;
+    meta = meta_next;
+  }
+  // block reduction in wave order (the router norm's sums: waves 1..3 take turns in one LDS buffer; the boundary norm's: wave 0
+  // adds the four private tables), then one partial row per block and table
+  for (int turn = 1; turn < 4; ++turn) {
+    __syncthreads();
+    if (wv == turn) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int cq = lane + 64 * i;
+        if (cq < Q) { red[cq] = agr[i]; red[Q + cq] = abr[i]; }
+      }
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int cq = lane + 64 * i;
+        if (cq < Q) {
+          const float4 u = red[cq], v = red[Q + cq];
+          agr[i].x += u.x; agr[i].y += u.y; agr[i].z += u.z; agr[i].w += u.w;
+          abr[i].x += v.x; abr[i].y += v.y; abr[i].z += v.z; abr[i].w += v.w;
+        }
+      }
+    }
+  }
+  if (wv == 0) {
+    float *dr = part_r + (int64_t)blockIdx.x * (NN * H + NN + 2 * H) + NN * H + NN;
+    float *dl = part_ln + (int64_t)blockIdx.x * 2 * H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int cq = lane + 64 * i;
+      if (cq < Q) {
+        float4 ag = acc[cq], ab = acc[Q + cq];
+        for (int w = 1; w < 4; ++w) {
+          const float4 u = acc[(size_t)w * 2 * Q + cq], v = acc[(size_t)w * 2 * Q + Q + cq];
+          ag.x += u.x; ag.y += u.y; ag.z += u.z; ag.w += u.w;
+          ab.x += v.x; ab.y += v.y; ab.z += v.z; ab.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(dr + cq * 4) = agr[i];
+        *reinterpret_cast<float4 *>(dr + H + cq * 4) = abr[i];
+        *reinterpret_cast<float4 *>(dl + cq * 4) = ag;
+        *reinterpret_cast<float4 *>(dl + H + cq * 4) = ab;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Tiny linear: y[T,N] = x[T,:K] W[N,K]^T + b with K <= 64, N <= 16 - the SSM's dt_proj_head
 // (Linear(dt_rank -> heads), reference core.py:361,382), whose input is a column slice of the
 // x_param_proj output (row stride ldx).  A GEMM library pays ~20 us forward and ~270 us backward
@@ -2543,6 +2791,43 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
                                   float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
   return apertis_router_bwd_rows(x, gamma, beta, mean, rstd, W, dlogits, dres, nullptr, nullptr, 0, dx, part, grads, T, H, N,
                                  dtype_x, stream);
+}
+
+extern "C" int apertis_boundary_router_bwd(const void *y, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                                           void *dx, void *dblk, float drop_p, uint64_t seed, const void *xn, const float *rgamma,
+                                           const float *rbeta, const float *rmean, const float *rrstd, const float *W,
+                                           const float *dlogits, const void *grows, const int32_t *slot_of, int64_t KS,
+                                           float *part, float *rgrads, float *dgamma, float *dbeta, int64_t T, int64_t H,
+                                           int64_t N, int dtype_x, int dtype_g, void *stream) {
+  // part: workspace [apertis_router_bwd_blocks(T)][N*H + N + 2H  |  2H]  (the router's table, then the boundary norm's);
+  // rgrads: out [N*H dW | N db | H dgamma_r | H dbeta_r]; dgamma / dbeta [H]: the boundary norm's
+  if (!y || !gamma || !mean || !rstd || !dx || !dblk || !xn || !rgamma || !rbeta || !rmean || !rrstd || !W || !dlogits || !part ||
+      !rgrads || !dgamma || !dbeta || T < 0)
+    return APERTIS_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f) return APERTIS_ERR_ARG;
+  if (grows && (!slot_of || KS < 1)) return APERTIS_ERR_ARG;
+  if (grows && KS > 2) return APERTIS_ERR_UNSUPPORTED;
+  if (H <= 0 || H % 4 || H > 1024 || N < 1 || N > 8) return APERTIS_ERR_UNSUPPORTED;
+  if (dtype_x != APERTIS_F32 || (dtype_g != APERTIS_BF16 && dtype_g != APERTIS_F32)) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = apertis_router_bwd_blocks(T), cols = N * H + N + 2 * H;
+  float *part_ln = part + nblk * cols;
+  dim3 grid((unsigned)nblk), block(256);
+  const size_t ldsf = (size_t)(N + 2 + 8 + 2) * H * sizeof(float), lds3 = (size_t)(2 * N + 2) * H * sizeof(float);
+#define BR_BWD(TGT) { auto kf = boundary_router_bwd_k<float, TGT, IT, NN>; auto k2 = router_bwd3_k<TGT, IT, NN, 2>; \
+    if (lds3 > 48 * 1024) hipFuncSetAttribute((const void *)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+    if (ldsf > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsf); \
+    hipLaunchKernelGGL(kf, grid, block, ldsf, st, (const float *)y, gamma, mean, rstd, (const float *)dres, (float *)dx, (TGT *)dblk, drop_p, seed, \
+                       (const TGT *)xn, rgamma, rbeta, rmean, rrstd, W, dlogits, (const TGT *)grows, slot_of, (int)KS, part, part_ln, T, (int)H); \
+    hipLaunchKernelGGL(k2, grid, block, lds3, st, (const TGT *)xn, rgamma, rbeta, rmean, rrstd, W, dlogits, (const TGT *)nullptr, \
+                       (const TGT *)nullptr, (const int32_t *)nullptr, 0, (TGT *)nullptr, part, T, (int)H); }
+  if (dtype_g == APERTIS_BF16) { SKINNY_N(N, SKINNY_IT(H, BR_BWD(bf16_t))); }
+  else { SKINNY_N(N, SKINNY_IT(H, BR_BWD(float))); }
+#undef BR_BWD
+  hipLaunchKernelGGL(fold_rows_k, dim3((unsigned)ceil_div64(cols, 64)), dim3(1024), 0, st, part, rgrads, nblk, cols);
+  hipLaunchKernelGGL(ln_fold_k, dim3((unsigned)ceil_div64(2 * H, 64)), dim3(1024), 0, st, part_ln, dgamma, dbeta, nblk, (int)H,
+                     (float *)nullptr, (int64_t)0);
+  return apertis_check_launch();
 }
 
 extern "C" int64_t apertis_moe_gate_aux_blocks(int64_t S) { return ceil_div64(S > 0 ? S : 1, 256); }

@@ -52,6 +52,9 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_SCHED_TOKEN
 #define LB_SCHED_TOKEN 1
 #endif
+#ifndef LB_PACK
+#define LB_PACK 0
+#endif
 constexpr int LB_LATE = LB_LATE_;
 static_assert(LB_LATE % 4 == 0 && LB_LATE >= 0 && LB_LATE <= 12, "whole groups of four tokens");        // forward: tokens whose C, xc, z loads are issued inside the replay
 
@@ -119,10 +122,23 @@ __device__ __forceinline__ bool lb_take(GateWsHead *head, uint32_t epoch, int *s
   k = item / G.nbw;
   const int bw = item - k * G.nbw;
 #endif
+#if LB_PACK == 2      // rows packed over the waves' lanes in units of 16 lanes = one 128-byte line of a bf16 row: a line is read by one wave
+  const int upr = (G.g + 15) >> 4, un = bw * 4 + (ln >> 4);
+  ln_.b = un / upr;
+  ln_.q = (un - ln_.b * upr) * 16 + (ln & 15);
+  ln_.ok = ln_.b < d.B && ln_.q < G.g;
+  if (!ln_.ok) ln_.q = 0;
+#elif LB_PACK == 1    // (probe: rows packed end to end - a row's lines split between two work-groups: slower)
+  const int f = bw * 64 + ln;
+  ln_.b = f / G.g;
+  ln_.q = f - ln_.b * G.g;
+  ln_.ok = ln_.b < d.B;
+#else
   const int r = ln / G.g;
   ln_.q = ln - r * G.g;
   ln_.b = bw * G.R + r;
   ln_.ok = r < G.R && ln_.b < d.B;
+#endif
   ln_.c0 = 4 * ln_.q;
   ln_.hh = ln_.c0 >> 4;
   return true;
@@ -253,8 +269,12 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       vb[u].x = u < rows ? vb[u].x : 0u; vb[u].y = u < rows ? vb[u].y : 0u;
       unpack4(vb[u], bv);
       sumdl += dlv;
+#ifndef LB_PROBE_NOAGG   // (probe builds: what the aggregate's arithmetic costs - results wrong)
 #pragma unroll
       for (int k = 0; k < 4; ++k) S[k] = fmaf(__builtin_amdgcn_exp2f(dlv * A2[k]), S[k], bv[k]);
+#else
+      S[0] += bv[0] + bv[1] + bv[2] + bv[3];
+#endif
     }
   }
 #if LB_CXZ_AFTER_AGG   // (the aggregate's rows - delta, Bt - first on every wave of the CU; C, xc, z ride under the poll)
@@ -359,7 +379,11 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
         const float y = cv[k] * hst[k];
         const float dx = Dk[k] * xv[k];
         const float val = y + dx;
+#ifndef LB_PROBE_NOGATE   // (probe builds: what the gate's two transcendentals per channel cost - results wrong)
         o[k] = val * silu_g(zv[k]);
+#else
+        o[k] = val * zv[k];
+#endif
       }
       const lean_u2 ov = {lean_pack2(o[0], o[1]), lean_pack2(o[2], o[3])};
       if (u < rows) __builtin_amdgcn_raw_buffer_store_b64(ov, ro, (int)oo, (int)((uint32_t)u * to.rs * 2u), 2);   // (wave-uniform branch)
@@ -683,7 +707,7 @@ int lb_shape(LbShape &s, int64_t B, int64_t L, int64_t h, int64_t N, int softplu
   LbGeo &G = s.G;
   G.g = (int)(s.d.Dn / 4);
   G.R = 64 / G.g;
-  G.nbw = (int)ceil_div64(B, G.R);
+  G.nbw = LB_PACK == 2 ? (int)ceil_div64(B * ((G.g + 15) / 16), 4) : LB_PACK == 1 ? (int)ceil_div64(B * G.g, 64) : (int)ceil_div64(B, G.R);
   G.nsup = (int)ceil_div64(s.d.nchunks, LB_SUP);
   G.nck16 = (int)ceil_div64(L, LB_TW);
   int64_t rs_max = 0;

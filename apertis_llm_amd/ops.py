@@ -1943,6 +1943,7 @@ class _DropoutAddLNRouter(torch.autograd.Function):
         ctx.cfg = (shape, float(p), int(seed), weight.dtype, bias.dtype, blk.dtype, out_dtype, tuple(blk.shape))
         ctx.rcfg = (r_ln_w.dtype, r_ln_b.dtype, r_w.dtype, None if r_b is None else r_b.dtype)
         ctx.link = _RowsGrad()
+        ctx.set_materialize_grads(False)      # (an unused output's gradient arrives as None, not as a [T, H] tensor of zeros)
         return y.reshape(shape), xn.reshape(shape), logits, ctx.link
 
     @staticmethod
@@ -1955,6 +1956,32 @@ class _DropoutAddLNRouter(torch.autograd.Function):
         if dxn is not None and rows is not None and dxn.stride() == (0,) * dxn.dim():
             dxn = None                                            # the gather op's placeholder: its gradient is `rows`
         r_grads = (None, None, None, None, None)
+        if (dlogits is not None and dxn is None and FUSE_ROUTER_BOUNDARY_BWD and y.dtype == torch.float32 and
+                (rows is None or KS <= 2)):
+            # one pass: the router's dx half + the boundary norm's backward (xn's gradient stays in registers)
+            shape, p, seed, wdt, bdt, blkdt, odt, _ = ctx.cfg
+            dres = None if dy is None else dy.reshape(T, H).to(y.dtype).contiguous()
+            dx = torch.empty_like(y)
+            dblk = torch.empty(T, H, device=y.device, dtype=odt)
+            nblk = lib.apertis_router_bwd_blocks(T)
+            cols = N * H + N + 2 * H
+            part = torch.empty(nblk * (cols + 2 * H), device=y.device, dtype=torch.float32)
+            out = torch.empty(cols, device=y.device, dtype=torch.float32)
+            dg = torch.empty(H, device=y.device, dtype=torch.float32)
+            db = torch.empty(H, device=y.device, dtype=torch.float32)
+            rc = lib.apertis_boundary_router_bwd(ptr(y), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dblk), p, seed,
+                                                 ptr(xn), ptr(rg), ptr(rbe), ptr(rmean), ptr(rrstd), ptr(rw),
+                                                 ptr(dlogits.float().contiguous()), ptr(rows), ptr(slot_of), KS or 0, ptr(part),
+                                                 ptr(out), ptr(dg), ptr(db), T, H, N, dtype_code(y), dtype_code(xn), stream_ptr())
+            if rc != -2:                 # (-2 = APERTIS_ERR_UNSUPPORTED: the two calls below)
+                check(rc, "apertis_boundary_router_bwd")
+                global FUSED_ROUTER_BWD_CALLS
+                FUSED_ROUTER_BWD_CALLS += 1
+                gdt, bedt, rwdt, rbdt = ctx.rcfg
+                r_grads = (out[N * H + N:N * H + N + H].to(gdt), out[N * H + N + H:].to(bedt), None,
+                           out[:N * H].reshape(N, H).to(rwdt), (out[N * H:N * H + N].to(rbdt) if rbdt is not None else None))
+                dblk_in, _ = _DropoutAddLN._to_inputs(ctx, dblk)
+                return (dblk_in, dx.reshape(shape), dg.to(wdt), db.to(bdt), None, None, None, None) + r_grads
         if dlogits is not None:
             dres = None if dxn is None else dxn.reshape(T, H).to(xn.dtype).contiguous()
             dxn_t = torch.empty_like(xn)
@@ -2012,6 +2039,9 @@ def layer_norm_pass(x, weight, bias, eps, out_dtype=None):
     return _LayerNormPass.apply(x, weight, bias, eps, out_dtype or x.dtype)
 
 
+# APERTIS_NO_FUSE_ROUTER_BWD=1: the router backward and the boundary's LayerNorm backward as two calls (xn's gradient through HBM)
+FUSE_ROUTER_BOUNDARY_BWD = not _os.environ.get("APERTIS_NO_FUSE_ROUTER_BWD")
+FUSED_ROUTER_BWD_CALLS = 0        # (times the one-pass form ran: the tests look at it)
 FUSE_ACT_BWD = not _os.environ.get("APERTIS_NO_FUSE_ACT_BWD")
 SAVE_ACT_GRAD = True    # expert MLP: the forward leaves act'(pre) * mask / (1-p) instead of pre (tests switch it off to compare)
 

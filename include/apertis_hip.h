@@ -48,7 +48,7 @@ extern "C" {
 /* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
-#define APERTIS_ABI_VERSION ((4 << 16) | 5)
+#define APERTIS_ABI_VERSION ((4 << 16) | 6)
 int apertis_abi_version(void);
 /* Name of the code-object architecture this library was compiled for ("gfx950"). */
 const char *apertis_arch(void);
@@ -335,6 +335,22 @@ int apertis_router_bwd_rows(const void *x, const float *gamma, const float *beta
                             const void *grows, const int32_t *slot_of, int64_t KS, void *dx, float *part,
                             float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream);
 int64_t apertis_router_bwd_blocks(int64_t T);
+/* The router backward and the backward of the block boundary in front of it (apertis_dropout_add_layernorm_router_fwd's
+ * two halves, core.py:481-482 behind :888,:847) in ONE pass over the rows: the total gradient of the normalised stream xn is
+ * formed per row in registers - apertis_router_bwd_rows' arithmetic and rounding - and handed to apertis_layernorm_bwd's
+ * arithmetic for the same row, so xn's gradient [T,H] is neither written nor read back.  dx (the residual stream's gradient:
+ * LayerNorm backward + dres) and dblk (its masked copy, the block output's gradient) are bit-identical to the two calls;
+ * the router's dW / db come from a second short launch, every affine gradient from a fixed-order fold.
+ * y, dres, dx: dtype_x (fp32); xn, grows, dblk: dtype_g (bf16 / fp32).  No dense gradient term on xn (the caller uses the
+ * two calls then).  part: workspace [apertis_router_bwd_blocks(T)][(N*H + N + 2H) + 2H] fp32;
+ * rgrads: out [N*H dW | N db | H dgamma_r | H dbeta_r]; dgamma / dbeta [H]: the boundary norm's. */
+int apertis_boundary_router_bwd(const void *y, const float *gamma, const float *mean, const float *rstd,
+                                const void *dres, void *dx, void *dblk, float drop_p, uint64_t seed,
+                                const void *xn, const float *rgamma, const float *rbeta, const float *rmean,
+                                const float *rrstd, const float *W, const float *dlogits, const void *grows,
+                                const int32_t *slot_of, int64_t KS, float *part, float *rgrads, float *dgamma,
+                                float *dbeta, int64_t T, int64_t H, int64_t N, int dtype_x, int dtype_g,
+                                void *stream);
 
 /* Tiny linear y[T,N] = x[T,:K] W[N,K]^T + b for K <= 64, N <= 16: the SSM's
  * dt_proj_head (core.py:361,382) applied to a column slice of the x_param_proj output, read in

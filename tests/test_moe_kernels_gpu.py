@@ -762,6 +762,52 @@ def test_boundary_with_router_logits_in_one_pass(dev, T, H, E, dt_blk, p):
         assert torch.equal(a, c), (name, float((a.float() - c.float()).abs().max()))
 
 
+@pytest.mark.parametrize("T,H,E,K,dt,p,with_gather", [(3001, 704, 8, 2, torch.bfloat16, 0.1, True), (2048, 256, 8, 2, torch.bfloat16, 0.0, True),
+                                                      (777, 1024, 4, 1, torch.bfloat16, 0.1, True), (513, 256, 4, 2, torch.float32, 0.1, True),
+                                                      (1000, 704, 8, 2, torch.bfloat16, 0.1, False)])
+def test_boundary_and_router_backward_in_one_pass(dev, T, H, E, K, dt, p, with_gather):
+    """apertis_boundary_router_bwd (the router's dx half + the boundary norm's backward in one pass over the rows, xn's
+    gradient never in HBM) against the two calls: the residual stream's and the block output's gradients bit-identical, the
+    router's dW / db bit-identical (the same second launch), the four norm-affine gradients equal to summation order."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(T + H)
+    blk, res = torch.randn(T, H).to(dt), torch.randn(T, H)
+    w, b = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    rw, rb = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    W, wb = torch.randn(E, H) / H ** 0.5, torch.randn(E) * 0.1
+    eg, eb = torch.randn(E, H) * 0.2 + 1, torch.randn(E, H) * 0.1
+    gy, gl, G = torch.randn(T, H), torch.randn(T, E), torch.randn(T * K, H).to(dt)
+    seed_state = torch.get_rng_state()
+
+    def run(fused):
+        ops.FUSE_ROUTER_BOUNDARY_BWD = fused
+        try:
+            torch.set_rng_state(seed_state)
+            L = [t.to(dev).requires_grad_(True) for t in (blk, res, w, b, rw, rb, W, wb, eg, eb)]
+            y, xn, logits = ops.dropout_add_layer_norm_router(L[0], L[1], L[2], L[3], 1e-5, p, True, L[4], L[5], 1e-5, L[6], L[7], out_dtype=dt)
+            loss = (y * gy.to(dev)).sum() + (logits * gl.to(dev)).sum()
+            if with_gather:
+                idx, wk, _, _ = ops.moe_gate_topk_aux(logits.detach(), K, 0.01, 0.001)
+                plan = ops.moe_plan(idx, wk, E, capacity=int(T * K / E * 1.25))
+                xg = ops.moe_gather_ln(xn, L[8], L[9], plan, 1e-12, out_dtype=dt)
+                loss = loss + (xg.float() * G.to(dev)[:xg.shape[0]].float()).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            return [t.grad.clone() for t in L[:8]]
+        finally:
+            ops.FUSE_ROUTER_BOUNDARY_BWD = True
+
+    two = run(False)
+    n0 = ops.FUSED_ROUTER_BWD_CALLS
+    one = run(True)
+    assert ops.FUSED_ROUTER_BWD_CALLS == n0 + 1
+    for name, a, c in zip(("dblk", "dres", "dw", "db", "drw", "drb", "dW", "dwb"), two, one):
+        if name in ("dblk", "dres", "dW", "dwb"):
+            assert torch.equal(a, c), (name, float((a.float() - c.float()).abs().max()))
+        else:
+            assert torch.allclose(a, c, rtol=2e-5, atol=2e-5 * float(a.abs().max())), (name, float((a - c).abs().max()), float(a.abs().max()))
+
+
 @pytest.mark.parametrize("dt,extra_consumer", [(torch.bfloat16, False), (torch.float32, False), (torch.bfloat16, True)])
 def test_gather_gradient_reaches_the_router_as_rows(dev, dt, extra_consumer):
     """The gather-LN backward hands its gradient to the router backward as rows + slot table (ops._RowsGrad) instead of a

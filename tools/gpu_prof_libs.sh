@@ -13,7 +13,9 @@ for rep in 1 2; do for v in "$@"; do
   python3 - "$f" >> $L <<'PY'
 import csv, re, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: -float(r["TotalDurationNs"]))
-for r in rows[:10]:
+import os
+keep = os.environ.get("KFILTER")      # (KFILTER=substring: every kernel whose name holds it instead of the ten heaviest)
+for r in ([r for r in rows if keep in r["Name"]] if keep else rows[:10]):
     m = re.search(r"([a-z0-9_]+_k)\b", r["Name"])
     print("   %-34s calls %4s  avg %9.1f us  total %8.2f ms" % (m.group(1) if m else r["Name"][:34], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6))
 PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_scan_lb3.sh <log> [variants...]: in-tree library over all shapes of tools/scan_lean_check.py, then every variant (and the
+# tools/gpu_scan_check.sh <log> [variants...]: in-tree library over all shapes of tools/scan_lean_check.py, then every variant (and the
 # in-tree library again, "-") at the bench shapes under rocprofv3 for kernel-level times
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 L=gpurun_out/$1.log; : > $L; shift

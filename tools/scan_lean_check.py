@@ -1,7 +1,8 @@
 """The scan + gate op's three forms against each other: staged single-pass kernels, lean (three launches), look-back (one
 launch) - outputs, gradients, run-to-run bits, time (cold caches: 1 GiB is read between launches).
-    python tools/scan_lean_check.py [B L h N]"""
-import math, sys, torch
+    python tools/scan_lean_check.py [B L h N]        (SCAN_CHECK_TIMES_ONLY=1: exit 0 whatever the comparison says - probe
+    builds with arithmetic or waits compiled out)"""
+import math, os, sys, torch
 sys.path.insert(0, ".")
 from apertis_llm_amd import ops
 dev = torch.device("cuda:0")
@@ -84,4 +85,4 @@ for (B, L, h, N) in shapes:
                   f"  pad cols zero: {pad_ok if n == 'p' else '-'}{flag}")
     print("   scan error word", ops.scan_gate_error())
 print("FAILURES", bad)
-sys.exit(1 if bad else 0)
+sys.exit(1 if bad and os.environ.get("SCAN_CHECK_TIMES_ONLY") != "1" else 0)
