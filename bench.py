@@ -364,6 +364,10 @@ def main():
             else:
                 traffic_source = {"file": os.path.relpath(tf, ROOT), "stale": True,
                                   "note": "taken on other kernel sources than this tree's: traffic is null"}
+        else:
+            traffic_source = {"file": None,
+                              "note": "no rocprofv3 --pmc passes in profiles/ for this configuration and batch (they were taken on the "
+                                      "headline workload's launches only: tools/run_pmc.sh benchmix replays the 1.5b-moe shapes): traffic is null"}
         result["traffic_source"] = traffic_source
         for name, d in summ.items():
             if not d["launches"]:
