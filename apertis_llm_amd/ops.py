@@ -237,10 +237,14 @@ SCAN_SINGLE_PASS = _os.environ.get("APERTIS_SCAN_SINGLE_PASS", "1") != "0"
 # N = 16, 128 < Dn <= 256, 8-byte aligned slices); everything else on the forms above
 SCAN_LEAN = _os.environ.get("APERTIS_SCAN_LEAN", "1") == "1"
 SCAN_LEAN_BWD = _os.environ.get("APERTIS_SCAN_LEAN_BWD", "1") == "1"   # ... and the backward, from the lean forward's checkpoints
-# APERTIS_SCAN_LOOKBACK (round 5, default on; 0 = off): ONE launch per direction in the lean layout - a work-group per 64-token
-# chunk, 16 tokens per wave held in registers, chunk carries by a decoupled look-back through the workspace below (every operand
-# row read once; csrc/scan_lookback.hip) - for bf16, N = 16, Dn <= 256; takes precedence over the three-launch lean form
-SCAN_LOOKBACK = _os.environ.get("APERTIS_SCAN_LOOKBACK", "1") == "1"
+# APERTIS_SCAN_LOOKBACK (round 5; 1 = default, 0 = off, all): ONE launch per direction in the lean layout - a work-group per
+# 64-token chunk, 16 tokens per wave held in registers, chunk carries by a decoupled look-back through the workspace below (every
+# operand row read once; csrc/scan_lookback.hip) - for bf16, N = 16, Dn <= 256; takes precedence over the three-launch lean form.
+# Default: where it is the fastest form measured (128 < Dn <= 256: 87 / 168 us against the staged kernels' 104 / 230 at the bench
+# shape); narrower models stay on the staged kernels, which are as fast there (Dn = 64, B = 16, L = 4096: 32 / 53 us staged,
+# 32 / 61 us look-back: profiles/r5_scan_lookback_vs_lean_vs_staged.log).  "all": every shape the entry points take (the tests).
+_lb_env = _os.environ.get("APERTIS_SCAN_LOOKBACK", "1")
+SCAN_LOOKBACK = "all" if _lb_env == "all" else _lb_env == "1"
 _gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
 
 
@@ -304,6 +308,15 @@ def scan_gate_raise_on_error(device=None):
     if bad:
         raise ApertisHipError(f"single-pass scan: look-back wait timed out (error word {bad:#x}); the step's activations "
                               "are invalid - rerun with APERTIS_SCAN_SINGLE_PASS=0 (two-launch form, same bits)")
+
+
+def scan_gate_clear_error(device=None):
+    """Zero the look-back error word(s) of `device` (all devices: None) after the caller has dealt with a time-out: the word
+    is sticky - it poisons every later optimizer step (`ApertisAdamW`) until it is cleared."""
+    device = None if device is None else _indexed(device)
+    for (dev, _), ent in _gate_ws.items():
+        if device is None or dev == device:
+            ent[0][8:12].zero_()
 
 
 # Whether the CALLER of an op runs under autograd.  Inside Function.forward grad mode is always off, and
@@ -428,7 +441,7 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
     ckpt, lean = None, False
     dt_done = dtp is None
     kind = "staged"
-    if SCAN_LOOKBACK and xc.dtype == torch.bfloat16 and N == 16 and Dn <= 256:
+    if SCAN_LOOKBACK and xc.dtype == torch.bfloat16 and N == 16 and Dn <= 256 and (Dn > 128 or SCAN_LOOKBACK == "all"):
         if not dt_done:
             _tiny_linear_into(lib, dtp, dlt)
             dt_done = True

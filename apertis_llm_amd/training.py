@@ -47,7 +47,14 @@ class ApertisAdamW(torch.optim.Optimizer):
     (pipeline.py:544-546) in two passes over the gradients.  Same update rule, parameter-group options and state keys
     (`step`, `exp_avg`, `exp_avg_sq`) as torch.optim.AdamW, so LR schedulers and optimizer state dicts carry over.
     `step(max_grad_norm=...)` clips by the global norm over ALL groups first; `last_grad_norm` (a device scalar) holds
-    that norm afterwards.  fp32 CUDA parameters only - anything else raises."""
+    that norm afterwards.  fp32 CUDA parameters only - anything else raises.
+
+    A poisoned step: if the fused scan's look-back time-out word (`ops.scan_gate_error`) is set when `step` runs, the norm
+    comes out NaN and the update kernel returns without touching parameters or moments - but the host-side `step` counts
+    (bias correction) and any LR scheduler the caller steps still advance, and the word is STICKY: every later step is
+    skipped the same way until the caller clears it (`ops.scan_gate_clear_error()`).  `ApertisTrainer` raises behind its
+    `loss.item()` (`ops.scan_gate_raise_on_error()`), `TrainStep` returns a NaN loss; a bare user of this optimizer should
+    poll `ops.scan_gate_error()` as well, or check `last_grad_norm` for NaN."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))

@@ -511,6 +511,11 @@ def test_scan_lookback_timeout_word_rejects_the_step(dev):
         assert all(torch.equal(p.detach(), b) for p, b in zip(model.parameters(), before)), "a poisoned step must not touch the parameters"
         with pytest.raises(ApertisHipError, match="look-back"):
             ops.scan_gate_raise_on_error(dev)
+        ops.scan_gate_clear_error(dev)                     # the word is sticky until the caller clears it ...
+        assert ops.scan_gate_error(dev) == 0
+        loss = step(input_ids=ids, labels=ids)             # ... and the next step trains again
+        assert torch.isfinite(loss) and torch.isfinite(step.optimizer.last_grad_norm)
+        assert any(not torch.equal(p.detach(), b) for p, b in zip(model.parameters(), before))
     finally:
         word.zero_()
     assert ops.scan_gate_error(dev) == 0

@@ -59,7 +59,7 @@ def _oracle(i, use_h0):
     return out.detach(), hl.detach(), {k: v.grad for k, v in leaves.items()}
 
 
-KINDS = {"staged": (False, False), "lean": (True, False), "lookback": (False, True)}      # (SCAN_LEAN, SCAN_LOOKBACK)
+KINDS = {"staged": (False, False), "lean": (True, False), "lookback": (False, "all")}      # (SCAN_LEAN, SCAN_LOOKBACK)
 
 
 class _kind:

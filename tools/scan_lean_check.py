@@ -12,7 +12,7 @@ if len(sys.argv) > 4:
     shapes = [tuple(int(a) for a in sys.argv[1:5])]
 flush = torch.empty(1 << 28, dtype=torch.int32, device=dev)
 names = ("dl", "A", "p", "xz", "xc", "D")
-MODES = {"staged": (False, False), "lean": (True, False), "lookback": (False, True)}
+MODES = {"staged": (False, False), "lean": (True, False), "lookback": (False, "all")}
 
 
 def set_mode(mode):
