@@ -72,6 +72,8 @@ SIGNATURES = {
     "apertis_dwconv_silu_fwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_dwconv_silu_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
                                        _i64, _i32, _vp]),
+    "apertis_dwconv_silu_bwd2": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i64,
+                                        _i64, _i32, _vp]),
     "apertis_dwconv_bwd_blocks": (_i64, [_i64, _i64, _i64]),
     "apertis_moe_gate_topk_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     "apertis_moe_gate_topk_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),

@@ -273,7 +273,8 @@ dwconv_silu_fwd_tile_k(const T *__restrict__ x, int64_t x_rs, const float *__res
 template <typename T, int KW>
 __global__ void __launch_bounds__(256)
 dwconv_silu_bwd_k(const T *__restrict__ x, int64_t x_rs, const float *__restrict__ w, const float *__restrict__ bias,
-                  const T *__restrict__ dout, int64_t dout_rs, T *__restrict__ dx, int64_t dx_rs,
+                  const T *__restrict__ dout, int64_t dout_rs, const T *__restrict__ dout2, int64_t dout2_rs,
+                  T *__restrict__ dx, int64_t dx_rs,
                   float *__restrict__ dw_part, float *__restrict__ db_part, int64_t B, int64_t L, int Dn) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *red = reinterpret_cast<float *>(smem);  // [RP][CPR][4*(KW+1)]
@@ -301,6 +302,9 @@ dwconv_silu_bwd_k(const T *__restrict__ x, int64_t x_rs, const float *__restrict
         const int64_t b = run / runs_per_seq, t0 = (run - b * runs_per_seq) * CONV_TT;
         const T *xb = x + b * L * x_rs + c * 4;
         const T *gb = dout + b * L * dout_rs + c * 4;
+        // dout2: a second gradient of the same output (its other consumer's), added here as autograd's add kernel would have
+        // added it - the sum rounded to T - instead of in a pass of its own
+        const T *gb2 = dout2 ? dout2 + b * L * dout2_rs + c * 4 : nullptr;
         T *dxb = dx + b * L * dx_rs + c * 4;
         const int64_t t1 = min(t0 + CONV_TT, L);
         // sliding x window win[q] = x[t-(KW-1)+q] and dpre history dp[q] = dpre[t-(KW-1)+q];
@@ -322,6 +326,11 @@ dwconv_silu_bwd_k(const T *__restrict__ x, int64_t x_rs, const float *__restrict
             for (int j = 0; j < 4; ++j) { win[q][j] = win[q + 1][j]; dp[q][j] = dp[q + 1][j]; }
           if (t < L) {
             float4 v = ld4<T>(xb + t * x_rs), gv = ld4<T>(gb + t * dout_rs);
+            if (gb2) {
+              const float4 g2 = ld4<T>(gb2 + t * dout2_rs);
+              gv = make_float4(to_f32(from_f32<T>(gv.x + g2.x)), to_f32(from_f32<T>(gv.y + g2.y)), to_f32(from_f32<T>(gv.z + g2.z)),
+                               to_f32(from_f32<T>(gv.w + g2.w)));
+            }
             win[KW - 1][0] = v.x; win[KW - 1][1] = v.y; win[KW - 1][2] = v.z; win[KW - 1][3] = v.w;
             const float g_[4] = {gv.x, gv.y, gv.z, gv.w};
 #pragma unroll
@@ -662,12 +671,13 @@ extern "C" int apertis_dwconv_silu_fwd(const void *x, int64_t x_rs, const float 
   return apertis_check_launch();
 }
 
-extern "C" int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float *w, const float *bias, const void *dout,
-                                       int64_t dout_rs, void *dx, int64_t dx_rs, float *dw_part, float *db_part,
-                                       float *dw, float *db, int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
-                                       void *stream) {
+extern "C" int apertis_dwconv_silu_bwd2(const void *x, int64_t x_rs, const float *w, const float *bias, const void *dout,
+                                        int64_t dout_rs, const void *dout2, int64_t dout2_rs, void *dx, int64_t dx_rs,
+                                        float *dw_part, float *db_part, float *dw, float *db, int64_t B, int64_t L, int64_t Dn,
+                                        int64_t k, int dtype_io, void *stream) {
   if (!x || !w || !bias || !dout || !dx || !dw_part || !db_part || !dw || !db || B < 0 || L < 0) return APERTIS_ERR_ARG;
-  if (!rows_ok(Dn) || (x_rs | dout_rs | dx_rs) % 4 || k < 2 || k > 4) return APERTIS_ERR_UNSUPPORTED;
+  if (!dout2) dout2_rs = 0;
+  if (!rows_ok(Dn) || (x_rs | dout_rs | dout2_rs | dx_rs) % 4 || k < 2 || k > 4) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = conv_blocks(B, L, Dn);
   {
@@ -675,13 +685,21 @@ extern "C" int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float 
     size_t lds = (size_t)g.RP * std::min(g.CPR, 256) * 4 * (k + 1) * sizeof(float);
     dim3 grid(nblk), block(256);
     CONV_DISPATCH(k, dtype_io, hipLaunchKernelGGL((dwconv_silu_bwd_k<T, KW>), grid, block, lds, st, (const T *)x, x_rs, w,
-                                                  bias, (const T *)dout, dout_rs, (T *)dx, dx_rs, dw_part, db_part, B, L,
-                                                  (int)Dn));
+                                                  bias, (const T *)dout, dout_rs, (const T *)dout2, dout2_rs, (T *)dx, dx_rs,
+                                                  dw_part, db_part, B, L, (int)Dn));
   }
   hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn * k, 64)), dim3(1024), 0, st, dw_part, dw, (int64_t)nblk,
                      Dn * k);
   hipLaunchKernelGGL(colsum_rows_k, dim3((unsigned)ceil_div64(Dn, 64)), dim3(1024), 0, st, db_part, db, (int64_t)nblk, Dn);
   return apertis_check_launch();
+}
+
+extern "C" int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float *w, const float *bias, const void *dout,
+                                       int64_t dout_rs, void *dx, int64_t dx_rs, float *dw_part, float *db_part,
+                                       float *dw, float *db, int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
+                                       void *stream) {
+  return apertis_dwconv_silu_bwd2(x, x_rs, w, bias, dout, dout_rs, nullptr, 0, dx, dx_rs, dw_part, db_part, dw, db, B, L, Dn, k,
+                                  dtype_io, stream);
 }
 
 extern "C" int apertis_cast_transpose(const float *src, void *dst, void *dstT, int64_t E, int64_t R, int64_t C,

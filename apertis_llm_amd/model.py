@@ -429,8 +429,15 @@ class SelectiveLinearAttention(nn.Module):
             # (core.py:369-373); reproduced as is so cached decode matches `apertis chat`
             conv_in = torch.cat([conv_prev.transpose(1, 2).to(xp.dtype), xp], dim=1)
         conv_state = conv_in[:, -(kw - 1):].transpose(1, 2).detach() if use_cache else None
-        xc = ops.dwconv_silu(conv_in, self.conv1d.weight, self.conv1d.bias)[:, :L]      # core.py:373-375
-        p = _mfma_linear(xc, wp)                                             # x_param_proj (core.py:376), padded layout
+        if hidden_states.is_cuda and ops.DWCONV_PAIR:
+            # (two views of the one conv output, one per consumer - x_param_proj and the scan: the conv backward adds their
+            #  gradients where it reads the rows)
+            xc_p, xc = ops.dwconv_silu_pair(conv_in, self.conv1d.weight, self.conv1d.bias)  # core.py:373-375
+        else:
+            xc_p = xc = ops.dwconv_silu(conv_in, self.conv1d.weight, self.conv1d.bias)
+        if have_window:
+            xc_p, xc = xc_p[:, :L], xc[:, :L]
+        p = _mfma_linear(xc_p, wp)                                           # x_param_proj (core.py:376), padded layout
         # Bt / C / dt are column slices of p taken in place (core.py:382-385); the Bt and C slices keep their zero pad
         Btp, Cp, dt_in = ops.split_cols(p, (Wb, Wb, R, Wr - R))[:3]
         h0 = ssm_prev.reshape(B, Dn) if (use_cache and ssm_prev is not None) else None

@@ -663,12 +663,18 @@ class _DwConvSilu(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dout2=None):
         lib = _lib.load()
         x, w2, b2 = ctx.saved_tensors
         B, L, Dn = x.shape
         k = w2.shape[1]
+        if dout is None:
+            dout, dout2 = dout2, None
+        if dout is None:
+            return None, None, None
         dout = dout.contiguous()
+        if dout2 is not None:
+            dout2 = dout2.contiguous()
         nblk = lib.apertis_dwconv_bwd_blocks(B, L, Dn)
         dev = x.device
         dx, dx_rs = _grad_out(ctx.slot, (B, L), Dn, x.dtype, dev)
@@ -676,16 +682,38 @@ class _DwConvSilu(torch.autograd.Function):
         db_part = torch.empty(nblk, Dn, device=dev, dtype=torch.float32)
         dw = torch.empty(Dn, k, device=dev, dtype=torch.float32)
         db = torch.empty(Dn, device=dev, dtype=torch.float32)
-        check(lib.apertis_dwconv_silu_bwd(ptr(x), x.stride(-2), ptr(w2), ptr(b2), ptr(dout), Dn, ptr(dx), dx_rs,
-                                          ptr(dw_part), ptr(db_part), ptr(dw), ptr(db), B, L, Dn, k, dtype_code(x),
-                                          stream_ptr()), "apertis_dwconv_silu_bwd")
+        check(lib.apertis_dwconv_silu_bwd2(ptr(x), x.stride(-2), ptr(w2), ptr(b2), ptr(dout), Dn, ptr(dout2), Dn, ptr(dx), dx_rs,
+                                           ptr(dw_part), ptr(db_part), ptr(dw), ptr(db), B, L, Dn, k, dtype_code(x),
+                                           stream_ptr()), "apertis_dwconv_silu_bwd")
         return dx, dw.reshape(ctx.wshape), db
+
+
+# APERTIS_NO_DWCONV_PAIR=1: the conv output as ONE tensor for both consumers (autograd adds their gradients in a pass of its own)
+DWCONV_PAIR = not _os.environ.get("APERTIS_NO_DWCONV_PAIR")
+
+
+class _DwConvSiluPair(_DwConvSilu):
+    """The conv output handed out TWICE (two views of one tensor) for its two consumers - x_param_proj and the scan
+    (reference core.py:376 and :388-396): their gradients then reach this node separately and the backward kernel adds them
+    where it reads the rows, instead of autograd running a [B, L, Dn] add in front of it (30 us per layer at the bench shape;
+    the sum is rounded to the io dtype as that add rounds it: the same bits)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        out = _DwConvSilu.forward(ctx, x, w, b)
+        ctx.set_materialize_grads(False)
+        return out, out.view_as(out)
 
 
 def dwconv_silu(x, weight, bias):
     """silu(causal depthwise conv1d(x)) on token-major x [B,L,Dn] (reference core.py:368-375).
     weight [Dn,1,k] (nn.Conv1d layout), bias [Dn]."""
     return _DwConvSilu.apply(x, weight, bias)
+
+
+def dwconv_silu_pair(x, weight, bias):
+    """dwconv_silu as two views of the one output, one per consumer: see _DwConvSiluPair."""
+    return _DwConvSiluPair.apply(x, weight, bias)
 
 
 class _DropoutAdd(torch.autograd.Function):

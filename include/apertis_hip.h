@@ -254,6 +254,14 @@ int apertis_dwconv_silu_bwd(const void *x, int64_t x_rs, const float *w, const f
                             int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
                             void *stream); /* nblk = apertis_dwconv_bwd_blocks(B,L,Dn) */
 int64_t apertis_dwconv_bwd_blocks(int64_t B, int64_t L, int64_t Dn);
+/* apertis_dwconv_silu_bwd with a SECOND gradient of the same output (dout2, row stride dout2_rs; NULL: none): the conv's
+ * output feeds x_param_proj and the scan (core.py:376,388-396), and the sum of their two gradients - rounded to the io dtype as
+ * the framework's add kernel rounds it - is formed where the rows are read instead of in a [B, L, Dn] pass of its own. */
+int apertis_dwconv_silu_bwd2(const void *x, int64_t x_rs, const float *w, const float *bias,
+                             const void *dout, int64_t dout_rs, const void *dout2, int64_t dout2_rs,
+                             void *dx, int64_t dx_rs, float *dw_part, float *db_part, float *dw,
+                             float *db, int64_t B, int64_t L, int64_t Dn, int64_t k, int dtype_io,
+                             void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * MoE router gating  (replaces AdaptiveExpertSystem.forward core.py:491-492,529)

@@ -244,3 +244,36 @@ def test_split_cols_shared_gradient_buffer(dev):
     p = base.to(dev).requires_grad_(True)
     loss(p, lambda t: ops.split_cols(t, (R, Dn, Dn, 2))).backward()
     assert torch.allclose(p.grad.cpu(), ref.grad, rtol=1e-4, atol=1e-5), float((p.grad.cpu() - ref.grad).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt,B,L,Dn", [(torch.bfloat16, 3, 777, 176), (torch.float32, 2, 300, 64), (torch.bfloat16, 2, 4096, 224)])
+def test_dwconv_pair_adds_its_two_gradients_in_the_backward_kernel(dev, dt, B, L, Dn):
+    """ops.dwconv_silu_pair hands the conv output out twice (one view per consumer) so that the two gradients reach the
+    backward kernel separately and are added where the rows are read (apertis_dwconv_silu_bwd2): the same bits as the single
+    output followed by autograd's add, also when only one of the two views is used."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(B, L, Dn).to(dt)
+    w, b = torch.randn(Dn, 1, 4) * 0.3, torch.randn(Dn) * 0.1
+    g1, g2 = torch.randn(B, L, Dn).to(dt), torch.randn(B, L, Dn).to(dt)
+
+    def run(pair, both=True):
+        L_ = [t.to(dev).requires_grad_(True) for t in (x, w, b)]
+        if pair:
+            ya, yb = ops.dwconv_silu_pair(*L_)
+        else:
+            ya = yb = ops.dwconv_silu(*L_)
+        loss = (ya.float() * g1.to(dev).float()).sum()
+        if both:
+            loss = loss + (yb.float() * g2.to(dev).float()).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return ya.detach(), [t.grad for t in L_]
+
+    for both in (True, False):
+        y0, gr0 = run(False, both)
+        y1, gr1 = run(True, both)
+        assert torch.equal(y0, y1)
+        for name, a, c in zip(("dx", "dw", "db"), gr0, gr1):
+            assert torch.equal(a, c), (both, name, float((a.float() - c.float()).abs().max()))

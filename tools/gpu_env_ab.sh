@@ -6,5 +6,5 @@ TAG=$1; VAR=$2; VA=$3; VB=$4; shift 4
 for rep in 1 2; do for v in "$VA" "$VB"; do
   export $VAR=$v
   timeout -k 10 500 python bench.py --steps 16 --warmup 4 --no-cpu-baseline "$@" > gpurun_out/${TAG}_${v}_${rep}.json 2> gpurun_out/${TAG}.err || { tail -5 gpurun_out/${TAG}.err; exit 1; }
-  echo "== $VAR=$v (pass $rep)"; python tools/show_bench.py gpurun_out/${TAG}_${v}_${rep}.json | head -12
+  echo "== $VAR=$v (pass $rep)"; python tools/show_bench.py gpurun_out/${TAG}_${v}_${rep}.json 2>/dev/null | head -${SHOW:-12}
 done; done
