@@ -46,6 +46,9 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_ORDER
 #define LB_ORDER 0
 #endif
+#ifndef LB_GROUP
+#define LB_GROUP 22
+#endif
 #ifndef LB_CXZ_AFTER_AGG
 #define LB_CXZ_AFTER_AGG 0
 #endif
@@ -117,6 +120,12 @@ __device__ __forceinline__ bool lb_take(GateWsHead *head, uint32_t epoch, int *s
   const int kg = item / (G.nbw * LB_SUP), rem = item - kg * (G.nbw * LB_SUP), bw = rem / LB_SUP;
   k = kg * LB_SUP + (rem - bw * LB_SUP);
   if (k >= d.nchunks) return false;                            // (the last super-chunk may be short; nobody waits for such an item)
+#elif LB_ORDER == 3   // (probe: chunk-major inside groups of LB_GROUP waves of sequences, group after group - fewer pages in flight)
+  if (item >= d.nchunks * G.nbw) return false;
+  const int per = LB_GROUP * d.nchunks, grp = item / per, rem = item - grp * per;
+  const int gw = min(LB_GROUP, G.nbw - grp * LB_GROUP);      // (the last group may be short)
+  k = rem / gw;
+  const int bw = grp * LB_GROUP + (rem - k * gw);
 #else                 // chunk-major
   if (item >= d.nchunks * G.nbw) return false;
   k = item / G.nbw;
