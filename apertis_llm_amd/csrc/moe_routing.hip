@@ -21,15 +21,11 @@ constexpr int MAXK = 8;   // experts per token
 // gate: softmax -> top-K (ties: lowest expert index) -> renormalised weights
 // ------------------------------------------------------------------------------------------
 template <int EC>  // EC > 0: compile-time expert count; EC == 0: runtime E <= MAXE
-__global__ void gate_topk_fwd_k(const float *__restrict__ logits, float *__restrict__ gates,
-                                int32_t *__restrict__ idx, float *__restrict__ w, int64_t S, int E_rt,
-                                int K) {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
+__device__ __forceinline__ void gate_topk_row(const float *__restrict__ row, float *__restrict__ gates_row, int32_t *idx_row,
+                                              float *w_row, int E_rt, int K) {
   constexpr int CAP = EC > 0 ? EC : MAXE;
   const int E = EC > 0 ? EC : E_rt;
   float v[CAP];
-  const float *row = logits + s * E;
   float m = -INFINITY;
 #pragma unroll
   for (int i = 0; i < CAP; ++i)
@@ -40,7 +36,7 @@ __global__ void gate_topk_fwd_k(const float *__restrict__ logits, float *__restr
     if (i < E) { v[i] = expf(v[i] - m); sum += v[i]; }
 #pragma unroll
   for (int i = 0; i < CAP; ++i)
-    if (i < E) { v[i] = v[i] / sum; gates[s * E + i] = v[i]; }
+    if (i < E) { v[i] = v[i] / sum; gates_row[i] = v[i]; }
   uint64_t chosen = 0;
   float p[MAXK];
   float psum = 0.f;
@@ -53,7 +49,7 @@ __global__ void gate_topk_fwd_k(const float *__restrict__ logits, float *__restr
       for (int i = 0; i < CAP; ++i)
         if (i < E && !((chosen >> i) & 1) && v[i] > best) { best = v[i]; bi = i; }
       chosen |= 1ull << bi;
-      idx[s * K + k] = bi;
+      idx_row[k] = bi;
       p[k] = best;
       psum += best;
     }
@@ -61,7 +57,17 @@ __global__ void gate_topk_fwd_k(const float *__restrict__ logits, float *__restr
   const float den = psum + 1e-6f;  // core.py:529
 #pragma unroll
   for (int k = 0; k < MAXK; ++k)
-    if (k < K) w[s * K + k] = p[k] / den;
+    if (k < K) w_row[k] = p[k] / den;
+}
+
+template <int EC>
+__global__ void gate_topk_fwd_k(const float *__restrict__ logits, float *__restrict__ gates,
+                                int32_t *__restrict__ idx, float *__restrict__ w, int64_t S, int E_rt,
+                                int K) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int E = EC > 0 ? EC : E_rt;
+  gate_topk_row<EC>(logits + s * E, gates + s * E, idx + s * K, w + s * K, E_rt, K);
 }
 
 // dlogits from dw (through renorm + top-k gather) and dgates (aux losses), softmax backward
@@ -447,10 +453,11 @@ __global__ void plan_assign_k(PlanWs w, const int32_t *__restrict__ idx, const f
 // lane = token.  Same semantics: candidates idx[s, k] == e; per expert the capacity is consumed k-major; an overflowing
 // slot keeps its `keep` largest gate weights (compared as bits, as the radix select does), ties at the threshold in token
 // order; the kept rows of a slot sit in token order, the slots expert-major then k.
-__global__ void __launch_bounds__(1024)
-plan_small_k(const int32_t *__restrict__ idx, const float *__restrict__ wk, const uint8_t *__restrict__ active, int64_t capacity,
-             int32_t *__restrict__ offsets, int32_t *__restrict__ row_token, int32_t *__restrict__ row_k,
-             int32_t *__restrict__ slot_of, int S, int E, int K) {
+__device__ __forceinline__ void
+plan_small_body(const int32_t *idx, const float *wk, const uint8_t *__restrict__ active, int64_t capacity,
+                int32_t *__restrict__ offsets, int32_t *__restrict__ row_token, int32_t *__restrict__ row_k,
+                int32_t *__restrict__ slot_of, int S, int E, int K, int32_t *s_off, int32_t *s_rtok) {
+  // (s_off [E + 1] / s_rtok [S * K]: optional LDS copies of offsets / row_token for a caller that carries on in the same launch)
   __shared__ int32_t s_tot[16], s_keep[16], s_start[16];
   const int P = E * K, p = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int e = p / K, k = p - e * K;
@@ -485,9 +492,11 @@ plan_small_k(const int32_t *__restrict__ idx, const float *__restrict__ wk, cons
     int run = 0;
     for (int ee = 0; ee < E; ++ee) {
       offsets[ee] = run;
+      if (s_off) s_off[ee] = run;
       for (int kk = 0; kk < K; ++kk) { s_start[ee * K + kk] = run; run += s_keep[ee * K + kk]; }
     }
     offsets[E] = run;
+    if (s_off) s_off[E] = run;
   }
   __syncthreads();
   if (p >= P) return;
@@ -510,12 +519,20 @@ plan_small_k(const int32_t *__restrict__ idx, const float *__restrict__ wk, cons
         slot = s_start[p] + __popcll(km & lt);
         row_token[slot] = lane;
         row_k[slot] = k;
+        if (s_rtok) s_rtok[slot] = lane;
       }
       slot_of[lane * K + k] = slot;
     } else if (e == 0 && (es < 0 || es >= E)) {
       slot_of[lane * K + k] = -1;     // an index outside [0, E): no expert's wave claims the pair
     }
   }
+}
+
+__global__ void __launch_bounds__(1024)
+plan_small_k(const int32_t *__restrict__ idx, const float *__restrict__ wk, const uint8_t *__restrict__ active, int64_t capacity,
+             int32_t *__restrict__ offsets, int32_t *__restrict__ row_token, int32_t *__restrict__ row_k,
+             int32_t *__restrict__ slot_of, int S, int E, int K) {
+  plan_small_body(idx, wk, active, capacity, offsets, row_token, row_k, slot_of, S, E, K, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -646,6 +663,70 @@ gather_ln_fwd_k(const TX *__restrict__ x, const int32_t *__restrict__ row_token,
     }
   }
   if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+}
+
+// ------------------------------------------------------------------------------------------
+// A handful of tokens (the single-token decode step, reference core.py:1578-1603: S = batch <= 64 rows): gate, dispatch plan
+// and gather-LayerNorm in ONE launch - as three they are three dependent 3-5 us kernels per layer of a token step that
+// together move a few KB.  One work-group of E*K waves (plan_small_body's shape): threads < S run the gate (gate_topk_row:
+// the same arithmetic as apertis_moe_gate_topk_fwd), idx / w go through LDS into the plan, whose offsets / row_token stay in
+// LDS for the rows' LayerNorm (gather_ln_fwd_k's arithmetic, a wave per row).  Eval mode: no capacity, no dropped experts.
+// ------------------------------------------------------------------------------------------
+template <typename TX, typename TO, int IT, int EC>
+__global__ void __launch_bounds__(1024)
+moe_route_small_k(const float *__restrict__ logits, float *__restrict__ gates, int32_t *__restrict__ idx_o, float *__restrict__ w_o,
+                  int32_t *__restrict__ offsets, int32_t *__restrict__ row_token, int32_t *__restrict__ row_k,
+                  int32_t *__restrict__ slot_of, const TX *__restrict__ x, const float *__restrict__ gamma,
+                  const float *__restrict__ beta, float eps, TO *__restrict__ xg, float *__restrict__ mean_o,
+                  float *__restrict__ rstd_o, int S, int E, int K, int H) {
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
+  __shared__ int32_t s_idx[64 * MAXK], s_off[17], s_rtok[64 * MAXK];
+  __shared__ float s_w[64 * MAXK];
+  const int t = (int)threadIdx.x;
+  if (t < S) {
+    gate_topk_row<EC>(logits + (int64_t)t * E, gates + (int64_t)t * E, s_idx + t * K, s_w + t * K, E, K);
+    for (int k = 0; k < K; ++k) { idx_o[t * K + k] = s_idx[t * K + k]; w_o[t * K + k] = s_w[t * K + k]; }
+  }
+  __syncthreads();
+  plan_small_body(s_idx, s_w, nullptr, 0, offsets, row_token, row_k, slot_of, S, E, K, s_off, s_rtok);
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6, nwaves = (int)blockDim.x >> 6, rows = s_off[E];
+  for (int r = wave; r < rows; r += nwaves) {
+    const int e = expert_of_row(s_off, E, r);
+    const TX *src = x + (int64_t)s_rtok[r] * H;
+    float4 v[IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      v[i] = c < H ? load4s<TX>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) * inv_h(H);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
+    const float *ga = gamma + (int64_t)e * H, *be = beta + (int64_t)e * H;
+    TO *dst = xg + (int64_t)r * H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float4 g4 = load4<float>(ga + c), b4 = load4<float>(be + c);
+        float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                               (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+        store4<TO>(dst + c, o);
+      }
+    }
+    if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+  }
 }
 
 // Gather-LayerNorm backward per row, structured like layernorm_bwd_k (8 rows per wave, two rows in
@@ -2791,6 +2872,25 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
                                   float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
   return apertis_router_bwd_rows(x, gamma, beta, mean, rstd, W, dlogits, dres, nullptr, nullptr, 0, dx, part, grads, T, H, N,
                                  dtype_x, stream);
+}
+
+extern "C" int apertis_moe_route_small(const float *logits, float *gates, int32_t *idx, float *w, int32_t *expert_offsets,
+                                       int32_t *row_token, int32_t *row_k, int32_t *slot_of, const void *x, const float *gamma,
+                                       const float *beta, float eps, void *xg, float *mean, float *rstd, int64_t S, int64_t H,
+                                       int64_t E, int64_t K, int dtype_x, int dtype_xg, void *stream) {
+  if (!logits || !gates || !idx || !w || !expert_offsets || !row_token || !row_k || !slot_of || !x || !gamma || !beta || !xg ||
+      !mean || !rstd || S < 0)
+    return APERTIS_ERR_ARG;
+  if (S < 1 || S > 64 || (E != 4 && E != 8 && E != 16) || K < 1 || K > E || K > MAXK || E * K > 16) return APERTIS_ERR_UNSUPPORTED;
+  if (check_H(H) || H > 1024) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(1), block(64 * (unsigned)(E * K));
+#define RS_GO(EC_) hipLaunchKernelGGL((moe_route_small_k<TA, TB, IT, EC_>), grid, block, 0, st, logits, gates, idx, w, expert_offsets, \
+                                      row_token, row_k, slot_of, (const TA *)x, gamma, beta, eps, (TB *)xg, mean, rstd, (int)S, (int)E, \
+                                      (int)K, (int)H)
+  DISPATCH_2T(dtype_x, dtype_xg, SKINNY_IT(H, { if (E == 4) RS_GO(4); else if (E == 8) RS_GO(8); else RS_GO(16); }));
+#undef RS_GO
+  return apertis_check_launch();
 }
 
 extern "C" int apertis_boundary_router_bwd(const void *y, const float *gamma, const float *mean, const float *rstd, const void *dres,

@@ -598,6 +598,19 @@ class AdaptiveExpertSystem(nn.Module):
         lb_coef = self.load_balancing_loss_coef if (self.use_load_balancing_loss and self.training) else 0.0
         rz_coef = self.router_z_loss_coef if (self.use_router_z_loss and self.training) else 0.0
         noisy = self.use_noisy_top_k_routing and self.training
+        cd = _compute_dtype(xf)
+        if (not self.training and lb_coef == 0 and rz_coef == 0 and not noisy and logits.is_cuda
+                and ops.moe_route_small_supported(logits, xf, K)):
+            # a handful of rows under no_grad (the decode step, core.py:1578-1603): gate, plan and gather-LN in one launch
+            _g, idx, w, plan, xg = ops.moe_route_small(logits, xf, self.expert_ln_weight, self.expert_ln_bias,
+                                                       self.config.layer_norm_eps, K, out_dtype=cd)
+            yr = ops.expert_mlp(xg, self.expert_w1, self.expert_b1, self.expert_w2, self.expert_b2, plan.offsets,
+                                plan.max_rows, act=self.activation, drop_p=0.0, seed=0, compute_dtype=cd)
+            out = _LazyCombine(yr, w, plan, (B, L, H), xf.dtype)
+            if not lazy_combine:
+                out = out.materialise()
+            zero = _zero_scalar(hidden_states.device, aux_dtype)
+            return out, zero, zero
         fused_gate = logits.is_cuda and S > 0 and (lb_coef > 0 or rz_coef > 0)
         if noisy and not fused_gate:                                                      # core.py:485-488
             logits = logits + torch.randn_like(logits) * (F.softplus(self.w_noise) * self.noisy_routing_alpha)
@@ -1194,7 +1207,9 @@ class ApertisForCausalLM(nn.Module):
         live in static buffers that the graph updates in place; the host looks at the alive flags every 16 steps only."""
         B, dev = tokens.shape[0], tokens.device
         s_tok = tokens[:, -1:].clone()
-        s_past = [(c.clone(), st.clone()) for (c, st) in past]
+        # (contiguous copies: the prefill hands the conv window over as a transposed view, and a cache that is not contiguous
+        #  is copied in and out of every token step instead of being updated in place - two launches per layer)
+        s_past = [(c.clone(memory_format=torch.contiguous_format), st.clone(memory_format=torch.contiguous_format)) for (c, st) in past]
         s_alive = alive.clone()
         s_idx = torch.zeros(1, dtype=torch.long, device=dev)
         s_out = torch.full((B, left), pad, dtype=tokens.dtype, device=dev)

@@ -1201,6 +1201,43 @@ def moe_plan(idx, w, E, capacity=None, active=None):
     return p
 
 
+def moe_route_small_supported(logits, x, K):
+    """Shapes apertis_moe_route_small takes: a handful of rows (the decode step), inference only."""
+    S, E = logits.shape
+    # (the entry point takes S <= 64; past 16 rows its one work-group walks the gather-LN rows slower than the row kernel's many)
+    return (x.is_cuda and not torch.is_grad_enabled() and 1 <= S <= 16 and E in (4, 8, 16) and E * K <= 16 and K <= E
+            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and x.dtype in (torch.float32, torch.bfloat16))
+
+
+def moe_route_small(logits, x, gamma, beta, eps, K, out_dtype=None):
+    """moe_gate_topk + moe_plan (no capacity, every expert active) + moe_gather_ln for S <= 64 rows as ONE launch (reference
+    core.py:491-492,529,547-593 for a single-token step): returns (gates, idx, w, plan, xg) - the same values as the three ops."""
+    _require_gpu(logits, x, gamma, beta)
+    lib = _lib.load()
+    S, E = logits.shape
+    H = x.shape[-1]
+    dev = x.device
+    out_dtype = out_dtype or x.dtype
+    lg = logits.float().contiguous()
+    x = x.contiguous()
+    gates = torch.empty(S, E, device=dev, dtype=torch.float32)
+    idx = torch.empty(S, K, device=dev, dtype=torch.int32)
+    w = torch.empty(S, K, device=dev, dtype=torch.float32)
+    p = MoePlan()
+    p.S, p.E, p.K, p.max_rows = S, E, K, S * K
+    p.offsets = torch.empty(E + 1, device=dev, dtype=torch.int32)
+    p.row_token = torch.empty(S * K, device=dev, dtype=torch.int32)
+    p.row_k = torch.empty(S * K, device=dev, dtype=torch.int32)
+    p.slot_of = torch.empty(S, K, device=dev, dtype=torch.int32)
+    xg = torch.empty(S * K, H, device=dev, dtype=out_dtype)
+    mean = torch.empty(S * K, device=dev, dtype=torch.float32)
+    rstd = torch.empty(S * K, device=dev, dtype=torch.float32)
+    check(lib.apertis_moe_route_small(ptr(lg), ptr(gates), ptr(idx), ptr(w), ptr(p.offsets), ptr(p.row_token), ptr(p.row_k),
+                                      ptr(p.slot_of), ptr(x), ptr(_f32(gamma)), ptr(_f32(beta)), float(eps), ptr(xg), ptr(mean),
+                                      ptr(rstd), S, H, E, K, dtype_code(x), dtype_code(xg), stream_ptr()), "apertis_moe_route_small")
+    return gates, idx, w, p, xg
+
+
 class _GatherLN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, plan, eps, out_dtype, link):

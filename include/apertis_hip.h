@@ -377,6 +377,14 @@ int apertis_tiny_linear_bwd_pad(const void *x, int64_t ldx, const float *W, cons
                                 int64_t N, int64_t zero_to, int dtype_x, void *stream);
 int64_t apertis_tiny_linear_bwd_blocks(int64_t T);
 
+/* A handful of tokens (S <= 64, E*K <= 16: the single-token decode step, core.py:1578-1603): apertis_moe_gate_topk_fwd,
+ * apertis_moe_plan (no capacity, no dropped experts) and apertis_moe_gather_ln_fwd as ONE launch of one work-group - the same
+ * arithmetic, the same outputs (gates [S,E], idx / w [S,K]; the plan; xg [S*K,H] with mean / rstd per row). */
+int apertis_moe_route_small(const float *logits, float *gates, int32_t *idx, float *w,
+                            int32_t *expert_offsets, int32_t *row_token, int32_t *row_k,
+                            int32_t *slot_of, const void *x, const float *gamma, const float *beta,
+                            float eps, void *xg, float *mean, float *rstd, int64_t S, int64_t H,
+                            int64_t E, int64_t K, int dtype_x, int dtype_xg, void *stream);
 /* ------------------------------------------------------------------------------------------
  * MoE dispatch plan  (replaces the K x E Python loop core.py:547-591: nonzero / capacity /
  * overflow top-n by gate weight).  Canonical row order: expert-major, then k, then token

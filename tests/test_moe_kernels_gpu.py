@@ -1176,3 +1176,31 @@ def test_cast_transpose_plain_and_transposed(dev, E, R, C):
     assert torch.equal(tr[:, :, :R], ref.transpose(1, 2)) and (Rp == R or bool((tr[:, :, R:] == 0).all()))
     p32, t32 = ops.cast_transpose(w, torch.float32)
     assert torch.equal(p32, w) and torch.equal(t32, w.transpose(1, 2))
+
+
+@pytest.mark.parametrize("S,E,K,H,dt", [(1, 8, 2, 704, torch.bfloat16), (16, 8, 2, 704, torch.bfloat16), (64, 8, 2, 704, torch.bfloat16),
+                                        (7, 4, 1, 256, torch.float32), (33, 16, 1, 1024, torch.bfloat16), (5, 4, 4, 128, torch.float32)])
+def test_route_small_equals_gate_plan_gather(dev, S, E, K, H, dt):
+    """apertis_moe_route_small (gate + plan + gather-LN of a handful of rows in one launch: the decode step) against the three
+    ops it replaces: every output bit-identical, also with ties in the logits and with experts nobody chose."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(S * 131 + E)
+    logits = torch.randn(S, E)
+    if S > 2:
+        logits[1] = logits[0]                       # identical rows
+        logits[2, :] = 0.25                         # an all-tie row: lowest expert indices win
+    x = torch.randn(S, H).to(dt)
+    g, b = torch.randn(E, H) * 0.2 + 1, torch.randn(E, H) * 0.1
+    with torch.no_grad():
+        lg, xd, gd, bd = logits.to(dev), x.to(dev), g.to(dev), b.to(dev)
+        assert ops.moe_route_small_supported(lg, xd, K) == (S <= 16)
+        gates0, idx0, w0 = ops.moe_gate_topk(lg, K)
+        plan0 = ops.moe_plan(idx0, w0, E)
+        xg0 = ops.moe_gather_ln(xd, gd, bd, plan0, 1e-5, out_dtype=dt)
+        gates1, idx1, w1, plan1, xg1 = ops.moe_route_small(lg, xd, gd, bd, 1e-5, K, out_dtype=dt)
+        torch.cuda.synchronize()
+    assert torch.equal(gates0, gates1) and torch.equal(idx0.to(torch.int32), idx1) and torch.equal(w0, w1)
+    rows = int(plan0.offsets[-1])
+    assert rows == S * K and torch.equal(plan0.offsets, plan1.offsets) and torch.equal(plan0.slot_of, plan1.slot_of)
+    assert torch.equal(plan0.row_token[:rows], plan1.row_token[:rows]) and torch.equal(plan0.row_k[:rows], plan1.row_k[:rows])
+    assert torch.equal(xg0[:rows], xg1[:rows])
