@@ -2031,6 +2031,193 @@ router_bwd3_k(const TX *__restrict__ x, const float *__restrict__ gamma, const f
 }
 
 // ------------------------------------------------------------------------------------------
+// The entrance of an MoE feed-forward for a handful of rows (the single-token decode step, core.py:1578-1603; S <= 16), ONE
+// launch of one work-group: the block boundary y = res + blk with xn = LayerNorm(y), the router's norm + projection on xn
+// (dropadd_ln_router_fwd_k's row arithmetic, a wave per row; no dropout: inference), then gate, dispatch plan and the
+// gather-LayerNorm of moe_route_small_k with xn taken from LDS instead of from HBM.  As separate launches these were two
+// dependent 5-8 us kernels per layer of a token step.  y [S,H] TX, logits / gates / idx / w, the plan, xg [S*K,H] TO come
+// out; xn only if the caller wants it (xn_o != NULL).
+// ------------------------------------------------------------------------------------------
+template <typename TX, typename TO, int IT, int NN>
+__global__ void __launch_bounds__(1024)
+moe_enter_small_k(const TO *__restrict__ blk, const TX *__restrict__ res, const float *__restrict__ gamma,
+                  const float *__restrict__ beta, float eps, TX *__restrict__ y, TO *__restrict__ xn_o,
+                  const float *__restrict__ rgamma, const float *__restrict__ rbeta, float reps, const float *__restrict__ W,
+                  const float *__restrict__ rb, float *__restrict__ logits, float *__restrict__ gates, int32_t *__restrict__ idx_o,
+                  float *__restrict__ w_o, int32_t *__restrict__ offsets, int32_t *__restrict__ row_token,
+                  int32_t *__restrict__ row_k, int32_t *__restrict__ slot_of, const float *__restrict__ lgamma,
+                  const float *__restrict__ lbeta, float leps, TO *__restrict__ xg, float *__restrict__ mean_o,
+                  float *__restrict__ rstd_o, int S, int K, int H) {
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
+  typedef typename raw4<TO>::type rawo_t;
+  typedef typename raw4<TX>::type rawx_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Q = H / 4;
+  float4 *sW = reinterpret_cast<float4 *>(smem);   // [NN][Q]
+  float4 *sG = sW + NN * Q, *sB = sG + Q, *sRG = sB + Q, *sRB = sRG + Q;
+  rawo_t *sXN = reinterpret_cast<rawo_t *>(sRB + Q);   // [S][Q]: xn as stored
+  __shared__ int32_t s_idx[16 * MAXK], s_off[17], s_rtok[16 * MAXK];
+  __shared__ float s_w[16 * MAXK], s_lg[16 * NN];
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = (int)blockDim.x >> 6;
+  for (int i = t; i < NN * Q; i += (int)blockDim.x) sW[i] = reinterpret_cast<const float4 *>(W)[i];
+  for (int i = t; i < Q; i += (int)blockDim.x) {
+    sG[i] = reinterpret_cast<const float4 *>(gamma)[i]; sB[i] = reinterpret_cast<const float4 *>(beta)[i];
+    sRG[i] = reinterpret_cast<const float4 *>(rgamma)[i]; sRB[i] = reinterpret_cast<const float4 *>(rbeta)[i];
+  }
+  // (the rows' operands are fetched before the barrier: they do not depend on the staged vectors)
+  rawo_t bc[IT];
+  rawx_t rc[IT];
+  {
+    const int r = wave;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      const bool ok = c < H && r < S;
+      bc[i] = ok ? *reinterpret_cast<const rawo_t *>(blk + (int64_t)r * H + c) : rawo_t{};
+      rc[i] = ok ? *reinterpret_cast<const rawx_t *>(res + (int64_t)r * H + c) : rawx_t{};
+    }
+  }
+  __syncthreads();
+  for (int r = wave; r < S; r += nwaves) {
+    if (r != wave) {
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        bc[i] = c < H ? *reinterpret_cast<const rawo_t *>(blk + (int64_t)r * H + c) : rawo_t{};
+        rc[i] = c < H ? *reinterpret_cast<const rawx_t *>(res + (int64_t)r * H + c) : rawx_t{};
+      }
+    }
+    float4 v[IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 a = raw_to_f4(bc[i]), rr = raw_to_f4(rc[i]);
+        v[i] = make_float4(rr.x + a.x, rr.y + a.y, rr.z + a.z, rr.w + a.w);
+        store4<TX>(y + (int64_t)r * H + c, v[i]);
+        v[i] = make_float4(to_f32(from_f32<TX>(v[i].x)), to_f32(from_f32<TX>(v[i].y)), to_f32(from_f32<TX>(v[i].z)), to_f32(from_f32<TX>(v[i].w)));
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float mean = wave_sum(sum) * inv_h(H);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
+    float rsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 g4 = sG[lane + 64 * i], b4 = sB[lane + 64 * i];
+        const float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                                     (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+        if (xn_o) store4<TO>(xn_o + (int64_t)r * H + c, o);
+        v[i] = make_float4(to_f32(from_f32<TO>(o.x)), to_f32(from_f32<TO>(o.y)), to_f32(from_f32<TO>(o.z)), to_f32(from_f32<TO>(o.w)));
+        if constexpr (sizeof(TO) == 2) {
+          typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+          const bf4 pk = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+          sXN[r * Q + lane + 64 * i] = __builtin_bit_cast(rawo_t, pk);
+        } else {
+          sXN[r * Q + lane + 64 * i] = __builtin_bit_cast(rawo_t, o);
+        }
+        rsum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float rmean = wave_sum(rsum) * inv_h(H);
+    float rsq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float a = v[i].x - rmean, b = v[i].y - rmean, cc = v[i].z - rmean, d = v[i].w - rmean;
+        rsq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rrstd = rsqrtf(wave_sum(rsq) * inv_h(H) + reps);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const bool in = lane + 64 * i < Q;
+      const float4 g4 = in ? sRG[lane + 64 * i] : make_float4(0, 0, 0, 0), b4 = in ? sRB[lane + 64 * i] : make_float4(0, 0, 0, 0);
+      v[i] = make_float4((v[i].x - rmean) * rrstd * g4.x + b4.x, (v[i].y - rmean) * rrstd * g4.y + b4.y,
+                         (v[i].z - rmean) * rrstd * g4.z + b4.z, (v[i].w - rmean) * rrstd * g4.w + b4.w);
+    }
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const float4 wn = lane + 64 * i < Q ? sW[n * Q + lane + 64 * i] : make_float4(0, 0, 0, 0);
+        a += (v[i].x * wn.x + v[i].y * wn.y) + (v[i].z * wn.z + v[i].w * wn.w);
+      }
+      acc[n] = wave_sum(a);
+    }
+    if (lane < NN) {
+      float o = 0.f;
+#pragma unroll
+      for (int n = 0; n < NN; ++n) if (lane == n) o = acc[n];
+      o += rb ? rb[lane] : 0.f;
+      logits[r * NN + lane] = o;
+      s_lg[r * NN + lane] = o;
+    }
+  }
+  __syncthreads();
+  if (t < S) {
+    gate_topk_row<NN>(s_lg + t * NN, gates + (int64_t)t * NN, s_idx + t * K, s_w + t * K, NN, K);
+    for (int k = 0; k < K; ++k) { idx_o[t * K + k] = s_idx[t * K + k]; w_o[t * K + k] = s_w[t * K + k]; }
+  }
+  __syncthreads();
+  plan_small_body(s_idx, s_w, nullptr, 0, offsets, row_token, row_k, slot_of, S, NN, K, s_off, s_rtok);
+  __syncthreads();
+  const int rows = s_off[NN];
+  for (int r = wave; r < rows; r += nwaves) {
+    const int e = expert_of_row(s_off, NN, r);
+    const rawo_t *src = sXN + s_rtok[r] * Q;
+    float4 v[IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      v[i] = lane + 64 * i < Q ? raw_to_f4(src[lane + 64 * i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(sum) * inv_h(H);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + leps);
+    const float *ga = lgamma + (int64_t)e * H, *be = lbeta + (int64_t)e * H;
+    TO *dst = xg + (int64_t)r * H;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float4 g4 = load4<float>(ga + c), b4 = load4<float>(be + c);
+        float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
+                               (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
+        store4<TO>(dst + c, o);
+      }
+    }
+    if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Router backward (dx half) + the boundary's LayerNorm backward in ONE pass over the rows (round 5).  In front of an MoE
 // feed-forward the two kernels run back to back on the same rows: router_bwd3_k<MODE 1> writes the total gradient of the
 // normalised stream xn ([T,H] in the compute dtype) and layernorm_bwd_k reads it straight back as its `dy` - 2 x 253 MB per
@@ -2872,6 +3059,32 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
                                   float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
   return apertis_router_bwd_rows(x, gamma, beta, mean, rstd, W, dlogits, dres, nullptr, nullptr, 0, dx, part, grads, T, H, N,
                                  dtype_x, stream);
+}
+
+extern "C" int apertis_moe_enter_small(const void *blk, const void *res, const float *gamma, const float *beta, float eps, void *y,
+                                       void *xn, const float *rgamma, const float *rbeta, float reps, const float *W,
+                                       const float *rb, float *logits, float *gates, int32_t *idx, float *w,
+                                       int32_t *expert_offsets, int32_t *row_token, int32_t *row_k, int32_t *slot_of,
+                                       const float *lgamma, const float *lbeta, float leps, void *xg, float *mean, float *rstd,
+                                       int64_t S, int64_t H, int64_t E, int64_t K, int dtype_x, int dtype_y, void *stream) {
+  if (!blk || !res || !gamma || !beta || !y || !rgamma || !rbeta || !W || !logits || !gates || !idx || !w || !expert_offsets ||
+      !row_token || !row_k || !slot_of || !lgamma || !lbeta || !xg || !mean || !rstd)
+    return APERTIS_ERR_ARG;
+  if (S < 1 || S > 16 || (E != 4 && E != 8) || K < 1 || K > E || E * K > 16) return APERTIS_ERR_UNSUPPORTED;
+  if (H <= 0 || H % 4 || H > 1024) return APERTIS_ERR_UNSUPPORTED;
+  if (dtype_x != APERTIS_F32 || (dtype_y != APERTIS_BF16 && dtype_y != APERTIS_F32)) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(1), block(64 * (unsigned)(E * K));
+  const size_t lds = (size_t)(E + 4) * H * sizeof(float) + (size_t)S * H * (dtype_y == APERTIS_BF16 ? 2 : 4);
+#define ES_GO(TOT, NN_) { auto kf = moe_enter_small_k<float, TOT, IT, NN_>; \
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kf, grid, block, lds, st, (const TOT *)blk, (const float *)res, gamma, beta, eps, (float *)y, (TOT *)xn, rgamma, rbeta, \
+                       reps, W, rb, logits, gates, idx, w, expert_offsets, row_token, row_k, slot_of, lgamma, lbeta, leps, (TOT *)xg, \
+                       mean, rstd, (int)S, (int)K, (int)H); }
+  if (dtype_y == APERTIS_BF16) { SKINNY_IT(H, { if (E == 4) ES_GO(bf16_t, 4) else ES_GO(bf16_t, 8) }); }
+  else { SKINNY_IT(H, { if (E == 4) ES_GO(float, 4) else ES_GO(float, 8) }); }
+#undef ES_GO
+  return apertis_check_launch();
 }
 
 extern "C" int apertis_moe_route_small(const float *logits, float *gates, int32_t *idx, float *w, int32_t *expert_offsets,

@@ -808,6 +808,9 @@ class ApertisFeedForward(nn.Module):
         router = None
         if self.is_expert_system and self.ffn.router is not None and self.ffn.num_experts > 0:
             router = (self.ffn.router_norm, self.ffn.router)
+            small = self._small_entry(hidden_s, defer)
+            if small is not None:
+                return small
         x, hidden_s = _enter_block(self.pre_norm, hidden_s, router=router)
         if self.is_expert_system:
             out, lb, rz = self.ffn(x, lazy_combine=defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"),
@@ -818,6 +821,37 @@ class ApertisFeedForward(nn.Module):
         if defer:
             return _Pending(out, hidden_s, self.output_dropout), lb, rz
         return _dropout_add(self.output_dropout, out, hidden_s), lb, rz
+
+
+def _ffn_small_entry(self, h, defer):
+    """A handful of rows under no_grad (the single-token decode step, core.py:1578-1603): the block boundary, the router, the
+    gate, the dispatch plan and the per-expert LayerNorm as ONE launch (ops.moe_enter_small), then the two expert GEMMs.
+    None when the shapes / modes are not the ones that kernel takes (the general path runs then)."""
+    f = self.ffn
+    if not (isinstance(h, _Pending) and not isinstance(h.out, _LazyCombine) and not self.training and not f.training
+            and isinstance(self.pre_norm, HipLayerNorm) and isinstance(f.router_norm, nn.LayerNorm)
+            and h.res.is_cuda and _compute_dtype(h.res) == h.out.dtype
+            and ops.moe_enter_small_supported(h.out, h.res, f.num_experts, f.experts_per_token)):
+        return None
+    B, L, H = h.res.shape
+    cd = h.out.dtype
+    y, _logits, w, plan, xg = ops.moe_enter_small(h.out, h.res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps,
+                                                  f.router_norm.weight, f.router_norm.bias, f.router_norm.eps, f.router.weight,
+                                                  f.router.bias, f.expert_ln_weight, f.expert_ln_bias, f.config.layer_norm_eps,
+                                                  f.experts_per_token)
+    yr = ops.expert_mlp(xg, f.expert_w1, f.expert_b1, f.expert_w2, f.expert_b2, plan.offsets, plan.max_rows, act=f.activation,
+                        drop_p=0.0, seed=0, compute_dtype=cd)
+    out = _LazyCombine(yr, w, plan, (B, L, H), cd)
+    zero = _zero_scalar(y.device, y.dtype)
+    if defer and not os.environ.get("APERTIS_NO_LAZY_COMBINE"):
+        return _Pending(out, y, self.output_dropout), zero, zero
+    out = out.materialise()
+    if defer:
+        return _Pending(out, y, self.output_dropout), zero, zero
+    return _dropout_add(self.output_dropout, out, y), zero, zero
+
+
+ApertisFeedForward._small_entry = _ffn_small_entry
 
 
 class ApertisLayer(nn.Module):

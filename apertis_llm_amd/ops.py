@@ -1238,6 +1238,51 @@ def moe_route_small(logits, x, gamma, beta, eps, K, out_dtype=None):
     return gates, idx, w, p, xg
 
 
+def moe_enter_small_supported(blk, res, E, K):
+    """Shapes apertis_moe_enter_small takes: <= 16 rows of an fp32 residual stream under no_grad (the decode step)."""
+    S = res.numel() // res.shape[-1]
+    H = res.shape[-1]
+    return (res.is_cuda and not torch.is_grad_enabled() and 1 <= S <= 16 and E in (4, 8) and E * K <= 16 and K <= E
+            and H % 4 == 0 and H <= 1024 and res.dtype == torch.float32 and blk.dtype in (torch.float32, torch.bfloat16)
+            and tuple(blk.shape) == tuple(res.shape))
+
+
+def moe_enter_small(blk, res, weight, bias, eps, r_ln_w, r_ln_b, r_eps, r_w, r_b, e_ln_w, e_ln_b, e_eps, K):
+    """dropout_add_layer_norm_router (inference: no dropout) + moe_route_small as ONE launch for <= 16 rows: the residual
+    stream y = res + blk, the router's logits on LayerNorm(y), gate, plan and the per-expert LayerNorm of the routed rows
+    (reference core.py:888,847,481-482,491-492,529,547-593 for a single-token step).  Returns (y, logits, w, plan, xg)."""
+    _require_gpu(blk, res, weight, bias, r_ln_w, r_ln_b, r_w, e_ln_w, e_ln_b)
+    lib = _lib.load()
+    shape = res.shape
+    H = shape[-1]
+    E = r_w.shape[0]
+    blk2 = blk.reshape(-1, H).contiguous()
+    res2 = res.reshape(-1, H).contiguous()
+    S = res2.shape[0]
+    dev = res.device
+    y = torch.empty_like(res2)
+    logits = torch.empty(S, E, device=dev, dtype=torch.float32)
+    gates = torch.empty(S, E, device=dev, dtype=torch.float32)
+    idx = torch.empty(S, K, device=dev, dtype=torch.int32)
+    w = torch.empty(S, K, device=dev, dtype=torch.float32)
+    p = MoePlan()
+    p.S, p.E, p.K, p.max_rows = S, E, K, S * K
+    p.offsets = torch.empty(E + 1, device=dev, dtype=torch.int32)
+    p.row_token = torch.empty(S * K, device=dev, dtype=torch.int32)
+    p.row_k = torch.empty(S * K, device=dev, dtype=torch.int32)
+    p.slot_of = torch.empty(S, K, device=dev, dtype=torch.int32)
+    xg = torch.empty(S * K, H, device=dev, dtype=blk2.dtype)
+    mean = torch.empty(S * K, device=dev, dtype=torch.float32)
+    rstd = torch.empty(S * K, device=dev, dtype=torch.float32)
+    check(lib.apertis_moe_enter_small(ptr(blk2), ptr(res2), ptr(_f32(weight)), ptr(_f32(bias)), float(eps), ptr(y), None,
+                                      ptr(_f32(r_ln_w)), ptr(_f32(r_ln_b)), float(r_eps), ptr(_f32(r_w)),
+                                      ptr(None if r_b is None else _f32(r_b)), ptr(logits), ptr(gates), ptr(idx), ptr(w),
+                                      ptr(p.offsets), ptr(p.row_token), ptr(p.row_k), ptr(p.slot_of), ptr(_f32(e_ln_w)),
+                                      ptr(_f32(e_ln_b)), float(e_eps), ptr(xg), ptr(mean), ptr(rstd), S, H, E, K,
+                                      dtype_code(res2), dtype_code(blk2), stream_ptr()), "apertis_moe_enter_small")
+    return y.reshape(shape), logits, w, p, xg
+
+
 class _GatherLN(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, plan, eps, out_dtype, link):

@@ -377,6 +377,17 @@ int apertis_tiny_linear_bwd_pad(const void *x, int64_t ldx, const float *W, cons
                                 int64_t N, int64_t zero_to, int dtype_x, void *stream);
 int64_t apertis_tiny_linear_bwd_blocks(int64_t T);
 
+/* The entrance of an MoE feed-forward for S <= 16 rows (the single-token decode step) in ONE launch:
+ * apertis_dropout_add_layernorm_router_fwd without dropout (y = res + blk, xn = LayerNorm(y), logits = Linear(router_norm(xn)))
+ * followed by apertis_moe_route_small on those logits and on xn - which stays in LDS (xn may be NULL).  The same arithmetic
+ * and outputs as the two calls; E in {4, 8}, E*K <= 16, H <= 1024; res / y fp32 (dtype_x), blk / xn / xg dtype_y. */
+int apertis_moe_enter_small(const void *blk, const void *res, const float *gamma, const float *beta,
+                            float eps, void *y, void *xn, const float *rgamma, const float *rbeta,
+                            float reps, const float *W, const float *rb, float *logits, float *gates,
+                            int32_t *idx, float *w, int32_t *expert_offsets, int32_t *row_token,
+                            int32_t *row_k, int32_t *slot_of, const float *lgamma, const float *lbeta,
+                            float leps, void *xg, float *mean, float *rstd, int64_t S, int64_t H,
+                            int64_t E, int64_t K, int dtype_x, int dtype_y, void *stream);
 /* A handful of tokens (S <= 64, E*K <= 16: the single-token decode step, core.py:1578-1603): apertis_moe_gate_topk_fwd,
  * apertis_moe_plan (no capacity, no dropped experts) and apertis_moe_gather_ln_fwd as ONE launch of one work-group - the same
  * arithmetic, the same outputs (gates [S,E], idx / w [S,K]; the plan; xg [S*K,H] with mean / rstd per row). */

@@ -1204,3 +1204,30 @@ def test_route_small_equals_gate_plan_gather(dev, S, E, K, H, dt):
     assert rows == S * K and torch.equal(plan0.offsets, plan1.offsets) and torch.equal(plan0.slot_of, plan1.slot_of)
     assert torch.equal(plan0.row_token[:rows], plan1.row_token[:rows]) and torch.equal(plan0.row_k[:rows], plan1.row_k[:rows])
     assert torch.equal(xg0[:rows], xg1[:rows])
+
+
+@pytest.mark.parametrize("S,E,K,H,dt", [(1, 8, 2, 704, torch.bfloat16), (16, 8, 2, 704, torch.bfloat16), (5, 4, 2, 256, torch.float32),
+                                        (3, 8, 1, 1024, torch.bfloat16)])
+def test_moe_entrance_of_a_handful_of_rows_in_one_launch(dev, S, E, K, H, dt):
+    """apertis_moe_enter_small (block boundary + router + gate + plan + gather-LN for <= 16 rows: the decode step) against
+    dropout_add_layer_norm_router followed by the gate / plan / gather-LN ops: every output bit-identical."""
+    from apertis_llm_amd import ops
+    torch.manual_seed(S * 7 + H)
+    blk, res = torch.randn(S, H).to(dt), torch.randn(S, H)
+    w, b = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    rw, rb = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    W, wb = torch.randn(E, H) / H ** 0.5, torch.randn(E) * 0.1
+    eg, eb = torch.randn(E, H) * 0.2 + 1, torch.randn(E, H) * 0.1
+    with torch.no_grad():
+        d = [t.to(dev) for t in (blk, res, w, b, rw, rb, W, wb, eg, eb)]
+        assert ops.moe_enter_small_supported(d[0], d[1], E, K)
+        y0, xn0, lg0 = ops.dropout_add_layer_norm_router(d[0], d[1], d[2], d[3], 1e-5, 0.1, False, d[4], d[5], 1e-5, d[6], d[7],
+                                                         out_dtype=dt)
+        _g, idx0, w0 = ops.moe_gate_topk(lg0, K)
+        plan0 = ops.moe_plan(idx0, w0, E)
+        xg0 = ops.moe_gather_ln(xn0, d[8], d[9], plan0, 1e-12, out_dtype=dt)
+        y1, lg1, w1, plan1, xg1 = ops.moe_enter_small(d[0], d[1], d[2], d[3], 1e-5, d[4], d[5], 1e-5, d[6], d[7], d[8], d[9], 1e-12, K)
+        torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(lg0, lg1) and torch.equal(w0, w1)
+    assert torch.equal(plan0.offsets, plan1.offsets) and torch.equal(plan0.slot_of, plan1.slot_of)
+    assert torch.equal(plan0.row_token[:S * K], plan1.row_token[:S * K]) and torch.equal(xg0[:S * K], xg1[:S * K])
