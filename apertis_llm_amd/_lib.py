@@ -76,6 +76,10 @@ SIGNATURES = {
                                         _i64, _i32, _vp]),
     "apertis_dwconv_bwd_blocks": (_i64, [_i64, _i64, _i64]),
     "apertis_moe_gate_topk_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "apertis_decode_pre_conv": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_decode_pre_state": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
+                                        _i32, _i32, _vp]),
+    "apertis_decode_post": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
     "apertis_moe_enter_small": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     "apertis_moe_route_small": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64,

@@ -198,6 +198,23 @@ class _LazyCombine:
         return ops.moe_combine(self.yr, self.w, self.plan, out_dtype=self.dtype).reshape(self.shape)
 
 
+class _StackedPast(list):
+    """generate()'s static cache of an all-SSM model as ONE tensor per kind - conv windows [NL,B,Dn,k-1], states [NL,B,Dn] fp32 -
+    with the usual per-layer (conv_state, ssm_state) tuples as views into them: the model then runs the cache-only half of a
+    token step for every layer at once (ApertisModel._decode_prepass)."""
+
+    def __init__(self, conv_all, state_all, heads, d_state):
+        NL, B = conv_all.shape[0], conv_all.shape[1]
+        super().__init__((conv_all[l], state_all[l].view(B, heads, d_state)) for l in range(NL))
+        self.conv_all, self.state_all = conv_all, state_all
+        self._offs = None
+
+    def offsets(self, NL, B):
+        if self._offs is None:
+            self._offs = (torch.arange(NL + 1, device=self.conv_all.device, dtype=torch.int32) * B).contiguous()
+        return self._offs
+
+
 class _Pending:
     """A sub-block's output that has not been added to the residual stream yet: the consumer either resolves
     it (`residual + dropout(out)`) or folds the add into its own pre-norm (`_enter_block`)."""
@@ -256,6 +273,8 @@ def _dropout_add(drop: nn.Dropout, out, residual):
 # graph (APERTIS_DECODE_GRAPH=0: always eager).  Capture costs about three eager steps.
 DECODE_GRAPH = os.environ.get("APERTIS_DECODE_GRAPH", "1") == "1"
 DECODE_GRAPH_MIN_STEPS = 24
+# APERTIS_DECODE_PREPASS=0: every layer runs its whole single-token SSM step itself (conv, x_param_proj, state update inside the layer loop)
+DECODE_PREPASS = os.environ.get("APERTIS_DECODE_PREPASS", "1") == "1"
 
 
 def _mfma_linear(x, weight, bias=None):
@@ -341,6 +360,7 @@ class SelectiveLinearAttention(nn.Module):
         self.use_cache = False
         self._pad_idx = None
         self._inplace_cache = False     # generate()'s graph replay: the single-token step updates the SSM state it is handed
+        self._decode_pre = None         # this layer's  C s + D xc  of the current token step, when the model ran it ahead
 
     def _pad_index(self, device):
         """Destination row of every row of x_param_proj.weight ([dt | Bt | C]) in the padded layout [Bt | 0 | C | 0 | dt | 0]."""
@@ -406,6 +426,13 @@ class SelectiveLinearAttention(nn.Module):
             # single-token decode step (generate(), core.py:1578-1603): two small kernels around the projections
             # instead of the chunk machinery
             xz2 = xz.reshape(B, 2 * Dn)
+            pre, self._decode_pre = self._decode_pre, None
+            if pre is not None:
+                # the step's first half - conv, x_param_proj, dt, state update: functions of the caches alone - ran for every
+                # layer at the start of the token step (ApertisModel._decode_prepass); the gate and the window push are left
+                gated = ops.decode_post(pre, xz2, conv_prev)
+                out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight)
+                return out, None, (conv_prev, ssm_prev)
             xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias,
                                                  inplace=self._inplace_cache)
             p = _mfma_linear(xc, wp)                                                   # [B, 2*Wb + Wr]
@@ -1001,10 +1028,15 @@ class ApertisModel(nn.Module):
 
         all_hs, all_att, all_cache = [], [], []
         lbs, rzs = [], []
+        pre_all = None
+        if isinstance(past_key_values, _StackedPast) and x.shape[1] == 1 and use_c and not out_att and not torch.is_grad_enabled():
+            pre_all = self._decode_prepass(past_key_values)
         for i, layer in enumerate(self.layers):
             if out_hs:
                 all_hs.append(x)
             past = past_key_values[i] if past_key_values and i < len(past_key_values) else None
+            if pre_all is not None:
+                layer.attention.attention_mechanism_impl._decode_pre = pre_all[i]
             if self.gradient_checkpointing and self.training and not use_c:             # core.py:1258
                 x, att_w, cache, lb, rz = torch.utils.checkpoint.checkpoint(layer, x, mask, pos_layers, past, out_att,
                                                                             use_c, use_reentrant=False)
@@ -1028,6 +1060,44 @@ class ApertisModel(nn.Module):
         return (x, tuple(all_hs) if out_hs and all_hs else None, tuple(all_att) if out_att and all_att else None,
                 tuple(all_cache) if use_c and all_cache else None,
                 lb_tot if cfg.use_expert_system else None, rz_tot if cfg.use_expert_system else None)
+
+    def _decode_prepass(self, st):
+        """The cache-only half of a single-token step for ALL layers in three launches (csrc/decode_step.hip): the reference keeps
+        the FIRST conv output of [cached window | new xp] (core.py:369-373), which sees window[0] only, so conv output,
+        x_param_proj, dt projection and state update of a token step do not depend on the token.  Returns pre [NL,B,Dn] fp32 =
+        C s + D xc per layer (the states in `st.state_all` are updated in place), or None when the stack is not uniform."""
+        impls = [l.attention.attention_mechanism_impl for l in self.layers]
+        m0 = impls[0]
+        NL = len(impls)
+        if (NL == 0 or any(not isinstance(m, SelectiveLinearAttention) for m in impls) or st.conv_all.shape[0] != NL
+                or not st.conv_all.is_cuda or m0.conv_kernel_size < 2 or m0.conv_kernel_size > 16
+                or st.conv_all.dtype not in (torch.float32, torch.bfloat16)):
+            return None
+        Dn, R, h, N = m0.d_inner, m0.dt_rank, m0.num_heads, m0.d_state
+        if any((m.d_inner, m.dt_rank, m.num_heads, m.d_state, m.conv_kernel_size) != (Dn, R, h, N, m0.conv_kernel_size) for m in impls):
+            return None
+        B = st.conv_all.shape[1]
+        if any((m.dt_proj_head.bias is None) != (m0.dt_proj_head.bias is None) or m.conv1d.bias is None for m in impls):
+            return None
+        srcs = tuple(t for m in impls for t in (m.conv1d.weight, m.conv1d.bias, m.x_param_proj.weight, m.dt_proj_head.weight,
+                                               m.dt_proj_head.bias, m.A_log, m.D) if t is not None)
+
+        def make():
+            pads = [m._padded_param_weight() for m in impls]
+            return (torch.stack([m.conv1d.weight.detach().float().reshape(Dn, -1) for m in impls]).contiguous(),
+                    torch.stack([m.conv1d.bias.detach().float() for m in impls]).contiguous(),
+                    torch.stack([p[0].detach().float() for p in pads]).contiguous(),
+                    torch.stack([m.dt_proj_head.weight.detach().float() for m in impls]).contiguous(),
+                    (None if impls[0].dt_proj_head.bias is None else
+                     torch.stack([m.dt_proj_head.bias.detach().float() for m in impls]).contiguous()),
+                    torch.stack([m.A_log.detach().float() for m in impls]).contiguous(),
+                    torch.stack([m.D.detach().float() for m in impls]).contiguous(), pads[0][1], pads[0][2])
+
+        conv_w, conv_b, wp, w_dt, b_dt, a_log, d_all, Wb, Wr = ops.cached_prep(("decode_stack", id(self)), srcs, make)
+        xc_all = ops.decode_pre_conv(st.conv_all, conv_w, conv_b)
+        offs = st.offsets(NL, B)
+        p_all = ops.grouped_linear(xc_all.reshape(NL * B, Dn), wp, None, offs, NL * B, compute_dtype=xc_all.dtype)
+        return ops.decode_pre_state(p_all, 0, Wb, 2 * Wb, w_dt, b_dt, a_log, d_all, xc_all, st.state_all)
 
     def vision_projection_forward(self, feats):
         """Linear(vision_embed_dim -> hidden) on the MFMA GEMM tile (core.py:1035,1209)."""
@@ -1244,6 +1314,13 @@ class ApertisForCausalLM(nn.Module):
         # (contiguous copies: the prefill hands the conv window over as a transposed view, and a cache that is not contiguous
         #  is copied in and out of every token step instead of being updated in place - two launches per layer)
         s_past = [(c.clone(memory_format=torch.contiguous_format), st.clone(memory_format=torch.contiguous_format)) for (c, st) in past]
+        if (DECODE_PREPASS and len(s_past) > 0 and all(c.dim() == 3 and st.dim() == 3 and st.dtype == torch.float32 and
+                                                       c.shape == s_past[0][0].shape and st.shape == s_past[0][1].shape
+                                                       and c.dtype == s_past[0][0].dtype for c, st in s_past)):
+            # one tensor per kind, the per-layer caches as views: the cache-only half of every layer's step runs at once
+            conv_all = torch.stack([c for c, _ in s_past]).contiguous()
+            state_all = torch.stack([st.reshape(st.shape[0], -1) for _, st in s_past]).contiguous()
+            s_past = _StackedPast(conv_all, state_all, s_past[0][1].shape[1], s_past[0][1].shape[2])
         s_alive = alive.clone()
         s_idx = torch.zeros(1, dtype=torch.long, device=dev)
         s_out = torch.full((B, left), pad, dtype=tokens.dtype, device=dev)

@@ -641,6 +641,50 @@ def ssm_decode_state_dt(dt_in, W_dt, b_dt, A_log, Bt, C, xc, z, D, state, delta_
     return out
 
 
+def decode_pre_conv(conv_all, conv_w, conv_b):
+    """The conv output of a single-token step for ALL layers at once (csrc/decode_step.hip): conv_all [NL,B,Dn,k-1] (the cached
+    windows), conv_w [NL,Dn,k], conv_b [NL,Dn] fp32 -> xc [NL,B,Dn].  The values ssm_decode_step returns per layer."""
+    _require_gpu(conv_all, conv_w, conv_b)
+    lib = _lib.load()
+    NL, B, Dn, km1 = conv_all.shape
+    xc = torch.empty(NL, B, Dn, device=conv_all.device, dtype=conv_all.dtype)
+    check(lib.apertis_decode_pre_conv(ptr(conv_all), ptr(conv_w), ptr(conv_b), ptr(xc), NL, B, Dn, km1 + 1, dtype_code(conv_all),
+                                      stream_ptr()), "apertis_decode_pre_conv")
+    return xc
+
+
+def decode_pre_state(p_all, off_bt, off_c, off_dt, W_dt, b_dt, A_log, D, xc_all, state_all, delta_softplus=True):
+    """dt_proj_head + state update of ALL layers at once: p_all [NL*B, P] (the x_param_proj outputs: Bt / C / dt columns at the
+    given offsets), W_dt [NL,h,R], b_dt [NL,h] or None, A_log [NL,h,N], D [NL,Dn], xc_all [NL,B,Dn]; state_all [NL,B,Dn] fp32 is
+    updated in place.  Returns pre [NL,B,Dn] fp32 = C s + D xc (what ssm_decode_state multiplies by silu(z))."""
+    _require_gpu(p_all, W_dt, A_log, D, xc_all, state_all)
+    lib = _lib.load()
+    NL, B, Dn = xc_all.shape
+    h, N = A_log.shape[1], A_log.shape[2]
+    R = W_dt.shape[2]
+    if state_all.dtype != torch.float32 or not state_all.is_contiguous() or not p_all.is_contiguous() or p_all.dtype != xc_all.dtype:
+        raise ApertisHipError("decode_pre_state: contiguous fp32 states, p and xc of one dtype")
+    pre = torch.empty(NL, B, Dn, device=xc_all.device, dtype=torch.float32)
+    check(lib.apertis_decode_pre_state(ptr(p_all), p_all.shape[1], off_bt, off_c, off_dt, ptr(W_dt), ptr(b_dt), R, ptr(A_log), ptr(D),
+                                       ptr(xc_all), ptr(state_all), ptr(pre), NL, B, h, N, int(delta_softplus), dtype_code(xc_all),
+                                       stream_ptr()), "apertis_decode_pre_state")
+    return pre
+
+
+def decode_post(pre, xz, conv_state):
+    """Between in_proj and out_proj of a single-token step whose first half ran ahead (decode_pre_*): gated [B,Dn] =
+    pre * silu(z) with xz [B, 2 Dn] = (xp | z), and xp is pushed into conv_state [B,Dn,k-1] IN PLACE."""
+    _require_gpu(pre, xz, conv_state)
+    lib = _lib.load()
+    B, Dn = pre.shape
+    if xz.stride(-1) != 1 or conv_state.dtype != xz.dtype or not conv_state.is_contiguous() or not pre.is_contiguous():
+        raise ApertisHipError("decode_post: xz rows contiguous, the window contiguous and of xz's dtype")
+    gated = torch.empty(B, Dn, device=xz.device, dtype=xz.dtype)
+    check(lib.apertis_decode_post(ptr(pre), ptr(xz), xz.stride(0), ptr(conv_state), ptr(gated), B, Dn, conv_state.shape[-1] + 1,
+                                  dtype_code(xz), stream_ptr()), "apertis_decode_post")
+    return gated
+
+
 # ----------------------------------------------------------------------------------------------
 # SSM companions: depthwise causal conv + SiLU, post-scan gate
 # ----------------------------------------------------------------------------------------------

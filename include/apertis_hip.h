@@ -211,6 +211,25 @@ int apertis_scan_lookback_bwd(const float *dlt, const float *A_log, const void *
                               int64_t store_w, void *dxc, int64_t dxc_rs, void *dz, int64_t dz_rs, float *d_dlt, float *dA_dD,
                               float *fold, float *part, void *ws, uint32_t epoch, int64_t B, int64_t L, int64_t h, int64_t N,
                               int delta_softplus, void *stream);
+/* Single-token decode step, re-ordered (csrc/decode_step.hip; core.py:364-400 with L = 1, called by generate() :1578-1603): the
+ * reference keeps the FIRST conv output of [cached window | new xp] - which sees window[0] only -, so the conv output, x_param_proj,
+ * the dt projection, the state update and  pre = C s + D xc  of EVERY layer depend on the caches alone and run at the start of
+ * the token step, the NL layers as one more batch dimension:
+ *   apertis_decode_pre_conv   conv_state [NL,B,Dn,k-1], w [NL,Dn,k], bias [NL,Dn] -> xc [NL,B,Dn]        (apertis_ssm_decode_conv's value)
+ *   (x_param_proj of all layers: apertis_grouped_gemm_nt with one group per layer)
+ *   apertis_decode_pre_state  p [NL*B, p_rs] (columns off_bt / off_c: Bt, C of width h*N; off_dt: the R dt columns), W_dt [NL,h,R],
+ *                             b_dt [NL,h] or NULL, A_log [NL,h,N], D [NL,h*N], xc -> state [NL,B,h*N] fp32 in place, pre [NL,B,h*N] fp32
+ * and per layer, between in_proj and out_proj:
+ *   apertis_decode_post       pre [B,Dn], xz [B, >= 2 Dn] (xp | z) -> gated [B,Dn] = pre * silu(z); conv_state [B,Dn,k-1] shifted by xp
+ * Same arithmetic as apertis_ssm_decode_conv + apertis_ssm_decode_state_dt: bit-identical values and caches.  2 <= k <= 16. */
+int apertis_decode_pre_conv(const void *conv_state, const float *w, const float *bias, void *xc, int64_t NL,
+                            int64_t B, int64_t Dn, int64_t k, int dtype, void *stream);
+int apertis_decode_pre_state(const void *p, int64_t p_rs, int64_t off_bt, int64_t off_c, int64_t off_dt,
+                             const float *W_dt, const float *b_dt, int64_t R, const float *A_log,
+                             const float *D, const void *xc, float *state, float *pre, int64_t NL, int64_t B,
+                             int64_t h, int64_t N, int delta_softplus, int dtype, void *stream);
+int apertis_decode_post(const float *pre, const void *xz, int64_t xz_rs, void *conv_state, void *gated,
+                        int64_t B, int64_t Dn, int64_t k, int dtype, void *stream);
 /* Single-token decode step of the SSM block (core.py:364-400 with L = 1 and a cache, called from generate()
  * core.py:1578-1603), two kernels around the caller's x_param_proj / dt projections:
  *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the

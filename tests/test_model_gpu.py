@@ -735,3 +735,60 @@ def test_train_step_overfits_one_batch(dev):
     assert losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert sum(losses[60:]) / 20 < sum(losses[20:40]) / 20 < sum(losses[:20]) / 20
     assert ops.scan_gate_error(dev) == 0
+
+
+@pytest.mark.parametrize("experts,bf16,batch", [(8, True, 1), (8, True, 16), (0, False, 3), (4, True, 5)])
+def test_decode_prepass_runs_the_cache_only_half_of_every_layer_at_once(dev, experts, bf16, batch):
+    """The reference keeps the FIRST conv output of [cached window | new xp] (core.py:369-373), so conv output, x_param_proj, dt
+    projection and state update of a single-token step are functions of the caches alone: with the caches stacked
+    (model._StackedPast) the model runs them for all layers in three launches at the start of the step (_decode_prepass,
+    csrc/decode_step.hip).  Against the ordinary per-layer steps over ten tokens: logits, conv windows and states bit-identical."""
+    import contextlib
+    import apertis_llm_amd as A
+    from apertis_llm_amd import model as M, ops
+    torch.manual_seed(17)
+    cfg = A.ApertisConfig(vocab_size=131, hidden_size=128, num_hidden_layers=4, num_attention_heads=4, intermediate_size=256,
+                          attention_type="selective_ssm", use_expert_system=experts > 0, num_experts=max(experts, 1),
+                          experts_per_token=2 if experts else 1, pad_token_id=0)
+    model = A.ApertisForCausalLM(cfg).to(dev).eval()
+    prompt = torch.randint(4, 131, (batch, 19), device=dev)
+    ac = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if bf16 else contextlib.nullcontext
+
+    def run(stacked):
+        outs = []
+        with torch.no_grad(), ac(), ops.prep_cache_scope():
+            o = model(input_ids=prompt, use_cache=True)
+            past = [(c.clone(memory_format=torch.contiguous_format), st.clone()) for c, st in o[4]]
+            if stacked:
+                past = M._StackedPast(torch.stack([c for c, _ in past]).contiguous(),
+                                      torch.stack([st.reshape(batch, -1) for _, st in past]).contiguous(), past[0][1].shape[1], past[0][1].shape[2])
+            tok = o[1][:, -1].argmax(-1, keepdim=True)
+            for _ in range(10):
+                o = model(input_ids=tok, past_key_values=past, use_cache=True)
+                if not stacked:
+                    past = o[4]
+                tok = o[1][:, -1].argmax(-1, keepdim=True)
+                outs.append(o[1].float().clone())
+        torch.cuda.synchronize()
+        return outs, [(c.clone(), s.clone()) for c, s in past]
+
+    base, cache0 = run(False)
+    calls = {"n": 0}
+    real = model.model._decode_prepass
+
+    def spy(st):
+        calls["n"] += 1
+        r = real(st)
+        assert r is not None
+        return r
+
+    model.model._decode_prepass = spy
+    try:
+        fused, cache1 = run(True)
+    finally:
+        del model.model._decode_prepass
+    assert calls["n"] == 10
+    for a, b in zip(base, fused):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    for (c0, s0), (c1, s1) in zip(cache0, cache1):
+        assert torch.equal(c0.reshape(c1.shape), c1) and torch.equal(s0.reshape(s1.shape), s1)
