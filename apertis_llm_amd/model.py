@@ -430,9 +430,11 @@ class SelectiveLinearAttention(nn.Module):
             if pre is not None:
                 # the step's first half - conv, x_param_proj, dt, state update: functions of the caches alone - ran for every
                 # layer at the start of the token step (ApertisModel._decode_prepass); the gate and the window push are left
-                gated = ops.decode_post(pre, xz2, conv_prev)
-                out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight)
-                return out, None, (conv_prev, ssm_prev)
+                out = ops.decode_gate_outproj(pre, xz2, conv_prev, self.out_proj.weight, self.out_proj.bias)
+                if out is None:
+                    gated = ops.decode_post(pre, xz2, conv_prev)
+                    out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight, self.out_proj.bias)
+                return out.reshape(B, 1, -1), None, (conv_prev, ssm_prev)
             xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias,
                                                  inplace=self._inplace_cache)
             p = _mfma_linear(xc, wp)                                                   # [B, 2*Wb + Wr]

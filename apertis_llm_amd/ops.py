@@ -685,6 +685,26 @@ def decode_post(pre, xz, conv_state):
     return gated
 
 
+def decode_gate_outproj(pre, xz, conv_state, weight, bias=None):
+    """decode_post + the out_proj product as ONE launch (bf16, <= 16 rows): returns out [B, N] = (pre * silu(z)) @ weight.T
+    (+ bias), the window pushed in place; None when the shapes are not the kernel's (the caller runs the two ops)."""
+    lib = _lib.load()
+    B, Dn = pre.shape
+    N = weight.shape[0]
+    # (B <= 4: every work-group forms the B x Dn gated values for itself with one wave - at B = 16 that prologue costs more than
+    #  the launch it saves: 5742 -> 4655 tokens/s; the entry point itself takes B <= 16)
+    if not (xz.dtype == torch.bfloat16 and conv_state.dtype == torch.bfloat16 and B <= 4 and Dn % 8 == 0 and Dn < 512 and N % 4 == 0
+            and xz.stride(-1) == 1 and conv_state.is_contiguous() and pre.is_contiguous() and 2 <= conv_state.shape[-1] + 1 <= 16):
+        return None
+    _require_gpu(pre, xz, conv_state, weight)
+    wc = cast_transpose(weight.unsqueeze(0), torch.bfloat16, want_transposed=False, cache=True)[0]      # [1, N, Dn padded to 64]
+    out = torch.empty(B, N, device=xz.device, dtype=torch.bfloat16)
+    check(lib.apertis_decode_gate_outproj(ptr(pre), ptr(xz), xz.stride(0), ptr(conv_state), ptr(wc), wc.shape[-1],
+                                          ptr(None if bias is None else _f32(bias)), ptr(out), B, Dn, N, conv_state.shape[-1] + 1,
+                                          stream_ptr()), "apertis_decode_gate_outproj")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # SSM companions: depthwise causal conv + SiLU, post-scan gate
 # ----------------------------------------------------------------------------------------------

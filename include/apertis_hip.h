@@ -230,6 +230,12 @@ int apertis_decode_pre_state(const void *p, int64_t p_rs, int64_t off_bt, int64_
                              int64_t h, int64_t N, int delta_softplus, int dtype, void *stream);
 int apertis_decode_post(const float *pre, const void *xz, int64_t xz_rs, void *conv_state, void *gated,
                         int64_t B, int64_t Dn, int64_t k, int dtype, void *stream);
+/* apertis_decode_post as the prologue of the out_proj product (bf16, B <= 16, Dn < 512): out [B,N] = gated W^T (+ bias) with
+ * W [N, ldw] bf16 (K = Dn zero-padded to ldw) - apertis_grouped_gemm_nt's skinny kernel for a handful of rows, the same bits -,
+ * gated formed by every work-group for itself, the window push spread over the work-groups. */
+int apertis_decode_gate_outproj(const float *pre, const void *xz, int64_t xz_rs, void *conv_state,
+                                const void *W, int64_t ldw, const float *bias, void *out, int64_t B,
+                                int64_t Dn, int64_t N, int64_t k, void *stream);
 /* Single-token decode step of the SSM block (core.py:364-400 with L = 1 and a cache, called from generate()
  * core.py:1578-1603), two kernels around the caller's x_param_proj / dt projections:
  *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the
