@@ -2957,7 +2957,10 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // a handful of rows (the decode step): a wave per 16 output columns, operands straight from global memory
     if (max_rows <= 64 && !flagged && !pre_act && !mul_pre && drop_p <= 0.f && K % 8 == 0 && N % 4 == 0 && ldw % 8 == 0 && E <= 65535 &&
         ceil_div64(N, 16) <= 0x7fffffff) {
-      if (K >= 512)   // (a wave's share is then one batch of eight 32-deep steps or a few: the K walk is a chain of round trips)
+      if (K >= 2048)  // (sixteen waves: a wave's share of K = 2816 is six 32-deep steps = ONE batch in flight instead of three dependent ones)
+        hipLaunchKernelGGL((grouped_gemm_nt_skinny_k<TO, 16>), dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(1024), 0, st,
+                           (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
+      else if (K >= 512)   // (a wave's share is then one batch of eight 32-deep steps or a few: the K walk is a chain of round trips)
         hipLaunchKernelGGL((grouped_gemm_nt_skinny_k<TO, 4>), dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(256), 0, st,
                            (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
       else

@@ -2218,6 +2218,130 @@ moe_enter_small_k(const TO *__restrict__ blk, const TX *__restrict__ res, const 
 }
 
 // ------------------------------------------------------------------------------------------
+// Single-token decode step (S <= 16 rows, bf16 activations, fp32 residual stream): the block boundary in front of the SSM block
+// - y = res + blk (blk dense, or the MoE combine sum_k wk yr[slot_of] taken on the fly), xn = LayerNorm(y): dropadd_ln_fwd_k's
+// arithmetic without dropout - as the PROLOGUE of the in_proj product xz = xn W^T: every work-group of the skinny NT kernel
+// (grouped_gemm_nt_skinny_k<KS = 4>, grouped_gemm.hip: 16 output columns per work-group, four waves that split K in
+// 32-aligned quarters and meet in LDS in wave order; W rows on the MFMA A operand straight from global memory, requested
+// first) normalises the S rows for itself into LDS - no dependency between work-groups, the weight stream stays spread over
+// the chip; work-group 0 also writes y.  The same bits as the two launches it replaces.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) bf16_t dl_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float dl_f32x4;
+
+template <int IT>
+__global__ void __launch_bounds__(256)
+decode_ln_inproj_k(const bf16_t *__restrict__ blk, const int32_t *__restrict__ slot_of, const float *__restrict__ wk, int KK,
+                   const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                   float *__restrict__ y, const bf16_t *__restrict__ W, int ldw, bf16_t *__restrict__ out, int S, int H, int N) {
+  if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
+  constexpr int KS = 4, U = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t *sX = reinterpret_cast<bf16_t *>(smem);                 // [S][H]: xn as stored
+  __shared__ dl_f32x4 s_part[KS - 1][64];
+  const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6, n0 = blockIdx.x * 16;
+  const int K = H;
+  const int kq = ((K + KS * 32 - 1) / (KS * 32)) * 32;          // this wave's K range: [ks * kq, min(K, ks * kq + kq))
+  const int kbeg = ks * kq, kend = min(K, kbeg + kq);
+  const int l15 = lane & 15, fg = lane >> 4, kc = fg * 8;
+  const int wcol = n0 + l15;
+  const bf16_t *wrow = W + (int64_t)min(wcol, N - 1) * ldw;
+  const bool w_ok = wcol < N;
+  const dl_bf16x8 zero = {};
+  dl_bf16x8 a0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {          // the wave's first batch of W (all of it for K <= 1024)
+    const int k = kbeg + u * 32 + kc;
+    a0[u] = (k < kend && w_ok) ? *reinterpret_cast<const dl_bf16x8 *>(wrow + k) : zero;
+  }
+  // ---- the boundary: a wave per row (dropadd_ln_fwd_k, drop_p = 0) ----
+  for (int r = ks; r < S; r += KS) {
+    float4 v[IT];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float4 a;
+        if (slot_of) {
+          float4 acc = make_float4(0, 0, 0, 0);
+          for (int k = 0; k < KK; ++k) {
+            const int slot = slot_of[r * KK + k];
+            if (slot < 0) continue;
+            const float wv = wk[r * KK + k];
+            const float4 t = load4s<bf16_t>(blk + (int64_t)slot * H + c);
+            acc.x += t.x * wv; acc.y += t.y * wv; acc.z += t.z * wv; acc.w += t.w * wv;
+          }
+          a = make_float4(to_f32(from_f32<bf16_t>(acc.x)), to_f32(from_f32<bf16_t>(acc.y)), to_f32(from_f32<bf16_t>(acc.z)), to_f32(from_f32<bf16_t>(acc.w)));
+        } else {
+          a = load4s<bf16_t>(blk + (int64_t)r * H + c);
+        }
+        const float4 rr = load4s<float>(res + (int64_t)r * H + c);
+        v[i] = make_float4(rr.x + a.x, rr.y + a.y, rr.z + a.z, rr.w + a.w);
+        if (blockIdx.x == 0) store4<float>(y + (int64_t)r * H + c, v[i]);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    const float mean = wave_sum(sum) * inv_h(H);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + eps);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        const float4 g4 = load4<float>(gamma + c), b4 = load4<float>(beta + c);
+        typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
+        const bf4 pk = {(bf16_t)((v[i].x - mean) * rstd * g4.x + b4.x), (bf16_t)((v[i].y - mean) * rstd * g4.y + b4.y),
+                        (bf16_t)((v[i].z - mean) * rstd * g4.z + b4.z), (bf16_t)((v[i].w - mean) * rstd * g4.w + b4.w)};
+        *reinterpret_cast<bf4 *>(sX + (int64_t)r * H + c) = pk;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the product (grouped_gemm_nt_skinny_k<TO, 4>, one block of <= 16 rows) ----
+  const bool x_ok = l15 < S;
+  const bf16_t *xrow = sX + (int64_t)min(l15, S - 1) * H;
+  dl_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kbeg; k0 < kend; k0 += 32 * U) {
+    dl_bf16x8 a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * 32 + kc;
+      const bool ok = k < kend;
+      a[u] = k0 == kbeg ? a0[u] : ((ok && w_ok) ? *reinterpret_cast<const dl_bf16x8 *>(wrow + k) : zero);
+      b[u] = (ok && x_ok) ? *reinterpret_cast<const dl_bf16x8 *>(xrow + k) : zero;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+  }
+  if (ks > 0) s_part[ks - 1][lane] = acc;
+  __syncthreads();
+  if (ks == 0) {
+#pragma unroll
+    for (int w2 = 0; w2 < KS - 1; ++w2) { const dl_f32x4 t = s_part[w2][lane]; acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3]; }
+    const int nq = n0 + fg * 4;
+    if (x_ok && nq < N) {
+      bf16_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = from_f32<bf16_t>(acc[q] + 0.f);
+      bf16_t *dst = out + (int64_t)l15 * N + nq;
+      if (nq + 3 < N) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
+      else for (int q = 0; q < 4 && nq + q < N; ++q) dst[q] = o[q];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Router backward (dx half) + the boundary's LayerNorm backward in ONE pass over the rows (round 5).  In front of an MoE
 // feed-forward the two kernels run back to back on the same rows: router_bwd3_k<MODE 1> writes the total gradient of the
 // normalised stream xn ([T,H] in the compute dtype) and layernorm_bwd_k reads it straight back as its `dy` - 2 x 253 MB per
@@ -3059,6 +3183,21 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
                                   float *grads, int64_t T, int64_t H, int64_t N, int dtype_x, void *stream) {
   return apertis_router_bwd_rows(x, gamma, beta, mean, rstd, W, dlogits, dres, nullptr, nullptr, 0, dx, part, grads, T, H, N,
                                  dtype_x, stream);
+}
+
+extern "C" int apertis_decode_ln_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK, const float *res,
+                                        const float *gamma, const float *beta, float eps, float *y, const void *W, int64_t ldw,
+                                        void *out, int64_t S, int64_t H, int64_t N, void *stream) {
+  if (!blk || !res || !gamma || !beta || !y || !W || !out || (slot_of && (!wk || KK < 1))) return APERTIS_ERR_ARG;
+  if (S < 1 || S > 16 || H < 512 || H % 8 || H > 1024 || N < 4 || N % 4 || ldw < H || ldw % 8) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)ceil_div64(N, 16)), block(256);
+  const size_t lds = (size_t)S * H * 2;
+#define DL_GO { hipLaunchKernelGGL((decode_ln_inproj_k<IT>), grid, block, lds, st, (const bf16_t *)blk, slot_of, wk, (int)KK, res, gamma, beta, \
+                                   eps, y, (const bf16_t *)W, (int)ldw, (bf16_t *)out, (int)S, (int)H, (int)N); }
+  SKINNY_IT(H, DL_GO);
+#undef DL_GO
+  return apertis_check_launch();
 }
 
 extern "C" int apertis_moe_enter_small(const void *blk, const void *res, const float *gamma, const float *beta, float eps, void *y,

@@ -397,6 +397,26 @@ class SelectiveLinearAttention(nn.Module):
         zr = w.new_zeros(Wr - R, Dn)
         return torch.cat([w[R:R + Dn], zb, w[R + Dn:], zb, w[:R], zr], dim=0), Wb, Wr
 
+    def _stacked_in_proj(self):
+        """in_proj_x | in_proj_z as one [2 Dn, H] weight (core.py:366-367 share their input): prepared per step / per generate()."""
+        w_xz = ops.prepared_weight(("in_proj_xz", id(self)), (self.in_proj_x.weight, self.in_proj_z.weight))
+        if w_xz is None:
+            w_xz = ops.cached_prep("in_proj_xz", (self.in_proj_x.weight, self.in_proj_z.weight),
+                                   lambda: torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
+        return w_xz
+
+    def decode_from_xz(self, xz2, past_key_value):
+        """The rest of a single-token step whose cache-only half ran ahead (`_decode_pre`) and whose in_proj output xz2 [B, 2 Dn]
+        the caller formed (ops.decode_ln_inproj): the gate, the window push, out_proj."""
+        conv_prev, ssm_prev = past_key_value
+        pre, self._decode_pre = self._decode_pre, None
+        B, Dn = xz2.shape[0], self.d_inner
+        out = ops.decode_gate_outproj(pre, xz2, conv_prev, self.out_proj.weight, self.out_proj.bias)
+        if out is None:
+            gated = ops.decode_post(pre, xz2, conv_prev)
+            out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight, self.out_proj.bias)
+        return out.reshape(B, 1, -1), None, (conv_prev, ssm_prev)
+
     @_on_input_device
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions: bool = False, use_cache: bool = False):
@@ -412,11 +432,7 @@ class SelectiveLinearAttention(nn.Module):
         # (under no_grad - generate() - the stacked and the padded weight are prepared once, not per token)
         # (inside a training step the stacked and the padded weight come prepared - ops.TrainPrep: one launch per step for the
         # whole model - and these are placeholders that carry shape and gradient route only)
-        w_xz = ops.prepared_weight(("in_proj_xz", id(self)), (self.in_proj_x.weight, self.in_proj_z.weight))
-        if w_xz is None:
-            w_xz = ops.cached_prep("in_proj_xz", (self.in_proj_x.weight, self.in_proj_z.weight),
-                                   lambda: torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
-        xz = _mfma_linear(hidden_states, w_xz)
+        xz = _mfma_linear(hidden_states, self._stacked_in_proj())
         Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
         wp = ops.prepared_weight(("x_param_padded", id(self)), (self.x_param_proj.weight,))
         if wp is None:
@@ -729,6 +745,30 @@ class ApertisAttention(nn.Module):
         if config.position_embedding_type == "rotary" and not self._ssm:
             self.rope = RotaryEmbedding(config.hidden_size, config.max_position_embeddings, config.rope_theta)
 
+    def _decode_entry(self, h, past_kv, use_c, output_att):
+        """A single-token step whose cache-only half ran ahead (the SSM module's `_decode_pre` is set): the block boundary as the
+        prologue of the in_proj product (ops.decode_ln_inproj), then the rest of the step.  None: the general path."""
+        impl = self.attention_mechanism_impl
+        if (impl._decode_pre is None or not isinstance(h, _Pending) or past_kv is None or not use_c or output_att
+                or not isinstance(self.pre_norm, HipLayerNorm) or torch.is_grad_enabled() or self.training):
+            return None
+        out, res = h.out, h.res
+        if res.shape[1] != 1 or not res.is_cuda:
+            return None
+        lazy = out if isinstance(out, _LazyCombine) else None
+        if lazy is not None:
+            r = ops.decode_ln_inproj(lazy.yr, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, impl._stacked_in_proj(),
+                                     combine=(lazy.w, lazy.plan)) if lazy.yr.dtype == torch.bfloat16 == lazy.dtype else None
+        elif isinstance(out, torch.Tensor) and tuple(out.shape) == tuple(res.shape):
+            r = ops.decode_ln_inproj(out, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, impl._stacked_in_proj()) \
+                if out.dtype == torch.bfloat16 else None
+        else:
+            r = None
+        if r is None:
+            return None
+        y, xz2 = r
+        return y, impl.decode_from_xz(xz2, past_kv)
+
     def _heads(self, t):
         B, L, _ = t.shape
         return t.view(B, L, self.num_attention_heads, self.attention_head_size).transpose(1, 2)
@@ -736,8 +776,14 @@ class ApertisAttention(nn.Module):
     def forward(self, hidden_s, att_mask=None, pos_ids=None, past_kv=None, output_att=False, use_c=False, defer=False):
         """hidden_s: the residual stream, or the previous sub-block's _Pending output (its residual add is then
         folded into this block's pre-norm).  defer=True returns this block's output as a _Pending too."""
-        x, hidden_s = _enter_block(self.pre_norm, hidden_s)
-        if self._ssm:
+        fused = self._decode_entry(hidden_s, past_kv, use_c, output_att) if self._ssm else None
+        if fused is not None:
+            hidden_s, (out, proxy, cache) = fused
+        else:
+            x, hidden_s = _enter_block(self.pre_norm, hidden_s)
+        if fused is not None:
+            pass
+        elif self._ssm:
             out, proxy, cache = self.attention_mechanism_impl(x, attention_mask=att_mask, position_ids=pos_ids,
                                                               past_key_value=past_kv, output_attentions=output_att,
                                                               use_cache=use_c)

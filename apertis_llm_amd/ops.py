@@ -685,6 +685,40 @@ def decode_post(pre, xz, conv_state):
     return gated
 
 
+def decode_ln_inproj(blk, res, weight, bias, eps, w_in, combine=None):
+    """dropout_add_layer_norm (inference: no dropout; combine=(w, plan): blk is the MoE expert output and the block output its
+    weighted combine) + the in_proj product as ONE launch for <= 16 rows of a single-token step (bf16 activations, fp32
+    residual stream): returns (y, xz) with xz [S, N] = LayerNorm(y) @ w_in.T, or None when the shapes are not the kernel's."""
+    lib = _lib.load()
+    H = res.shape[-1]
+    S = res.numel() // H
+    N = w_in.shape[0]
+    # (S <= 2: every work-group normalises the S rows for itself - at S = 16 that prologue costs far more than the launch it
+    #  saves: 5553 -> 4519 tokens/s; the entry point itself takes S <= 16)
+    if not (res.is_cuda and not torch.is_grad_enabled() and 1 <= S <= 2 and 512 <= H <= 1024 and H % 8 == 0 and N % 4 == 0
+            and res.dtype == torch.float32 and blk.dtype == torch.bfloat16 and tuple(w_in.shape) == (N, H)):
+        return None
+    _require_gpu(blk, res, weight, bias, w_in)
+    res2 = res.reshape(S, H).contiguous()
+    blk2 = blk.reshape(-1, H).contiguous()
+    wk = slot = None
+    KK = 0
+    if combine is not None:
+        wv, plan = combine
+        wk, slot, KK = _f32(wv), plan.slot_of, plan.K
+    elif blk2.shape[0] != S:
+        return None
+    wc = cast_transpose(w_in.unsqueeze(0), torch.bfloat16, want_transposed=False, cache=True)[0]       # [1, N, H padded to 64]
+    y = torch.empty_like(res2)
+    xz = torch.empty(S, N, device=res.device, dtype=torch.bfloat16)
+    rc = lib.apertis_decode_ln_inproj(ptr(blk2), ptr(slot), ptr(wk), KK, ptr(res2), ptr(_f32(weight)), ptr(_f32(bias)), float(eps),
+                                      ptr(y), ptr(wc), wc.shape[-1], ptr(xz), S, H, N, stream_ptr())
+    if rc == -2:
+        return None
+    check(rc, "apertis_decode_ln_inproj")
+    return y.reshape(res.shape), xz
+
+
 def decode_gate_outproj(pre, xz, conv_state, weight, bias=None):
     """decode_post + the out_proj product as ONE launch (bf16, <= 16 rows): returns out [B, N] = (pre * silu(z)) @ weight.T
     (+ bias), the window pushed in place; None when the shapes are not the kernel's (the caller runs the two ops)."""

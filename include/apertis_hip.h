@@ -402,6 +402,14 @@ int apertis_tiny_linear_bwd_pad(const void *x, int64_t ldx, const float *W, cons
                                 int64_t N, int64_t zero_to, int dtype_x, void *stream);
 int64_t apertis_tiny_linear_bwd_blocks(int64_t T);
 
+/* Single-token decode step: the block boundary in front of the SSM block (apertis_dropout_add_layernorm_fwd without dropout:
+ * y = res + blk - blk [S,H] bf16, or with slot_of / wk [S,KK] the MoE combine of yr rows taken on the fly -, xn = LayerNorm(y))
+ * as the prologue of the in_proj product xz [S,N] = xn W^T (W [N, ldw] bf16; apertis_grouped_gemm_nt's skinny kernel for
+ * K >= 512, the same bits): every work-group normalises the S <= 16 rows for itself.  y fp32 [S,H]; 512 <= H <= 1024. */
+int apertis_decode_ln_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK,
+                             const float *res, const float *gamma, const float *beta, float eps, float *y,
+                             const void *W, int64_t ldw, void *out, int64_t S, int64_t H, int64_t N,
+                             void *stream);
 /* The entrance of an MoE feed-forward for S <= 16 rows (the single-token decode step) in ONE launch:
  * apertis_dropout_add_layernorm_router_fwd without dropout (y = res + blk, xn = LayerNorm(y), logits = Linear(router_norm(xn)))
  * followed by apertis_moe_route_small on those logits and on xn - which stays in LDS (xn may be NULL).  The same arithmetic
