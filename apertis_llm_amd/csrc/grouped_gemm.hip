@@ -1495,6 +1495,9 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 // ------------------------------------------------------------------------------------------
 // KS > 1 (long K: the experts' second GEMM, K = I): KS waves of a work-group split the K range, their partial sums meet in LDS
 // and wave 0 adds them in wave order - a wave alone walked 88 dependent load -> MFMA batches' worth of K = 2816.
+#ifndef SKINNY_LONG_K_WAVES
+#define SKINNY_LONG_K_WAVES 16      // (probe switch: 4 = the K >= 512 form for every long K)
+#endif
 template <typename TO, int KS>
 __global__ void __launch_bounds__(64 * KS)
 grouped_gemm_nt_skinny_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
@@ -2957,7 +2960,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // a handful of rows (the decode step): a wave per 16 output columns, operands straight from global memory
     if (max_rows <= 64 && !flagged && !pre_act && !mul_pre && drop_p <= 0.f && K % 8 == 0 && N % 4 == 0 && ldw % 8 == 0 && E <= 65535 &&
         ceil_div64(N, 16) <= 0x7fffffff) {
-      if (K >= 2048)  // (sixteen waves: a wave's share of K = 2816 is six 32-deep steps = ONE batch in flight instead of three dependent ones)
+      if (K >= 2048 && SKINNY_LONG_K_WAVES == 16)  // (sixteen waves: a wave's share of K = 2816 is six 32-deep steps = ONE batch in flight instead of three dependent ones)
         hipLaunchKernelGGL((grouped_gemm_nt_skinny_k<TO, 16>), dim3((unsigned)ceil_div64(N, 16), (unsigned)E), dim3(1024), 0, st,
                            (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C, (int)N, (int)K, (int)ldw, act, (int)max_rows);
       else if (K >= 512)   // (a wave's share is then one batch of eight 32-deep steps or a few: the K walk is a chain of round trips)
