@@ -79,9 +79,10 @@ SIGNATURES = {
     "apertis_decode_pre_conv": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_decode_pre_state": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64,
                                         _i32, _i32, _vp]),
-    "apertis_decode_gate_outproj": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
+    "apertis_decode_dense_gemv": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _vp]),
     "apertis_decode_post": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
-    "apertis_decode_ln_inproj": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "apertis_decode_inproj": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64,
+                                     _i64, _vp]),
     "apertis_moe_enter_small": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp]),
     "apertis_moe_route_small": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i64, _i64,

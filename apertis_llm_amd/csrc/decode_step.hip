@@ -75,71 +75,38 @@ decode_post_k(const float *__restrict__ pre, const T *__restrict__ xz, int64_t x
   cs[k - 2] = last;
 }
 
-// decode_post_k as the PROLOGUE of the out_proj product (bf16): out[b, n] = sum_k gated[b, k] W[n, k] (+ bias) with
-// gated = pre * silu(z) formed by every work-group for itself in LDS - 16 rows x Dn values, no dependency between
-// work-groups - and the window push spread over the work-groups (each pushes its slice of the B x Dn windows; nothing in this
-// launch reads them).  The product is grouped_gemm_nt_skinny_k's for K < 512 (grouped_gemm.hip): a wave owns 16 output
-// columns, W rows on the MFMA A operand straight from global memory (requested first: they fly under the prologue), the
-// rows of gated on B, eight 32-deep steps per batch in that order, one 8-byte store per lane - the same bits.
+// out [B, N] = x W^T (+ bias) for a handful of rows with the row count by VALUE: grouped_gemm_nt_skinny_k's K < 512 form
+// (grouped_gemm.hip: a wave owns 16 output columns, W rows on the MFMA A operand straight from global memory, the rows of x on
+// B, eight 32-deep steps per batch in that order, one 8-byte store per lane - the same bits) without the load of the group
+// offsets in front of everything else: one dependent round trip less in a kernel that is a chain of three.
 typedef __attribute__((ext_vector_type(8))) bf16_t ds_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float ds_f32x4;
 
 __global__ void __launch_bounds__(64)
-decode_gate_outproj_k(const float *__restrict__ pre, const bf16_t *__restrict__ xz, int64_t xz_rs, bf16_t *conv_state,
-                      const bf16_t *__restrict__ W, int ldw, const float *__restrict__ bias, bf16_t *__restrict__ out, int B, int Dn,
-                      int N, int k) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  bf16_t *sX = reinterpret_cast<bf16_t *>(smem);          // [B][Dn]
+decode_dense_gemv_k(const bf16_t *__restrict__ x, const bf16_t *__restrict__ W, int ldw, const float *__restrict__ bias,
+                    bf16_t *__restrict__ out, int B, int K, int N) {
   constexpr int U = 8;
   const int lane = threadIdx.x, n0 = blockIdx.x * 16, l15 = lane & 15, fg = lane >> 4, kc = fg * 8;
   const int wcol = n0 + l15;
   const bf16_t *wrow = W + (int64_t)min(wcol, N - 1) * ldw;
   const bool w_ok = wcol < N;
   const ds_bf16x8 zero = {};
-  ds_bf16x8 a0[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {          // the first batch of W (all of it for Dn <= 256)
-    const int kk = u * 32 + kc;
-    a0[u] = (kk < Dn && w_ok) ? *reinterpret_cast<const ds_bf16x8 *>(wrow + kk) : zero;
-  }
   const int nq = n0 + fg * 4;
   float bq[4] = {0.f, 0.f, 0.f, 0.f};
   if (bias) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) bq[q] = nq + q < N ? bias[nq + q] : 0.f;
   }
-  for (int i = lane; i < B * Dn; i += 64) {
-    const int b = i / Dn, c = i - b * Dn;
-    sX[i] = from_f32<bf16_t>(pre[i] * silu_g(to_f32(xz[(int64_t)b * xz_rs + Dn + c])));
-  }
-  {   // this work-group's slice of the window pushes
-    const int per = (B * Dn + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int lo = (int)blockIdx.x * per, hi = min(lo + per, B * Dn);
-    for (int i = lo + lane; i < hi; i += 64) {
-      const int b = i / Dn, c = i - b * Dn;
-      bf16_t *cs = conv_state + (int64_t)i * (k - 1);
-      constexpr int KEEP = 14;
-      bf16_t keep[KEEP];
-#pragma unroll
-      for (int j = 0; j < KEEP; ++j) keep[j] = j + 1 < k - 1 ? cs[j + 1] : bf16_t(0);
-      const bf16_t last = xz[(int64_t)b * xz_rs + c];
-#pragma unroll
-      for (int j = 0; j < KEEP; ++j)
-        if (j + 1 < k - 1) cs[j] = keep[j];
-      cs[k - 2] = last;
-    }
-  }
-  __syncthreads();
   const bool x_ok = l15 < B;
-  const bf16_t *xrow = sX + min(l15, B - 1) * Dn;
+  const bf16_t *xrow = x + (int64_t)min(l15, B - 1) * K;
   ds_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < Dn; k0 += 32 * U) {
+  for (int k0 = 0; k0 < K; k0 += 32 * U) {
     ds_bf16x8 a[U], bb[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int kk = k0 + u * 32 + kc;
-      const bool ok = kk < Dn;
-      a[u] = k0 == 0 ? a0[u] : ((ok && w_ok) ? *reinterpret_cast<const ds_bf16x8 *>(wrow + kk) : zero);
+      const bool ok = kk < K;
+      a[u] = (ok && w_ok) ? *reinterpret_cast<const ds_bf16x8 *>(wrow + kk) : zero;
       bb[u] = (ok && x_ok) ? *reinterpret_cast<const ds_bf16x8 *>(xrow + kk) : zero;
     }
 #pragma unroll
@@ -157,14 +124,12 @@ decode_gate_outproj_k(const float *__restrict__ pre, const bf16_t *__restrict__ 
 
 }  // namespace
 
-extern "C" int apertis_decode_gate_outproj(const float *pre, const void *xz, int64_t xz_rs, void *conv_state, const void *W,
-                                           int64_t ldw, const float *bias, void *out, int64_t B, int64_t Dn, int64_t N, int64_t k,
-                                           void *stream) {
-  if (!pre || !xz || !conv_state || !W || !out || xz_rs < 2 * Dn || ldw < Dn) return APERTIS_ERR_ARG;
-  if (B < 1 || B > 16 || Dn < 8 || Dn % 8 || Dn >= 512 || N < 4 || N % 4 || ldw % 8 || k < 2 || k > 16) return APERTIS_ERR_UNSUPPORTED;
-  const unsigned grid = (unsigned)ceil_div64(N, 16);
-  hipLaunchKernelGGL(decode_gate_outproj_k, dim3(grid), dim3(64), (size_t)(B * Dn * 2), (hipStream_t)stream, pre, (const bf16_t *)xz, xz_rs,
-                     (bf16_t *)conv_state, (const bf16_t *)W, (int)ldw, bias, (bf16_t *)out, (int)B, (int)Dn, (int)N, (int)k);
+extern "C" int apertis_decode_dense_gemv(const void *x, const void *W, int64_t ldw, const float *bias, void *out, int64_t B, int64_t K,
+                                         int64_t N, void *stream) {
+  if (!x || !W || !out || ldw < K) return APERTIS_ERR_ARG;
+  if (B < 1 || B > 16 || K < 8 || K % 8 || K >= 512 || N < 4 || N % 4 || ldw % 8) return APERTIS_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(decode_dense_gemv_k, dim3((unsigned)ceil_div64(N, 16)), dim3(64), 0, (hipStream_t)stream, (const bf16_t *)x,
+                     (const bf16_t *)W, (int)ldw, bias, (bf16_t *)out, (int)B, (int)K, (int)N);
   return apertis_check_launch();
 }
 

@@ -2224,16 +2224,21 @@ moe_enter_small_k(const TO *__restrict__ blk, const TX *__restrict__ res, const 
 // (grouped_gemm_nt_skinny_k<KS = 4>, grouped_gemm.hip: 16 output columns per work-group, four waves that split K in
 // 32-aligned quarters and meet in LDS in wave order; W rows on the MFMA A operand straight from global memory, requested
 // first) normalises the S rows for itself into LDS - no dependency between work-groups, the weight stream stays spread over
-// the chip; work-group 0 also writes y.  The same bits as the two launches it replaces.
+// the chip; work-group 0 also writes y.  The same bits as the two launches it replaces.  LN = false: xn [S,H] is given (more than
+// a couple of rows: the prologue would be redone by every work-group) and the product reads it from global memory.
+// The EPILOGUE, when the step's cache-only half ran ahead (`pre`, decode_step.hip): the xp columns go straight into the conv
+// windows and the z columns gate pre - apertis_decode_post's arithmetic on the bf16 values xz would have held; xz is not written.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) bf16_t dl_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float dl_f32x4;
 
-template <int IT>
+template <int IT, bool LN>
 __global__ void __launch_bounds__(256)
 decode_ln_inproj_k(const bf16_t *__restrict__ blk, const int32_t *__restrict__ slot_of, const float *__restrict__ wk, int KK,
                    const float *__restrict__ res, const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                   float *__restrict__ y, const bf16_t *__restrict__ W, int ldw, bf16_t *__restrict__ out, int S, int H, int N) {
+                   float *__restrict__ y, const bf16_t *__restrict__ xn, const bf16_t *__restrict__ W, int ldw,
+                   bf16_t *__restrict__ out, const float *__restrict__ pre, bf16_t *conv_state, int kconv,
+                   bf16_t *__restrict__ gated, int Dn, int S, int H, int N) {
   if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   constexpr int KS = 4, U = 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2255,7 +2260,7 @@ decode_ln_inproj_k(const bf16_t *__restrict__ blk, const int32_t *__restrict__ s
     a0[u] = (k < kend && w_ok) ? *reinterpret_cast<const dl_bf16x8 *>(wrow + k) : zero;
   }
   // ---- the boundary: a wave per row (dropadd_ln_fwd_k, drop_p = 0) ----
-  for (int r = ks; r < S; r += KS) {
+  for (int r = ks; LN && r < S; r += KS) {
     float4 v[IT];
     float sum = 0.f;
 #pragma unroll
@@ -2307,10 +2312,10 @@ decode_ln_inproj_k(const bf16_t *__restrict__ blk, const int32_t *__restrict__ s
       }
     }
   }
-  __syncthreads();
+  if constexpr (LN) __syncthreads();
   // ---- the product (grouped_gemm_nt_skinny_k<TO, 4>, one block of <= 16 rows) ----
   const bool x_ok = l15 < S;
-  const bf16_t *xrow = sX + (int64_t)min(l15, S - 1) * H;
+  const bf16_t *xrow = (LN ? sX : xn) + (int64_t)min(l15, S - 1) * H;
   dl_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int k0 = kbeg; k0 < kend; k0 += 32 * U) {
     dl_bf16x8 a[U], b[U];
@@ -2334,9 +2339,33 @@ decode_ln_inproj_k(const bf16_t *__restrict__ blk, const int32_t *__restrict__ s
       bf16_t o[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = from_f32<bf16_t>(acc[q] + 0.f);
-      bf16_t *dst = out + (int64_t)l15 * N + nq;
-      if (nq + 3 < N) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
-      else for (int q = 0; q < 4 && nq + q < N; ++q) dst[q] = o[q];
+      if (pre) {
+        // the step's cache-only half ran ahead (decode_step.hip): xz = (xp | z) is not needed as a tensor - the xp columns are
+        // pushed into the conv windows, the z columns gate `pre` (apertis_decode_post's arithmetic on the values as stored)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nq + q;
+          if (n < Dn) {
+            bf16_t *cs = conv_state + ((int64_t)l15 * Dn + n) * (kconv - 1);
+            constexpr int KEEP = 14;
+            bf16_t keep[KEEP];
+#pragma unroll
+            for (int j = 0; j < KEEP; ++j) keep[j] = j + 1 < kconv - 1 ? cs[j + 1] : bf16_t(0);
+#pragma unroll
+            for (int j = 0; j < KEEP; ++j)
+              if (j + 1 < kconv - 1) cs[j] = keep[j];
+            cs[kconv - 2] = o[q];
+          } else if (n < 2 * Dn) {
+            const int c = n - Dn;
+            const float zf = to_f32(o[q]);
+            gated[(int64_t)l15 * Dn + c] = from_f32<bf16_t>(pre[(int64_t)l15 * Dn + c] * (zf * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-zf * LOG2E_F))));
+          }
+        }
+      } else {
+        bf16_t *dst = out + (int64_t)l15 * N + nq;
+        if (nq + 3 < N) *reinterpret_cast<uint2 *>(dst) = *reinterpret_cast<const uint2 *>(o);
+        else for (int q = 0; q < 4 && nq + q < N; ++q) dst[q] = o[q];
+      }
     }
   }
 }
@@ -3185,17 +3214,22 @@ extern "C" int apertis_router_bwd(const void *x, const float *gamma, const float
                                  dtype_x, stream);
 }
 
-extern "C" int apertis_decode_ln_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK, const float *res,
-                                        const float *gamma, const float *beta, float eps, float *y, const void *W, int64_t ldw,
-                                        void *out, int64_t S, int64_t H, int64_t N, void *stream) {
-  if (!blk || !res || !gamma || !beta || !y || !W || !out || (slot_of && (!wk || KK < 1))) return APERTIS_ERR_ARG;
+extern "C" int apertis_decode_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK, const float *res,
+                                     const float *gamma, const float *beta, float eps, float *y, const void *xn, const void *W,
+                                     int64_t ldw, void *xz, const float *pre, void *conv_state, int64_t kconv, void *gated,
+                                     int64_t S, int64_t H, int64_t N, int64_t Dn, void *stream) {
+  if (!W) return APERTIS_ERR_ARG;
+  if (xn ? false : (!blk || !res || !gamma || !beta || !y || (slot_of && (!wk || KK < 1)))) return APERTIS_ERR_ARG;
+  if (pre ? (!conv_state || !gated || N != 2 * Dn || Dn < 1) : !xz) return APERTIS_ERR_ARG;
   if (S < 1 || S > 16 || H < 512 || H % 8 || H > 1024 || N < 4 || N % 4 || ldw < H || ldw % 8) return APERTIS_ERR_UNSUPPORTED;
+  if (pre && (kconv < 2 || kconv > 16)) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)ceil_div64(N, 16)), block(256);
-  const size_t lds = (size_t)S * H * 2;
-#define DL_GO { hipLaunchKernelGGL((decode_ln_inproj_k<IT>), grid, block, lds, st, (const bf16_t *)blk, slot_of, wk, (int)KK, res, gamma, beta, \
-                                   eps, y, (const bf16_t *)W, (int)ldw, (bf16_t *)out, (int)S, (int)H, (int)N); }
-  SKINNY_IT(H, DL_GO);
+#define DL_GO(LN_) { hipLaunchKernelGGL((decode_ln_inproj_k<IT, LN_>), grid, block, (LN_) ? (size_t)S * H * 2 : (size_t)0, st, (const bf16_t *)blk, \
+                                        slot_of, wk, (int)KK, res, gamma, beta, eps, y, (const bf16_t *)xn, (const bf16_t *)W, (int)ldw, \
+                                        (bf16_t *)xz, pre, (bf16_t *)conv_state, (int)kconv, (bf16_t *)gated, (int)Dn, (int)S, (int)H, (int)N); }
+  if (xn) { SKINNY_IT(H, DL_GO(false)); }
+  else { SKINNY_IT(H, DL_GO(true)); }
 #undef DL_GO
   return apertis_check_launch();
 }

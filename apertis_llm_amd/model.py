@@ -405,17 +405,14 @@ class SelectiveLinearAttention(nn.Module):
                                    lambda: torch.cat([self.in_proj_x.weight, self.in_proj_z.weight], dim=0))
         return w_xz
 
-    def decode_from_xz(self, xz2, past_key_value):
-        """The rest of a single-token step whose cache-only half ran ahead (`_decode_pre`) and whose in_proj output xz2 [B, 2 Dn]
-        the caller formed (ops.decode_ln_inproj): the gate, the window push, out_proj."""
-        conv_prev, ssm_prev = past_key_value
-        pre, self._decode_pre = self._decode_pre, None
-        B, Dn = xz2.shape[0], self.d_inner
-        out = ops.decode_gate_outproj(pre, xz2, conv_prev, self.out_proj.weight, self.out_proj.bias)
+    def decode_finish(self, gated, past_key_value):
+        """out_proj of a single-token step whose gate already ran (ops.decode_inproj's epilogue; `_decode_pre` is consumed)."""
+        self._decode_pre = None
+        B = gated.shape[0]
+        out = ops.decode_dense_gemv(gated, self.out_proj.weight, self.out_proj.bias)
         if out is None:
-            gated = ops.decode_post(pre, xz2, conv_prev)
-            out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight, self.out_proj.bias)
-        return out.reshape(B, 1, -1), None, (conv_prev, ssm_prev)
+            out = _mfma_linear(gated.reshape(B, 1, self.d_inner), self.out_proj.weight, self.out_proj.bias)
+        return out.reshape(B, 1, -1), None, tuple(past_key_value)
 
     @_on_input_device
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
@@ -432,6 +429,13 @@ class SelectiveLinearAttention(nn.Module):
         # (under no_grad - generate() - the stacked and the padded weight are prepared once, not per token)
         # (inside a training step the stacked and the padded weight come prepared - ops.TrainPrep: one launch per step for the
         # whole model - and these are placeholders that carry shape and gradient route only)
+        if (self._decode_pre is not None and L == 1 and have_window and hidden_states.is_cuda and hidden_states.dtype == torch.bfloat16
+                and not torch.is_grad_enabled() and not output_attentions):
+            # single-token step whose cache-only half ran ahead (ApertisModel._decode_prepass): in_proj with the gate and the window
+            # push in its epilogue - xz is never written
+            gated = ops.decode_inproj(self._stacked_in_proj(), self._decode_pre, conv_prev, xn=hidden_states)
+            if gated is not None:
+                return self.decode_finish(gated, past_key_value)
         xz = _mfma_linear(hidden_states, self._stacked_in_proj())
         Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
         wp = ops.prepared_weight(("x_param_padded", id(self)), (self.x_param_proj.weight,))
@@ -446,11 +450,9 @@ class SelectiveLinearAttention(nn.Module):
             if pre is not None:
                 # the step's first half - conv, x_param_proj, dt, state update: functions of the caches alone - ran for every
                 # layer at the start of the token step (ApertisModel._decode_prepass); the gate and the window push are left
-                out = ops.decode_gate_outproj(pre, xz2, conv_prev, self.out_proj.weight, self.out_proj.bias)
-                if out is None:
-                    gated = ops.decode_post(pre, xz2, conv_prev)
-                    out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight, self.out_proj.bias)
-                return out.reshape(B, 1, -1), None, (conv_prev, ssm_prev)
+                gated = ops.decode_post(pre, xz2, conv_prev)
+                out = _mfma_linear(gated.reshape(B, 1, Dn), self.out_proj.weight, self.out_proj.bias)
+                return out, None, (conv_prev, ssm_prev)
             xc, conv_state = ops.ssm_decode_step(xz2[:, :Dn], conv_prev, self.conv1d.weight, self.conv1d.bias,
                                                  inplace=self._inplace_cache)
             p = _mfma_linear(xc, wp)                                                   # [B, 2*Wb + Wr]
@@ -747,7 +749,7 @@ class ApertisAttention(nn.Module):
 
     def _decode_entry(self, h, past_kv, use_c, output_att):
         """A single-token step whose cache-only half ran ahead (the SSM module's `_decode_pre` is set): the block boundary as the
-        prologue of the in_proj product (ops.decode_ln_inproj), then the rest of the step.  None: the general path."""
+        prologue of the in_proj product (ops.decode_inproj with `boundary`), whose epilogue gates and pushes the window.  None: the general path."""
         impl = self.attention_mechanism_impl
         if (impl._decode_pre is None or not isinstance(h, _Pending) or past_kv is None or not use_c or output_att
                 or not isinstance(self.pre_norm, HipLayerNorm) or torch.is_grad_enabled() or self.training):
@@ -756,18 +758,22 @@ class ApertisAttention(nn.Module):
         if res.shape[1] != 1 or not res.is_cuda:
             return None
         lazy = out if isinstance(out, _LazyCombine) else None
+        conv_prev = past_kv[0]
         if lazy is not None:
-            r = ops.decode_ln_inproj(lazy.yr, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, impl._stacked_in_proj(),
-                                     combine=(lazy.w, lazy.plan)) if lazy.yr.dtype == torch.bfloat16 == lazy.dtype else None
-        elif isinstance(out, torch.Tensor) and tuple(out.shape) == tuple(res.shape):
-            r = ops.decode_ln_inproj(out, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, impl._stacked_in_proj()) \
-                if out.dtype == torch.bfloat16 else None
+            if not (lazy.yr.dtype == torch.bfloat16 == lazy.dtype):
+                return None
+            bnd = (lazy.yr, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, (lazy.w, lazy.plan))
+        elif isinstance(out, torch.Tensor) and tuple(out.shape) == tuple(res.shape) and out.dtype == torch.bfloat16:
+            bnd = (out, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, None)
         else:
-            r = None
+            return None
+        if res.shape[0] > 2 or conv_prev.dim() != 3:
+            return None
+        r = ops.decode_inproj(impl._stacked_in_proj(), impl._decode_pre, conv_prev, boundary=bnd)
         if r is None:
             return None
-        y, xz2 = r
-        return y, impl.decode_from_xz(xz2, past_kv)
+        y, gated = r
+        return y, impl.decode_finish(gated, past_kv)
 
     def _heads(self, t):
         B, L, _ = t.shape

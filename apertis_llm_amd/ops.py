@@ -685,58 +685,63 @@ def decode_post(pre, xz, conv_state):
     return gated
 
 
-def decode_ln_inproj(blk, res, weight, bias, eps, w_in, combine=None):
-    """dropout_add_layer_norm (inference: no dropout; combine=(w, plan): blk is the MoE expert output and the block output its
-    weighted combine) + the in_proj product as ONE launch for <= 16 rows of a single-token step (bf16 activations, fp32
-    residual stream): returns (y, xz) with xz [S, N] = LayerNorm(y) @ w_in.T, or None when the shapes are not the kernel's."""
+def decode_dense_gemv(x, weight, bias=None):
+    """x [B, K] @ weight.T (+ bias) for <= 16 bf16 rows and K < 512 under no_grad: linear_mfma's skinny kernel with the row count
+    by value (csrc/decode_step.hip: one dependent round trip less; the same bits).  None when the shapes are not the kernel's."""
+    B, K = x.shape
+    N = weight.shape[0]
+    if not (x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and 1 <= B <= 16 and K % 8 == 0 and 8 <= K < 512
+            and N % 4 == 0 and x.is_contiguous() and weight.shape[1] == K):
+        return None
     lib = _lib.load()
-    H = res.shape[-1]
-    S = res.numel() // H
-    N = w_in.shape[0]
-    # (S <= 2: every work-group normalises the S rows for itself - at S = 16 that prologue costs far more than the launch it
-    #  saves: 5553 -> 4519 tokens/s; the entry point itself takes S <= 16)
-    if not (res.is_cuda and not torch.is_grad_enabled() and 1 <= S <= 2 and 512 <= H <= 1024 and H % 8 == 0 and N % 4 == 0
-            and res.dtype == torch.float32 and blk.dtype == torch.bfloat16 and tuple(w_in.shape) == (N, H)):
+    wc = cast_transpose(weight.unsqueeze(0), torch.bfloat16, want_transposed=False, cache=True)[0]
+    out = torch.empty(B, N, device=x.device, dtype=torch.bfloat16)
+    check(lib.apertis_decode_dense_gemv(ptr(x), ptr(wc), wc.shape[-1], ptr(None if bias is None else _f32(bias)), ptr(out), B, K, N,
+                                        stream_ptr()), "apertis_decode_dense_gemv")
+    return out
+
+
+def decode_inproj(w_in, pre, conv_state, xn=None, boundary=None):
+    """The in_proj product of a single-token step whose cache-only half ran ahead (bf16, <= 16 rows, 512 <= H <= 1024) with the gate
+    and the window push in its epilogue: returns gated [S, Dn] = pre * silu(z) - conv_state [S,Dn,k-1] is pushed in place, xz is
+    never written.  Either xn [S, H] is given, or boundary = (blk, res, weight, bias, eps, combine) and the block boundary
+    (dropout_add_layer_norm without dropout; combine = (w, plan) or None) runs as the product's prologue in every work-group
+    (taken for S <= 2): then (y, gated) comes back.  None when the shapes are not the kernel's."""
+    lib = _lib.load()
+    N, H = w_in.shape
+    S, Dn = pre.shape
+    if not (pre.is_cuda and not torch.is_grad_enabled() and 1 <= S <= 16 and 512 <= H <= 1024 and H % 8 == 0 and N == 2 * Dn
+            and conv_state.dtype == torch.bfloat16 and conv_state.is_contiguous() and pre.is_contiguous() and pre.dtype == torch.float32
+            and 2 <= conv_state.shape[-1] + 1 <= 16):
         return None
-    _require_gpu(blk, res, weight, bias, w_in)
-    res2 = res.reshape(S, H).contiguous()
-    blk2 = blk.reshape(-1, H).contiguous()
-    wk = slot = None
-    KK = 0
-    if combine is not None:
-        wv, plan = combine
-        wk, slot, KK = _f32(wv), plan.slot_of, plan.K
-    elif blk2.shape[0] != S:
-        return None
+    blk2 = res2 = g = b = y = slot = wk = x2 = None
+    KK, eps = 0, 0.0
+    if xn is not None:
+        if xn.dtype != torch.bfloat16 or xn.numel() != S * H:
+            return None
+        x2 = xn.reshape(S, H).contiguous()
+    else:
+        blk, res, weight, bias, eps, combine = boundary
+        if S > 2 or res.dtype != torch.float32 or blk.dtype != torch.bfloat16 or res.numel() != S * H:
+            return None     # (S <= 2: every work-group normalises the rows for itself - at S = 16 that costs far more than a launch)
+        res2 = res.reshape(S, H).contiguous()
+        blk2 = blk.reshape(-1, H).contiguous()
+        if combine is not None:
+            wv, plan = combine
+            wk, slot, KK = _f32(wv), plan.slot_of, plan.K
+        elif blk2.shape[0] != S:
+            return None
+        g, b = _f32(weight), _f32(bias)
+        y = torch.empty_like(res2)
     wc = cast_transpose(w_in.unsqueeze(0), torch.bfloat16, want_transposed=False, cache=True)[0]       # [1, N, H padded to 64]
-    y = torch.empty_like(res2)
-    xz = torch.empty(S, N, device=res.device, dtype=torch.bfloat16)
-    rc = lib.apertis_decode_ln_inproj(ptr(blk2), ptr(slot), ptr(wk), KK, ptr(res2), ptr(_f32(weight)), ptr(_f32(bias)), float(eps),
-                                      ptr(y), ptr(wc), wc.shape[-1], ptr(xz), S, H, N, stream_ptr())
+    gated = torch.empty(S, Dn, device=pre.device, dtype=torch.bfloat16)
+    rc = lib.apertis_decode_inproj(ptr(blk2), ptr(slot), ptr(wk), KK, ptr(res2), ptr(g), ptr(b), float(eps), ptr(y), ptr(x2), ptr(wc),
+                                   wc.shape[-1], None, ptr(pre), ptr(conv_state), conv_state.shape[-1] + 1, ptr(gated), S, H, N, Dn,
+                                   stream_ptr())
     if rc == -2:
         return None
-    check(rc, "apertis_decode_ln_inproj")
-    return y.reshape(res.shape), xz
-
-
-def decode_gate_outproj(pre, xz, conv_state, weight, bias=None):
-    """decode_post + the out_proj product as ONE launch (bf16, <= 16 rows): returns out [B, N] = (pre * silu(z)) @ weight.T
-    (+ bias), the window pushed in place; None when the shapes are not the kernel's (the caller runs the two ops)."""
-    lib = _lib.load()
-    B, Dn = pre.shape
-    N = weight.shape[0]
-    # (B <= 4: every work-group forms the B x Dn gated values for itself with one wave - at B = 16 that prologue costs more than
-    #  the launch it saves: 5742 -> 4655 tokens/s; the entry point itself takes B <= 16)
-    if not (xz.dtype == torch.bfloat16 and conv_state.dtype == torch.bfloat16 and B <= 4 and Dn % 8 == 0 and Dn < 512 and N % 4 == 0
-            and xz.stride(-1) == 1 and conv_state.is_contiguous() and pre.is_contiguous() and 2 <= conv_state.shape[-1] + 1 <= 16):
-        return None
-    _require_gpu(pre, xz, conv_state, weight)
-    wc = cast_transpose(weight.unsqueeze(0), torch.bfloat16, want_transposed=False, cache=True)[0]      # [1, N, Dn padded to 64]
-    out = torch.empty(B, N, device=xz.device, dtype=torch.bfloat16)
-    check(lib.apertis_decode_gate_outproj(ptr(pre), ptr(xz), xz.stride(0), ptr(conv_state), ptr(wc), wc.shape[-1],
-                                          ptr(None if bias is None else _f32(bias)), ptr(out), B, Dn, N, conv_state.shape[-1] + 1,
-                                          stream_ptr()), "apertis_decode_gate_outproj")
-    return out
+    check(rc, "apertis_decode_inproj")
+    return gated if xn is not None else (y.reshape(boundary[1].shape), gated)
 
 
 # ----------------------------------------------------------------------------------------------

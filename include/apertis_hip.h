@@ -230,12 +230,6 @@ int apertis_decode_pre_state(const void *p, int64_t p_rs, int64_t off_bt, int64_
                              int64_t h, int64_t N, int delta_softplus, int dtype, void *stream);
 int apertis_decode_post(const float *pre, const void *xz, int64_t xz_rs, void *conv_state, void *gated,
                         int64_t B, int64_t Dn, int64_t k, int dtype, void *stream);
-/* apertis_decode_post as the prologue of the out_proj product (bf16, B <= 16, Dn < 512): out [B,N] = gated W^T (+ bias) with
- * W [N, ldw] bf16 (K = Dn zero-padded to ldw) - apertis_grouped_gemm_nt's skinny kernel for a handful of rows, the same bits -,
- * gated formed by every work-group for itself, the window push spread over the work-groups. */
-int apertis_decode_gate_outproj(const float *pre, const void *xz, int64_t xz_rs, void *conv_state,
-                                const void *W, int64_t ldw, const float *bias, void *out, int64_t B,
-                                int64_t Dn, int64_t N, int64_t k, void *stream);
 /* Single-token decode step of the SSM block (core.py:364-400 with L = 1 and a cache, called from generate()
  * core.py:1578-1603), two kernels around the caller's x_param_proj / dt projections:
  *   apertis_ssm_decode_conv : window = [conv_state (k-1 tokens) | xp]; xc = silu(w[:, k-1]*window[0] + bias) - the
@@ -402,14 +396,21 @@ int apertis_tiny_linear_bwd_pad(const void *x, int64_t ldx, const float *W, cons
                                 int64_t N, int64_t zero_to, int dtype_x, void *stream);
 int64_t apertis_tiny_linear_bwd_blocks(int64_t T);
 
-/* Single-token decode step: the block boundary in front of the SSM block (apertis_dropout_add_layernorm_fwd without dropout:
- * y = res + blk - blk [S,H] bf16, or with slot_of / wk [S,KK] the MoE combine of yr rows taken on the fly -, xn = LayerNorm(y))
- * as the prologue of the in_proj product xz [S,N] = xn W^T (W [N, ldw] bf16; apertis_grouped_gemm_nt's skinny kernel for
- * K >= 512, the same bits): every work-group normalises the S <= 16 rows for itself.  y fp32 [S,H]; 512 <= H <= 1024. */
-int apertis_decode_ln_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK,
-                             const float *res, const float *gamma, const float *beta, float eps, float *y,
-                             const void *W, int64_t ldw, void *out, int64_t S, int64_t H, int64_t N,
-                             void *stream);
+/* out [B,N] = x W^T (+ bias [N] or NULL) for B <= 16 bf16 rows, K < 512, W [N, ldw] bf16 (K zero-padded to ldw): apertis_grouped_gemm_nt's
+ * skinny kernel for one group with the row count by value (no load of group offsets in front of the operands) - the same bits. */
+int apertis_decode_dense_gemv(const void *x, const void *W, int64_t ldw, const float *bias, void *out, int64_t B,
+                              int64_t K, int64_t N, void *stream);
+/* Single-token decode step, the in_proj product xz [S,N] = xn W^T (W [N, ldw] bf16; apertis_grouped_gemm_nt's skinny kernel for
+ * K >= 512, the same bits; S <= 16, 512 <= H <= 1024) with
+ *  - an optional PROLOGUE (xn == NULL): the block boundary in front of the SSM block - apertis_dropout_add_layernorm_fwd without
+ *    dropout: y = res + blk (blk [S,H] bf16, or with slot_of / wk [S,KK] the MoE combine of yr rows taken on the fly), xn =
+ *    LayerNorm(y) - which every work-group runs for itself (meant for S <= 2); y [S,H] fp32 is written;
+ *  - an optional EPILOGUE (pre != NULL, N == 2 Dn; apertis_decode_post's arithmetic): the xp columns are pushed into conv_state
+ *    [S,Dn,kconv-1] in place, gated [S,Dn] = pre * silu(z); xz itself is not written then (xz may be NULL). */
+int apertis_decode_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK, const float *res,
+                          const float *gamma, const float *beta, float eps, float *y, const void *xn,
+                          const void *W, int64_t ldw, void *xz, const float *pre, void *conv_state,
+                          int64_t kconv, void *gated, int64_t S, int64_t H, int64_t N, int64_t Dn, void *stream);
 /* The entrance of an MoE feed-forward for S <= 16 rows (the single-token decode step) in ONE launch:
  * apertis_dropout_add_layernorm_router_fwd without dropout (y = res + blk, xn = LayerNorm(y), logits = Linear(router_norm(xn)))
  * followed by apertis_moe_route_small on those logits and on xn - which stays in LDS (xn may be NULL).  The same arithmetic
