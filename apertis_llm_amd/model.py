@@ -767,7 +767,7 @@ class ApertisAttention(nn.Module):
             bnd = (out, res, self.pre_norm.weight, self.pre_norm.bias, self.pre_norm.eps, None)
         else:
             return None
-        if res.shape[0] > 2 or conv_prev.dim() != 3:
+        if res.shape[0] > 4 or conv_prev.dim() != 3:
             return None
         r = ops.decode_inproj(impl._stacked_in_proj(), impl._decode_pre, conv_prev, boundary=bnd)
         if r is None:

@@ -706,7 +706,7 @@ def decode_inproj(w_in, pre, conv_state, xn=None, boundary=None):
     and the window push in its epilogue: returns gated [S, Dn] = pre * silu(z) - conv_state [S,Dn,k-1] is pushed in place, xz is
     never written.  Either xn [S, H] is given, or boundary = (blk, res, weight, bias, eps, combine) and the block boundary
     (dropout_add_layer_norm without dropout; combine = (w, plan) or None) runs as the product's prologue in every work-group
-    (taken for S <= 2): then (y, gated) comes back.  None when the shapes are not the kernel's."""
+    (taken for S <= 4: a row per wave): then (y, gated) comes back.  None when the shapes are not the kernel's."""
     lib = _lib.load()
     N, H = w_in.shape
     S, Dn = pre.shape
@@ -722,8 +722,8 @@ def decode_inproj(w_in, pre, conv_state, xn=None, boundary=None):
         x2 = xn.reshape(S, H).contiguous()
     else:
         blk, res, weight, bias, eps, combine = boundary
-        if S > 2 or res.dtype != torch.float32 or blk.dtype != torch.bfloat16 or res.numel() != S * H:
-            return None     # (S <= 2: every work-group normalises the rows for itself - at S = 16 that costs far more than a launch)
+        if S > 4 or res.dtype != torch.float32 or blk.dtype != torch.bfloat16 or res.numel() != S * H:
+            return None     # (S <= 4 = a row per wave: every work-group normalises the rows for itself - at S = 16 that costs far more than a launch)
         res2 = res.reshape(S, H).contiguous()
         blk2 = blk.reshape(-1, H).contiguous()
         if combine is not None:

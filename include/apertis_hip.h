@@ -404,7 +404,7 @@ int apertis_decode_dense_gemv(const void *x, const void *W, int64_t ldw, const f
  * K >= 512, the same bits; S <= 16, 512 <= H <= 1024) with
  *  - an optional PROLOGUE (xn == NULL): the block boundary in front of the SSM block - apertis_dropout_add_layernorm_fwd without
  *    dropout: y = res + blk (blk [S,H] bf16, or with slot_of / wk [S,KK] the MoE combine of yr rows taken on the fly), xn =
- *    LayerNorm(y) - which every work-group runs for itself (meant for S <= 2); y [S,H] fp32 is written;
+ *    LayerNorm(y) - which every work-group runs for itself (meant for S <= 4: a row per wave); y [S,H] fp32 is written;
  *  - an optional EPILOGUE (pre != NULL, N == 2 Dn; apertis_decode_post's arithmetic): the xp columns are pushed into conv_state
  *    [S,Dn,kconv-1] in place, gated [S,Dn] = pre * silu(z); xz itself is not written then (xz may be NULL). */
 int apertis_decode_inproj(const void *blk, const int32_t *slot_of, const float *wk, int64_t KK, const float *res,
