@@ -2055,11 +2055,17 @@ moe_enter_small_k(const TO *__restrict__ blk, const TX *__restrict__ res, const 
   const int Q = H / 4;
   float4 *sW = reinterpret_cast<float4 *>(smem);   // [NN][Q]
   float4 *sG = sW + NN * Q, *sB = sG + Q, *sRG = sB + Q, *sRB = sRG + Q;
-  rawo_t *sXN = reinterpret_cast<rawo_t *>(sRB + Q);   // [S][Q]: xn as stored
+  float4 *sLG = sRB + Q, *sLB = sLG + NN * Q;         // [NN][Q] each: the experts' LayerNorm vectors (the last phase meets them
+                                                      // with the expert known only then: fetched from HBM there they were a round trip in the kernel's tail)
+  rawo_t *sXN = reinterpret_cast<rawo_t *>(sLB + NN * Q);   // [S][Q]: xn as stored
   __shared__ int32_t s_idx[16 * MAXK], s_off[17], s_rtok[16 * MAXK];
   __shared__ float s_w[16 * MAXK], s_lg[16 * NN];
   const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6, nwaves = (int)blockDim.x >> 6;
-  for (int i = t; i < NN * Q; i += (int)blockDim.x) sW[i] = reinterpret_cast<const float4 *>(W)[i];
+  for (int i = t; i < NN * Q; i += (int)blockDim.x) {
+    sW[i] = reinterpret_cast<const float4 *>(W)[i];
+    sLG[i] = reinterpret_cast<const float4 *>(lgamma)[i];
+    sLB[i] = reinterpret_cast<const float4 *>(lbeta)[i];
+  }
   for (int i = t; i < Q; i += (int)blockDim.x) {
     sG[i] = reinterpret_cast<const float4 *>(gamma)[i]; sB[i] = reinterpret_cast<const float4 *>(beta)[i];
     sRG[i] = reinterpret_cast<const float4 *>(rgamma)[i]; sRB[i] = reinterpret_cast<const float4 *>(rbeta)[i];
@@ -2201,13 +2207,13 @@ moe_enter_small_k(const TO *__restrict__ blk, const TX *__restrict__ res, const 
       }
     }
     const float rstd = rsqrtf(wave_sum(sq) * inv_h(H) + leps);
-    const float *ga = lgamma + (int64_t)e * H, *be = lbeta + (int64_t)e * H;
+    const float4 *ga = sLG + e * Q, *be = sLB + e * Q;
     TO *dst = xg + (int64_t)r * H;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       int c = (lane + 64 * i) * 4;
       if (c < H) {
-        float4 g4 = load4<float>(ga + c), b4 = load4<float>(be + c);
+        float4 g4 = ga[lane + 64 * i], b4 = be[lane + 64 * i];
         float4 o = make_float4((v[i].x - mean) * rstd * g4.x + b4.x, (v[i].y - mean) * rstd * g4.y + b4.y,
                                (v[i].z - mean) * rstd * g4.z + b4.z, (v[i].w - mean) * rstd * g4.w + b4.w);
         store4<TO>(dst + c, o);
@@ -3248,7 +3254,8 @@ extern "C" int apertis_moe_enter_small(const void *blk, const void *res, const f
   if (dtype_x != APERTIS_F32 || (dtype_y != APERTIS_BF16 && dtype_y != APERTIS_F32)) return APERTIS_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(1), block(64 * (unsigned)(E * K));
-  const size_t lds = (size_t)(E + 4) * H * sizeof(float) + (size_t)S * H * (dtype_y == APERTIS_BF16 ? 2 : 4);
+  const size_t lds = (size_t)(3 * E + 4) * H * sizeof(float) + (size_t)S * H * (dtype_y == APERTIS_BF16 ? 2 : 4);
+  if (lds > 160 * 1024) return APERTIS_ERR_UNSUPPORTED;
 #define ES_GO(TOT, NN_) { auto kf = moe_enter_small_k<float, TOT, IT, NN_>; \
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kf, grid, block, lds, st, (const TOT *)blk, (const float *)res, gamma, beta, eps, (float *)y, (TOT *)xn, rgamma, rbeta, \
