@@ -437,6 +437,11 @@ class SelectiveLinearAttention(nn.Module):
             if gated is not None:
                 return self.decode_finish(gated, past_key_value)
         xz = _mfma_linear(hidden_states, self._stacked_in_proj())
+        if self._decode_pre is not None and not (L == 1 and have_window and ssm_prev is not None and not output_attentions
+                                                  and not torch.is_grad_enabled() and hidden_states.is_cuda and kw > 1):
+            self._decode_pre = None
+            raise ops.ApertisHipError("SelectiveLinearAttention: the model ran this step's cache-only half ahead (_decode_prepass: the "
+                                      "SSM state is already updated) but the layer is not on its single-token path")
         Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
         wp = ops.prepared_weight(("x_param_padded", id(self)), (self.x_param_proj.weight,))
         if wp is None:
@@ -1129,6 +1134,11 @@ class ApertisModel(nn.Module):
             return None
         Dn, R, h, N = m0.d_inner, m0.dt_rank, m0.num_heads, m0.d_state
         if any((m.d_inner, m.dt_rank, m.num_heads, m.d_state, m.conv_kernel_size) != (Dn, R, h, N, m0.conv_kernel_size) for m in impls):
+            return None
+        # (the layers' decode branch must take what is computed here - the states are updated in place, once: the caches have to be
+        #  exactly what that branch accepts as a window)
+        if (tuple(st.conv_all.shape[2:]) != (Dn, m0.conv_kernel_size - 1) or tuple(st.state_all.shape[1:]) != (st.conv_all.shape[1], Dn)
+                or st.state_all.dtype != torch.float32 or not (1 <= R <= 64 and 1 <= h <= 16)):    # (ops.tiny_linear_supported: dt inside the state kernel)
             return None
         B = st.conv_all.shape[1]
         if any((m.dt_proj_head.bias is None) != (m0.dt_proj_head.bias is None) or m.conv1d.bias is None for m in impls):
