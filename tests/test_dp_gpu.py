@@ -33,6 +33,7 @@ def _batch(rank, dev):
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # (the box's hostname may not resolve: gloo's pair connections over loopback)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import apertis_llm_amd as A
@@ -81,22 +82,56 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_hip_kernels_reduce_to_mean_and_stay_identical(dev):
-    import numpy as np
-    world = 2
+def _probe_worker(rank, world, port, out):
+    """Two gloo ranks on ONE card exchanging CUDA tensors - nothing of this repo in it: can the box do what the test needs?"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.full((4096,), float(rank + 1), device="cuda:0")
+        dist.broadcast(x, src=0)
+        y = torch.full((4096,), float(rank + 1), device="cuda:0")
+        dist.all_reduce(y)
+        torch.cuda.synchronize()
+        out.put((rank, float(x[0]), float(y[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_ranks(target, world, timeout):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
+    res = None
     try:
-        res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+        import queue
+        try:
+            res = sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+        except queue.Empty:
+            res = None
     finally:
         for p in procs:
-            p.join(timeout=120)
+            p.join(timeout=30 if res is None else 120)
             if p.is_alive():
                 p.kill()
+    return res, procs
+
+
+def test_two_ranks_on_hip_kernels_reduce_to_mean_and_stay_identical(dev):
+    import numpy as np
+    world = 2
+    # (seen once on this pool: for half an hour, on six boxes in a row, the two ranks of this test hung INSIDE gloo's broadcast /
+    #  all_reduce of CUDA tensors - first in the wrapper's parameter broadcast, with no kernel of this repo in flight - and then
+    #  not again on the same code.  A box that cannot pass the plain probe below cannot run this test: skip it, loudly, instead of
+    #  hanging the suite; a time-out of the real workers on a box that DOES pass the probe is a failure)
+    probe, _ = _run_ranks(_probe_worker, world, 90)
+    if probe is None or [t[1:] for t in probe] != [(1.0, 3.0), (1.0, 3.0)]:
+        pytest.skip(f"two gloo ranks on one card cannot exchange CUDA tensors on this box (probe: {probe})")
+    res, procs = _run_ranks(_worker, world, 420)
+    assert res is not None, "the two data-parallel ranks did not finish within 420 s (the gloo probe in front of them did)"
     assert all(p.exitcode == 0 for p in procs)
     (_, l0, r0, ib0, nb0, cp0, tot0, loss0, p0), (_, l1, r1, ib1, nb1, cp1, tot1, loss1, p1) = res
     assert ib0 and ib1, "after finish() every gradient must live in its bucket slice"
