@@ -29,6 +29,7 @@ def _data(rank):
 
 def _worker(rank, world, port, bucket_bytes, reduce_dtype, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (the container's hostname may not resolve: pair connections over loopback)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from apertis_llm_amd.parallel import BucketedDataParallel
@@ -99,6 +100,7 @@ def test_bucketed_allreduce_equals_mean_of_shard_gradients(bucket_bytes, reduce_
 
 def _train_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (the container's hostname may not resolve: pair connections over loopback)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import apertis_llm_amd as A
@@ -168,6 +170,7 @@ def _toy_dataset(path):
 
 def _trainer_worker(rank, world, port, tmp, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK=str(rank))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (the container's hostname may not resolve: pair connections over loopback)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from apertis_llm_amd.trainer import ApertisTrainer
