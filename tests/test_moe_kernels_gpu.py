@@ -1231,3 +1231,22 @@ def test_moe_entrance_of_a_handful_of_rows_in_one_launch(dev, S, E, K, H, dt):
     assert torch.equal(y0, y1) and torch.equal(lg0, lg1) and torch.equal(w0, w1)
     assert torch.equal(plan0.offsets, plan1.offsets) and torch.equal(plan0.slot_of, plan1.slot_of)
     assert torch.equal(plan0.row_token[:S * K], plan1.row_token[:S * K]) and torch.equal(xg0[:S * K], xg1[:S * K])
+
+
+@pytest.mark.parametrize("S,H,dt,ok", [(16, 928, torch.float32, True), (16, 932, torch.float32, False), (13, 1000, torch.float32, False),
+                                       (16, 1024, torch.bfloat16, True), (16, 1024, torch.float32, False)])
+def test_moe_entrance_predicate_mirrors_the_kernels_lds_bound(dev, S, H, dt, ok):
+    """moe_enter_small_supported must decline exactly the shapes apertis_moe_enter_small declines on its 160 KiB of
+    LDS ((3E+4)*H*4 + S*H*sizeof(blk)) - generate() has advanced every layer's SSM state by the time the launch would return -2."""
+    from apertis_llm_amd import ops
+    E, K = 8, 2
+    torch.manual_seed(H + S)
+    with torch.no_grad():
+        blk, res = torch.randn(S, H, device=dev).to(dt), torch.randn(S, H, device=dev)
+        assert ops.moe_enter_small_supported(blk, res, E, K) == ok
+        if ok:   # and an accepted shape at the edge really launches
+            v = lambda *s: torch.randn(*s, device=dev)
+            y, lg, w, plan, xg = ops.moe_enter_small(blk, res, v(H), v(H), 1e-5, v(H), v(H), 1e-5, v(E, H) / H ** 0.5, v(E), v(E, H),
+                                                     v(E, H), 1e-12, K)
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all() and int(plan.offsets[-1]) == S * K
