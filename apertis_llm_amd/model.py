@@ -1090,25 +1090,33 @@ class ApertisModel(nn.Module):
         pre_all = None
         if isinstance(past_key_values, _StackedPast) and x.shape[1] == 1 and use_c and not out_att and not torch.is_grad_enabled():
             pre_all = self._decode_prepass(past_key_values)
-        for i, layer in enumerate(self.layers):
-            if out_hs:
-                all_hs.append(x)
-            past = past_key_values[i] if past_key_values and i < len(past_key_values) else None
+        try:
+            for i, layer in enumerate(self.layers):
+                if out_hs:
+                    all_hs.append(x)
+                past = past_key_values[i] if past_key_values and i < len(past_key_values) else None
+                if pre_all is not None:
+                    layer.attention.attention_mechanism_impl._decode_pre = pre_all[i]
+                if self.gradient_checkpointing and self.training and not use_c:             # core.py:1258
+                    x, att_w, cache, lb, rz = torch.utils.checkpoint.checkpoint(layer, x, mask, pos_layers, past, out_att,
+                                                                                use_c, use_reentrant=False)
+                else:
+                    # hidden states are only materialised at layer boundaries when somebody asked for them
+                    x, att_w, cache, lb, rz = layer(x, mask, pos_layers, past, out_att, use_c, defer=not out_hs)
+                if out_att:
+                    all_att.append(att_w)
+                if use_c:
+                    all_cache.append(cache)
+                if cfg.use_expert_system:
+                    lbs.append(lb)
+                    rzs.append(rz)
+        finally:
+            #  the pre-pass has advanced every layer's SSM state in place; its per-layer results travel through the
+            # module attribute _decode_pre.  A layer that raised or left its single-token path must not leave a stale tensor
+            # behind for the next, unrelated forward on that module: whatever happened above, nothing stays pending.
             if pre_all is not None:
-                layer.attention.attention_mechanism_impl._decode_pre = pre_all[i]
-            if self.gradient_checkpointing and self.training and not use_c:             # core.py:1258
-                x, att_w, cache, lb, rz = torch.utils.checkpoint.checkpoint(layer, x, mask, pos_layers, past, out_att,
-                                                                            use_c, use_reentrant=False)
-            else:
-                # hidden states are only materialised at layer boundaries when somebody asked for them
-                x, att_w, cache, lb, rz = layer(x, mask, pos_layers, past, out_att, use_c, defer=not out_hs)
-            if out_att:
-                all_att.append(att_w)
-            if use_c:
-                all_cache.append(cache)
-            if cfg.use_expert_system:
-                lbs.append(lb)
-                rzs.append(rz)
+                for layer in self.layers:
+                    layer.attention.attention_mechanism_impl._decode_pre = None
         x, _ = _enter_block(self.final_post_norm, x)
         if out_hs:
             all_hs.append(x)

@@ -64,28 +64,39 @@ class KernelTimer:
         return out
 
 
-def _launch(name, fn, args, work=0.0, detail=None, nbytes=0.0):
+def _launch(name, fn, args, work=0.0, detail=None, nbytes=0.0, unwind=None):
+    """`unwind` (optional) runs when the entry point returns non-zero, BEFORE check() raises: a caller that took a per-launch
+    resource (the scan workspace's epoch) gives it back - no kernel went out, and a consumed epoch would leave the next launch
+    on that stream a stale ticket counter."""
     t = _TIMER
     if t is None or not t.on or name not in t.names:
-        check(fn(*args), name.split("[")[0])
+        rc = fn(*args)
+        if rc != 0 and unwind is not None:
+            unwind()
+        check(rc, name.split("[")[0])
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     rc = fn(*args)
     e.record()
+    if rc != 0 and unwind is not None:
+        unwind()
     check(rc, name.split("[")[0])
     t.records.append((name, s, e, work, detail, nbytes))
 
 
-def _try_launch(name, fn, args, work=0.0):
+def _try_launch(name, fn, args, work=0.0, unwind=None):
     """_launch for an entry point that may decline the shape: returns False on APERTIS_ERR_UNSUPPORTED (-2) WITHOUT recording
-    a timed launch (the caller then takes another form, which records its own), True when the launch went out."""
+    a timed launch (the caller then takes another form, which records its own), True when the launch went out.  `unwind` runs
+    on EVERY non-zero return (declined, or an argument / launch error that check() is about to raise): see _launch."""
     t = _TIMER
     timed = t is not None and t.on and name in t.names
     if timed:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
     rc = fn(*args)
+    if rc != 0 and unwind is not None:
+        unwind()
     if rc == -2:
         return False
     if timed:
@@ -450,13 +461,12 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
         lean = _try_launch("apertis_scan_gate_fwd", lib.apertis_scan_lookback_fwd,
                            (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0),
                             ptr(out), out.stride(-2), ptr(h_last), ptr(None if need_grad else h_in), ptr(ckpt), ptr(ws), epoch,
-                            B, L, h, N, int(delta_softplus), stream_ptr()), work)
+                            B, L, h, N, int(delta_softplus), stream_ptr()), work, unwind=lambda: _scan_gate_ws_unused(dev))
         if lean:
             kind = "lookback"
             if need_grad:
                 h_in = None              # (ckpt16[:, ::4] is the state entering every chunk)
         else:
-            _scan_gate_ws_unused(dev)
             ckpt = None
     if not lean and SCAN_LEAN and xc.dtype == torch.bfloat16 and N == 16 and 128 < Dn <= 256:
         kind = "lean"
@@ -490,7 +500,8 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
         _launch("apertis_scan_gate_fwd", lib.apertis_scan_gate_fwd,
                 (ptr(dlt), ptr(A_log), ptr(Bt), bt_rs, ptr(C), c_rs, ptr(xc), xc_rs, ptr(z), z_rs, ptr(Df), ptr(h0), ptr(out),
                  out.stride(-2), ptr(h_last), ptr(agg), ptr(h_in), ptr(ws), epoch, B, L, h, N, dtype_code(xc),
-                 int(delta_softplus), int(SCAN_SINGLE_PASS), stream_ptr()), work)
+                 int(delta_softplus), int(SCAN_SINGLE_PASS), stream_ptr()), work,
+                unwind=(lambda: _scan_gate_ws_unused(dev)) if SCAN_SINGLE_PASS else None)
     ctx.save_for_backward(dlt, A_log, Bt, C, xc, z, Df, h_in, ckpt)
     ctx.cfg = (B, L, h, N, bool(delta_softplus), wB, D.dtype)
     ctx.scan_kind = kind
@@ -531,9 +542,8 @@ def _scan_gate_backward(ctx, dout):
                        (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z),
                         z.stride(-2), ptr(Df), ptr(dout), do_rs, ptr(ckpt), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs,
                         ptr(dz), dz_rs, ptr(d_dlt), ptr(dA_dD), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, int(sp),
-                        stream_ptr()), work):
+                        stream_ptr()), work, unwind=lambda: _scan_gate_ws_unused(dev)):
             return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt)
-        _scan_gate_ws_unused(dev)
         h_in = ckpt[:, ::4].contiguous()         # (declined: the staged kernels below, from the chunk-entry states)
     if kind == "lean" and ckpt is not None and SCAN_LEAN_BWD:       # the lean forward left its checkpoints: the lean backward
         agg = torch.empty(B, nch, Dn, 2, device=dev, dtype=torch.float32)
@@ -555,7 +565,7 @@ def _scan_gate_backward(ctx, dout):
             (ptr(dlt), ptr(A_log), ptr(Bt), Bt.stride(-2), ptr(C), C.stride(-2), ptr(xc), xc.stride(-2), ptr(z), z.stride(-2),
              ptr(Df), ptr(dout), do_rs, ptr(h_in), ptr(dBt), dbt_rs, ptr(dC), dc_rs, wB, ptr(dxc), dxc_rs, ptr(dz), dz_rs,
              ptr(d_dlt), ptr(dA_dD), ptr(agg), ptr(fold), ptr(part), ptr(ws), epoch, B, L, h, N, dtype_code(xc), int(sp),
-             int(SCAN_SINGLE_PASS), stream_ptr()), work)
+             int(SCAN_SINGLE_PASS), stream_ptr()), work, unwind=(lambda: _scan_gate_ws_unused(dev)) if SCAN_SINGLE_PASS else None)
     return d_dlt, dA_dD[0].reshape(h, N), dBt, dC, dxc, dz, dA_dD[1].to(Ddt)
 
 
@@ -775,9 +785,11 @@ class _DwConvSilu(torch.autograd.Function):
             dout, dout2 = dout2, None
         if dout is None:
             return None, None, None
-        dout = dout.contiguous()
+        # (the kernel reads both gradients in the io dtype: the "same bits as autograd's add" claim of the pair form holds only
+        # then - a consumer that hands back another dtype is cast here, as autograd's own accumulation would cast it)
+        dout = dout.to(x.dtype).contiguous()
         if dout2 is not None:
-            dout2 = dout2.contiguous()
+            dout2 = dout2.to(x.dtype).contiguous()
         nblk = lib.apertis_dwconv_bwd_blocks(B, L, Dn)
         dev = x.device
         dx, dx_rs = _grad_out(ctx.slot, (B, L), Dn, x.dtype, dev)
@@ -799,7 +811,10 @@ class _DwConvSiluPair(_DwConvSilu):
     """The conv output handed out TWICE (two views of one tensor) for its two consumers - x_param_proj and the scan
     (reference core.py:376 and :388-396): their gradients then reach this node separately and the backward kernel adds them
     where it reads the rows, instead of autograd running a [B, L, Dn] add in front of it (30 us per layer at the bench shape;
-    the sum is rounded to the io dtype as that add rounds it: the same bits)."""
+    the sum is rounded to the io dtype as that add rounds it: the same bits).
+    CONTRACT: the two outputs alias one storage, so neither may be written in place by a consumer (autograd marks the second a
+    view made inside a custom Function and raises on an in-place op under grad mode; the model's two consumers only read).
+    For the grad-enabled path only - without a gradient to merge there is nothing to gain from the alias (dwconv_silu_pair)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -815,7 +830,10 @@ def dwconv_silu(x, weight, bias):
 
 
 def dwconv_silu_pair(x, weight, bias):
-    """dwconv_silu as two views of the one output, one per consumer: see _DwConvSiluPair."""
+    """dwconv_silu as two views of the one output, one per consumer: see _DwConvSiluPair (under no_grad: one tensor, twice)."""
+    if not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or bias.requires_grad)):
+        out = _DwConvSilu.apply(x, weight, bias)
+        return out, out
     return _DwConvSiluPair.apply(x, weight, bias)
 
 

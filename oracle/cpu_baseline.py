@@ -45,14 +45,48 @@ def _random_layer_state(H, h, N, I, E, R, moe, gen):
     return sd
 
 
-def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, reps=3):
+def cpu_model():
+    """The host CPU's model string ("state the core count and CPU model")."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
+def _time_scan_only(h, N, L, threads, gen):
+    """Forward of the two scan restatements alone at B=1 (SURVEY section 8(d) tensors), effective GB/s on the GPU's formula
+    T*(3*Dn*e + 4*h) with e = 4 (this oracle runs fp32)."""
+    torch.set_num_threads(threads)
+    Dn = h * N
+    delta = F.softplus(torch.randn(1, L, h, generator=gen) - 4.0)
+    A_log = torch.empty(h, N).uniform_(math.log(0.5), math.log(0.99), generator=gen)
+    Bt, C = torch.randn(1, L, Dn, generator=gen), torch.randn(1, L, Dn, generator=gen)
+    nbytes = L * (3 * Dn * 4 + 4 * h)
+    out = {}
+    with torch.no_grad():
+        for name, fn in (("recurrent", ref_cpu.scan_recurrent), ("vectorised", ref_cpu.scan_chunked_vectorised)):
+            fn(delta, A_log, Bt, C)
+            t0 = time.perf_counter()
+            fn(delta, A_log, Bt, C)
+            out[name] = nbytes / (time.perf_counter() - t0) / 1e9
+    return out
+
+
+def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, reps=2):
     """fwd+bwd of ONE layer of the given shape at B=1 and the benchmark's sequence length L, in TRAIN mode (expert
     capacity on, dropout p = 0 for determinism), plus the lm_head + CE, through the oracle with torch autograd:
-    one warm-up repetition, then the median of `reps`; extrapolated to n_layers_total layers.  Returns a dict."""
+    one warm-up repetition, then the median of `reps`; extrapolated to n_layers_total layers.  Three legs (BASELINE.md
+    section 3): the sequential-recurrence scan (core.py:337-353, what the reference trainer executes) on every host core
+    (`value` = `value_recurrent`), the same on 32 threads (`value_recurrent_32t`: the recurrence is a Python loop of tiny ops
+    and a large pool is mostly overhead), and the vectorised scan (core.py:324-335 per 64-token chunk, `value_vectorised`, the
+    fair CPU comparison).  Returns a dict."""
     avail = os.cpu_count() or 1
-    # the recurrence is a Python loop of tiny ops: more threads than ~32 only adds pool overhead
-    threads = threads or min(avail, 32)
-    torch.set_num_threads(threads)
+    threads = threads or avail
     gen = torch.Generator().manual_seed(0)
     R = math.ceil(H / 16)
     sd = _random_layer_state(H, h, N, I, E, R, moe, gen)
@@ -61,11 +95,11 @@ def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, re
     emb = (torch.randn(vocab, H, generator=gen) * 0.02).requires_grad_(True)
     ids = torch.randint(4, vocab, (1, L), generator=gen)
 
-    def one_layer():
+    def one_layer(scan):
         x = F.embedding(ids, emb)
         lp = "model.layers.0."
         hh = F.layer_norm(x, (H,), sd[lp + "attention.pre_norm.weight"], sd[lp + "attention.pre_norm.bias"], 1e-12)
-        x = x + ref_cpu.ssm_layer(sd, lp + "attention.attention_mechanism_impl.", hh, h, N, R)
+        x = x + ref_cpu.ssm_layer(sd, lp + "attention.attention_mechanism_impl.", hh, h, N, R, scan=scan)
         hh = F.layer_norm(x, (H,), sd[lp + "feed_forward.pre_norm.weight"], sd[lp + "feed_forward.pre_norm.bias"], 1e-12)
         if moe:
             f, lb, rz, _ = ref_cpu.moe_layer(sd, lp + "feed_forward.ffn.", hh, E, K, "gelu", 1e-12, training=True)
@@ -74,12 +108,12 @@ def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, re
                      sd[lp + "feed_forward.ffn.3.weight"], sd[lp + "feed_forward.ffn.3.bias"])
         return x + f, x.new_zeros(())
 
-    def one_rep():
+    def one_rep(scan):
         for v in sd.values():
             v.grad = None
         emb.grad = None
         t0 = time.perf_counter()
-        y, aux = one_layer()
+        y, aux = one_layer(scan)
         t_fwd = time.perf_counter() - t0
         t0 = time.perf_counter()
         (y.sum() + aux).backward()
@@ -93,16 +127,30 @@ def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, re
         t_head = time.perf_counter() - t0
         return t_fwd, t_bwd, t_head
 
-    one_rep()                                                   # warm-up: allocator, thread pool, page-in
-    runs = sorted(one_rep() for _ in range(reps))               # by forward time; medians taken per leg below
-    med = lambda i: sorted(r[i] for r in runs)[len(runs) // 2]
-    t_fwd, t_bwd, t_head = med(0), med(1), med(2)
-    step_s = n_layers_total * (t_fwd + t_bwd) + t_head
-    return {"value": L / step_s, "unit": "tokens/s", "cores": threads, "cores_available": avail, "kind": "port",
-            "sample": f"oracle (torch-CPU restatement, sequential-recurrence scan as the reference trainer executes it) "
-                      f"fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, fp32, train mode (expert "
-                      f"capacity on, dropout p=0), 1 warm-up + median of {reps}: layer fwd {t_fwd:.2f}s bwd {t_bwd:.2f}s "
-                      f"head {t_head:.2f}s; step time extrapolated as {n_layers_total}x layer + head"}
+    def leg(scan, nthreads, warm):
+        torch.set_num_threads(nthreads)
+        if warm:
+            one_rep(scan)                                       # warm-up: allocator, thread pool, page-in
+        runs = [one_rep(scan) for _ in range(reps)]
+        med = lambda i: sorted(r[i] for r in runs)[len(runs) // 2]
+        t_fwd, t_bwd, t_head = med(0), med(1), med(2)
+        return L / (n_layers_total * (t_fwd + t_bwd) + t_head), (t_fwd, t_bwd, t_head)
+
+    v_rec, (t_fwd, t_bwd, t_head) = leg(ref_cpu.scan_recurrent, threads, True)
+    v_vec, (v_fwd, v_bwd, _) = leg(ref_cpu.scan_chunked_vectorised, threads, True)
+    t32 = min(32, avail)
+    v_rec32 = leg(ref_cpu.scan_recurrent, t32, False)[0] if t32 != threads else v_rec
+    scan_gbps = _time_scan_only(h, N, L, threads, gen)
+    return {"value": v_rec, "unit": "tokens/s", "cores": threads, "cores_available": avail, "cpu_model": cpu_model(),
+            "kind": "port", "value_recurrent": v_rec, "value_vectorised": v_vec, "value_recurrent_32t": v_rec32,
+            "threads_second_figure": t32,
+            "scan_fwd_gbps": {"recurrent": scan_gbps["recurrent"], "vectorised": scan_gbps["vectorised"],
+                              "formula": "T*(3*Dn*4 + 4*h) bytes / forward time, B=1, fp32"},
+            "sample": f"oracle (torch-CPU restatement) fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, fp32, "
+                      f"train mode (expert capacity on, dropout p=0), {threads} threads, 1 warm-up + median of {reps}: "
+                      f"recurrent scan (as the reference trainer executes it, core.py:337-353) layer fwd {t_fwd:.2f}s bwd "
+                      f"{t_bwd:.2f}s head {t_head:.2f}s; vectorised scan (core.py:324-335 per 64-token chunk) layer fwd "
+                      f"{v_fwd:.2f}s bwd {v_bwd:.2f}s; step time extrapolated as {n_layers_total}x layer + head"}
 
 
 if __name__ == "__main__":   # child process of bench.py: prints one JSON object

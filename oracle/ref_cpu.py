@@ -75,29 +75,26 @@ def scan_backward(delta, A_log, Bt, C, dy, h0=None):
     return d_delta, dA_log, dBt, dC
 
 
-def scan_chunked_vectorised(delta, A_log, Bt, C, chunk=64):
-    """A fair vectorised CPU formulation (chunked log-space-free scan) used only as the faster of
-    the two cpu_baseline timings; numerically it composes (a,b) pairs like the HIP kernel."""
+def scan_chunked_vectorised(delta, A_log, Bt, C, chunk=64, h0=None):
+    """The reference's VECTORISED scan (core.py:324-335: h_t = P_t * cumsum(B_s / P_s), P = exp(cumsum(log a))) applied per
+    chunk of `chunk` tokens with the state carried across chunks: L/chunk Python iterations of whole-tensor ops instead of L.
+    Over a whole sequence the reference form divides by P -> 0 and goes non-finite (golden `scan_bigdelta` counts them); inside
+    64 tokens P >= exp(-64*delta*|A|) stays far from fp32's floor for the model's delta range, so this is the fair vectorised
+    CPU timing of BASELINE.md section 3 and agrees with the recurrence to ~1e-5 (tests/test_host_cpu.py)."""
     B, L, h = delta.shape
     N = A_log.shape[1]
-    A = -torch.exp(A_log).reshape(1, 1, h * N)
-    a = torch.exp(delta.repeat_interleave(N, dim=2) * A)
-    y = torch.empty_like(Bt, dtype=delta.dtype)
-    s = torch.zeros(B, h * N, dtype=delta.dtype)
+    dt = delta.dtype
+    A = -torch.exp(A_log.to(dt)).reshape(1, 1, h * N)                                    # :326
+    loga = delta.repeat_interleave(N, dim=2) * A                                         # log(Ab) of :327-328, exactly
+    ys = []
+    s = torch.zeros(B, h * N, dtype=dt) if h0 is None else h0.clone()
     for t0 in range(0, L, chunk):
-        ac = a[:, t0:t0 + chunk]
-        bc = Bt[:, t0:t0 + chunk].to(delta.dtype)
-        P = torch.cumprod(ac, dim=1)
-        # local states from zero: sequential inside the chunk keeps it stable
-        loc = torch.empty_like(bc)
-        r = torch.zeros_like(s)
-        for i in range(ac.shape[1]):
-            r = ac[:, i] * r + bc[:, i]
-            loc[:, i] = r
-        st = loc + P * s.unsqueeze(1)
-        y[:, t0:t0 + chunk] = C[:, t0:t0 + chunk].to(delta.dtype) * st
+        P = torch.exp(torch.cumsum(loga[:, t0:t0 + chunk], dim=1))                       # :329-330
+        bc = Bt[:, t0:t0 + chunk].to(dt)
+        st = P * (torch.cumsum(bc / P, dim=1) + s.unsqueeze(1))                          # :331-333 + the carried-in state
+        ys.append(C[:, t0:t0 + chunk].to(dt) * st)                                       # :334
         s = st[:, -1]
-    return y, s
+    return torch.cat(ys, dim=1), s
 
 
 # ----------------------------------------------------------------------------------------------
@@ -112,8 +109,9 @@ def dwconv_silu(xp, w, b):
     return F.silu(xc.transpose(1, 2))
 
 
-def ssm_layer(sd, pre, x, n_heads, d_state, dt_rank, h0=None, return_parts=False):
-    """sd: state dict, pre: '...attention_mechanism_impl.'; x [B,L,H] (already pre-normed)."""
+def ssm_layer(sd, pre, x, n_heads, d_state, dt_rank, h0=None, return_parts=False, scan=None):
+    """sd: state dict, pre: '...attention_mechanism_impl.'; x [B,L,H] (already pre-normed).  `scan`: the scan restatement to
+    use (default scan_recurrent = what the reference executes; cpu_baseline also times scan_chunked_vectorised)."""
     Dn = n_heads * d_state
     xp = F.linear(x, sd[pre + "in_proj_x.weight"])                      # :366
     z = F.linear(x, sd[pre + "in_proj_z.weight"])                       # :367
@@ -121,7 +119,7 @@ def ssm_layer(sd, pre, x, n_heads, d_state, dt_rank, h0=None, return_parts=False
     p = F.linear(xc, sd[pre + "x_param_proj.weight"])                   # :376
     dtf, Bt, C = torch.split(p, [dt_rank, Dn, Dn], dim=-1)               # :377-381
     delta = F.softplus(F.linear(dtf, sd[pre + "dt_proj_head.weight"], sd[pre + "dt_proj_head.bias"]))  # :382-383
-    y, h_last = scan_recurrent(_up(delta), _up(sd[pre + "A_log"]), Bt, C, h0)             # :391
+    y, h_last = (scan or scan_recurrent)(_up(delta), _up(sd[pre + "A_log"]), Bt, C, h0=h0)   # :391
     ys = y + sd[pre + "D"].view(1, 1, -1) * xc                           # :395
     g = ys * F.silu(z)                                                   # :396
     out = F.linear(g, sd[pre + "out_proj.weight"])                       # :397

@@ -129,7 +129,12 @@ def test_two_ranks_on_hip_kernels_reduce_to_mean_and_stay_identical(dev):
     #  hanging the suite; a time-out of the real workers on a box that DOES pass the probe is a failure)
     probe, _ = _run_ranks(_probe_worker, world, 90)
     if probe is None or [t[1:] for t in probe] != [(1.0, 3.0), (1.0, 3.0)]:
-        pytest.skip(f"two gloo ranks on one card cannot exchange CUDA tensors on this box (probe: {probe})")
+        # a skipped data-parallel test reads green in GPUTEST.  It is RED unless the operator allows the skip
+        # explicitly (APERTIS_ALLOW_DP_SKIP=1: a box known to have the gloo problem above).
+        msg = f"two gloo ranks on one card cannot exchange CUDA tensors on this box (probe: {probe})"
+        if os.environ.get("APERTIS_ALLOW_DP_SKIP") == "1":
+            pytest.skip(msg)
+        pytest.fail(msg + " - set APERTIS_ALLOW_DP_SKIP=1 to skip the data-parallel GPU test on such a box")
     res, procs = _run_ranks(_worker, world, 420)
     assert res is not None, "the two data-parallel ranks did not finish within 420 s (the gloo probe in front of them did)"
     assert all(p.exitcode == 0 for p in procs)
