@@ -631,11 +631,7 @@ __device__ __forceinline__ void nt256p_out_round(const f32x4 (&acc)[4][8], const
         if (ACT < 0 && mul_pre && !raw)
           v = actbwd_chunk<TO, true>(v, *reinterpret_cast<const uint4 *>(mul_pre + g), cur.row0 + row, cur.n0 + ncol, N, act,
                                      drop_p, seed, keep_scale, thresh16);
-#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 2   // tools/probes only: the epilogue without its global stores
-        asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(g));
-#else
         out_store16(dst + g, v);
-#endif
       }
     }
     }
@@ -743,17 +739,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     };
     if (nxt.valid) stage(0, 0);
 
-#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 1   // tools/probes only: no epilogue at all (the accumulators stay live)
-    if (cur.valid) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
-    }
-    if (false) {
-#else
     if (cur.valid) {   // epilogue of the previous tile, staged through ring buffer 1
-#endif
       float bv[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -787,9 +773,7 @@ grouped_gemm_nt256p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
       // must not wait there (its output stores are still draining)
       if (wave < 4 || kt > solo) wait_vmcnt<0>();
       __syncthreads();
-#ifndef NT_PROBE_NODMA   // (tools/probes only: the K loop on stale LDS contents - what the steps cost without their fills)
       if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-#endif
       const char *xs = smem + (kt & 1) * 2 * TILE2_BYTES, *ws = xs + TILE2_BYTES;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -916,17 +900,7 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
     };
     if (nxt.valid) stage(0, 0);
 
-#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 1   // tools/probes only: no epilogue at all (the accumulators stay live)
-    if (cur.valid) {
-#pragma unroll
-      for (int i = 0; i < 11; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(acc[i][j]));
-    }
-    if (false) {
-#else
     if (cur.valid) {   // epilogue of the previous tile: four rounds of 64 rows through ring buffer 1
-#endif
       int frow_e = frow, tid_e = tid;   // (pinned: the staging addresses are not to live across the K loop)
       asm volatile("" : "+v"(frow_e), "+v"(tid_e));
 #pragma unroll
@@ -957,11 +931,7 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
             const int row = (srow >> 4) * 64 + r * 16 + (srow & 15);
             if (row < cur.rows_valid && c * 8 < cur.cols_valid) {
               const uint4 v = *reinterpret_cast<const uint4 *>(stg + srow * STG5_PITCH + ((c ^ (srow & 15)) << 4));
-#if defined(NT_PROBE_EPI) && NT_PROBE_EPI == 2   // tools/probes only: the epilogue without its global stores
-              asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-#else
               out_store16(C + (cur.row0 + row) * N + cur.n0 + c * 8, v);
-#endif
             }
           }
         }
@@ -998,15 +968,12 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
       // below: this wave's four X pieces, then its six W pieces (waves 4-7 have five).
       const int nkt = kt + 1;
       const bool spread = nkt < nk && nkt > solo;
-#ifndef NT_PROBE_NODMA   // (tools/probes only: the K loop on stale LDS contents - what the steps cost without their fills)
       if (nkt < nk && nkt <= solo) stage(nkt & 1, nkt);
-#endif
       char *fxs = smem + (nkt & 1) * BUF5 + wave * 4 * 1024, *fws = smem + (nkt & 1) * BUF5 + TILE2_BYTES + pw0 * 1024;
       // a piece's row term goes into its buffer descriptor (base advanced and range shortened by 8 rows per piece: scalar
       // arithmetic), so that every piece uses the SAME lane offset voff0 - a running per-lane offset cost two registers the
       // kernel does not have (hipcc spilled it around every DMA)
       auto fill_piece = [&](int q) {   // q = 0..9, a compile-time constant at every call site
-#ifndef NT_PROBE_NODMA
         if (q < 4) {
           const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
               const_cast<T *>(fxw + q * 8 * K), 0, max(rows_w - q * 8, 0) * ldb, 0x00020000);
@@ -1021,7 +988,6 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(fws + j * 1024), 16, voff0,
                                                    nkt * BK * (int)sizeof(T), 0, 0);
         }
-#endif
       };
       const char *xs = smem + (kt & 1) * BUF5, *ws = xs + TILE2_BYTES;
 #pragma unroll
@@ -1048,19 +1014,11 @@ grouped_gemm_nt352p_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W
 #pragma unroll
           for (int j = 0; j < 4; ++j) mma(acc[i][j], wf[i], xf[j]);
           const int g = kk * 11 + i;           // MFMA group 0..21 of the step
-#ifdef NT_PROBE_FILL_EARLY   // tools/probes only: the ten pieces behind the FIRST ten groups (the last one then has 12 groups to land)
-          if (g < 10) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (spread) fill_piece(g);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-#else
           if (!(g & 1) && g < 20) {
             __builtin_amdgcn_sched_barrier(0);
             if (spread) fill_piece(g >> 1);
             __builtin_amdgcn_sched_barrier(0);
           }
-#endif
         }
         __builtin_amdgcn_s_setprio(0);
       }
@@ -1169,11 +1127,7 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
 #define NT_EPI_AUX 2
 #endif
   auto put = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-#ifdef NT_PROBE_NOSTORE   // tools/probes only: the epilogue's arithmetic without its stores (the values stay live)
-    asm volatile("" ::"v"(a), "v"(b), "v"(c), "v"(d), "v"(off));
-#else
     __builtin_amdgcn_raw_buffer_store_b128((u4_t){a, b, c, d}, rs, (int)off, 0, NT_EPI_AUX);
-#endif
   };
   // the saved tensor's pieces: two batches of four rows in flight ahead of the arithmetic
   [[maybe_unused]] uint4 pc[2][4];
@@ -1217,7 +1171,6 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
       if constexpr (MODE == EPI_BOTH) {
         // mask words: 0xFFFF where the element is dropped (one hash word per pair of elements)
         uint32_t og[4], dm[4] = {0u, 0u, 0u, 0u};
-#ifndef NT_PROBE_NOHASH   // tools/probes only: bound on what the mask hash costs
         if (DROP) {
           const uint32_t rmix = gd_rowmix(seed, (uint64_t)(row0 + rl + r));
 #pragma unroll
@@ -1225,19 +1178,13 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
 #pragma unroll
           for (int w = 0; w < 4; ++w) dm[w] = drop_mask2(dm[w], thresh16);
         }
-#endif
         v2f x[4], hv[4], gv[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {   // the pre-activation as the other form stores it (rounded to bf16)
           const uint32_t xpk = pack_bf16x2(v[2 * w], v[2 * w + 1]);
           x[w] = (v2f){__builtin_bit_cast(float, xpk << 16), __builtin_bit_cast(float, xpk & 0xffff0000u)};
         }
-#if defined(NT_PROBE_NOGELU)   // tools/probes only: bound on what the activation arithmetic costs
-#pragma unroll
-        for (int w = 0; w < 4; ++w) { hv[w] = x[w] * splat2(keep_scale); gv[w] = x[w] * splat2(0.5f * keep_scale); }
-#else
         gelu_both_fast8(x, gk, hv, gv);   // (scaled by 1 / (1 - p) already)
-#endif
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           o[w] = pack_bf16x2(hv[w].x, hv[w].y) & ~dm[w];
@@ -1285,9 +1232,6 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
   }
 }
 
-#ifdef NT_PROBE_STAMPS   // tools/probes only: wall-clock (10 ns ticks) sums per phase of the two-per-CU kernel's work-groups
-__device__ unsigned long long nt2x_stamps[8];   // [0] prologue (entry -> stage 0 landed) [1] K loop [2] epilogue issue [3] work-groups
-#endif
 // RAGGED: K % 32 != 0 - W's rows are zero-padded to whole sub-steps (row pitch ldw), X's last sub-step over-reads into
 // the next row (finite values against W's zeros) and the K offset moves into the range-checked lane offset so that
 // the tile's last row reads zeros past the buffer instead
@@ -1352,21 +1296,7 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     for (int q = 0; q < 6; ++q) issue_piece(slot_off, s, q);
   };
   const int nk = (K + 31) / 32;   // >= 3 (launcher)
-#ifdef NT_PROBE_WALK   // tools/probes only (NT_SPREAD = microseconds): the work-groups of the first dispatch round that sit in an odd
-  // wave slot of their SIMD start late, so that the two work-groups of a CU run their K loops and epilogues out of phase
-  if (spread_fill > 0 && blockIdx.x < 512) {
-    const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID: wave slot in bits 3:0
-    if (hw & 1) {
-      const uint64_t t0 = wall_clock64();
-      while (wall_clock64() - t0 < (uint64_t)spread_fill * 100) __builtin_amdgcn_s_sleep(32);
-    }
-  }
-#else
   (void)spread_fill;
-#endif
-#ifdef NT_PROBE_STAMPS
-  const uint64_t st0 = wall_clock64();
-#endif
   issue(0, 0); issue(SLOT3, 1); issue(2 * SLOT3, 2);
 
   f32x4 acc[4][8];
@@ -1409,9 +1339,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       __builtin_amdgcn_s_setprio(0);
   wait_vmcnt<12>();   // stage 0 (vmcnt retires in order)
   lds_barrier();
-#ifdef NT_PROBE_STAMPS
-  const uint64_t st1 = wall_clock64();
-#endif
   load_a(af[0], 0);
 #pragma unroll
   for (int j = 0; j < 8; ++j) bfr[j] = *reinterpret_cast<const frag *>(bbase + j * 16 * ROWB3);
@@ -1439,20 +1366,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   // (no barrier: the epilogue leaves straight from the accumulators, the ring is not touched again)
-#ifdef NT_PROBE_STAMPS
-  const uint64_t st2 = wall_clock64();
-  auto stamp_end = [&]() {
-    const uint64_t st3 = wall_clock64();
-    if (tid == 0) {
-      atomicAdd(&nt2x_stamps[0], st1 - st0); atomicAdd(&nt2x_stamps[1], st2 - st1); atomicAdd(&nt2x_stamps[2], st3 - st2);
-      atomicAdd(&nt2x_stamps[3], 1ull);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      atomicAdd(&nt2x_stamps[4], wall_clock64() - st3);   // until this wave's own stores have been acknowledged
-    }
-  };
-#else
-  auto stamp_end = [&]() {};
-#endif
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
@@ -1467,7 +1380,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   if (save_grad && pre_act) {   // (GELU: launch_nt refuses the flag for other activations)
     if (drop_p > 0.f) OUT(EPI_BOTH, APERTIS_ACT_GELU, true, C, pre_act);
     else OUT(EPI_BOTH, APERTIS_ACT_GELU, false, C, pre_act);
-    stamp_end();
     return;
   }
   if (pre_act) OUT(EPI_RAW, APERTIS_ACT_NONE, false, pre_act, nullptr);
@@ -1481,7 +1393,6 @@ grouped_gemm_nt2x_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   else if (act == APERTIS_ACT_GELU) OUT(EPI_ACT, APERTIS_ACT_GELU, false, C, nullptr);
   else OUT(EPI_ACT, -1, false, C, nullptr);
 #undef OUT
-  stamp_end();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1586,9 +1497,6 @@ constexpr int RING4 = 4 * SLOT4;
 
 struct Tile4 { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
 
-#ifdef NT_PROBE_STAMPS
-__device__ unsigned long long nt4r_stamps[8];   // [0] K loops [1] epilogues [2] tiles
-#endif
 template <typename TO, bool RAGGED = false>
 __global__ void __launch_bounds__(NT4)
 grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
@@ -1696,36 +1604,22 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   auto sub_step = [&](const frag (&acur)[4], frag (&anxt)[4], int nxt_off, uint32_t fill_off, bool late) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-#ifndef NT4R_PROBE_NOREAD   // tools/probes only: the run without its fragment reads (MFMAs on whatever the registers hold)
       if (j == 0) { anxt[0] = *reinterpret_cast<const frag *>(abase + nxt_off); anxt[1] = *reinterpret_cast<const frag *>(abase + nxt_off + 16 * ROWB4); }
       if (j == 1) { anxt[2] = *reinterpret_cast<const frag *>(abase + nxt_off + 32 * ROWB4); anxt[3] = *reinterpret_cast<const frag *>(abase + nxt_off + 48 * ROWB4); }
-#else
-      if (j < 4) asm volatile("" : "+v"(anxt[j]));
-#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i) mma(acc[i][j], acur[i], bfr[j]);
-#ifndef NT4R_PROBE_NOREAD
       bfr[j] = *reinterpret_cast<const frag *>(bbase + nxt_off + j * 16 * ROWB4);
-#else
-      asm volatile("" : "+v"(bfr[j]));
-#endif
       __builtin_amdgcn_sched_barrier(0);
-#ifndef NT4R_PROBE_NODMA    // tools/probes only: the run without its fills (stale LDS)
       // (a wave-uniform branch around the hand-issued piece only: nothing the compiler tracks is pending differently on its
       // two sides, so the join costs no wait)
       if (late == (j >= 4)) issue_piece(fill_off, j & 3);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 #ifndef NT4R_STAGGER   // measured (B = 44, K = 704): 1037-1045 us with the stagger, 1013 without; priorities move time between the
 #define NT4R_STAGGER 0 // K loop and the epilogue, not the sum (profiles/r4_probe_nt4r_stagger.log)
 #endif
-#ifdef NT4R_PROBE_NOBAR     // tools/probes only: the K loop without its barriers (wrong results)
-#define NT4R_BARRIER
-#else
 #define NT4R_BARRIER lds_barrier();
-#endif
 #ifndef NT4R_PRIO      // 0: every wave at priority 1 inside the MFMA run; 1: waves 4-7 at priority 1 throughout, waves 0-3 at 0
 #define NT4R_PRIO 0
 #endif
@@ -1754,14 +1648,8 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
-#ifdef NT_PROBE_STAMPS
-  unsigned long long stk[3] = {0, 0, 0}, stw[3] = {0, 0, 0};
-#endif
   for (;;) {
     nxt = next_valid();
-#ifdef NT_PROBE_STAMPS
-    const uint64_t st1 = wall_clock64();
-#endif
     // Stage 0's fragments.  (A tile's last sub-step has read them already, like every sub-step reads its successor's, but
     // 48 registers held across the epilogue leave its arithmetic no room to interleave: they are read again here - the slot is
     // not refilled before sub-step 0's barrier - and the stage has landed: the wait + barrier of the prologue resp. of the
@@ -1784,22 +1672,13 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     // top of sub-step s: this wave holds the fragments of s; stage s+1 of the stream must have landed - two stages are younger
     // (8 pieces), and through the first three sub-steps behind an epilogue so are its S stores; behind the barrier stage s+1 is
     // complete everywhere and every wave has read s, so the fill stage (s + 4 of the stream) may overwrite slot(s)
-#ifdef NT_PROBE_STAMPS   // [3] waits + barriers of sub-steps 0..2 (stores behind), [4] of sub-step 3 (the stores retired), [5] the rest
-#define NT4R_STAMP_A const uint64_t sw0 = wall_clock64();
-#define NT4R_STAMP_B(S_) stw[(S_) < 3 ? 0 : (S_) == 3 ? 1 : 2] += wall_clock64() - sw0;   // (no memory operation here: the vmcnt is kept by hand)
-#else
-#define NT4R_STAMP_A
-#define NT4R_STAMP_B(S_)
-#endif
 #define SUB4(S_, AC, AN)                                                                                       \
     {                                                                                                          \
       const int nxt_off = cur_off + SLOT4 == RING4 ? 0 : cur_off + SLOT4;                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
       const int stores_behind = (S_) < 3 ? prev_stores : 0;                                                    \
-      NT4R_STAMP_A                                                                                             \
       if (stores_behind == 0) wait_vmcnt<8>(); else if (stores_behind == 16) wait_vmcnt<24>(); else wait_vmcnt<40>(); \
       NT4R_BARRIER                                                                                             \
-      NT4R_STAMP_B(S_)                                                                                         \
       if (fs == 0 && bias && fvalid) issue_bias();                                                             \
       if (NT4R_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                       \
       sub_step(AC, AN, nxt_off, (uint32_t)cur_off, late);                                                      \
@@ -1816,9 +1695,6 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       }
     }
 #undef SUB4
-#ifdef NT_PROBE_STAMPS
-    const uint64_t st2 = wall_clock64();
-#endif
     {
       const int n0w = cur.n0 + wn * 128, cvw = cur.cols_valid - wn * 128;
 #define OUT(MODE, A, D, DST, DST2) \
@@ -1840,20 +1716,12 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       }
 #undef OUT
     }
-#ifdef NT_PROBE_STAMPS
-    stk[0] += st2 - st1; stk[1] += wall_clock64() - st2; stk[2] += 1;
-#endif
     if (!nxt.valid) break;
     cur = nxt;
     prev_stores = S;
   }
   // (the empty pieces of the stream's last sub-steps are still in flight: they write zeros into this work-group's own LDS)
   wait_vmcnt<0>();
-#ifdef NT_PROBE_STAMPS
-  if (tid == 0) {
-    for (int i = 0; i < 3; ++i) { atomicAdd(&nt4r_stamps[i], stk[i]); atomicAdd(&nt4r_stamps[3 + i], stw[i]); }
-  }
-#endif
 }
 
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
@@ -2402,11 +2270,7 @@ grouped_gemm_tn3_k(Tn3Args a, const int32_t *__restrict__ offsets) {
       auto piece32 = [&](int u, int q) {
         const uint32_t as = lds0 + (u & 3) * 2 * OPH, bs = as + OPH;
         const int p = (q >> 1) * 8 + wave;
-#ifdef TN_PROBE_WRAP   // tools/probes only: every k-row from the group's first 256 rows - the kernel with all fills hitting in L2
-        const uint32_t row = (uint32_t)((s0 * BKR + u * 32 + 2 * p) & 255);
-#else
         const uint32_t row = (uint32_t)(s0 * BKR + u * 32 + 2 * p);
-#endif
         const bool live = u < nsub;
         if (q & 1) lds_dma16(brs, bs + p * 1024, live ? vb0 + row * (uint32_t)ldB : 0xfffffff0u);
         else lds_dma16(ars, as + p * 1024, live ? va0 + row * (uint32_t)ldA : 0xfffffff0u);
@@ -2870,9 +2734,6 @@ int launch_tn3(const Tn3Problem &q0, const Tn3Problem *q1, int64_t E, int64_t ma
   if (a.ctr && hipMemsetAsync(a.ctr, 0, (size_t)groups * TN3_CTR_STRIDE * sizeof(int), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
   const size_t lds = 4 * 64 * 512 + 16;
   int ring = 2;
-#ifdef TN_PROBE_RING   // tools/probes only: TN_RING=0 selects the double-buffered 64-deep form, 1 the ring without the stagger
-  if (const char *rv = getenv("TN_RING")) ring = atoi(rv);
-#endif
   auto k3 = ring == 2 ? grouped_gemm_tn3_k<true, true> : ring == 1 ? grouped_gemm_tn3_k<true, false> : grouped_gemm_tn3_k<false, false>;
   hipFuncSetAttribute((const void *)k3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k3, dim3((unsigned)grid), dim3(NT2), lds, st, a, offsets);
@@ -2979,10 +2840,6 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     // second output on a short K); long K loops run faster on the 256 x 256 tile (fewer operand bytes per flop).
     // ... and for the SSM block's dense projections (one group, short K, HBM-bound): 92 vs 114 us at N=352/K=704, 72 vs 89
     // at N=704/K=176, 56 vs 64 at N=400/K=176; the N=176 data gradients stay on the 256-wide tile (63 vs 60 us)
-#ifdef NT_PROBE_FORCE   // tools/probes only: 1 = two-per-CU kernel wherever it applies, 2 = never, 3 = never and no 352-wide tile
-    const bool use2x = NT_PROBE_FORCE == 1;
-    (void)act; (void)drop_p;
-#else
     const bool use2x = ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
                        // (one 352-wide n-tile reads X once: 114 vs 121 us on the SSM input projection, N = 352, K = 704)
                        (E == 1 && K <= 1024 && N >= 256 && !(N == BN5 && K % 64 == 0 && ldw == K)) ||
@@ -2992,14 +2849,9 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
                        // narrow dense outputs (the H = 256 family's x_param / out_proj data gradients, N = 64): one half-empty
                        // 128-wide n-tile of this kernel instead of the 128 x 128 register-staged kernel (29 us for 42 MB there)
                        (E == 1 && K <= 1024 && N >= 64 && N < 128);
-#endif
     // outputs a multiple of 352 wide with a plain epilogue: the 256 x 352 tile (two passes over X for N = 704 instead of three)
-#if defined(NT_PROBE_FORCE) && NT_PROBE_FORCE == 3
-    const bool use352 = false;
-#else
     const bool use352 = !use2x && act == APERTIS_ACT_NONE && drop_p <= 0.f && !pre_act && !mul_pre && N % BN5 == 0 && K % 64 == 0 &&
                         ldw == K && K >= 128 && max_rows >= 4096 && E <= 1024;
-#endif
     if (use352) {
       const int nt5 = (int)(N / BN5);
       const int64_t grid5 = (ceil_div64(max_rows, BM2) + E) * nt5;
@@ -3024,9 +2876,6 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     //   H=256 I=1024 B=16: 193 -> 154-166, 181 -> 108            H=896 I=3584: 820-882 -> 749-757, 715-725 -> 612-628
     // Plain epilogues stay where they were (N=1024, K=256: 78 us there, 88 here; N=3584, K=896: 565 there, 508 here - not routed).
     // A caller that passes a tile queue (data-parallel runs: a collective may hold CUs) keeps the non-persistent kernel.
-#ifdef NT_PROBE_FORCE   // tools/probes only: 4 = wherever it applies, otherwise never
-    const bool use4r = NT_PROBE_FORCE == 4;
-#else
     const bool use4r = ((act != APERTIS_ACT_NONE || drop_p > 0.f || pre_act || mul_pre) && K <= 1024 && N >= 512) ||
                        // ... and for the SSM block's dense projections (one group, short K: byte- and latency-bound - the stage
                        // stream through tile boundaries hides a tile's prologue and epilogue, and 256-wide n-tiles read X half as
@@ -3034,7 +2883,6 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
                        // 102 us, N=704 K=352 162 -> 141, N=448 K=176 83 -> 74, N=176 K=448 63-67 -> 60, N=176 K=704 85-92 -> 83;
                        // N=352 K=704 stays on the 352-wide tile (107-110 there, 111 here)
                        (E == 1 && K <= 1024 && N >= 128 && !(N == BN5 && K % 64 == 0 && ldw == K));
-#endif
     if (use4r && !tile_queue && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 && N >= 128 &&
         max_rows >= 4096 && E <= 1024) {
       const int nt4 = (int)ceil_div64(N, BN4);
@@ -3045,9 +2893,6 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         const int lds4 = RING4 + 8 * 1024;   // ring + a bias area per wave
         hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
         int walk_g = nt4 > 4 ? 8 : 0, walk_nb = 2;
-#ifdef NT_PROBE_WALK
-        if (const char *wv = getenv("NT_WALK4")) sscanf(wv, "%d,%d", &walk_g, &walk_nb);
-#endif
         hipLaunchKernelGGL(k4, dim3((unsigned)gp), dim3(NT4), lds4, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt4, (int)grid4, act_flags,
                            drop_p, seed, walk_g, walk_nb);
@@ -3066,10 +2911,6 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         // forward) / 1255-1293 (fc2 data gradient); (8,4) 1379 / 1190; (32,4) 1374 / 1230; (12,11) 1400 / 1181; (16,8) 1471 / 1236
         int walk_g = nt3 > 8 ? 8 : 0, walk_nb = 4;
         int spread_fill = 0;
-#ifdef NT_PROBE_WALK   // tools/probes only: NT_WALK="G,NB" and NT_SPREAD=0|1 from the environment
-        if (const char *wv = getenv("NT_WALK")) sscanf(wv, "%d,%d", &walk_g, &walk_nb);
-        if (const char *sv = getenv("NT_SPREAD")) spread_fill = atoi(sv);
-#endif
         hipLaunchKernelGGL(k3, dim3((unsigned)grid3), dim3(NT3), RING3, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt3, act_flags, drop_p, seed,
                            walk_g, walk_nb, spread_fill);
@@ -3266,9 +3107,6 @@ extern "C" int apertis_grouped_gemm_tn_pair_q(const void *A0, const void *B0, fl
     Tn3Problem p1{(const bf16_t *)A1, (const bf16_t *)B1, dW1, dbias1, (int)M1, (int)N1, (int)ceil_div64(M1, 256),
                   (int)ceil_div64(N1, 256)};
     bool v5 = true;
-#ifdef TN_PROBE_RING   // tools/probes only: TN_V5=0 keeps the 256 x 256 kernel
-    if (const char *ev = getenv("TN_V5")) v5 = atoi(ev) != 0;
-#endif
     if (v5) {   // the 704-wide family: 256 x 352 / 352 x 256 tiles
       const int rc5 = launch_tn5(p0, &p1, E, max_rows, offsets, (float *)ws, ws_bytes, item_queue != 0, (hipStream_t)stream);
       if (rc5 != APERTIS_ERR_UNSUPPORTED) return rc5;

@@ -572,21 +572,13 @@ template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
 template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   f4 o = {v.x, v.y, v.z, v.w};
-#ifdef ROW_PROBE_NOSTORE
-  asm volatile("" ::"v"(o), "v"(p));
-#else
   __builtin_nontemporal_store(o, reinterpret_cast<f4 *>(p));
-#endif
 }
 template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v) {
   typedef __attribute__((ext_vector_type(4))) bf16_t bf4;
   typedef __attribute__((ext_vector_type(2))) unsigned u2;
   bf4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-#ifdef ROW_PROBE_NOSTORE
-  asm volatile("" ::"v"(__builtin_bit_cast(u2, o)), "v"(p));
-#else
   __builtin_nontemporal_store(__builtin_bit_cast(u2, o), reinterpret_cast<u2 *>(p));
-#endif
 }
 
 // Sum over the 64 lanes, the same value in every lane.  DPP adds inside the rows of 16 (quad swaps, half-row and row

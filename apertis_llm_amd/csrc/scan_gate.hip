@@ -36,12 +36,6 @@
 namespace {
 
 
-#ifdef SCAN_PROBE   // tools/probes/scan_gate_probe.hip: per-work-group phase timestamps (never defined in the library build)
-__device__ unsigned long long g_probe[8192 * 8];
-#define PROBE(k) do { if (threadIdx.x == 0 && item_s[2] < 8192) g_probe[item_s[2] * 8 + (k)] = wall_clock64(); } while (0)
-#else
-#define PROBE(k) do { } while (0)
-#endif
 
 #ifndef SCAN_GATE_LT
 #define SCAN_GATE_LT 64
@@ -220,9 +214,6 @@ __device__ __forceinline__ void take_item(GateWsHead *head, uint32_t epoch, int 
   } else {
     chunk = blockIdx.x; cs = blockIdx.y; b = blockIdx.z;
   }
-#ifdef SCAN_PROBE
-  if (tid == 0) item_s[2] = (chunk * (int)d.B + b) * ncs + cs;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -346,10 +337,6 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
     const int64_t tok0 = (int64_t)b * d.L + t0;
     const bool chan_ok = c < d.Dn;
     const int vb = ch_valid * (int)sizeof(T);
-#ifdef SCAN_PROBE
-    if (tid == 0) item_s[2] = it.id;
-#endif
-    PROBE(0);
     const float A2 = chan_ok ? -expf(A_log[c]) * LOG2E_F : 0.f;
     if constexpr (MODE != 2) {
       if (tid < CWC) dtab[tid] = (c0 + tid < d.Dn) ? Dv[c0 + tid] : 0.f;
@@ -361,7 +348,6 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
       if (idx < LT * HTC) dl[idx] = dreg[k] == -INFINITY ? 0.f : (d.softplus ? softplus_f(dreg[k]) : dreg[k]);
     }
     __syncthreads();   // Bt and delta tiles are in LDS
-    PROBE(1);
 
     float a[TS];
     float P = 1.f, S = 0.f;
@@ -374,7 +360,6 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
     }
     segs[seg * CWC + cl] = make_float2(P, S);
     __syncthreads();
-    PROBE(2);
 
     // composite of the segments in front of this wave's
     float Ppre = 1.f, Spre = 0.f;
@@ -423,10 +408,8 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
           lkX[cl] = make_float2(PX, SX);
         }
       }
-      PROBE(3);
       rc.store(reinterpret_cast<char *>(cc), tid);
       __syncthreads();
-      PROBE(4);
 
       float hcar = (h0 && chan_ok) ? h0[(int64_t)b * d.Dn + c] : 0.f;
       { const float2 rX = lkX[cl], rA = lkA[cl]; hcar = fmaf(rX.x, hcar, rX.y); hcar = fmaf(rA.x, hcar, rA.y); }
@@ -441,8 +424,6 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
       }
       if (h_last && chunk == d.nchunks - 1 && seg == NS - 1 && chan_ok) h_last[(int64_t)b * d.Dn + c] = hst;
       __syncthreads();   // y (in the Bt / C slots) is complete
-      PROBE(5);
-      PROBE(6);
 
       // row-major epilogue: out = (y + D*xc) * silu(z), 16-byte pieces straight to global memory
       char *og = reinterpret_cast<char *>(out + tok0 * out_rs + c0);
@@ -466,7 +447,6 @@ scan_gate_fwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
         }
       }
     }
-    PROBE(7);
   }
 }
 
@@ -537,7 +517,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, cw = w / NS, seg = w - cw * NS, cl = cw * 64 + lane;
   int chunk, cs, b;
   take_item<MODE>(head, epoch, item_s, d, ncs, true, tid, chunk, cs, b);
-  PROBE(0);
   const int c0 = cs * CWC, c = c0 + cl;
   const int64_t t0 = (int64_t)chunk * LT;
   const int rows_valid = (int)min((int64_t)LT, d.L - t0);
@@ -577,7 +556,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
     __builtin_amdgcn_sched_barrier(0);                              // one piece at a time: interleaved, their temporaries spill
   }
   __syncthreads();   // C, dv, delta tiles are in LDS
-  PROBE(1);
 
   // a_t = exp2(delta_t*A2) is recomputed wherever it is needed (three times per token) instead of living in 16 registers:
   // the kernel runs one work-group per CU and every array that spills turns its column walk into scratch traffic
@@ -596,7 +574,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
   segs[(seg * CWC + cl) * 3 + 0] = P;
   segs[(seg * CWC + cl) * 3 + 2] = M;
   __syncthreads();
-  PROBE(2);
 
   // composite of the segments behind this wave's (right to left)
   float Psuf = 1.f, Msuf = 0.f;
@@ -653,10 +630,8 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
       lkX[cl] = make_float2(PX, MX);
     }
   }
-  PROBE(3);
   rb.store(reinterpret_cast<char *>(bt), tid);
   __syncthreads();   // Bt tile and the look-back records are in LDS
-  PROBE(4);
 
   // forward segment aggregates (need Bt) for the states inside the chunk
   float S = 0.f;
@@ -706,7 +681,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
     }
   }
   __syncthreads();   // dBt / dC / y / ddl tiles complete
-  PROBE(5);
   TR::tile_out(reinterpret_cast<const char *>(bt), reinterpret_cast<char *>(dBt + tok0 * dbt_rs + c0), dbt_rs * sizeof(T), rows_valid,
                ch_store * (int)sizeof(T), tid);
   TR::tile_out(reinterpret_cast<const char *>(cc), reinterpret_cast<char *>(dC + tok0 * dc_rs + c0), dc_rs * sizeof(T), rows_valid,
@@ -720,7 +694,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
     }
   }
   __syncthreads();   // the Bt / C tiles have left: the dv*xc tile takes their place
-  PROBE(6);
 
   // row-major epilogue: dz = dout*silu'(z)*(y + D*xc), dxc = dv*D straight to global memory; dv*xc into the tile
   char *zg = reinterpret_cast<char *>(dz + tok0 * dz_rs + c0), *xg = reinterpret_cast<char *>(dxc + tok0 * dxc_rs + c0);
@@ -769,7 +742,6 @@ scan_gate_bwd_k(const float *__restrict__ dlt, const float *__restrict__ A_log, 
     for (int k = 0; k < NS; ++k) s += seg == 0 ? red[k * CWC + cl].x : red[k * CWC + cl].y;
     part[(((int64_t)b * d.nchunks + chunk) * 2 + seg) * d.Dn + c] = s;
   }
-  PROBE(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -160,10 +160,6 @@ __device__ __forceinline__ void lb_poll(lb_i4 rw, uint32_t off, uint32_t pstep, 
   static_assert(NP == 2 || NP == 3, "an inclusive record or an aggregate");
   lb_u4 p[NP];
   unsigned spins = 0;
-#ifdef LB_PROBE_NOPOLL   // (tools/ probe builds only: what the waits cost - one look, never a second; the results are wrong)
-  spins = LB_SPIN_MAX + 1;
-  (void)err;
-#endif
   while (true) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) p[i] = lb_load16(rw, lane_ok ? off + (uint32_t)i * pstep : 0xfffffff0u);   // (select LAST: bad + step wraps)
@@ -173,9 +169,6 @@ __device__ __forceinline__ void lb_poll(lb_i4 rw, uint32_t off, uint32_t pstep, 
 #pragma unroll
     for (int i = 0; i < NP; ++i) okk = okk && p[i][0] == epoch && p[i][2] == epoch;
     if (__all(okk || !lane_ok)) break;
-#ifdef LB_PROBE_NOPOLL
-    break;
-#endif
     if (++spins > LB_SPIN_MAX) { if ((threadIdx.x & 63) == 0) atomicOr(err, 2); break; }
     __builtin_amdgcn_s_sleep(2);
   }
@@ -183,19 +176,6 @@ __device__ __forceinline__ void lb_poll(lb_i4 rw, uint32_t off, uint32_t pstep, 
   sd = NP > 2 ? __uint_as_float(p[NP - 1][1]) : 0.f;
 }
 
-// tools/ probe builds (-DLB_PROBE, never the library build): waves 0 and 3 of every work-group stamp their phases
-// (s_memrealtime, 100 MHz) into a buffer handed over by apertis_scan_lookback_set_probe: [item][2][8] u64
-#ifdef LB_PROBE
-#define LB_STAMP(k) do { if (probe && ln == 0 && (wv == 0 || wv == LB_NW - 1)) \
-    probe[((size_t)s_item * 2 + (wv ? 1 : 0)) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define LB_PROBE_PARAM , unsigned long long *probe
-#define LB_PROBE_ARG , (unsigned long long *)g_lb_probe
-void *g_lb_probe = nullptr;
-#else
-#define LB_STAMP(k) do { } while (0)
-#define LB_PROBE_PARAM
-#define LB_PROBE_ARG
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward
@@ -206,21 +186,14 @@ void *g_lb_probe = nullptr;
 __global__ void __launch_bounds__(64 * LB_NW, LB_FWD_MINW)
 scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, LeanT tx, LeanT tz, const float *__restrict__ Dv,
               const float *__restrict__ h0, float *__restrict__ h_in, float *__restrict__ h_last, float *__restrict__ ckpt, LeanT to,
-              GateWsHead *__restrict__ head, uint32_t epoch, ScanDims d, LbGeo G LB_PROBE_PARAM) {
+              GateWsHead *__restrict__ head, uint32_t epoch, ScanDims d, LbGeo G) {
   __shared__ float4 sS[2][LB_NW][64];    // [0]: the waves' aggregates (state from zero); [1]: the records the waves polled
   __shared__ float sD[2][LB_NW][64];     // ... and their sums of delta
   __shared__ int s_item;
   int chunk;
   LbLane L;
-#ifdef LB_PROBE
-  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
-#endif
   if (!lb_take(head, epoch, &s_item, d, G, chunk, L)) return;
   const int ln = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), qi = ln & 3;
-#ifdef LB_PROBE
-  if (probe && ln == 0 && (wv == 0 || wv == LB_NW - 1)) probe[((size_t)s_item * 2 + (wv ? 1 : 0)) * 8 + 0] = t_entry;
-#endif
-  LB_STAMP(1);
   const int sup = chunk / LB_SUP, sib = chunk - sup * LB_SUP;
   const int t0 = chunk * LB_LT + wv * LB_TW;
   const int rows = min(LB_TW, (int)d.L - t0);              // (<= 0: this wave's tokens are all past the end)
@@ -263,7 +236,6 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
 #pragma unroll
   for (int u = 0; u < LB_TW - LB_LATE; ++u) ld_late(u);
 #endif
-  LB_STAMP(2);
   // ---- aggregate of the 16 tokens: (sum of delta, state from zero) ----
   float sp[4], S[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
 #pragma unroll
@@ -278,12 +250,8 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       vb[u].x = u < rows ? vb[u].x : 0u; vb[u].y = u < rows ? vb[u].y : 0u;
       unpack4(vb[u], bv);
       sumdl += dlv;
-#ifndef LB_PROBE_NOAGG   // (probe builds: what the aggregate's arithmetic costs - results wrong)
 #pragma unroll
       for (int k = 0; k < 4; ++k) S[k] = fmaf(__builtin_amdgcn_exp2f(dlv * A2[k]), S[k], bv[k]);
-#else
-      S[0] += bv[0] + bv[1] + bv[2] + bv[3];
-#endif
     }
   }
 #if LB_CXZ_AFTER_AGG   // (the aggregate's rows - delta, Bt - first on every wave of the CU; C, xc, z ride under the poll)
@@ -292,9 +260,7 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
 #endif
   sS[0][wv][ln] = make_float4(S[0], S[1], S[2], S[3]);
   sD[0][wv][ln] = sumdl;
-  LB_STAMP(3);
   lb_barrier();
-  LB_STAMP(4);
   // ---- wave 0 publishes the chunk's aggregate; every wave polls one record of the carry ----
   const uint32_t pstep = (uint32_t)G.g * 16u;
   float Sa[4] = {0.f, 0.f, 0.f, 0.f}, sda = 0.f;
@@ -327,9 +293,7 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
     sS[1][wv][ln] = make_float4(rv[0], rv[1], rv[2], rv[3]);
     sD[1][wv][ln] = rsd;
   }
-  LB_STAMP(5);
   lb_barrier();
-  LB_STAMP(6);
   // ---- the state entering the chunk, then this wave's tokens ----
   float hst[4];
   {
@@ -388,11 +352,7 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
         const float y = cv[k] * hst[k];
         const float dx = Dk[k] * xv[k];
         const float val = y + dx;
-#ifndef LB_PROBE_NOGATE   // (probe builds: what the gate's two transcendentals per channel cost - results wrong)
         o[k] = val * silu_g(zv[k]);
-#else
-        o[k] = val * zv[k];
-#endif
       }
       const lean_u2 ov = {lean_pack2(o[0], o[1]), lean_pack2(o[2], o[3])};
       if (u < rows) __builtin_amdgcn_raw_buffer_store_b64(ov, ro, (int)oo, (int)((uint32_t)u * to.rs * 2u), 2);   // (wave-uniform branch)
@@ -408,7 +368,6 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   }
   if (h_last && wv == LB_NW - 1 && chunk == d.nchunks - 1 && L.ok)
     *reinterpret_cast<float4 *>(h_last + (int64_t)L.b * d.Dn + L.c0) = make_float4(hst[0], hst[1], hst[2], hst[3]);
-  LB_STAMP(7);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -741,9 +700,6 @@ int64_t lb_grid(const LbShape &s) {
 
 }  // namespace
 
-#ifdef LB_PROBE
-extern "C" void apertis_scan_lookback_set_probe(void *p) { g_lb_probe = p; }
-#endif
 
 extern "C" int64_t apertis_scan_lookback_workspace_bytes(int64_t B, int64_t L, int64_t Dn) {
   if (B <= 0 || L <= 0 || Dn <= 0 || Dn % 4) return 0;
@@ -766,7 +722,7 @@ extern "C" int apertis_scan_lookback_fwd(const float *dlt, const float *A_log, c
   const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
   const unsigned grid = (unsigned)lb_grid(s);
   hipLaunchKernelGGL(scan_lb_fwd_k, dim3(grid), dim3(64 * LB_NW), 0, (hipStream_t)stream, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs),
-                     lt(xc, xc_rs), lt(z, z_rs), D, h0, h_in, h_last, ckpt16, lt(out, out_rs), (GateWsHead *)ws, epoch, s.d, s.G LB_PROBE_ARG);
+                     lt(xc, xc_rs), lt(z, z_rs), D, h0, h_in, h_last, ckpt16, lt(out, out_rs), (GateWsHead *)ws, epoch, s.d, s.G);
   return apertis_check_launch();
 }
 

@@ -417,7 +417,7 @@ def main():
             result["roofline_steps"] = args.steps // timer.every    # the steps whose launches carry event pairs (`launches` counts those)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU oracle in a CHILD process (never touches the GPU), bounded sample: one layer of the same shape at
-        # B=1 and the benchmark's sequence length, train mode, 1 warm-up + median of 3 (about 20 s of CPU work); a
+        # B=1 and the benchmark's sequence length, train mode: three legs (all cores / 32 threads / vectorised scan), each 1 warm-up + median of 2; a
         # hard timeout keeps the default run within minutes
         import subprocess
         log("cpu baseline (oracle on host cores, child process)")
@@ -425,7 +425,7 @@ def main():
             cfg.hidden_size, cfg.num_attention_heads, cfg.ssm_d_state, cfg.intermediate_size, max(cfg.num_experts, 1),
             max(cfg.experts_per_token, 1), int(moe), seq, cfg.vocab_size, cfg.num_hidden_layers)]
         try:
-            out = subprocess.run(argv, cwd=ROOT, capture_output=True, text=True, timeout=180)
+            out = subprocess.run(argv, cwd=ROOT, capture_output=True, text=True, timeout=360)
             result["cpu_baseline"] = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as exc:  # timeout / parse error: report it, never fail the bench line
             result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": None, "kind": "port",
