@@ -479,6 +479,73 @@ def test_generate_matches_reference_tokens_and_step_logits(dev, name):
     rel_error_report(f"{name}: last-position logits of all 16 generate() steps vs reference capture", logits, g["step_logits"])
 
 
+@pytest.mark.parametrize("name", ["generate_ssm_dense_long", "generate_ssm_moe_long"])
+def test_generate_graph_tail_matches_reference_long_capture(dev, name, monkeypatch):
+    """the round-5 decode path pinned against the REFERENCE, not against its own eager form.  56 new tokens at
+    B = 2, sequence 0 reaching eos mid-way (reference generate(), core.py:1520-1644, captured by tools/gen_golden.py
+    generate_long): with more than DECODE_GRAPH_MIN_STEPS tokens left the product decodes through the captured HIP graph, the
+    stacked caches and the cache-only pre-pass of every layer (csrc/decode_step.hip; core.py:369-373 is why that half of a
+    step depends on the caches alone), and - MoE - the small-batch entrance kernel.  Tokens must be EQUAL (incl. the padding
+    behind the eos) and every step's last-position logits within 1e-4; spies assert that the graph tail and the pre-pass ran."""
+    import apertis_llm_amd as A
+    from apertis_llm_amd import model as M
+    g = load_golden(name)
+    assert M.DECODE_GRAPH and M.DECODE_PREPASS, "this test pins the graph / pre-pass decode path: run it with the defaults"
+    cfg = A.ApertisConfig.from_dict(json.loads(str(g["config_json"])))
+    model = A.ApertisForCausalLM(cfg)
+    model.load_state_dict(g["sd"])
+    model = model.to(dev).eval()
+    NEW = g["step_logits"].shape[1]
+    V = cfg.vocab_size
+    # every call of forward leaves its last-position logits in a static device buffer at a device-side counter (a captured
+    # graph can replay that; a .cpu() inside the capture could not)
+    buf = torch.zeros(2, NEW + 8, V, device=dev)
+    ctr = torch.zeros(1, dtype=torch.long, device=dev)
+    seen = {"calls": 0, "first_capture_call": None, "prepass": 0, "graph_tail": 0}
+    fwd = model.forward
+
+    def spy(*a, **k):
+        out = fwd(*a, **k)
+        if torch.cuda.is_current_stream_capturing() and seen["first_capture_call"] is None:
+            seen["first_capture_call"] = seen["calls"]
+        seen["calls"] += 1
+        buf.index_copy_(1, ctr, out[1][:, -1:, :].float())
+        ctr.add_(1)
+        return out
+    model.forward = spy
+    pre = M.ApertisModel._decode_prepass
+    tail = M.ApertisForCausalLM._generate_graph_tail
+
+    def pre_spy(self, st):
+        seen["prepass"] += 1
+        return pre(self, st)
+
+    def tail_spy(self, *a, **k):
+        seen["graph_tail"] += 1
+        return tail(self, *a, **k)
+    monkeypatch.setattr(M.ApertisModel, "_decode_prepass", pre_spy)
+    monkeypatch.setattr(M.ApertisForCausalLM, "_generate_graph_tail", tail_spy)
+    toks = model.generate(input_ids=g["prompt"].to(dev), max_new_tokens=NEW, do_sample=False, use_cache=True,
+                          eos_token_id=int(g["eos"]), pad_token_id=0)
+    torch.cuda.synchronize()
+    model.forward = fwd
+    assert seen["graph_tail"] == 1, "the captured-graph tail did not engage"
+    assert seen["prepass"] >= 1, "the stacked-cache pre-pass (_decode_prepass) did not run"
+    assert float(g["min_gap"]) > 1e-3                      # no near-tie among the live greedy choices of the capture
+    assert torch.equal(toks.cpu(), g["tokens"]), (toks.cpu().tolist(), g["tokens"].tolist())
+    # device entries: the eager calls, the graph's two warm-up steps (same inputs as its first replayed step), the replays
+    E = seen["first_capture_call"] - 2
+    assert E >= 1 and seen["calls"] == E + 3
+    n_dev = int(ctr.item())
+    assert n_dev == E + 2 + (NEW - E), (n_dev, E)
+    logits = torch.cat([buf[:, :E], buf[:, E + 2:n_dev]], dim=1).cpu()
+    assert logits.shape == g["step_logits"].shape
+    fin, b = int(g["eos_step"]), int(g["eos_seq"])
+    assert int(toks[b, g["prompt"].shape[1] + fin]) == int(g["eos"]) and bool((toks[b, g["prompt"].shape[1] + fin + 1:] == 0).all())
+    rel_error_report(f"{name}: last-position logits of all {NEW} generate() steps (graph tail + pre-pass) vs reference capture",
+                     logits, g["step_logits"])
+
+
 def test_scan_lookback_timeout_word_rejects_the_step(dev):
     """The single-pass scan's bounded look-back wait leaves a non-zero error word in its workspace when it times out
     (scan_gate.hip); the activations of such a launch are wrong.  The product path must not train on them silently:

@@ -536,7 +536,76 @@ def gen_generate(core):
             **sd_arrays(sd))
 
 
-GENERATORS = ["scan", "ssm_layer", "moe", "vision", "models", "dims", "data_formats", "trainer_run", "config1", "generate"]
+def gen_generate_long(core):
+    """N1, the long capture: 56 new tokens at B = 2 with ONE sequence reaching eos mid-way - enough steps
+    for the product's captured-graph tail, the stacked-cache pre-pass and the small-batch decode kernels to engage (they need
+    >= 24 tokens left), pinned against the reference's own generate() (core.py:1520-1644) instead of against the eager form.
+    The eos id is chosen from a first, eos-free pass of the reference: a token sequence 0 emits for the first time at a step in
+    [14, 40) and sequence 1 never emits (so sequence 1 decodes to the end while sequence 0 is padded, core.py:1612-1628)."""
+    specs = {"generate_ssm_dense_long": dict(use_expert_system=False),
+             "generate_ssm_moe_long": dict(use_expert_system=True, num_experts=4, experts_per_token=2)}
+    NEW = 56
+    for name, extra in specs.items():
+      for bump in range(16):     # (the first seed whose capture has no near-tie among the live greedy choices: gap > 1e-3)
+        torch.manual_seed(zlib.crc32(name.encode()) % 1000 + bump)
+        cfg = core.ApertisConfig(vocab_size=96, hidden_size=32, num_hidden_layers=2, num_attention_heads=2,
+                                 intermediate_size=64, attention_type="selective_ssm", **extra)
+        model = core.ApertisForCausalLM(cfg).eval()
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if p.dim() > 1 and "token_embeddings" not in n_:
+                    p.mul_(8.0)
+        prompt = torch.randint(4, 96, (2, 9))
+        with torch.no_grad():
+            free = model.generate(input_ids=prompt, max_new_tokens=NEW, do_sample=False, use_cache=True, eos_token_id=10 ** 6,
+                                  pad_token_id=0)
+        new = free[:, prompt.shape[1]:]
+        eos, who = None, None
+        for b in (0, 1):
+            mine, other = new[b].tolist(), set(new[1 - b].tolist())
+            for s_ in range(14, 40):
+                if mine[s_] not in mine[:s_] and mine[s_] not in other and mine[s_] != 0:
+                    eos, who = mine[s_], (b, s_)
+                    break
+            if eos is not None:
+                break
+        if eos is None:
+            continue
+        steps = []
+        fwd = model.forward
+
+        def spy(*a, **k):
+            out = fwd(*a, **k)
+            steps.append(out[1][:, -1, :].detach().clone())
+            return out
+        model.forward = spy
+        with torch.no_grad():
+            toks = model.generate(input_ids=prompt, max_new_tokens=NEW, do_sample=False, use_cache=True, eos_token_id=eos,
+                                  pad_token_id=0)
+        model.forward = fwd
+        logits = torch.stack(steps, dim=1)                       # [B, steps, V]
+        # the greedy gap over the steps whose choice matters (a finished sequence is padded whatever its logits say)
+        newt = toks[:, prompt.shape[1]:]
+        live = torch.ones_like(newt, dtype=torch.bool)
+        fin = (newt[who[0]] == eos).nonzero()[0, 0].item()
+        live[who[0], fin + 1:] = False
+        top2 = torch.topk(logits, 2, dim=-1).values
+        gap = float((top2[..., 0] - top2[..., 1])[live].min())
+        if gap <= 1e-3:
+            continue
+        print(f"  {name} (seed bump {bump}): {newt.shape[1]} new tokens, {len(steps)} forward calls, eos {eos} ends sequence {who[0]} at step {fin}, "
+              f"min live top-2 gap {gap:.3e}")
+        assert newt.shape[1] == NEW and fin == who[1] and (newt[who[0], fin + 1:] == 0).all() and (newt[1 - who[0]] != eos).all()
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        npz(name, prompt=prompt, tokens=toks, step_logits=logits, min_gap=gap, eos=eos, eos_seq=who[0], eos_step=fin,
+            live=live, config_json=json.dumps(cfg.to_dict()), **sd_arrays(sd))
+        break
+      else:
+        raise SystemExit(f"{name}: no seed in 16 fits the eos rule with a clear greedy gap")
+
+
+GENERATORS = ["scan", "ssm_layer", "moe", "vision", "models", "dims", "data_formats", "trainer_run", "config1", "generate",
+              "generate_long"]
 
 
 if __name__ == "__main__":
