@@ -3247,7 +3247,9 @@ extern "C" int apertis_moe_enter_small(const void *blk, const void *res, const f
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(1), block(64 * (unsigned)(E * K));
   const size_t lds = (size_t)(3 * E + 4) * H * sizeof(float) + (size_t)S * H * (dtype_y == APERTIS_BF16 ? 2 : 4);
-  if (lds > 160 * 1024) return APERTIS_ERR_UNSUPPORTED;
+  // (+ 4 KiB: the kernel's and plan_small_body's static __shared__ tables share the CU's 160 KiB with the dynamic part;
+  //  ops.moe_enter_small_supported mirrors this bound)
+  if (lds + 4096 > 160 * 1024) return APERTIS_ERR_UNSUPPORTED;
 #define ES_GO(TOT, NN_) { auto kf = moe_enter_small_k<float, TOT, IT, NN_>; \
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kf, grid, block, lds, st, (const TOT *)blk, (const float *)res, gamma, beta, eps, (float *)y, (TOT *)xn, rgamma, rbeta, \

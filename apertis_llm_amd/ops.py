@@ -1364,9 +1364,9 @@ def moe_enter_small_supported(blk, res, E, K):
     S = res.numel() // res.shape[-1]
     H = res.shape[-1]
     # the kernel's own LDS bound (csrc/moe_routing.hip, apertis_moe_enter_small: the boundary / router / expert affine vectors
-    # in fp32 plus the S block rows in their own dtype, <= 160 KiB): a shape past it must take the general path HERE - by the
-    # time the launch declined it, _decode_prepass has already advanced every layer's SSM state
-    lds = (3 * E + 4) * H * 4 + S * H * blk.element_size()
+    # in fp32 plus the S block rows in their own dtype, plus 4 KiB for its static tables, <= 160 KiB): a shape past it must
+    # take the general path HERE - by the time the launch declined it, _decode_prepass has already advanced every layer's SSM state
+    lds = (3 * E + 4) * H * 4 + S * H * blk.element_size() + 4096
     return (res.is_cuda and not torch.is_grad_enabled() and 1 <= S <= 16 and E in (4, 8) and E * K <= 16 and K <= E
             and H % 4 == 0 and H <= 1024 and lds <= 160 * 1024 and res.dtype == torch.float32
             and blk.dtype in (torch.float32, torch.bfloat16) and tuple(blk.shape) == tuple(res.shape))

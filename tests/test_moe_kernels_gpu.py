@@ -1233,11 +1233,11 @@ def test_moe_entrance_of_a_handful_of_rows_in_one_launch(dev, S, E, K, H, dt):
     assert torch.equal(plan0.row_token[:S * K], plan1.row_token[:S * K]) and torch.equal(xg0[:S * K], xg1[:S * K])
 
 
-@pytest.mark.parametrize("S,H,dt,ok", [(16, 928, torch.float32, True), (16, 932, torch.float32, False), (13, 1000, torch.float32, False),
+@pytest.mark.parametrize("S,H,dt,ok", [(16, 904, torch.float32, True), (16, 908, torch.float32, False), (13, 1000, torch.float32, False),
                                        (16, 1024, torch.bfloat16, True), (16, 1024, torch.float32, False)])
 def test_moe_entrance_predicate_mirrors_the_kernels_lds_bound(dev, S, H, dt, ok):
     """moe_enter_small_supported must decline exactly the shapes apertis_moe_enter_small declines on its 160 KiB of
-    LDS ((3E+4)*H*4 + S*H*sizeof(blk)) - generate() has advanced every layer's SSM state by the time the launch would return -2."""
+    LDS ((3E+4)*H*4 + S*H*sizeof(blk) + 4 KiB of static tables) - generate() has advanced every layer's SSM state by the time the launch would return -2."""
     from apertis_llm_amd import ops
     E, K = 8, 2
     torch.manual_seed(H + S)
