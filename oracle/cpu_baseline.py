@@ -58,6 +58,34 @@ def cpu_model():
     return platform.processor() or platform.machine() or "unknown"
 
 
+def usable_cpus():
+    """(os.cpu_count(), CPUs this process may actually use): the scheduler affinity and the cgroup's CPU quota both bound it.
+    On the GPU boxes os.cpu_count() reports the whole host (256) while the container's share is 16: a thread pool of 256 on
+    16 CPUs' worth of quota does not finish the sample (measured: > 360 s against 15 s)."""
+    total = os.cpu_count() or 1
+    use = total
+    try:
+        use = min(use, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = parts[0], float(parts[1])
+            else:
+                quota = parts[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                    period = float(g.read().split()[0])
+            if quota not in ("max", "-1"):
+                use = min(use, max(1, int(float(quota) / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return total, max(1, use)
+
+
 def _time_scan_only(h, N, L, threads, gen):
     """Forward of the two scan restatements alone at B=1 (SURVEY section 8(d) tensors), effective GB/s on the GPU's formula
     T*(3*Dn*e + 4*h) with e = 4 (this oracle runs fp32)."""
@@ -77,16 +105,16 @@ def _time_scan_only(h, N, L, threads, gen):
     return out
 
 
-def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, reps=2):
+def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, reps=2, emit=None):
     """fwd+bwd of ONE layer of the given shape at B=1 and the benchmark's sequence length L, in TRAIN mode (expert
     capacity on, dropout p = 0 for determinism), plus the lm_head + CE, through the oracle with torch autograd:
     one warm-up repetition, then the median of `reps`; extrapolated to n_layers_total layers.  Three legs (BASELINE.md
     section 3): the sequential-recurrence scan (core.py:337-353, what the reference trainer executes) on every host core
-    (`value` = `value_recurrent`), the same on 32 threads (`value_recurrent_32t`: the recurrence is a Python loop of tiny ops
-    and a large pool is mostly overhead), and the vectorised scan (core.py:324-335 per 64-token chunk, `value_vectorised`, the
+    this process may use (`value` = `value_recurrent`; `cores` = min(os.cpu_count(), affinity, cgroup quota): the GPU boxes
+    report 256 host cores to a container that owns 16), the same on 32 threads (`value_recurrent_32t`, round 5's figure), and the vectorised scan (core.py:324-335 per 64-token chunk, `value_vectorised`, the
     fair CPU comparison).  Returns a dict."""
-    avail = os.cpu_count() or 1
-    threads = threads or avail
+    avail, usable = usable_cpus()
+    threads = threads or usable          # every core this process may use (BASELINE.md section 3), not the host's count
     gen = torch.Generator().manual_seed(0)
     R = math.ceil(H / 16)
     sd = _random_layer_state(H, h, N, I, E, R, moe, gen)
@@ -136,21 +164,34 @@ def time_layer(H, h, N, I, E, K, moe, L, vocab, n_layers_total, threads=None, re
         t_fwd, t_bwd, t_head = med(0), med(1), med(2)
         return L / (n_layers_total * (t_fwd + t_bwd) + t_head), (t_fwd, t_bwd, t_head)
 
-    v_rec, (t_fwd, t_bwd, t_head) = leg(ref_cpu.scan_recurrent, threads, True)
-    v_vec, (v_fwd, v_bwd, _) = leg(ref_cpu.scan_chunked_vectorised, threads, True)
-    t32 = min(32, avail)
-    v_rec32 = leg(ref_cpu.scan_recurrent, t32, False)[0] if t32 != threads else v_rec
-    scan_gbps = _time_scan_only(h, N, L, threads, gen)
-    return {"value": v_rec, "unit": "tokens/s", "cores": threads, "cores_available": avail, "cpu_model": cpu_model(),
-            "kind": "port", "value_recurrent": v_rec, "value_vectorised": v_vec, "value_recurrent_32t": v_rec32,
-            "threads_second_figure": t32,
-            "scan_fwd_gbps": {"recurrent": scan_gbps["recurrent"], "vectorised": scan_gbps["vectorised"],
-                              "formula": "T*(3*Dn*4 + 4*h) bytes / forward time, B=1, fp32"},
-            "sample": f"oracle (torch-CPU restatement) fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, fp32, "
-                      f"train mode (expert capacity on, dropout p=0), {threads} threads, 1 warm-up + median of {reps}: "
-                      f"recurrent scan (as the reference trainer executes it, core.py:337-353) layer fwd {t_fwd:.2f}s bwd "
-                      f"{t_bwd:.2f}s head {t_head:.2f}s; vectorised scan (core.py:324-335 per 64-token chunk) layer fwd "
-                      f"{v_fwd:.2f}s bwd {v_bwd:.2f}s; step time extrapolated as {n_layers_total}x layer + head"}
+    # legs in the order of their cost certainty: <= 32 threads first (round 5's figure: known to finish in ~20 s), its result
+    # is emitted at once (`emit`: bench.py keeps the LAST line it could parse, also when its time-out ends this process); the
+    # all-usable-cores leg, when it is a different thread count, comes last
+    t32 = min(32, threads)
+    v_rec, (t_fwd, t_bwd, t_head) = leg(ref_cpu.scan_recurrent, t32, True)
+    v_vec, (v_fwd, v_bwd, _) = leg(ref_cpu.scan_chunked_vectorised, t32, True)
+    scan_gbps = _time_scan_only(h, N, L, t32, gen)
+
+    def result(v_all):
+        best, cores = (v_all, threads) if v_all is not None and v_all > v_rec else (v_rec, t32)
+        return {"value": best, "unit": "tokens/s", "cores": cores, "cores_available": avail, "cores_usable": usable,
+                "cpu_model": cpu_model(), "kind": "port", "value_recurrent": best, "value_vectorised": v_vec,
+                "value_recurrent_32t": v_rec, "threads_second_figure": t32,
+                "value_recurrent_all_usable_cores": v_all, "threads_all_usable": threads,
+                "scan_fwd_gbps": {"recurrent": scan_gbps["recurrent"], "vectorised": scan_gbps["vectorised"],
+                                  "formula": "T*(3*Dn*4 + 4*h) bytes / forward time, B=1, fp32"},
+                "sample": f"oracle (torch-CPU restatement) fwd+bwd of 1 of {n_layers_total} layers + lm_head/CE at B=1 L={L}, "
+                          f"fp32, train mode (expert capacity on, dropout p=0), 1 warm-up + median of {reps}; at {t32} threads: "
+                          f"recurrent scan (as the reference trainer executes it, core.py:337-353) layer fwd {t_fwd:.2f}s bwd "
+                          f"{t_bwd:.2f}s head {t_head:.2f}s; vectorised scan (core.py:324-335 per 64-token chunk) layer fwd "
+                          f"{v_fwd:.2f}s bwd {v_bwd:.2f}s; step time extrapolated as {n_layers_total}x layer + head; `value` = the "
+                          f"faster recurrent figure of the {t32}-thread and the all-usable-cores ({threads}) legs"
+                          + ("" if v_all is not None or threads == t32 else " (the latter not finished when this line was written)")}
+
+    if emit is not None:
+        emit(result(None))
+    v_all = leg(ref_cpu.scan_recurrent, threads, False)[0] if threads != t32 else v_rec
+    return result(v_all)
 
 
 if __name__ == "__main__":   # child process of bench.py: prints one JSON object
@@ -158,4 +199,5 @@ if __name__ == "__main__":   # child process of bench.py: prints one JSON object
     import sys
     a = [int(v) for v in sys.argv[1:]]
     H, h, N, I, E, K, moe, L, vocab, layers = a
-    print(json.dumps(time_layer(H, h, N, I, E, K, bool(moe), L, vocab, layers)))
+    out = lambda d: print(json.dumps(d), flush=True)
+    out(time_layer(H, h, N, I, E, K, bool(moe), L, vocab, layers, emit=out))

@@ -18,8 +18,10 @@ what = sys.argv[2] if len(sys.argv) > 2 else "all"
 if what == "benchmix":
     # exactly the per-layer hot-kernel launches of bench.py's default workload (1.5b-moe, per-GPU batch 32)
     B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-    L, h, N, H, I, E = 4096, 11, 16, 704, 2816, 8
-    Dn, R = h * N, 44
+    # (argv[4]: the BASELINE configuration whose layer shapes are replayed - round 6: configs 3 and 5 get traffic files too)
+    L, h, N, H, I, E = {"1.5b-moe": (4096, 11, 16, 704, 2816, 8), "350m-moe": (4096, 4, 16, 256, 1024, 8),
+                        "1.5b-moe-mm": (2048 + 197, 11, 16, 704, 2816, 8)}[sys.argv[4] if len(sys.argv) > 4 else "1.5b-moe"]
+    Dn, R = h * N, math.ceil(H / 16)
     Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64                 # the model's padded x_param_proj layout [Bt | 0 | C | 0 | dt | 0]
     rows = E * int((B * L / E) * 1.25)      # capacity-limited rows of the train step
     p = torch.randn(B, L, 2 * Wb + Wr, device=dev).bfloat16().requires_grad_(True)
