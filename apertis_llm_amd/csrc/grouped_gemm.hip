@@ -3003,7 +3003,7 @@ extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_prob
 }
 
 // Which v5 tile a ONE-group [M, N] weight gradient takes through apertis_grouped_gemm_tn (1 = 352 x 256, 0 = 256 x 352), or -1:
-// the caller then cuts the rows into pseudo-groups for the 128 x 128 kernel and folds the partial sums itself (ops.py).
+// the caller then cuts the rows into pseudo-groups for the 128 x 128 kernel and folds the partial sums itself (ops/gemm.py).
 // Measured at 180 224 rows (tools/dense_wgrad_check.py; 128 x 128 kernel over pseudo-groups + fold -> this path): dW [704, 2816]
 // 1105 -> 637 us (647 -> 1122 TF), [768, 768] 328 -> 279, [352, 704] 191 -> 166, [896, 224] 156 -> 160, [704, 176] 133 -> 141:
 // every CU writes a whole 352 x 256 fp32 slice (93 MB of partial tiles + their fold per call, whatever the shape), so it pays

@@ -374,7 +374,7 @@ class SelectiveLinearAttention(nn.Module):
         return idx
 
     def register_train_prep(self, prep):
-        """This block's GEMM weights into a TrainPrep (ops.py): stacked in_proj, padded x_param_proj, out_proj."""
+        """This block's GEMM weights into a TrainPrep (ops/prep.py): stacked in_proj, padded x_param_proj, out_proj."""
         Dn, R = self.d_inner, self.dt_rank
         Wb, Wr = -(-Dn // 64) * 64, -(-R // 64) * 64
         prep.add_stack(("in_proj_xz", id(self)), (self.in_proj_x.weight, self.in_proj_z.weight))
@@ -550,7 +550,7 @@ class AdaptiveExpertSystem(nn.Module):
                 ("1.bias", "expert_b1"), ("4.weight", "expert_w2"), ("4.bias", "expert_b2"))
 
     def register_train_prep(self, prep):
-        """The stacked expert weights into a TrainPrep (ops.py): bf16 and transposed bf16 copies, one launch per step."""
+        """The stacked expert weights into a TrainPrep (ops/prep.py): bf16 and transposed bf16 copies, one launch per step."""
         prep.add_plain(self.expert_w1)
         prep.add_plain(self.expert_w2)
 

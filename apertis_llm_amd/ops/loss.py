@@ -1,0 +1,140 @@
+"""Loss operators: shifted cross-entropy and the fused LM-head + cross-entropy (no [B, L, V] logits tensor).
+
+Part of apertis_llm_amd.ops (split by subsystem in round 6; `from apertis_llm_amd import ops` exposes every name as before).
+torch is used for device memory, streams and autograd bookkeeping only; every computation is a HIP kernel launch through
+apertis_llm_amd._lib.  Tensors must live on a ROCm device.
+"""
+import os as _os
+
+import torch
+
+from .. import _lib
+from .._lib import check, dtype_code, ptr, stream_ptr
+from ._base import _apply, _grad_wanted, _require_gpu
+
+
+class _ShiftedCrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, n_pos, ignore_index):
+        _require_gpu(logits, labels)
+        lib = _lib.load()
+        B, L, V = logits.shape
+        logits = logits.contiguous()
+        labels = labels.contiguous()
+        lse = torch.empty(B * L, device=logits.device, dtype=torch.float32)
+        row_loss = torch.empty(B * L, device=logits.device, dtype=torch.float32)
+        check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(labels), ptr(lse), ptr(row_loss), B, L, V, labels.shape[1], n_pos,
+                                            ignore_index, dtype_code(logits), stream_ptr()), "apertis_cross_entropy_fwd")
+        # the same predicate as the kernel (a label outside [0, V) is skipped there): 0 targets -> nan, like
+        # F.cross_entropy; out-of-range labels are rejected by shifted_cross_entropy() unless it was told not to look
+        tgt = labels[:, 1:n_pos + 1]
+        count = ((tgt != ignore_index) & (tgt >= 0) & (tgt < V)).sum().to(torch.float32)
+        ctx.save_for_backward(logits, labels, lse, count)
+        ctx.cfg = (n_pos, ignore_index)
+        return row_loss.sum() / count
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        logits, labels, lse, count = ctx.saved_tensors
+        n_pos, ignore_index = ctx.cfg
+        B, L, V = logits.shape
+        gscale = (dloss.to(torch.float32) / count).reshape(1).contiguous()
+        dlogits = torch.empty_like(logits)
+        check(lib.apertis_cross_entropy_bwd(ptr(logits), ptr(labels), ptr(lse), ptr(gscale), ptr(dlogits), B, L, V,
+                                            labels.shape[1], n_pos, ignore_index, dtype_code(logits), stream_ptr()),
+              "apertis_cross_entropy_bwd")
+        return dlogits, None, None, None
+
+
+def shifted_cross_entropy_supported(logits, labels):
+    V = logits.shape[-1]
+    return (logits.is_cuda and labels.is_cuda and logits.dim() == 3 and labels.dim() == 2 and labels.dtype == torch.int64 and
+            logits.shape[0] == labels.shape[0] and logits.dtype in (torch.float32, torch.bfloat16) and
+            V % (8 if logits.dtype == torch.bfloat16 else 4) == 0 and logits.shape[0] * logits.shape[1] < 2 ** 31)
+
+
+def shifted_cross_entropy(logits, labels, ignore_index=-100):
+    """mean_{valid (b,l)} CE(logits[b, l, :], labels[b, l+1]) for l < min(L, L_labels) - 1, fp32 math on the
+    logits as stored: the reference's shift + CrossEntropyLoss(ignore_index) (core.py:1407-1416) without the
+    shifted / fp32 copies of the [B, L, V] tensor.  Labels must be in [0, V) or ignore_index."""
+    n_pos = min(logits.shape[1], labels.shape[1]) - 1
+    return _ShiftedCrossEntropy.apply(logits, labels, n_pos, ignore_index)
+
+
+# rows of logits held at a time by linear_cross_entropy (16384 x 32000 bf16 = 1 GiB): with one 4096-token sequence per
+# chunk the 32 weight-gradient partial GEMMs and their fp32 accumulation cost 4 ms of the 440 ms step, with four per chunk
+# the step time equals the logits path's and the peak is still 14 GiB lower at batch 32
+_LCE_CHUNK_ROWS = int(_os.environ.get("APERTIS_LCE_CHUNK_ROWS", "16384"))
+
+
+class _LinearCrossEntropy(torch.autograd.Function):
+    """loss = shifted CE(hidden @ W.T, labels) without the [B, L, V] logits tensor: the LM head and the loss are walked
+    a few sequences at a time - logits of the chunk (hipBLASLt GEMM), apertis_cross_entropy_fwd (log-sum-exp + loss),
+    apertis_cross_entropy_bwd IN PLACE on the chunk (softmax - onehot, already scaled by 1 / #targets), and the chunk's
+    two gradient GEMMs (d hidden, and d W accumulated in fp32) - so only one chunk of logits ever exists and nothing is
+    recomputed in the backward, which just scales the stored gradients by the incoming scalar."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, labels, ignore_index, compute_dtype):
+        _require_gpu(hidden, weight, labels)
+        lib = _lib.load()
+        B, L, H = hidden.shape
+        V = weight.shape[0]
+        labels = labels.contiguous()
+        n_pos = min(L, labels.shape[1]) - 1
+        need = _grad_wanted(ctx, 2)
+        x = hidden.to(compute_dtype).contiguous()
+        w = weight.detach().to(compute_dtype)
+        tgt = labels[:, 1:n_pos + 1]
+        count = ((tgt != ignore_index) & (tgt >= 0) & (tgt < V)).sum().to(torch.float32)
+        gscale = (1.0 / count).reshape(1).contiguous()
+        dev = hidden.device
+        code = dtype_code(x)
+        loss_sum = torch.zeros((), device=dev, dtype=torch.float32)
+        dx = torch.empty_like(x) if need else None
+        dw = torch.zeros(V, H, device=dev, dtype=torch.float32) if need else None
+        nb = max(1, _LCE_CHUNK_ROWS // L)                                     # sequences per chunk
+        lse = torch.empty(nb * L, device=dev, dtype=torch.float32)
+        row_loss = torch.empty(nb * L, device=dev, dtype=torch.float32)
+        for b0 in range(0, B, nb):
+            n = min(nb, B - b0)
+            xb = x[b0:b0 + n].reshape(n * L, H)
+            logits = torch.matmul(xb, w.t()).reshape(n, L, V)                 # n sequences of logits
+            lab = labels[b0:b0 + n]
+            check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(lab), ptr(lse), ptr(row_loss), n, L, V, labels.shape[1], n_pos,
+                                                ignore_index, code, stream_ptr()), "apertis_cross_entropy_fwd")
+            loss_sum += row_loss[:n * L].sum()
+            if need:
+                check(lib.apertis_cross_entropy_bwd(ptr(logits), ptr(lab), ptr(lse), ptr(gscale), ptr(logits), n, L, V,
+                                                    labels.shape[1], n_pos, ignore_index, code, stream_ptr()),
+                      "apertis_cross_entropy_bwd")
+                dl = logits.reshape(n * L, V)
+                torch.matmul(dl, w, out=dx[b0:b0 + n].reshape(n * L, H))
+                dw.add_(torch.matmul(dl.t(), xb))
+        ctx.save_for_backward(dx, dw)
+        ctx.cfg = (hidden.dtype, weight.dtype)
+        return loss_sum / count
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dx, dw = ctx.saved_tensors
+        hdt, wdt = ctx.cfg
+        g = dloss.to(torch.float32)
+        return ((dx * g.to(dx.dtype)).to(hdt) if ctx.needs_input_grad[0] else None,
+                (dw * g).to(wdt) if ctx.needs_input_grad[1] else None, None, None, None)
+
+
+def linear_cross_entropy_supported(hidden, weight, labels):
+    V = weight.shape[0]
+    cd = torch.bfloat16 if torch.is_autocast_enabled() else hidden.dtype
+    return (hidden.is_cuda and weight.is_cuda and labels.is_cuda and hidden.dim() == 3 and labels.dim() == 2 and
+            labels.dtype == torch.int64 and hidden.shape[0] == labels.shape[0] and cd in (torch.float32, torch.bfloat16) and
+            V % (8 if cd == torch.bfloat16 else 4) == 0 and hidden.shape[1] >= 2)
+
+
+def linear_cross_entropy(hidden, weight, labels, ignore_index=-100, compute_dtype=None):
+    """mean over valid (b, l) of CE((hidden @ weight.T)[b, l], labels[b, l + 1]): the LM head (reference core.py:1412) and
+    the shifted cross entropy (core.py:1417-1450) as one op that never holds more than one sequence of logits.
+    hidden [B, L, H], weight [V, H] (the tied embedding), labels [B, >= L] int64."""
+    return _apply(_LinearCrossEntropy, hidden, weight, labels, ignore_index, compute_dtype or hidden.dtype)

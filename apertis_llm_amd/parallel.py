@@ -50,9 +50,10 @@ class BucketedDataParallel(nn.Module):
         self._warned_partial = False
         import os as _os
         self._force = _os.environ.get("APERTIS_FORCE_DP") == "1"
-        if self.world_size > 1:
+        if self.world_size > 1 or self._force:
             # collectives will share the GPU with the persistent GEMM kernels: let those take their tiles from a queue,
             # so a work-group whose CU an RCCL kernel holds does not walk a full static share alone at the end
+            # (APERTIS_FORCE_DP=1 - the N > 1 step rehearsed on one rank - runs the very kernels the N > 1 step runs)
             from . import ops as _ops
             _ops.GEMM_DYNAMIC_QUEUE = True
         params = [p for p in module.parameters() if p.requires_grad]

@@ -26,14 +26,19 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     # name: (target params, moe, multimodal, seq, default per-GPU batch)   BASELINE.json configs[1..4]
     "125m": ("125M", False, False, 2048, 32),
-    "350m-moe": ("350M", True, False, 4096, 16),
+    # configs 3 and 5 fill the chip too (round 6 sweeps, profiles/r6_batch_sweep_configs_3_5.txt): at per-GPU
+    # batch 16 the 350m-moe step was bound by the HOST's launch rate (115 ms of thousands of small launches); 350m-moe 16 / 32 /
+    # 48 / 64 / 72 / 76: 570 k / 693 k / 764 k / 795 k / 798 k / 811 k tokens/s at 55 / 105 / 155 / 203 / 227 / 239 GiB
+    "350m-moe": ("350M", True, False, 4096, 72),
     # per-GPU batch 44 x 4096 tokens: ~232 GiB of the HBM3E (40: 214 GiB, 46: 242 GiB measured; the LM head + loss no longer
     # hold the [B, L, 32000] logits).  The batch follows the tile counts of the persistent expert GEMMs: with the 256 x 352
     # tile fc2 forward / fc1 dgrad have 40 * B tiles on 256 CUs - 6.25 rounds at B = 40 (run as 7), 6.875 at B = 44.  Same
     # box, end of round 2, 10 timed steps: 36: 348.3k tokens/s, 40: 348.5-352.6k, 44: 357.9-358.2k.  (Before that tile:
     # 34: 328.8k, 38: 333.7k, 40: 330.1-334.3k, 42: 332.4-337.3k, 46: 331.7-335.1k - inside the box-to-box spread.)
     "1.5b-moe": ("1.5B", True, False, 4096, 44),
-    "1.5b-moe-mm": ("1.5B", True, True, 2048, 16),
+    # 1.5b-moe-mm (224 x 224 image + 2048 text tokens per sequence) 16 / 32 / 48 / 64 / 72: 247 k / 304 k / 324 k / 338 k / 341 k
+    # tokens/s at 68 / 112 / 155 / 199 / 220 GiB
+    "1.5b-moe-mm": ("1.5B", True, True, 2048, 72),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
