@@ -1502,7 +1502,7 @@ __global__ void __launch_bounds__(NT4)
 grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
                     const TO *__restrict__ mul_pre, int N, int K, int ldw, int E, int n_tiles, int total_tiles, int act_flags,
-                    float drop_p, uint64_t seed, int walk_g, int walk_nb) {
+                    float drop_p, uint64_t seed, int walk_g, int walk_nb, int *__restrict__ queue) {
   typedef bf16x8 frag;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bool save_grad = (act_flags & APERTIS_ACT_SAVE_GRAD) != 0, mul_saved = (act_flags & APERTIS_ACT_MUL_SAVED) != 0;
@@ -1550,8 +1550,63 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     }
     return t;
   };
+  // ---- dynamic tile queue (queue != NULL: data-parallel steps, where an RCCL kernel may hold CUs - see ntq_next).  After its
+  // first, static tile a work-group draws virtual tile indices from ITS XCD's counter: ticket k of XCD x is
+  // v = (1 + k / 32) * G + (k % 32) * 8 + x - exactly the indices the static walk gives that XCD's work-groups, in the same order,
+  // so the tiles in flight on an XCD are still neighbours of the walk (launcher: G % 8 == 0, nk >= 11).  The ticket for the tile
+  // AFTER the next one would stall the ring if it were fetched with a compiler-tracked atomic (hipcc waits vmcnt(0) for its
+  // result: every stage in flight); wave 0 issues it by hand at the top of a tile - one more operation in the in-order vmcnt
+  // queue, younger than the epilogue's stores: wave 0's waits of sub-steps 0..2 let one more operation pass, sub-step 3's
+  // vmcnt(8) retires it - hands it round through LDS behind sub-step 3, and every wave decodes it behind sub-step 5 (two
+  // barriers later), well before the fill pointer enters the next tile (sub-step nk - 5).  A ticket past the XCD's share (or
+  // on one of the few padding tiles at the walk's end) takes the slow path: thread 0 steals from the other XCDs' counters
+  // with ordinary atomics behind a full barrier - the kernel's tail only.
+  const bool dyn = queue != nullptr;
+  const int home = (int)(blockIdx.x & 7), q_per = G >> 3;
+  int mt_valid = 0;
+  if (dyn)
+    for (int g = 0; g < E; ++g) mt_valid += (offsets[g + 1] - offsets[g] + BM4 - 1) / BM4;
+  auto ticket_v = [&](int x, int k) -> int { return (1 + k / q_per) * G + (k % q_per) * 8 + x; };
+  auto tile_ok = [&](int v) -> bool {
+    if (v >= total_tiles) return false;
+    int mt, ntile;
+    tile_walk(xcd_remap(v, total_tiles), total_tiles / n_tiles, n_tiles, walk_g, walk_nb, mt, ntile);
+    return mt < mt_valid;
+  };
+  int *s_tk = reinterpret_cast<int *>(smem + RING4 + 8 * 1024);   // [0] the ticket wave 0 drew, [1] the slow path's result, [2] a dump word
+  auto steal = [&]() -> int {   // thread 0 only: the next valid virtual index from any XCD's counter, -1 when all are drained
+    for (int i = 0; i < 8; ++i) {
+      const int x = (home + i) & 7;
+      while (true) {
+        const int v = ticket_v(x, atomicAdd(queue + x * NTQ_STRIDE, 1));
+        if (v >= total_tiles) break;          // this XCD's share is gone (tickets grow)
+        if (tile_ok(v)) return v;
+      }
+    }
+    return -1;
+  };
+  // EVERY wave issues the atomic (lane 0, by an exec mask set inside the asm) - wave 0 on the XCD's counter, waves 1..7 on
+  // dummy words beside it - so that all eight waves have the SAME in-order vmcnt sequence and the code has no branch around
+  // the instruction: behind a `if (wave == 0)` hipcc merged the result into another register at the join right behind the
+  // atomic, i.e. copied a register whose data had not arrived yet (the destination is written when the atomic RETURNS; its
+  // only reader is the hand-written ds_write of the hand-over behind sub-step 3's wait; tools/check_nt4r_ticket_isa.py checks
+  // the compiled kernels for exactly that).
+  int tkv;
+  auto issue_ticket = [&]() {
+    const uint64_t addr = (uint64_t)(uintptr_t)(queue + home * NTQ_STRIDE + (wave ? 8 + wave : 0));
+    uint64_t saved_exec;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                 : "=v"(tkv), "=&s"(saved_exec) : "v"(addr), "v"(1) : "memory");
+  };
 
   Tile4 cur = next_valid();
+  if (dyn && !cur.valid) {   // (the static first tile fell on padding: nothing is in flight yet, the slow path costs nothing)
+    if (tid == 0) s_tk[1] = steal();
+    __syncthreads();
+    const int v = __builtin_amdgcn_readfirstlane(s_tk[1]);
+    if (v >= 0) cur = decode(v);
+    __syncthreads();
+  }
   if (!cur.valid) return;
 
   // ---- the fill pointer: (tile, sub-step) of the next stage to issue, and that tile's descriptors.  Past the last tile the
@@ -1649,7 +1704,8 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
   for (;;) {
-    nxt = next_valid();
+    if (dyn) { nxt.valid = 0; issue_ticket(); }   // (handed over behind sub-step 3, decoded behind sub-step 5)
+    else nxt = next_valid();
     // Stage 0's fragments.  (A tile's last sub-step has read them already, like every sub-step reads its successor's, but
     // 48 registers held across the epilogue leave its arithmetic no room to interleave: they are read again here - the slot is
     // not refilled before sub-step 0's barrier - and the stage has landed: the wait + barrier of the prologue resp. of the
@@ -1677,7 +1733,9 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       const int nxt_off = cur_off + SLOT4 == RING4 ? 0 : cur_off + SLOT4;                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
       const int stores_behind = (S_) < 3 ? prev_stores : 0;                                                    \
-      if (stores_behind == 0) wait_vmcnt<8>(); else if (stores_behind == 16) wait_vmcnt<24>(); else wait_vmcnt<40>(); \
+      if ((S_) < 3 && dyn) {   /* the ticket atomic behind the stores: one more operation may pass */ \
+        if (stores_behind == 0) wait_vmcnt<9>(); else if (stores_behind == 16) wait_vmcnt<25>(); else wait_vmcnt<41>(); \
+      } else if (stores_behind == 0) wait_vmcnt<8>(); else if (stores_behind == 16) wait_vmcnt<24>(); else wait_vmcnt<40>(); \
       NT4R_BARRIER                                                                                             \
       if (fs == 0 && bias && fvalid) issue_bias();                                                             \
       if (NT4R_PRIO == 0) __builtin_amdgcn_s_setprio(1);                                                       \
@@ -1692,6 +1750,22 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       else {   // odd nk: keep the register roles of the loop
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[0][i] = af[1][i];
+      }
+      if (dyn) {
+        if (s == 2) {          // behind sub-step 3: its vmcnt(8) has retired wave 0's ticket atomic
+          // (wave 0 / lane 0's value is the ticket; every other lane writes what its register holds to a word nobody reads)
+          asm volatile("ds_write_b32 %0, %1" :: "v"(lds0 + (uint32_t)(RING4 + 8 * 1024) + ((wave | lane) ? 8u : 0u)), "v"(tkv) : "memory");
+        } else if (s == 4) {   // behind sub-step 5: two barriers after the hand-over (nk >= 11: the fill pointer is still in cur)
+          const int v = ticket_v(home, __builtin_amdgcn_readfirstlane(s_tk[0]));
+          if (tile_ok(v)) nxt = decode(v);
+          else {               // past this XCD's share, or padding: the slow path (a full barrier: every stage drains - tail only)
+            __syncthreads();
+            if (tid == 0) s_tk[1] = steal();
+            __syncthreads();
+            const int v2 = __builtin_amdgcn_readfirstlane(s_tk[1]);
+            if (v2 >= 0) nxt = decode(v2);
+          }
+        }
       }
     }
 #undef SUB4
@@ -2883,19 +2957,29 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
                        // 102 us, N=704 K=352 162 -> 141, N=448 K=176 83 -> 74, N=176 K=448 63-67 -> 60, N=176 K=704 85-92 -> 83;
                        // N=352 K=704 stays on the 352-wide tile (107-110 there, 111 here)
                        (E == 1 && K <= 1024 && N >= 128 && !(N == BN5 && K % 64 == 0 && ldw == K));
-    if (use4r && !tile_queue && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 && N >= 128 &&
-        max_rows >= 4096 && E <= 1024) {
+    // (a caller's tile queue - data-parallel steps - is taken when the kernel's ticket hand-over fits: K >= 352 and a grid that
+    //  is a multiple of the 8 XCDs; otherwise such calls stay on the queue-driven two-per-CU / 256 x 256 kernels below.  Round 6:
+    //  the N > 1 step used to lose this kernel altogether - 956 against 902 us per expert NT call at B = 44)
+    const int64_t grid4q = (ceil_div64(max_rows, BM4) + E) * ceil_div64(N, BN4);
+    const bool queue4_ok = tile_queue && ceil_div64(K, 32) >= 11 && grid4q >= device_cu_count() && device_cu_count() % 8 == 0;
+    if (use4r && (!tile_queue || queue4_ok) && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 &&
+        N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt4 = (int)ceil_div64(N, BN4);
       const int64_t grid4 = (ceil_div64(max_rows, BM4) + E) * nt4;
       if (grid4 < 0x7fffffffLL) {
         const int gp = (int)std::min<int64_t>(grid4, device_cu_count());   // one persistent work-group per CU
         auto k4 = ragged2x ? grouped_gemm_nt4r_k<TO, true> : grouped_gemm_nt4r_k<TO, false>;
-        const int lds4 = RING4 + 8 * 1024;   // ring + a bias area per wave
+        const int lds4 = RING4 + 8 * 1024 + 64;   // ring + a bias area per wave + the queue's two hand-over words
+        if (tile_queue && hipMemsetAsync(tile_queue, 0, NTQ_INTS * sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
         hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-        int walk_g = nt4 > 4 ? 8 : 0, walk_nb = 2;
+#ifndef NT4R_WALK_G
+#define NT4R_WALK_G 8
+#define NT4R_WALK_NB 2
+#endif
+        int walk_g = nt4 > 4 ? NT4R_WALK_G : 0, walk_nb = NT4R_WALK_NB;
         hipLaunchKernelGGL(k4, dim3((unsigned)gp), dim3(NT4), lds4, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt4, (int)grid4, act_flags,
-                           drop_p, seed, walk_g, walk_nb);
+                           drop_p, seed, walk_g, walk_nb, (int *)tile_queue);
         return apertis_check_launch();
       }
     }

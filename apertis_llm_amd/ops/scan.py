@@ -110,6 +110,7 @@ _lb_env = _os.environ.get("APERTIS_SCAN_LOOKBACK", "1")
 SCAN_LOOKBACK = "all" if _lb_env == "all" else _lb_env == "1"
 
 
+SCAN_LOOKBACK_MIN_WGS = int(_os.environ.get("APERTIS_SCAN_LOOKBACK_MIN_WGS", "768"))   # (Dn <= 128: work-groups from which it is the default)
 _gate_ws = {}      # (device, stream) -> [workspace (zeroed once), last epoch]
 
 
@@ -280,7 +281,12 @@ def _scan_gate_forward(ctx, dlt, A_log, Bt, C, xc, z, D, h0, delta_softplus, ret
     ckpt, lean = None, False
     dt_done = dtp is None
     kind = "staged"
-    if SCAN_LOOKBACK and xc.dtype == torch.bfloat16 and N == 16 and Dn <= 256 and (Dn > 128 or SCAN_LOOKBACK == "all"):
+    # Dn <= 128 (64 / (Dn / 4) sequences side by side in a wave): the look-back form wins once its grid fills the chip - at
+    # config 3's shape (Dn = 64, L = 4096) per-GPU batch 72 = 1152 work-groups: 58.8 / 107.3 us against the staged kernels'
+    # 78.9 / 133.1; at batch 16 = 256 work-groups the 16-hop carry chain is its whole time and staged ties / wins (32 / 61
+    # against 32 / 53 us) - profiles/r6_scan_config3_forms.txt
+    lb_small = Dn <= 128 and Dn % 4 == 0 and -(-B // max(1, 64 // max(Dn // 4, 1))) * nch >= SCAN_LOOKBACK_MIN_WGS
+    if SCAN_LOOKBACK and xc.dtype == torch.bfloat16 and N == 16 and Dn <= 256 and (Dn > 128 or lb_small or SCAN_LOOKBACK == "all"):
         if not dt_done:
             _tiny_linear_into(lib, dtp, dlt)
             dt_done = True

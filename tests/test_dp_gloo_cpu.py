@@ -209,3 +209,35 @@ def test_trainer_two_ranks_equal_and_checkpoint_on_rank0(tmp_path):
     flat1 = [tuple(x) for b in order1 for x in b]
     assert len(flat0) == len(flat1) == 4 and not set(flat0) & set(flat1), "the sampler must shard the epoch"
     assert sorted(os.listdir(tmp_path / "out")) == ["epoch-1", "epoch-2", "final"]
+
+
+def test_late_gradient_copies_land_before_the_next_backward():
+    """Round 6: gradients autograd produces outside the bucket are moved in with ONE multi-tensor copy per bucket
+    (parallel._Bucket.flush) instead of one copy per parameter.  A bucket that never completes in a backward (one of its
+    parameters got no gradient) must still hold its data when that backward ends - the next backward accumulates INTO the
+    views.  Single process, no process group: two backwards without finish() in between, gradients must be their sum."""
+    from apertis_llm_amd.parallel import BucketedDataParallel
+    torch.manual_seed(0)
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b, self.unused = nn.Linear(8, 8), nn.Linear(8, 4), nn.Linear(4, 4)
+
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x)))
+    m, ref = M(), M()
+    ref.load_state_dict(m.state_dict())
+    dp = BucketedDataParallel(m, bucket_bytes=1 << 20, broadcast_parameters=False)   # one bucket: `unused` keeps it incomplete
+    xs = [torch.randn(5, 8), torch.randn(5, 8)]
+    for x in xs:
+        dp(x).square().sum().backward()
+        ref(x).square().sum().backward()
+        assert all(not b.late_dst for b in dp.buckets), "the end-of-backward callback must have flushed the late copies"
+    dp.finish()
+    for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+        if q.grad is None:
+            continue
+        assert p.grad is not None and torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7), n
+        assert any(p.grad.data_ptr() >= b.flat.data_ptr() and p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4
+                   for b in dp.buckets), "gradients live in their bucket slices"

@@ -412,3 +412,17 @@ def test_kernel_timer_samples_every_kth_step():
     t1 = ops.KernelTimer(["a"])
     t1.next_step()
     assert t1.on and t1.every == 1
+
+
+def test_nt4r_ticket_register_is_touched_only_by_the_hand_over():
+    """grouped_gemm_nt4r_k's dynamic tile queue (round 6) issues its ticket atomic by hand; the destination VGPR is written when
+    the atomic RETURNS, which the compiler does not know.  The built code object must touch that register in exactly two
+    instructions: the atomic and the hand-written ds_write_b32 of the hand-over (tools/check_nt4r_ticket_isa.py)."""
+    import subprocess
+    import sys
+    obj = os.path.join(ROOT, "apertis_llm_amd", "csrc", "_obj", "grouped_gemm.o")
+    if not os.path.exists(obj):
+        import __graft_entry__ as g
+        g.build()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_nt4r_ticket_isa.py"), obj], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

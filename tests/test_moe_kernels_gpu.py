@@ -1250,3 +1250,50 @@ def test_moe_entrance_predicate_mirrors_the_kernels_lds_bound(dev, S, H, dt, ok)
                                                      v(E, H), 1e-12, K)
             torch.cuda.synchronize()
             assert torch.isfinite(y).all() and int(plan.offsets[-1]) == S * K
+
+
+@pytest.mark.parametrize("rows,H,I,ragged", [(16384, 704, 1408, False), (12000, 704, 1408, True), (33024, 384, 1024, True)])
+def test_ring_kernel_under_the_tile_queue_is_bit_identical(dev, rows, H, I, ragged):
+    """Round 6: grouped_gemm_nt4r_k takes a dynamic tile queue (data-parallel steps; one counter per XCD, the ticket fetched by
+    a hand-issued atomic one tile ahead).  The saved-gradient forward and the fused data gradient of the expert MLP under the
+    queue must equal the static walk bit for bit - a lost or doubled ticket shows as a missing tile - with even groups, with
+    ragged groups incl. an EMPTY expert (padding tiles: the slow path) and on a grid only a little larger than the chip (the
+    steal from other XCDs' counters).  K = H >= 352 and (rows / 256 + E) * ceil(I / 256) >= 256 tiles: the queue form's conditions."""
+    from apertis_llm_amd import ops
+    E = 8
+    torch.manual_seed(rows + H)
+    if ragged:
+        cuts = torch.sort(torch.randint(0, rows, (E - 2,))).values.tolist()
+        offs = [0] + cuts[:3] + [cuts[3]] + cuts[3:] + [rows]            # one expert with no rows
+        offs = sorted(offs)[:E + 1]
+        offs[-1] = rows
+    else:
+        offs = [rows // E * i for i in range(E)] + [rows]
+    offsets = torch.tensor(offs, dtype=torch.int32, device=dev)
+    xg = torch.randn(rows, H, device=dev).bfloat16()
+    w1, b1 = torch.randn(E, I, H, device=dev) * 0.03, torch.randn(E, I, device=dev) * 0.1
+    w2, b2 = torch.randn(E, H, I, device=dev) * 0.03, torch.randn(E, H, device=dev) * 0.1
+    dy = torch.randn(rows, H, device=dev).bfloat16()
+
+    def run(queue):
+        old = ops.GEMM_DYNAMIC_QUEUE
+        ops.GEMM_DYNAMIC_QUEUE = queue
+        try:
+            x = xg.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+            outs = []
+            for rep in range(2):       # (twice: the queue's counters are re-zeroed by every launch)
+                y = ops.expert_mlp(x, *ws, offsets, rows, act="gelu", drop_p=0.1, seed=99, compute_dtype=torch.bfloat16)
+                y.backward(dy)
+                outs.append([y.detach().clone(), x.grad.clone()] + [w.grad.clone() for w in ws])
+                x.grad = None
+                for w in ws:
+                    w.grad = None
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            ops.GEMM_DYNAMIC_QUEUE = old
+    a, b = run(False), run(True)
+    for rep in range(2):
+        for i, (p, q) in enumerate(zip(a[rep], b[rep])):
+            assert torch.equal(p, q), f"rep {rep}, tensor {i}: the queue-driven ring kernel differs from the static walk"

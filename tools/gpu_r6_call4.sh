@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 6, fourth GPU call: the ring kernel under the tile queue (tests, forced-DP A/B), the batched gradient copies of the DP
+# hooks, the ring kernel's tile walk (compile-time variants), config 3's scan forms at batch 32 / 48.
+cd "$GRAFT_REPO_ROOT"; O=gpurun_out/r6c4; mkdir -p $O
+timeout -k 10 600 python -m pytest tests/test_moe_kernels_gpu.py tests/test_dp_gpu.py -q -x -k "tile_queue or ring_kernel or dp or ranks or expert_mlp" > $O/tests.log 2>&1; rc=$?
+tail -3 $O/tests.log; [ $rc -eq 0 ] || { grep -n "Error\|FAILED\|assert" $O/tests.log | head -20; exit $rc; }
+run() { local tag=$1; shift
+  timeout -k 10 420 python bench.py "$@" > $O/$tag.json 2> $O/$tag.err || { echo "$tag failed"; tail -4 $O/$tag.err; return 1; }
+  python tools/show_bench.py $O/$tag.json 2>/dev/null | head -1
+}
+for i in 1 2; do
+  run base_$i --steps 12 --warmup 4 --no-cpu-baseline || exit 1
+  APERTIS_FORCE_DP=1 run forced_dp_$i --steps 12 --warmup 4 --no-cpu-baseline || exit 1
+done
+for b in 32 48; do
+  APERTIS_SCAN_LOOKBACK_MIN_WGS=1000000 run 350m_b${b}_staged --config 350m-moe --batch $b --steps 12 --warmup 4 --no-cpu-baseline || exit 1
+  APERTIS_SCAN_LOOKBACK=all run 350m_b${b}_lookback --config 350m-moe --batch $b --steps 12 --warmup 4 --no-cpu-baseline || exit 1
+done
+KFILTER=gemm bash tools/gpu_prof_libs.sh r6c4_walk "tools/prof_expert_mlp.py 10 44" - w44 w161 wnf w321 > $O/walk.log 2>&1 || { tail -5 $O/walk.log; exit 1; }
+grep -E '== lib|nt4r' $O/walk.log
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+APERTIS_FORCE_DP=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/forced_dp_trace -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-timers > $O/forced_dp_trace.log 2>&1 || { tail -5 $O/forced_dp_trace.log; exit 1; }
+f=$(ls $O/forced_dp_trace/*/*kernel_stats.csv | head -1); cp $f $O/forced_dp_kernel_stats.csv; rm -rf $O/forced_dp_trace
+head -8 $O/forced_dp_kernel_stats.csv | cut -c1-140
+echo call4 done
