@@ -1585,18 +1585,19 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
     }
     return -1;
   };
-  // EVERY wave issues the atomic (lane 0, by an exec mask set inside the asm) - wave 0 on the XCD's counter, waves 1..7 on
-  // dummy words beside it - so that all eight waves have the SAME in-order vmcnt sequence and the code has no branch around
-  // the instruction: behind a `if (wave == 0)` hipcc merged the result into another register at the join right behind the
-  // atomic, i.e. copied a register whose data had not arrived yet (the destination is written when the atomic RETURNS; its
-  // only reader is the hand-written ds_write of the hand-over behind sub-step 3's wait; tools/check_nt4r_ticket_isa.py checks
-  // the compiled kernels for exactly that).
+  // EVERY wave executes the instruction, under an exec mask set inside the asm - lane 0 in wave 0, NO lane in waves 1..7 (a
+  // no-op there) - so that the code has no branch around it: behind a C-level `if (wave == 0)` hipcc merged the result into
+  // another register at the join right behind the atomic, i.e. copied a register whose data had not arrived yet (the
+  // destination is written when the atomic RETURNS; its only reader is the hand-written ds_write of the hand-over behind
+  // sub-step 3's wait; tools/check_nt4r_ticket_isa.py checks the compiled kernels for exactly that).  (A first form had waves
+  // 1..7 add to dummy words beside the counter, to give all waves one vmcnt sequence: no faster, 8x the atomics.)
   int tkv;
   auto issue_ticket = [&]() {
-    const uint64_t addr = (uint64_t)(uintptr_t)(queue + home * NTQ_STRIDE + (wave ? 8 + wave : 0));
+    const uint64_t addr = (uint64_t)(uintptr_t)(queue + home * NTQ_STRIDE);
+    const int mask = __builtin_amdgcn_readfirstlane(wave == 0 ? 1 : 0);
     uint64_t saved_exec;
-    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
-                 : "=v"(tkv), "=&s"(saved_exec) : "v"(addr), "v"(1) : "memory");
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                 : "=v"(tkv), "=&s"(saved_exec) : "v"(addr), "v"(1), "s"(mask) : "memory");
   };
 
   Tile4 cur = next_valid();
@@ -1733,7 +1734,7 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       const int nxt_off = cur_off + SLOT4 == RING4 ? 0 : cur_off + SLOT4;                                      \
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
       const int stores_behind = (S_) < 3 ? prev_stores : 0;                                                    \
-      if ((S_) < 3 && dyn) {   /* the ticket atomic behind the stores: one more operation may pass */ \
+      if ((S_) < 3 && dyn && wave == 0) {   /* wave 0's ticket atomic behind the stores: one more operation may pass there */ \
         if (stores_behind == 0) wait_vmcnt<9>(); else if (stores_behind == 16) wait_vmcnt<25>(); else wait_vmcnt<41>(); \
       } else if (stores_behind == 0) wait_vmcnt<8>(); else if (stores_behind == 16) wait_vmcnt<24>(); else wait_vmcnt<40>(); \
       NT4R_BARRIER                                                                                             \
@@ -2972,11 +2973,11 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
         const int lds4 = RING4 + 8 * 1024 + 64;   // ring + a bias area per wave + the queue's two hand-over words
         if (tile_queue && hipMemsetAsync(tile_queue, 0, NTQ_INTS * sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
         hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-#ifndef NT4R_WALK_G
-#define NT4R_WALK_G 8
-#define NT4R_WALK_NB 2
-#endif
-        int walk_g = nt4 > 4 ? NT4R_WALK_G : 0, walk_nb = NT4R_WALK_NB;
+        // tile walk: groups of 8 m-tiles under panels of 2 n-tiles - the 32 work-groups of an XCD then work on 8 m-tiles x 4
+        // n-tiles (2.9 MB of X + 1.4 MB of W: its L2).  Round 6 sweep of the footprint at 225 280 rows, N = 2816, K = 704
+        // (avg of fc1 forward and fused fc2 data gradient, us; profiles/r6_probe_nt4r_walk.log): 8 x 4: 1228 | 4 x 8: 1250-1255 |
+        // 16 x 2: 1270 | n-fastest (3 x 11): 1284 | 32 x 1: 1340
+        int walk_g = nt4 > 4 ? 8 : 0, walk_nb = 2;
         hipLaunchKernelGGL(k4, dim3((unsigned)gp), dim3(NT4), lds4, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets,
                            (TO *)C, (TO *)pre_act, (const TO *)mul_pre, (int)N, (int)K, (int)ldw, (int)E, nt4, (int)grid4, act_flags,
                            drop_p, seed, walk_g, walk_nb, (int *)tile_queue);

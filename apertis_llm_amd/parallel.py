@@ -65,7 +65,7 @@ class BucketedDataParallel(nn.Module):
             # so a work-group whose CU an RCCL kernel holds does not walk a full static share alone at the end
             # (APERTIS_FORCE_DP=1 - the N > 1 step rehearsed on one rank - runs the very kernels the N > 1 step runs)
             from . import ops as _ops
-            _ops.GEMM_DYNAMIC_QUEUE = True
+            _ops.GEMM_DYNAMIC_QUEUE = _os.environ.get("APERTIS_DP_STATIC_WALK") != "1"   # (=1: A/B switch, static walks under DP)
         params = [p for p in module.parameters() if p.requires_grad]
         self.device = params[0].device
         self._cuda = self.device.type == "cuda"
