@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("APERTIS_HIP_LIB") or os.path.join(_HERE, "libapertis_
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU = 0, 1, 2, 3
 ACT_SAVE_GRAD, ACT_MUL_SAVED = 0x100, 0x200      # flags of apertis_grouped_gemm_nt's `act` (apertis_hip.h)
+ACT_INTERLEAVED = 0x400                          # ... with ACT_SAVE_GRAD: the interleaved-epilogue kernel (opt-in, round 6)
 
 
 class ApertisHipError(RuntimeError):

@@ -1799,6 +1799,8 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   wait_vmcnt<0>();
 }
 
+#include "gemm_nt2i.h"   // grouped_gemm_nt2i_k: the saved-gradient forward with its epilogue inside the next tile's K loop (round 6)
+
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
 template <typename T>
 __global__ void act_dropout_bwd_k(const T *__restrict__ dh, const T *__restrict__ pre, T *__restrict__ dpre,
@@ -2958,6 +2960,25 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
                        // 102 us, N=704 K=352 162 -> 141, N=448 K=176 83 -> 74, N=176 K=448 63-67 -> 60, N=176 K=704 85-92 -> 83;
                        // N=352 K=704 stays on the 352-wide tile (107-110 there, 111 here)
                        (E == 1 && K <= 1024 && N >= 128 && !(N == BN5 && K % 64 == 0 && ldw == K));
+    // the saved-gradient forward (GELU; the expert fc1 forward) with K >= 512: one wave per SIMD, the epilogue of tile i inside
+    // the K loop of tile i + 1 (grouped_gemm_nt2i_k, gemm_nt2i.h).  Not under a tile queue (data-parallel steps: the ring kernel).
+    // Bit-identical to the ring kernel and, at the bench shape, SLOWER (1678 against 1452 us: with one wave per SIMD the six
+    // LDS-DMA pieces of a sub-step stall the only wave that could feed the matrix pipe - profiles/r6_probe_nt2i_vs_nt4r.log): taken
+    // only when the caller asks for it (APERTIS_ACT_INTERLEAVED).
+    if ((act_flags & APERTIS_ACT_INTERLEAVED) && (act_flags & APERTIS_ACT_SAVE_GRAD) && pre_act && !mul_pre && act == APERTIS_ACT_GELU && !tile_queue && K % 32 == 0 &&
+        K >= 512 && ldw == K && N % 8 == 0 && N >= 512 && max_rows >= 4096 && E <= 1024) {
+      const int nt5 = (int)ceil_div64(N, BN3);
+      const int64_t grid5 = (ceil_div64(max_rows, BM3) + E) * nt5;
+      if (grid5 < 0x7fffffffLL) {
+        const int gp = (int)std::min<int64_t>(grid5, device_cu_count());
+        const int lds5 = RING5I + 4 * 1024;   // ring + a bias area per wave
+        auto k5 = drop_p > 0.f ? grouped_gemm_nt2i_k<TO, true> : grouped_gemm_nt2i_k<TO, false>;
+        hipFuncSetAttribute((const void *)k5, hipFuncAttributeMaxDynamicSharedMemorySize, lds5);
+        hipLaunchKernelGGL(k5, dim3((unsigned)gp), dim3(NT3), lds5, st, (const bf16_t *)A, (const bf16_t *)W, bias, offsets, (TO *)C,
+                           (TO *)pre_act, (int)N, (int)K, (int)ldw, (int)E, nt5, (int)grid5, drop_p, seed, 4, 8);
+        return apertis_check_launch();
+      }
+    }
     // (a caller's tile queue - data-parallel steps - is taken when the kernel's ticket hand-over fits: K >= 352 and a grid that
     //  is a multiple of the 8 XCDs; otherwise such calls stay on the queue-driven two-per-CU / 256 x 256 kernels below.  Round 6:
     //  the N > 1 step used to lose this kernel altogether - 956 against 902 us per expert NT call at B = 44)

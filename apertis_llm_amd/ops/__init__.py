@@ -27,8 +27,9 @@ _MODULES = (_base, prep, gemm, norm, ssm, scan, decode, moe, loss)
 # switches and counters that are REBOUND at run time (by tests, tools, parallel.py or the code itself): owner module per name
 _FORWARDED = {
     "SCAN_SINGLE_PASS": scan, "SCAN_LEAN": scan, "SCAN_LEAN_BWD": scan, "SCAN_LOOKBACK": scan, "SCAN_DT_FUSED": scan,
+    "SCAN_LOOKBACK_MIN_WGS": scan,
     "DWCONV_PAIR": ssm,
-    "FUSE_ACT_BWD": moe, "SAVE_ACT_GRAD": moe, "ROWS_GRADIENT": moe,
+    "FUSE_ACT_BWD": moe, "SAVE_ACT_GRAD": moe, "ROWS_GRADIENT": moe, "NT2I": moe,
     "FUSE_ROUTER_BOUNDARY_BWD": norm, "FUSED_ROUTER_BWD_CALLS": norm,
     "GEMM_DYNAMIC_QUEUE": gemm, "TN_DYNAMIC_QUEUE": gemm, "DENSE_WGRAD_WIDE": gemm, "_splitk_depth": gemm,
     "TRAIN_PREP": prep, "WEIGHT_EPOCH": prep, "_ACTIVE_TRAIN_PREP": prep, "_prep_scope_depth": prep,

@@ -327,6 +327,10 @@ def moe_combine(yr, w, plan, out_dtype=None):
 FUSE_ACT_BWD = not _os.environ.get("APERTIS_NO_FUSE_ACT_BWD")
 
 
+# APERTIS_NT2I=1 (round 6, default OFF): the saved-gradient forward on grouped_gemm_nt2i_k - one wave per SIMD, the epilogue of
+# tile i between the MFMA groups of tile i + 1.  Bit-identical outputs; 15 % slower than the ring kernel at the bench shape
+# (profiles/r6_probe_nt2i_vs_nt4r.log): kept for the record and under test, not used.
+NT2I = _os.environ.get("APERTIS_NT2I") == "1"
 SAVE_ACT_GRAD = True    # expert MLP: the forward leaves act'(pre) * mask / (1-p) instead of pre (tests switch it off to compare)
 
 
@@ -366,7 +370,8 @@ class _ExpertMLP(torch.autograd.Function):
                           lib.apertis_grouped_gemm_nt_saves_grad(max_rows, I, H, w1c.shape[-1], E, act_code, code, code))
         _launch_nt("apertis_grouped_gemm_nt", lib,
                 (ptr(xg), ptr(w1c), ptr(b1f), ptr(offsets), ptr(h), ptr(pre), None, max_rows, I, H, w1c.shape[-1], E,
-                 act_code | (_lib.ACT_SAVE_GRAD if saved_grad else 0), float(drop_p), int(seed), code, code, stream_ptr()),
+                 act_code | ((_lib.ACT_SAVE_GRAD | (_lib.ACT_INTERLEAVED if NT2I else 0)) if saved_grad else 0), float(drop_p),
+                 int(seed), code, code, stream_ptr()),
                 _RowsWork(offsets, E, 2.0 * I * H), xg.device)
         yr = torch.empty(R, H, device=xg.device, dtype=cd)
         _launch_nt("apertis_grouped_gemm_nt", lib,

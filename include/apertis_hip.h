@@ -44,6 +44,10 @@ extern "C" {
  *            the epilogue instead of the activation derivative and the mask hash. */
 #define APERTIS_ACT_SAVE_GRAD 0x100
 #define APERTIS_ACT_MUL_SAVED 0x200
+/* with APERTIS_ACT_SAVE_GRAD: ask for the interleaved-epilogue kernel (grouped_gemm_nt2i_k, round 6: one wave per SIMD, the
+ * epilogue of tile i between the MFMA groups of tile i + 1; K % 32 == 0, K >= 512, no tile queue).  Same bits as the default
+ * kernel; measured 15 % SLOWER at the bench shape (profiles/r6_probe_nt2i_vs_nt4r.log), so no caller sets it by default. */
+#define APERTIS_ACT_INTERLEAVED 0x400
 
 /* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should

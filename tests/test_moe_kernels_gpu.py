@@ -1297,3 +1297,36 @@ def test_ring_kernel_under_the_tile_queue_is_bit_identical(dev, rows, H, I, ragg
     for rep in range(2):
         for i, (p, q) in enumerate(zip(a[rep], b[rep])):
             assert torch.equal(p, q), f"rep {rep}, tensor {i}: the queue-driven ring kernel differs from the static walk"
+
+
+@pytest.mark.parametrize("rows,H,I,p", [(16384, 704, 1408, 0.1), (12000, 704, 1408, 0.0), (8448, 896, 1792, 0.1)])
+def test_interleaved_epilogue_kernel_is_bit_identical(dev, rows, H, I, p):
+    """Round 6: grouped_gemm_nt2i_k - the saved-gradient forward with one wave per SIMD and the epilogue
+    of tile i between the MFMA groups of tile i + 1 - against the ring kernel: h, the saved gradient (through the input and
+    weight gradients) and the output equal bit for bit, with and without dropout, ragged groups included.  (The kernel is
+    opt-in: it lost the A/B - profiles/r6_probe_nt2i_vs_nt4r.log - but stays under test.)"""
+    from apertis_llm_amd import ops
+    E = 8
+    torch.manual_seed(rows + I)
+    cuts = sorted(torch.randint(0, rows, (E - 1,)).tolist())
+    offsets = torch.tensor([0] + cuts + [rows], dtype=torch.int32, device=dev)
+    xg = torch.randn(rows, H, device=dev).bfloat16()
+    w1, b1 = torch.randn(E, I, H, device=dev) * 0.03, torch.randn(E, I, device=dev) * 0.1
+    w2, b2 = torch.randn(E, H, I, device=dev) * 0.03, torch.randn(E, H, device=dev) * 0.1
+    dy = torch.randn(rows, H, device=dev).bfloat16()
+
+    def run(flag):
+        old = ops.NT2I
+        ops.NT2I = flag
+        try:
+            x = xg.clone().requires_grad_(True)
+            ws = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+            y = ops.expert_mlp(x, *ws, offsets, rows, act="gelu", drop_p=p, seed=7, compute_dtype=torch.bfloat16)
+            y.backward(dy)
+            torch.cuda.synchronize()
+            return [y.detach(), x.grad] + [w.grad for w in ws]
+        finally:
+            ops.NT2I = old
+    a, b = run(False), run(True)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"tensor {i}: the interleaved-epilogue kernel differs from the ring kernel"
