@@ -58,10 +58,7 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_PACK
 #define LB_PACK 0
 #endif
-#ifndef LB_DMA      // (round 6 experiment; 0 = off) 1: xc, z of the forward through LDS-DMA landing buffers; 2: C as well
-#define LB_DMA 0
-#endif
-constexpr int LB_LATE = LB_DMA ? 0 : LB_LATE_;
+constexpr int LB_LATE = LB_LATE_;
 static_assert(LB_LATE % 4 == 0 && LB_LATE >= 0 && LB_LATE <= 12, "whole groups of four tokens");        // forward: tokens whose C, xc, z loads are issued inside the replay
 
 typedef unsigned lb_u4 __attribute__((ext_vector_type(4)));
@@ -92,12 +89,6 @@ __device__ __forceinline__ lb_u4 lb_load16(lb_i4 rs, uint32_t off) {
   //  v_readlane right in front of this would be read by the load before it has landed: five wait states, gfx9 VALU-SGPR -> VMEM)
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "=v"(v) : "v"(off), "s"(rs) : "memory");   // sc1: past this CU's L1
   return v;
-}
-// one 1 KiB LDS-DMA piece: 16 bytes per lane from rs + voff into LDS at lds_addr + lane * 16 (hand-issued: hipcc treats the
-// builtin as a store to LDS and waits vmcnt(0) before every LDS read it cannot prove disjoint)
-__device__ __forceinline__ void lb_dma16(lb_i4 rs, uint32_t lds_addr, uint32_t voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rs) : "memory", "m0");
 }
 // LDS-only barrier: the waves' row loads (and output stores) stay in flight across it
 __device__ __forceinline__ void lb_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -199,12 +190,6 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   __shared__ float4 sS[2][LB_NW][64];    // [0]: the waves' aggregates (state from zero); [1]: the records the waves polled
   __shared__ float sD[2][LB_NW][64];     // ... and their sums of delta
   __shared__ int s_item;
-#if LB_DMA
-  // landing buffers of the element-wise operands (round 6 experiment; one sequence per wave, Dn % 8 == 0): a wave's 16 rows of
-  // a tensor as 16-byte pieces per lane - 1 KiB per wave-instruction, whole lines, every lane busy, no register held while the
-  // rows fly - at row * (Dn * 2) in the wave's own area; the replay reads its 8 bytes per token from there
-  extern __shared__ __attribute__((aligned(16))) char lb_land[];
-#endif
   int chunk;
   LbLane L;
   if (!lb_take(head, epoch, &s_item, d, G, chunk, L)) return;
@@ -234,28 +219,6 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   // first meets them: the state passes through it and nothing else in the token loops needs a mask ----
   float vd[4];
   uint2 vb[LB_TW], vc[LB_TW], vx[LB_TW], vz[LB_TW];
-#if LB_DMA
-  constexpr int NLAND = LB_DMA == 2 ? 3 : 2;
-  const uint32_t rowb = (uint32_t)d.Dn * 2u, cpr = rowb >> 4;          // bytes and 16-byte chunks per row
-  const uint32_t area = (uint32_t)LB_TW * rowb;                          // a wave's rows of one tensor
-  char *land = lb_land + (size_t)wv * NLAND * area;
-  {
-    const uint32_t land_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) const char *)land;
-    const lb_i4 dx_ = lb_desc(tx.p, tx.bytes), dz_ = lb_desc(tz.p, tz.bytes), dc_ = lb_desc(tc.p, tc.bytes);
-    const int npieces = (int)((LB_TW * cpr + 63) >> 6);
-    const uint32_t tokw = (uint32_t)__builtin_amdgcn_readfirstlane((int)tok0);   // (lane 0's: lanes past the row's g belong to no sequence)
-    for (int pz = 0; pz < npieces; ++pz) {
-      const uint32_t c = (uint32_t)(pz * 64 + ln), row = c / cpr, ch = c - row * cpr;
-      const bool in = row < (uint32_t)LB_TW;
-      const uint32_t tk = tokw + min(row, (uint32_t)tlast);
-      if (in) {      // (exec-masked: a lane past the wave's rows must not write its zeros over the next area)
-        lb_dma16(dx_, land_lds + (uint32_t)pz * 1024u, tk * tx.rs * 2u + ch * 16u);
-        lb_dma16(dz_, land_lds + area + (uint32_t)pz * 1024u, tk * tz.rs * 2u + ch * 16u);
-        if (LB_DMA == 2) lb_dma16(dc_, land_lds + 2u * area + (uint32_t)pz * 1024u, tk * tc.rs * 2u + ch * 16u);
-      }
-    }
-  }
-#endif
 #pragma unroll
   for (int j = 0; j < 4; ++j)    // lane qi of a quad takes token 4j + qi (the token rides in the lane offset here)
     vd[j] = lean_ld4(rd, L.ok ? ((tok0 + (uint32_t)min(4 * j + qi, tlast)) * dl.rs + (uint32_t)L.hh) * 4u : bad, 0u);
@@ -263,13 +226,9 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   for (int u = 0; u < LB_TW; ++u) vb[u] = lean_ld8(rb, ob, (uint32_t)min(u, tlast) * tb_.rs * 2u);
   auto ld_late = [&](int u) {
     const uint32_t t = (uint32_t)min(u, tlast);
-#if LB_DMA != 2
     vc[u] = lean_ld8(rc, oc, t * tc.rs * 2u);
-#endif
-#if !LB_DMA
     vx[u] = lean_ld8(rx, ox, t * tx.rs * 2u);
     vz[u] = lean_ld8(rz, oz, t * tz.rs * 2u);
-#endif
   };
   // (the last LB_LATE tokens' C, xc, z follow group by group inside the replay, into the registers it frees: everything at once
   //  is 173 VGPRs against the 168 of three waves per SIMD)
@@ -385,13 +344,6 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       const int u = 4 * j + i;
       const float dlv = quad_bc(sp[j], i);
       float bv[4], cv[4], xv[4], zv[4], o[4];
-#if LB_DMA
-      // (the pieces were issued BEFORE the delta / Bt loads: vmcnt retires in order, so the wait hipcc put in front of the
-      //  aggregate's first use of Bt has covered them; each wave reads only what it fetched itself: no barrier)
-      vx[u] = *reinterpret_cast<const uint2 *>(land + (uint32_t)u * rowb + (uint32_t)L.q * 8u);
-      vz[u] = *reinterpret_cast<const uint2 *>(land + area + (uint32_t)u * rowb + (uint32_t)L.q * 8u);
-      if (LB_DMA == 2) vc[u] = *reinterpret_cast<const uint2 *>(land + 2u * area + (uint32_t)u * rowb + (uint32_t)L.q * 8u);
-#endif
       unpack4(vb[u], bv); unpack4(vc[u], cv); unpack4(vx[u], xv); unpack4(vz[u], zv);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -769,14 +721,6 @@ extern "C" int apertis_scan_lookback_fwd(const float *dlt, const float *A_log, c
   auto lt = [&](const void *p, int64_t rs) { return LeanT{p, (uint32_t)rs, (uint32_t)(((T - 1) * rs + Dn) * 2)}; };
   const LeanT tdl{dlt, (uint32_t)h, (uint32_t)(T * h * 4)};
   const unsigned grid = (unsigned)lb_grid(s);
-#if LB_DMA
-  if (s.G.R != 1 || Dn % 8) return APERTIS_ERR_UNSUPPORTED;    // (the experiment's form: one sequence per wave, 16-byte chunks)
-  const size_t land_bytes = (size_t)LB_NW * (LB_DMA == 2 ? 3 : 2) * LB_TW * Dn * 2;
-  hipFuncSetAttribute((const void *)scan_lb_fwd_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)land_bytes);
-  hipLaunchKernelGGL(scan_lb_fwd_k, dim3(grid), dim3(64 * LB_NW), land_bytes, (hipStream_t)stream, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs),
-                     lt(xc, xc_rs), lt(z, z_rs), D, h0, h_in, h_last, ckpt16, lt(out, out_rs), (GateWsHead *)ws, epoch, s.d, s.G);
-  return apertis_check_launch();
-#endif
   hipLaunchKernelGGL(scan_lb_fwd_k, dim3(grid), dim3(64 * LB_NW), 0, (hipStream_t)stream, tdl, A_log, lt(Bt, bt_rs), lt(C, c_rs),
                      lt(xc, xc_rs), lt(z, z_rs), D, h0, h_in, h_last, ckpt16, lt(out, out_rs), (GateWsHead *)ws, epoch, s.d, s.G);
   return apertis_check_launch();
