@@ -1497,7 +1497,8 @@ constexpr int RING4 = 4 * SLOT4;
 
 struct Tile4 { int valid, e, rows_valid, n0, cols_valid; int64_t row0; };
 
-template <typename TO, bool RAGGED = false>
+template <typename TO, bool RAGGED = false, bool DYN = false>   // DYN: the dynamic tile queue (its own instantiation: as a run-time
+// switch its bookkeeping cost the static walk 5 % - 1229 against 1165 us per call, profiles/r6_nt4r_queue_static_cost.log)
 __global__ void __launch_bounds__(NT4)
 grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, const float *__restrict__ bias,
                     const int32_t *__restrict__ offsets, TO *__restrict__ C, TO *__restrict__ pre_act,
@@ -1561,10 +1562,10 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   // barriers later), well before the fill pointer enters the next tile (sub-step nk - 5).  A ticket past the XCD's share (or
   // on one of the few padding tiles at the walk's end) takes the slow path: thread 0 steals from the other XCDs' counters
   // with ordinary atomics behind a full barrier - the kernel's tail only.
-  const bool dyn = queue != nullptr;
+  constexpr bool dyn = DYN;
   const int home = (int)(blockIdx.x & 7), q_per = G >> 3;
   int mt_valid = 0;
-  if (dyn)
+  if constexpr (dyn)
     for (int g = 0; g < E; ++g) mt_valid += (offsets[g + 1] - offsets[g] + BM4 - 1) / BM4;
   auto ticket_v = [&](int x, int k) -> int { return (1 + k / q_per) * G + (k % q_per) * 8 + x; };
   auto tile_ok = [&](int v) -> bool {
@@ -1601,7 +1602,7 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   };
 
   Tile4 cur = next_valid();
-  if (dyn && !cur.valid) {   // (the static first tile fell on padding: nothing is in flight yet, the slow path costs nothing)
+  if constexpr (dyn) if (!cur.valid) {   // (the static first tile fell on padding: nothing is in flight yet, the slow path costs nothing)
     if (tid == 0) s_tk[1] = steal();
     __syncthreads();
     const int v = __builtin_amdgcn_readfirstlane(s_tk[1]);
@@ -1705,7 +1706,7 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   const float keep_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const uint32_t thresh16 = (uint32_t)(drop_p * 65536.f);
   for (;;) {
-    if (dyn) { nxt.valid = 0; issue_ticket(); }   // (handed over behind sub-step 3, decoded behind sub-step 5)
+    if constexpr (dyn) { nxt.valid = 0; issue_ticket(); }   // (handed over behind sub-step 3, decoded behind sub-step 5)
     else nxt = next_valid();
     // Stage 0's fragments.  (A tile's last sub-step has read them already, like every sub-step reads its successor's, but
     // 48 registers held across the epilogue leave its arithmetic no room to interleave: they are read again here - the slot is
@@ -1752,7 +1753,7 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[0][i] = af[1][i];
       }
-      if (dyn) {
+      if constexpr (dyn) {
         if (s == 2) {          // behind sub-step 3: its vmcnt(8) has retired wave 0's ticket atomic
           // (wave 0 / lane 0's value is the ticket; every other lane writes what its register holds to a word nobody reads)
           asm volatile("ds_write_b32 %0, %1" :: "v"(lds0 + (uint32_t)(RING4 + 8 * 1024) + ((wave | lane) ? 8u : 0u)), "v"(tkv) : "memory");
@@ -1798,8 +1799,6 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
   // (the empty pieces of the stream's last sub-steps are still in flight: they write zeros into this work-group's own LDS)
   wait_vmcnt<0>();
 }
-
-#include "gemm_nt2i.h"   // grouped_gemm_nt2i_k: the saved-gradient forward with its epilogue inside the next tile's K loop (round 6)
 
 // dpre = dh * keepmask/(1-p) * act'(pre)   (elementwise, rows < offsets[E])
 template <typename T>
@@ -2873,6 +2872,9 @@ int launch_tn5(Tn3Problem q0, const Tn3Problem *q1p, int64_t E, int64_t max_rows
   return apertis_check_launch();
 }
 
+// (behind every other kernel of this file: the kernels in front keep their places in the code object)
+#include "gemm_nt2i.h"   // grouped_gemm_nt2i_k: the saved-gradient forward with its epilogue inside the next tile's K loop (round 6)
+
 template <typename T> bool aligned16(const void *p, int64_t ld) {
   return (((uintptr_t)p) & 15) == 0 && ((ld * sizeof(T)) & 15) == 0;
 }
@@ -2990,7 +2992,8 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
       const int64_t grid4 = (ceil_div64(max_rows, BM4) + E) * nt4;
       if (grid4 < 0x7fffffffLL) {
         const int gp = (int)std::min<int64_t>(grid4, device_cu_count());   // one persistent work-group per CU
-        auto k4 = ragged2x ? grouped_gemm_nt4r_k<TO, true> : grouped_gemm_nt4r_k<TO, false>;
+        auto k4 = tile_queue ? (ragged2x ? grouped_gemm_nt4r_k<TO, true, true> : grouped_gemm_nt4r_k<TO, false, true>)
+                             : (ragged2x ? grouped_gemm_nt4r_k<TO, true, false> : grouped_gemm_nt4r_k<TO, false, false>);
         const int lds4 = RING4 + 8 * 1024 + 64;   // ring + a bias area per wave + the queue's two hand-over words
         if (tile_queue && hipMemsetAsync(tile_queue, 0, NTQ_INTS * sizeof(int32_t), st) != hipSuccess) return APERTIS_ERR_LAUNCH;
         hipFuncSetAttribute((const void *)k4, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);

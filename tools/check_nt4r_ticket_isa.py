@@ -38,17 +38,27 @@ def check(lines):
         body = [l.split("//")[0] for l in lines[st:end]]
         at = [i for i, l in enumerate(body) if "global_atomic_add" in l and " off" in l and "sc0" in l]
         name = lines[st].split("<")[1][:70]
-        if len(at) != 1:
-            problems.append(f"{name}: expected ONE hand-issued ticket atomic, found {len(at)}")
+        m = re.search(r"nt4r_kI\w+?Lb(\d)ELb(\d)EEE", lines[st])     # <TO, RAGGED, DYN>: only the DYN instantiations draw tickets
+        dyn = bool(m and m.group(2) == "1")
+        if len(at) != (1 if dyn else 0):
+            problems.append(f"{name}: expected {1 if dyn else 0} hand-issued ticket atomic(s), found {len(at)}")
+            continue
+        if not dyn:
+            print(f"{name}: static walk (no ticket)")
             continue
         reg = re.search(r"global_atomic_add\s+(v\d+),", body[at[0]]).group(1)
         n = int(reg[1:])
-        uses = [l.strip() for j, l in enumerate(body) if j != at[0] and
-                (re.search(r"\b" + reg + r"\b", l) or any(int(x) <= n <= int(y) for x, y in re.findall(r"v\[(\d+):(\d+)\]", l)))]
-        ok = len(uses) == 1 and uses[0].startswith("ds_write_b32") and re.search(r",\s*" + reg + r"\b", uses[0])
-        print(f"{name}: ticket register {reg}; other instructions that touch it: {uses}")
-        if not ok:
-            problems.append(f"{name}: {reg} is touched outside the hand-over: {uses}")
+        touch = [(j, l.strip()) for j, l in enumerate(body) if j != at[0] and
+                 (re.search(r"\b" + reg + r"\b", l) or any(int(x) <= n <= int(y) for x, y in re.findall(r"v\[(\d+):(\d+)\]", l)))]
+        # the hand-over: the first ds_write_b32 of the register BEHIND the atomic in the code (the loop body is laid out in
+        # execution order: ticket at its top, sub-steps 0..3, hand-over); between the two nothing may touch the register.
+        # (Elsewhere - the epilogue behind the K loop, before the next ticket - the allocator may reuse it.)
+        hand = next((j for j, l in touch if j > at[0] and l.startswith("ds_write_b32") and re.search(r",\s*" + reg + r"\b", l)), None)
+        between = [l for j, l in touch if hand is not None and at[0] < j < hand]
+        print(f"{name}: ticket register {reg}; hand-over {hand - at[0] if hand else None} instructions behind the atomic; "
+              f"touches in between: {between}; reuses elsewhere: {len(touch) - 1 - len(between)}")
+        if hand is None or between:
+            problems.append(f"{name}: {reg} is touched between the atomic and its hand-over: {between if hand else 'no hand-over found'}")
     return problems
 
 
