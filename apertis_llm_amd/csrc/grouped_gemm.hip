@@ -1123,11 +1123,8 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t sv = __builtin_amdgcn_make_buffer_rsrc(const_cast<TO *>(MODE >= EPI_MULACT ? saved + tile0 : dst + tile0), 0, tile_bytes, 0x00020000);
   auto row_off = [&](int r) { return voff + (uint32_t)(r * N) * 2u; };
   // (non-temporal, like out_store16: the outputs are far larger than the caches and would only displace the operands)
-#ifndef NT_EPI_AUX   // tools/probes only: the stores' cache policy bits
-#define NT_EPI_AUX 2
-#endif
   auto put = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t off, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    __builtin_amdgcn_raw_buffer_store_b128((u4_t){a, b, c, d}, rs, (int)off, 0, NT_EPI_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128((u4_t){a, b, c, d}, rs, (int)off, 0, 2);
   };
   // the saved tensor's pieces: two batches of four rows in flight ahead of the arithmetic
   [[maybe_unused]] uint4 pc[2][4];
@@ -1673,23 +1670,15 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-#ifndef NT4R_STAGGER   // measured (B = 44, K = 704): 1037-1045 us with the stagger, 1013 without; priorities move time between the
-#define NT4R_STAGGER 0 // K loop and the epilogue, not the sum (profiles/r4_probe_nt4r_stagger.log)
-#endif
+  // (measured at B = 44, K = 704: 1037-1045 us with the pieces of waves 4-7 behind the LAST four groups, 1013 without; wave
+  //  priorities move time between the K loop and the epilogue, not the sum - profiles/r4_probe_nt4r_stagger.log)
+#define NT4R_STAGGER 0
 #define NT4R_BARRIER lds_barrier();
-#ifndef NT4R_PRIO      // 0: every wave at priority 1 inside the MFMA run; 1: waves 4-7 at priority 1 throughout, waves 0-3 at 0
-#define NT4R_PRIO 0
-#endif
+#define NT4R_PRIO 0    // 0: every wave at priority 1 inside the MFMA run; 1: waves 4-7 at priority 1 throughout, waves 0-3 at 0
   // (a per-wave branch between an EARLY and a LATE copy of the whole run made hipcc spill the accumulators: 528 B of scratch)
   const bool late = NT4R_STAGGER && wave >= 4;
   if (NT4R_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-#ifdef NT4R_PHASES   // tools/probes only: the work-groups start in NT4R_PHASES phases, NT4R_PHASE_TICKS (10 ns) apart
-  {
-    const uint64_t t0 = wall_clock64(), dly = (uint64_t)((blockIdx.x >> 3) % NT4R_PHASES) * NT4R_PHASE_TICKS;   // (blockIdx & 7 = the XCD)
-    while (wall_clock64() - t0 < dly) __builtin_amdgcn_s_sleep(32);
-  }
-#endif
   // prologue: the first four stages (nk >= 5: all of cur), stage 0's fragments
   if (bias) issue_bias();
 #pragma unroll 1

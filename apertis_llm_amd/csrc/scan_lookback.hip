@@ -43,20 +43,8 @@ constexpr unsigned LB_SPIN_MAX = 1u << 16;    // (~0.1 s of polling: a legitimat
 #ifndef LB_BWD_LAUNDER_DECAY
 #define LB_BWD_LAUNDER_DECAY 1
 #endif
-#ifndef LB_ORDER
-#define LB_ORDER 0
-#endif
-#ifndef LB_GROUP
-#define LB_GROUP 22
-#endif
-#ifndef LB_CXZ_AFTER_AGG
-#define LB_CXZ_AFTER_AGG 0
-#endif
 #ifndef LB_SCHED_TOKEN
 #define LB_SCHED_TOKEN 1
-#endif
-#ifndef LB_PACK
-#define LB_PACK 0
 #endif
 constexpr int LB_LATE = LB_LATE_;
 static_assert(LB_LATE % 4 == 0 && LB_LATE >= 0 && LB_LATE <= 12, "whole groups of four tokens");        // forward: tokens whose C, xc, z loads are issued inside the replay
@@ -99,55 +87,21 @@ struct LbLane { bool ok; int b, q, c0, hh; };
 // ticket -> (position in composition order, wave of sequences); lanes -> (sequence, four channels)
 __device__ __forceinline__ bool lb_take(GateWsHead *head, uint32_t epoch, int *s_item, const ScanDims &d, const LbGeo &G, int &k,
                                         LbLane &ln_) {
-#ifdef LB_NO_TICKET    // (probe builds only: dispatch order taken for ticket order - what the ticket costs)
-  if (threadIdx.x == 0) *s_item = (int)blockIdx.x;
-#else
   if (threadIdx.x == 0) {
     const unsigned t = atomicAdd(&head->ctr[epoch & 1], 1u);
     if (t == 0) atomicExch(&head->ctr[(epoch + 1) & 1], 0u);   // the next launch's counter (its last user has finished)
     *s_item = (int)t;
   }
-#endif
   __syncthreads();
   const int item = __builtin_amdgcn_readfirstlane(*s_item);     // (wave-uniform: the rows' token terms ride in scalar offsets)
   const int ln = (int)threadIdx.x & 63;
-#if LB_ORDER == 1     // (probe: tickets walk a sequence's chunks before the next sequence's - contiguous memory, a deeper look-back)
-  if (item >= d.nchunks * G.nbw) return false;
-  const int bw = item / d.nchunks;
-  k = item - bw * d.nchunks;
-#elif LB_ORDER == 2   // super-chunk-major: the four chunks of a super-chunk of one (wave of) sequence(s) hold consecutive tickets
-  if (item >= G.nsup * G.nbw * LB_SUP) return false;
-  const int kg = item / (G.nbw * LB_SUP), rem = item - kg * (G.nbw * LB_SUP), bw = rem / LB_SUP;
-  k = kg * LB_SUP + (rem - bw * LB_SUP);
-  if (k >= d.nchunks) return false;                            // (the last super-chunk may be short; nobody waits for such an item)
-#elif LB_ORDER == 3   // (probe: chunk-major inside groups of LB_GROUP waves of sequences, group after group - fewer pages in flight)
-  if (item >= d.nchunks * G.nbw) return false;
-  const int per = LB_GROUP * d.nchunks, grp = item / per, rem = item - grp * per;
-  const int gw = min(LB_GROUP, G.nbw - grp * LB_GROUP);      // (the last group may be short)
-  k = rem / gw;
-  const int bw = grp * LB_GROUP + (rem - k * gw);
-#else                 // chunk-major
   if (item >= d.nchunks * G.nbw) return false;
   k = item / G.nbw;
   const int bw = item - k * G.nbw;
-#endif
-#if LB_PACK == 2      // rows packed over the waves' lanes in units of 16 lanes = one 128-byte line of a bf16 row: a line is read by one wave
-  const int upr = (G.g + 15) >> 4, un = bw * 4 + (ln >> 4);
-  ln_.b = un / upr;
-  ln_.q = (un - ln_.b * upr) * 16 + (ln & 15);
-  ln_.ok = ln_.b < d.B && ln_.q < G.g;
-  if (!ln_.ok) ln_.q = 0;
-#elif LB_PACK == 1    // (probe: rows packed end to end - a row's lines split between two work-groups: slower)
-  const int f = bw * 64 + ln;
-  ln_.b = f / G.g;
-  ln_.q = f - ln_.b * G.g;
-  ln_.ok = ln_.b < d.B;
-#else
   const int r = ln / G.g;
   ln_.q = ln - r * G.g;
   ln_.b = bw * G.R + r;
   ln_.ok = r < G.R && ln_.b < d.B;
-#endif
   ln_.c0 = 4 * ln_.q;
   ln_.hh = ln_.c0 >> 4;
   return true;
@@ -232,10 +186,8 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
   };
   // (the last LB_LATE tokens' C, xc, z follow group by group inside the replay, into the registers it frees: everything at once
   //  is 173 VGPRs against the 168 of three waves per SIMD)
-#if !LB_CXZ_AFTER_AGG
 #pragma unroll
   for (int u = 0; u < LB_TW - LB_LATE; ++u) ld_late(u);
-#endif
   // ---- aggregate of the 16 tokens: (sum of delta, state from zero) ----
   float sp[4], S[4] = {0.f, 0.f, 0.f, 0.f}, sumdl = 0.f;
 #pragma unroll
@@ -254,10 +206,6 @@ scan_lb_fwd_k(LeanT dl, const float *__restrict__ A_log, LeanT tb_, LeanT tc, Le
       for (int k = 0; k < 4; ++k) S[k] = fmaf(__builtin_amdgcn_exp2f(dlv * A2[k]), S[k], bv[k]);
     }
   }
-#if LB_CXZ_AFTER_AGG   // (the aggregate's rows - delta, Bt - first on every wave of the CU; C, xc, z ride under the poll)
-#pragma unroll
-  for (int u = 0; u < LB_TW - LB_LATE; ++u) ld_late(u);
-#endif
   sS[0][wv][ln] = make_float4(S[0], S[1], S[2], S[3]);
   sD[0][wv][ln] = sumdl;
   lb_barrier();
@@ -675,7 +623,7 @@ int lb_shape(LbShape &s, int64_t B, int64_t L, int64_t h, int64_t N, int softplu
   LbGeo &G = s.G;
   G.g = (int)(s.d.Dn / 4);
   G.R = 64 / G.g;
-  G.nbw = LB_PACK == 2 ? (int)ceil_div64(B * ((G.g + 15) / 16), 4) : LB_PACK == 1 ? (int)ceil_div64(B * G.g, 64) : (int)ceil_div64(B, G.R);
+  G.nbw = (int)ceil_div64(B, G.R);
   G.nsup = (int)ceil_div64(s.d.nchunks, LB_SUP);
   G.nck16 = (int)ceil_div64(L, LB_TW);
   int64_t rs_max = 0;
@@ -693,9 +641,9 @@ int lb_shape(LbShape &s, int64_t B, int64_t L, int64_t h, int64_t N, int softplu
   return APERTIS_OK;
 }
 
-// one work-group per ticket (lb_take's orders; LB_ORDER 2 rounds the chunk count up to whole super-chunks)
+// one work-group per ticket (chunk-major)
 int64_t lb_grid(const LbShape &s) {
-  return LB_ORDER == 2 ? (int64_t)s.G.nsup * s.G.nbw * LB_SUP : (int64_t)s.d.nchunks * s.G.nbw;
+  return (int64_t)s.d.nchunks * s.G.nbw;
 }
 
 }  // namespace
