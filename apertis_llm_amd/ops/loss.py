@@ -11,6 +11,7 @@ import torch
 from .. import _lib
 from .._lib import check, dtype_code, ptr, stream_ptr
 from ._base import _apply, _grad_wanted, _require_gpu
+from . import gemm as _gemm
 
 
 class _ShiftedCrossEntropy(torch.autograd.Function):
@@ -66,6 +67,10 @@ def shifted_cross_entropy(logits, labels, ignore_index=-100):
 # chunk the 32 weight-gradient partial GEMMs and their fp32 accumulation cost 4 ms of the 440 ms step, with four per chunk
 # the step time equals the logits path's and the peak is still 14 GiB lower at batch 32
 _LCE_CHUNK_ROWS = int(_os.environ.get("APERTIS_LCE_CHUNK_ROWS", "16384"))
+# the chunk's weight gradient dl.T @ x on the library's own wide-tile TN kernel (fp32 partials straight into the fp32 sum)
+# instead of a stock bf16 GEMM + add
+LCE_OWN_WGRAD = _os.environ.get("APERTIS_LCE_OWN_WGRAD", "1") == "1"
+LCE_OWN_LOGITS = _os.environ.get("APERTIS_LCE_OWN_LOGITS", "0") == "1"     # A/B: the chunk's logits on the library's NT kernel
 
 
 class _LinearCrossEntropy(torch.autograd.Function):
@@ -93,14 +98,26 @@ class _LinearCrossEntropy(torch.autograd.Function):
         code = dtype_code(x)
         loss_sum = torch.zeros((), device=dev, dtype=torch.float32)
         dx = torch.empty_like(x) if need else None
-        dw = torch.zeros(V, H, device=dev, dtype=torch.float32) if need else None
+        dw = part = None
         nb = max(1, _LCE_CHUNK_ROWS // L)                                     # sequences per chunk
         lse = torch.empty(nb * L, device=dev, dtype=torch.float32)
         row_loss = torch.empty(nb * L, device=dev, dtype=torch.float32)
+        own_wgrad = (need and LCE_OWN_WGRAD and compute_dtype == torch.bfloat16 and V % 8 == 0 and H % 8 == 0
+                     and lib.apertis_grouped_gemm_tn_dense_variant(V, H) >= 0)
+        own_logits = LCE_OWN_LOGITS and compute_dtype == torch.bfloat16 and V % 8 == 0 and H % 8 == 0
+        if need:   # the first chunk's weight gradient is written, the later ones are added
+            dw = torch.empty(V, H, device=dev, dtype=torch.float32)
+            part = torch.empty(V, H, device=dev, dtype=torch.float32) if own_wgrad and B > nb else None
         for b0 in range(0, B, nb):
             n = min(nb, B - b0)
             xb = x[b0:b0 + n].reshape(n * L, H)
-            logits = torch.matmul(xb, w.t()).reshape(n, L, V)                 # n sequences of logits
+            if own_logits:
+                logits = torch.empty(n, L, V, device=dev, dtype=compute_dtype)
+                check(lib.apertis_grouped_gemm_nt(ptr(xb), ptr(w), None, ptr(_gemm._dense_offsets(n * L, dev)), ptr(logits), None,
+                                                  None, n * L, V, H, H, 1, _lib.ACT_NONE, 0.0, 0, code, code, stream_ptr()),
+                      "apertis_grouped_gemm_nt")
+            else:
+                logits = torch.matmul(xb, w.t()).reshape(n, L, V)             # n sequences of logits
             lab = labels[b0:b0 + n]
             check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(lab), ptr(lse), ptr(row_loss), n, L, V, labels.shape[1], n_pos,
                                                 ignore_index, code, stream_ptr()), "apertis_cross_entropy_fwd")
@@ -111,7 +128,17 @@ class _LinearCrossEntropy(torch.autograd.Function):
                       "apertis_cross_entropy_bwd")
                 dl = logits.reshape(n * L, V)
                 torch.matmul(dl, w, out=dx[b0:b0 + n].reshape(n * L, H))
-                dw.add_(torch.matmul(dl.t(), xb))
+                if own_wgrad:
+                    ws, ws_bytes = _gemm._tn_workspace(1, 1, dev, n * L)
+                    check(lib.apertis_grouped_gemm_tn(ptr(dl), ptr(xb), ptr(_gemm._dense_offsets(n * L, dev)),
+                                                      ptr(part if b0 else dw), None, n * L, V, H, 1, ptr(ws), ws_bytes, code,
+                                                      stream_ptr()), "apertis_grouped_gemm_tn")
+                    if b0:
+                        dw.add_(part)
+                elif b0:
+                    dw.add_(torch.matmul(dl.t(), xb))
+                else:
+                    dw.copy_(torch.matmul(dl.t(), xb))
         ctx.save_for_backward(dx, dw)
         ctx.cfg = (hidden.dtype, weight.dtype)
         return loss_sum / count
