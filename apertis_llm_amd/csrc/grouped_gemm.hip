@@ -22,7 +22,6 @@
 // the MFMAs of the current one: one barrier per K step).
 #include "common.h"
 #include <algorithm>
-#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -2768,17 +2767,13 @@ __global__ void __launch_bounds__(256) tn5_fold_k(Tn5Args a, int cpb) {
   }
 }
 
-// apertis_set_cu_limit: the CU budget of the persistent kernels' launches (0: the whole device)
-std::atomic<int> g_cu_limit{0};
-
 int device_cu_count() {
   static const int ncu = [] {   // queried once: hipGetDeviceProperties costs ~1 ms of host time per call
     int n = 256, dev_id = 0;
     if (hipGetDevice(&dev_id) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id);
     return n > 0 ? n : 256;
   }();
-  const int lim = g_cu_limit.load(std::memory_order_relaxed);
-  return lim > 0 && lim < ncu ? lim : ncu;
+  return ncu;
 }
 
 // returns APERTIS_ERR_UNSUPPORTED when the shape does not fit v3's assumptions (the caller falls back to v2)
@@ -3119,8 +3114,6 @@ extern "C" int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_prob
 #ifndef TN_DENSE_MIN_AREA
 #define TN_DENSE_MIN_AREA 240000
 #endif
-extern "C" int apertis_set_cu_limit(int n) { return g_cu_limit.exchange(n > 0 ? n : 0, std::memory_order_relaxed); }
-
 extern "C" int apertis_grouped_gemm_tn_dense_variant(int64_t M, int64_t N) {
   if (M < 128 || N < 128 || M % 8 || N % 8 || M * N < TN_DENSE_MIN_AREA) return -1;
   auto area = [&](int64_t tm, int64_t tn) { return ceil_div64(M, tm) * ceil_div64(N, tn) * tm * tn; };

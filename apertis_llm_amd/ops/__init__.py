@@ -33,7 +33,7 @@ _FORWARDED = {
     "FUSE_ROUTER_BOUNDARY_BWD": norm, "FUSED_ROUTER_BWD_CALLS": norm,
     "GEMM_DYNAMIC_QUEUE": gemm, "TN_DYNAMIC_QUEUE": gemm, "DENSE_WGRAD_WIDE": gemm, "_splitk_depth": gemm,
     "TRAIN_PREP": prep, "WEIGHT_EPOCH": prep, "_ACTIVE_TRAIN_PREP": prep, "_prep_scope_depth": prep,
-    "_TIMER": _base, "SIDE_WGRAD_CUS": _base,
+    "_TIMER": _base,
 }
 for _m in _MODULES:
     for _k, _v in vars(_m).items():

@@ -4,7 +4,6 @@ Part of apertis_llm_amd.ops (split by subsystem in round 6; `from apertis_llm_am
 torch is used for device memory, streams and autograd bookkeeping only; every computation is a HIP kernel launch through
 apertis_llm_amd._lib.  Tensors must live on a ROCm device.
 """
-import os as _os
 import threading
 
 import torch
@@ -65,90 +64,6 @@ class KernelTimer:
                 b["work"] += wk
                 b["bytes"] += float(nbytes)
         return out
-
-
-# ---- weight gradients BESIDE the data-gradient chain (round 6) ---------------------------------------------------------
-# The backward has no order between a layer's weight gradients and the rest of the chain (reference core.py: autograd's graph;
-# their only reader is the optimizer).  The weight-gradient GEMMs are matrix-pipe-bound persistent kernels, the chain between
-# them is half HBM-bound row kernels that leave the matrix pipes idle: inside a side_wgrad_scope the expert MLP's
-# weight-gradient pair goes out on a SIDE stream with a share of `cus` CUs (apertis_set_cu_limit), the chain's own persistent
-# GEMMs take the other CUs, and the row kernels run on whatever the side kernel does not hold.  The scope ends with the
-# launching stream waiting for the side stream, so everything behind it (clipping, the optimizer) sees finished gradients.
-# Only for a backward whose weight gradients nobody touches before the scope ends: first micro-step (param.grad is None:
-# autograd adopts the tensor, no accumulation kernel) and no data-parallel hooks - training.TrainStep checks both.
-SIDE_WGRAD_CUS = int(_os.environ.get("APERTIS_SIDE_WGRAD_CUS", "0"))     # 0: off
-_SIDE = {"on": False, "cus": 0, "ncu": 0, "streams": {}}
-
-
-def _side_stream(device):
-    st = _SIDE["streams"].get(device)
-    if st is None:
-        st = _SIDE["streams"][device] = torch.cuda.Stream(device=device)
-    return st
-
-
-class side_wgrad_scope:
-    def __init__(self, device, cus=None):
-        self.device = torch.device(device)
-        self.cus = SIDE_WGRAD_CUS if cus is None else int(cus)
-
-    def __enter__(self):
-        if self.cus <= 0 or self.device.type != "cuda":
-            return self
-        from .. import _lib
-        ncu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        if not 0 < self.cus < ncu:
-            raise ApertisHipError(f"side_wgrad_scope: {self.cus} of {ncu} CUs")
-        _SIDE.update(on=True, cus=self.cus, ncu=ncu, device=self.device)
-        _lib.load().apertis_set_cu_limit(ncu - self.cus)
-        return self
-
-    def __exit__(self, *exc):
-        if _SIDE["on"]:
-            from .. import _lib
-            _SIDE["on"] = False
-            _lib.load().apertis_set_cu_limit(0)
-            torch.cuda.current_stream(self.device).wait_stream(_side_stream(self.device))
-        return False
-
-
-class _SideLaunch:
-    """with _side_launch(device, tensors...): the launches inside go out on the side stream with the side share of the CUs,
-    behind everything the current stream has queued so far; the tensors are kept from reuse until the side stream is done."""
-
-    def __init__(self, device, tensors):
-        self.device, self.tensors = device, tensors
-
-    def __enter__(self):
-        from .. import _lib
-        self.lib = _lib.load()
-        side = _side_stream(self.device)
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        self.lib.apertis_set_cu_limit(_SIDE["cus"])
-        return self
-
-    def __exit__(self, *exc):
-        self.lib.apertis_set_cu_limit(_SIDE["ncu"] - _SIDE["cus"])
-        self.ctx.__exit__(*exc)
-        side = _side_stream(self.device)
-        for t in self.tensors:
-            if t is not None:
-                t.record_stream(side)
-        return False
-
-
-class _NoScope:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
-
-
-def side_wgrad_on(device):
-    return _SIDE["on"] and _SIDE.get("device") == device
 
 
 def _launch(name, fn, args, work=0.0, detail=None, nbytes=0.0, unwind=None):

@@ -70,7 +70,8 @@ _LCE_CHUNK_ROWS = int(_os.environ.get("APERTIS_LCE_CHUNK_ROWS", "16384"))
 # the chunk's weight gradient dl.T @ x on the library's own wide-tile TN kernel (fp32 partials straight into the fp32 sum)
 # instead of a stock bf16 GEMM + add
 LCE_OWN_WGRAD = _os.environ.get("APERTIS_LCE_OWN_WGRAD", "1") == "1"
-LCE_OWN_LOGITS = _os.environ.get("APERTIS_LCE_OWN_LOGITS", "0") == "1"     # A/B: the chunk's logits on the library's NT kernel
+# (the chunk's logits on the library's NT kernel instead: 761 against 760 us alone, the step within noise - stays on hipBLASLt;
+# d hidden = dl @ W, K = 32000: 1 019 against 802 us - stays too.  tools/prof_lm_head.py)
 
 
 class _LinearCrossEntropy(torch.autograd.Function):
@@ -104,20 +105,13 @@ class _LinearCrossEntropy(torch.autograd.Function):
         row_loss = torch.empty(nb * L, device=dev, dtype=torch.float32)
         own_wgrad = (need and LCE_OWN_WGRAD and compute_dtype == torch.bfloat16 and V % 8 == 0 and H % 8 == 0
                      and lib.apertis_grouped_gemm_tn_dense_variant(V, H) >= 0)
-        own_logits = LCE_OWN_LOGITS and compute_dtype == torch.bfloat16 and V % 8 == 0 and H % 8 == 0
         if need:   # the first chunk's weight gradient is written, the later ones are added
             dw = torch.empty(V, H, device=dev, dtype=torch.float32)
             part = torch.empty(V, H, device=dev, dtype=torch.float32) if own_wgrad and B > nb else None
         for b0 in range(0, B, nb):
             n = min(nb, B - b0)
             xb = x[b0:b0 + n].reshape(n * L, H)
-            if own_logits:
-                logits = torch.empty(n, L, V, device=dev, dtype=compute_dtype)
-                check(lib.apertis_grouped_gemm_nt(ptr(xb), ptr(w), None, ptr(_gemm._dense_offsets(n * L, dev)), ptr(logits), None,
-                                                  None, n * L, V, H, H, 1, _lib.ACT_NONE, 0.0, 0, code, code, stream_ptr()),
-                      "apertis_grouped_gemm_nt")
-            else:
-                logits = torch.matmul(xb, w.t()).reshape(n, L, V)             # n sequences of logits
+            logits = torch.matmul(xb, w.t()).reshape(n, L, V)                 # n sequences of logits
             lab = labels[b0:b0 + n]
             check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(lab), ptr(lse), ptr(row_loss), n, L, V, labels.shape[1], n_pos,
                                                 ignore_index, code, stream_ptr()), "apertis_cross_entropy_fwd")

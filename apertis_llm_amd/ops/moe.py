@@ -12,7 +12,6 @@ from .. import _lib
 from .._lib import check, dtype_code, ptr, stream_ptr
 from ._base import _apply, _f32, _grad_wanted, _launch, _require_gpu, _zero_placeholder
 from .prep import cast_transpose
-from . import _base
 from . import gemm as _gemm
 from .gemm import _ACTS, _RowsWork, _launch_nt, _tn_workspace
 
@@ -425,16 +424,12 @@ class _ExpertMLP(torch.autograd.Function):
         db2 = torch.empty(E, H, device=dev, dtype=torch.float32)
         dw1 = grad_destination(ctx.wparams[0], (E, I, H), dev)
         db1 = torch.empty(E, I, device=dev, dtype=torch.float32)
-        # (inside a side_wgrad_scope: on the side stream with its share of the CUs, beside the rest of the backward)
-        side = _base.side_wgrad_on(dev) and dw1.dtype == w1dt and dw2.dtype == w2dt
-        with (_base._SideLaunch(dev, (dyr, h, dpre, xg, offsets, dw2, db2, dw1, db1)) if side else _base._NoScope()):
-            ws, ws_bytes = _tn_workspace(E, 2, dev, max_rows)
-            # (item queue of the weight-gradient kernels: only with TN_DYNAMIC_QUEUE on top of GEMM_DYNAMIC_QUEUE - measured
-            # slower than static shares under a CU hog with the 352-wide tiles)
-            _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair_q,
-                    (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
-                     max_rows, E, ptr(ws), ws_bytes, code, int(_gemm.GEMM_DYNAMIC_QUEUE and _gemm.TN_DYNAMIC_QUEUE), stream_ptr()),
-                    _RowsWork(offsets, E, 4.0 * I * H))
+        ws, ws_bytes = _tn_workspace(E, 2, dev, max_rows)
+        # (item queue of the weight-gradient kernels: only with TN_DYNAMIC_QUEUE on top of GEMM_DYNAMIC_QUEUE - measured slower
+        # than static shares under a CU hog with the 352-wide tiles)
+        _launch("apertis_grouped_gemm_tn", lib.apertis_grouped_gemm_tn_pair_q,
+                (ptr(dyr), ptr(h), ptr(dw2), ptr(db2), H, I, ptr(dpre), ptr(xg), ptr(dw1), ptr(db1), I, H, ptr(offsets),
+                 max_rows, E, ptr(ws), ws_bytes, code, int(_gemm.GEMM_DYNAMIC_QUEUE and _gemm.TN_DYNAMIC_QUEUE), stream_ptr()), _RowsWork(offsets, E, 4.0 * I * H))
         return dxg, dw1.to(w1dt), db1, dw2.to(w2dt), db2, None, None, None, None, None, None
 
 

@@ -297,10 +297,7 @@ class TrainStep:
         with ctx, prepared_step(self.prep):
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
                 loss = self.model(**batch)[0]
-            # (a single micro-step without data-parallel hooks: the expert weight gradients beside the chain - ops/_base.py)
-            side = self.dp is None and self.accum == 1 and loss.is_cuda
-            with (_side_scope(loss.device) if side else _null()):
-                (loss / self.accum).backward()
+            (loss / self.accum).backward()
         if last:
             if self.dp is not None:
                 self.dp.finish()
@@ -317,11 +314,6 @@ class TrainStep:
             if word is not None:
                 loss = torch.where(word[0] != 0, torch.full_like(loss, float("nan")), loss)
         return loss
-
-
-def _side_scope(device):
-    from .ops import _base
-    return _base.side_wgrad_scope(device)
 
 
 class _null:

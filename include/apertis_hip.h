@@ -49,10 +49,10 @@ extern "C" {
  * kernel; measured 15 % SLOWER at the bench shape (profiles/r6_probe_nt2i_vs_nt4r.log), so no caller sets it by default. */
 #define APERTIS_ACT_INTERLEAVED 0x400
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 6: 4.7 - apertis_set_cu_limit; round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
-#define APERTIS_ABI_VERSION ((4 << 16) | 7)
+#define APERTIS_ABI_VERSION ((4 << 16) | 6)
 int apertis_abi_version(void);
 /* Name of the code-object architecture this library was compiled for ("gfx950"). */
 const char *apertis_arch(void);
@@ -591,13 +591,6 @@ int64_t apertis_grouped_gemm_tn_workspace_bytes(int64_t E, int n_problems);
  * pseudo-groups (offsets every 1024-2048 rows, E = their count, dW = [E, M, N] partial sums) and fold them with
  * apertis_colsum_f32, as the narrow shapes (under about 240 000 output elements, or tiles mostly padding) still do. */
 int apertis_grouped_gemm_tn_dense_variant(int64_t M, int64_t N);
-/* CU budget of the PERSISTENT GEMM kernels (one work-group per CU: apertis_grouped_gemm_nt / _tn / _tn_pair and their _q
- * forms) launched by this process from now on: n > 0 caps their grids at n work-groups (and the weight-gradient kernels'
- * CUs per group accordingly), 0 restores the device's CU count.  Returns the previous value.  For a host that runs two
- * such kernels CONCURRENTLY on two streams (the weight gradients of a layer beside the data-gradient chain, core.py's
- * backward has no order between them): give each stream's launches a share and the two grids together fill the chip instead
- * of queueing behind each other.  Process-global and read at launch time: set it from the thread that launches. */
-int apertis_set_cu_limit(int n);
 int apertis_grouped_gemm_tn(const void *A, const void *Bm, const int32_t *offsets,
                             float *dW, float *dbias, int64_t max_rows, int64_t M, int64_t N,
                             int64_t E, void *ws, int64_t ws_bytes, int dtype, void *stream);
