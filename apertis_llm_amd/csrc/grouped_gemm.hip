@@ -1103,7 +1103,11 @@ __device__ __forceinline__ uint32_t drop_mask2(uint32_t h, uint32_t thresh16) {
 //   EPI_MULSAVED dst  = bf16(acc) * saved g'                         (APERTIS_ACT_MUL_SAVED)
 enum { EPI_RAW = 0, EPI_ACT = 1, EPI_BOTH = 2, EPI_MULACT = 3, EPI_MULSAVED = 4 };
 
-template <typename TO, int MODE, int ACT, bool DROP>
+// HASB = false: no bias term (the data-gradient forms of the ring kernel, whose launcher refuses a bias beside mul_pre): the
+// add of eight zeros cost the row piece a v_pk_add_f32 per pair AND two v_mov_b32 per pair that bring the addends - which sit
+// in eight different accumulator quads - into adjacent registers: 384 of the ~1 000 VALU instructions of the saved-gradient
+// multiply's epilogue.  (acc + 0.0f == acc bit for bit: an accumulator that starts at +0 is never -0.)
+template <typename TO, int MODE, int ACT, bool DROP, bool HASB = true>
 __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const float (&bv)[8], TO *__restrict__ dst,
                                               TO *__restrict__ dst2, const TO *__restrict__ saved, int64_t row0, int rows_valid,
                                               int n0, int cols_valid, int N, int act, float drop_p, uint64_t seed,
@@ -1144,9 +1148,14 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
   // hashes (gd_colmix: once per tile; a row then costs one gd_rowmix and its pairs one xor-multiply-xorshift each)
   [[maybe_unused]] const GeluK gk = gelu_consts(keep_scale);
   [[maybe_unused]] uint32_t cmix[4] = {0u, 0u, 0u, 0u};
+  // ... and the row halves: the 16 lanes of a row group would each run the full finaliser for each of their 16 rows (144 of the
+  // row pieces' 2 441 VALU instructions per tile); lane l computes the one of the wave's row l instead and a row's lanes fetch
+  // it through the LDS crossbar (ds_bpermute: no VALU slot, no LDS memory)
+  [[maybe_unused]] int rmix_mine = 0;
   if constexpr (MODE == EPI_BOTH && DROP) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) cmix[w] = gd_colmix(seed, (uint32_t)((n0 + frow * 8) >> 1) + (uint32_t)w);
+    rmix_mine = (int)gd_rowmix(seed, (uint64_t)(row0 + wave * 64 + (frow + fg * 16)));
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -1162,14 +1171,14 @@ __device__ __forceinline__ void nt2x_epilogue(const f32x4 (&acc)[4][8], const fl
         for (int j = 0; j < 8; ++j) asm("v_add_f32 %0, %1, %2" : "=v"(v[j]) : "v"(acc[i][j][q]), "v"(bv[j]));
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = acc[i][j][q] + bv[j];
+        for (int j = 0; j < 8; ++j) v[j] = HASB ? acc[i][j][q] + bv[j] : acc[i][j][q];
       }
       uint32_t o[4];
       if constexpr (MODE == EPI_BOTH) {
         // mask words: 0xFFFF where the element is dropped (one hash word per pair of elements)
         uint32_t og[4], dm[4] = {0u, 0u, 0u, 0u};
         if (DROP) {
-          const uint32_t rmix = gd_rowmix(seed, (uint64_t)(row0 + rl + r));
+          const uint32_t rmix = (uint32_t)__builtin_amdgcn_ds_bpermute((fg * 4 + r) * 4, rmix_mine);   // row rl + r of the tile
 #pragma unroll
           for (int w = 0; w < 4; ++w) dm[w] = gd_pair(rmix, cmix[w]);
 #pragma unroll
@@ -1769,11 +1778,14 @@ grouped_gemm_nt4r_k(const bf16_t *__restrict__ X, const bf16_t *__restrict__ W, 
         else OUT(EPI_BOTH, APERTIS_ACT_GELU, false, C, pre_act);
       } else {
         if (pre_act) OUT(EPI_RAW, APERTIS_ACT_NONE, false, pre_act, nullptr);
-        if (mul_pre) {
-          if (mul_saved) OUT(EPI_MULSAVED, APERTIS_ACT_NONE, false, C, nullptr);
-          else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(EPI_MULACT, APERTIS_ACT_GELU, true, C, nullptr);
-          else if (act == APERTIS_ACT_GELU) OUT(EPI_MULACT, APERTIS_ACT_GELU, false, C, nullptr);
-          else OUT(EPI_MULACT, -1, false, C, nullptr);
+        if (mul_pre) {   // (no bias beside mul_pre: launch_nt)
+#define OUTNB(MODE, A, D, DST, DST2) \
+  nt2x_epilogue<TO, MODE, A, D, false>(acc, bv, DST, DST2, mul_pre, cur.row0, cur.rows_valid, n0w, cvw, N, act, drop_p, seed, keep_scale, thresh16, wm, frow, fg)
+          if (mul_saved) OUTNB(EPI_MULSAVED, APERTIS_ACT_NONE, false, C, nullptr);
+          else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUTNB(EPI_MULACT, APERTIS_ACT_GELU, true, C, nullptr);
+          else if (act == APERTIS_ACT_GELU) OUTNB(EPI_MULACT, APERTIS_ACT_GELU, false, C, nullptr);
+          else OUTNB(EPI_MULACT, -1, false, C, nullptr);
+#undef OUTNB
         } else if (act == APERTIS_ACT_NONE && drop_p <= 0.f) OUT(EPI_RAW, APERTIS_ACT_NONE, false, C, nullptr);
         else if (act == APERTIS_ACT_GELU && drop_p > 0.f) OUT(EPI_ACT, APERTIS_ACT_GELU, true, C, nullptr);
         else if (act == APERTIS_ACT_GELU) OUT(EPI_ACT, APERTIS_ACT_GELU, false, C, nullptr);
@@ -2975,7 +2987,7 @@ int launch_nt(const void *A, const void *W, const float *bias, const int32_t *of
     //  the N > 1 step used to lose this kernel altogether - 956 against 902 us per expert NT call at B = 44)
     const int64_t grid4q = (ceil_div64(max_rows, BM4) + E) * ceil_div64(N, BN4);
     const bool queue4_ok = tile_queue && ceil_div64(K, 32) >= 11 && grid4q >= device_cu_count() && device_cu_count() % 8 == 0;
-    if (use4r && (!tile_queue || queue4_ok) && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 &&
+    if (use4r && !(mul_pre && bias) && (!tile_queue || queue4_ok) && (!ragged2x || ldw >= ceil_div64(K, 32) * 32) && K > 128 && K % 8 == 0 && N % 8 == 0 &&
         N >= 128 && max_rows >= 4096 && E <= 1024) {
       const int nt4 = (int)ceil_div64(N, BN4);
       const int64_t grid4 = (ceil_div64(max_rows, BM4) + E) * nt4;

@@ -263,6 +263,47 @@ def test_linear_cross_entropy_matches_lm_head_then_loss(dev, dt, B, L, H, V, Ll)
     assert float(hd.grad[:, n:].abs().max()) == 0.0     # positions without a target get an exact zero gradient
 
 
+@pytest.mark.parametrize("B,L,chunk_rows", [(5, 48, 96), (2, 1100, 16384)])
+def test_linear_cross_entropy_weight_gradient_on_the_library_kernel(dev, monkeypatch, B, L, chunk_rows):
+    """N4 at the bench's LM-head width (H = 704, V = 32000: apertis_grouped_gemm_tn_dense_variant accepts the shape), where the
+    chunk's weight gradient dl.T @ x runs on the library's wide-tile TN kernel with fp32 partial sums (round 6) instead of a
+    stock bf16 GEMM: three chunks with a short last one (first chunk written, later ones added; the 128 x 128 kernel: few rows)
+    and one chunk of 2 200 rows (the wide-tile kernel with its workspace).  Against the fp64 reference as the test above, and
+    against the stock-GEMM path of the same op (switch off): same loss bit for bit, d hidden bit for bit (its GEMM is untouched),
+    d W to the bf16 rounding the stock path adds per chunk."""
+    from apertis_llm_amd import ops
+    from apertis_llm_amd import _lib as L_
+    H, V = 704, 32000
+    assert L_.load().apertis_grouped_gemm_tn_dense_variant(V, H) >= 0
+    monkeypatch.setattr(ops.loss, "_LCE_CHUNK_ROWS", chunk_rows)
+    torch.manual_seed(B * 1000 + L)
+    h = (torch.randn(B, L, H) * 0.7).bfloat16()
+    W = torch.randn(V, H) * 0.05
+    labels = torch.randint(0, V, (B, L))
+    labels[0, 3] = -100
+    n = L - 1
+    hr, Wr = h.double().clone().requires_grad_(True), W.bfloat16().double().clone().requires_grad_(True)
+    ref = F.cross_entropy(F.linear(hr, Wr)[:, :n].reshape(-1, V), labels[:, 1:n + 1].reshape(-1), ignore_index=-100)
+    (ref * 1.3).backward()
+    out = {}
+    for own in (True, False):
+        monkeypatch.setattr(ops.loss, "LCE_OWN_WGRAD", own)
+        hd, Wd = h.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+        loss = ops.linear_cross_entropy(hd, Wd, labels.to(dev), compute_dtype=torch.bfloat16)
+        (loss * 1.3).backward()
+        out[own] = (loss.detach(), hd.grad.clone(), Wd.grad.clone())
+    loss, dh, dW = out[True]
+    assert abs(float(loss) - float(ref)) <= 2e-3 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    _close(dh, hr.grad, "d hidden", rtol=3e-2, atol_scale=2e-2)
+    _close(dW, Wr.grad, "d W", rtol=3e-2, atol_scale=2e-2)
+    assert dW.dtype == torch.float32 and float(dh[:, n:].abs().max()) == 0.0
+    assert torch.equal(loss, out[False][0]) and torch.equal(dh, out[False][1])
+    _close(dW, out[False][2], "d W vs the stock-GEMM path", rtol=2e-2, atol_scale=1e-2)
+    # fp32 partial sums are the closer ones to the fp64 reference
+    e_own = float((dW.double().cpu() - Wr.grad).abs().max()), float((out[False][2].double().cpu() - Wr.grad).abs().max())
+    assert e_own[0] <= e_own[1] * 1.05 + 1e-12, e_own
+
+
 def test_fused_lm_head_loss_equals_the_logits_path(dev):
     """The model with fused_lm_head_loss (what TrainStep / ApertisTrainer switch on) against its own logits path: same loss,
     same parameter gradients (fp32, 1e-5), and the logits slot of the 7-tuple is None."""
