@@ -567,8 +567,8 @@ template <> __device__ __forceinline__ float4 load4s<bf16_t>(const bf16_t *p) {
                      __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
 }
 template <typename T> __device__ __forceinline__ void store4(T *p, float4 v);
-// (-DROW_PROBE_NOSTORE, tools/ probe builds only - never the library: the row kernels' DATA stores compiled out, the values and
-//  the address kept live, to see what the write-heavy kernels spend on their stores; profiles/r5_probe_row_kernels_nostore.log)
+// (what the write-heavy kernels spend on their stores - round 5, a probe build with the data stores compiled out:
+//  profiles/r5_probe_row_kernels_nostore.log; the switch left this file in round 6, round 5's tree has it - tools/probes/README.md)
 template <> __device__ __forceinline__ void store4<float>(float *p, float4 v) {
   typedef __attribute__((ext_vector_type(4))) float f4;
   f4 o = {v.x, v.y, v.z, v.w};
