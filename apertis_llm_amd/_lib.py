@@ -29,7 +29,7 @@ _vp, _i64, _i32, _f32, _u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, cty
 _f64 = ctypes.c_double
 
 # name -> (restype, argtypes).  Order and meaning mirror include/apertis_hip.h exactly.
-ABI_VERSION = (4 << 16) | 6      # = APERTIS_ABI_VERSION of include/apertis_hip.h (tests/test_host_cpu.py compares them)
+ABI_VERSION = (4 << 16) | 7      # = APERTIS_ABI_VERSION of include/apertis_hip.h (tests/test_host_cpu.py compares them)
 SIGNATURES = {
     "apertis_abi_version": (ctypes.c_int, []),
     "apertis_arch": (ctypes.c_char_p, []),
@@ -144,6 +144,7 @@ SIGNATURES = {
     "apertis_tiny_linear_bwd_blocks": (_i64, [_i64]),
     "apertis_cross_entropy_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_cross_entropy_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "apertis_cross_entropy_fwd_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "apertis_colsum_f32": (_i32, [_vp, _vp, _i64, _i64, _vp]),
     "apertis_act_dropout_bwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _u64, _i32, _vp]),
     "apertis_opt_chunk_elems": (_i64, []),

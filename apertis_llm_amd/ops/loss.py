@@ -70,6 +70,7 @@ _LCE_CHUNK_ROWS = int(_os.environ.get("APERTIS_LCE_CHUNK_ROWS", "16384"))
 # the chunk's weight gradient dl.T @ x on the library's own wide-tile TN kernel (fp32 partials straight into the fp32 sum)
 # instead of a stock bf16 GEMM + add
 LCE_OWN_WGRAD = _os.environ.get("APERTIS_LCE_OWN_WGRAD", "1") == "1"
+LCE_FUSED_CE = _os.environ.get("APERTIS_LCE_FUSED_CE", "1") == "1"     # apertis_cross_entropy_fwd_bwd on the chunk (tests switch it off)
 # (the chunk's logits on the library's NT kernel instead: 761 against 760 us alone, the step within noise - stays on hipBLASLt;
 # d hidden = dl @ W, K = 32000: 1 019 against 802 us - stays too.  tools/prof_lm_head.py)
 
@@ -113,13 +114,25 @@ class _LinearCrossEntropy(torch.autograd.Function):
             xb = x[b0:b0 + n].reshape(n * L, H)
             logits = torch.matmul(xb, w.t()).reshape(n, L, V)                 # n sequences of logits
             lab = labels[b0:b0 + n]
-            check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(lab), ptr(lse), ptr(row_loss), n, L, V, labels.shape[1], n_pos,
-                                                ignore_index, code, stream_ptr()), "apertis_cross_entropy_fwd")
+            # (with gradients wanted: log-sum-exp, loss and softmax - onehot of a row in ONE pass over it - the row waits in its
+            #  work-group's registers - when the vocabulary fits; else, and without gradients, the two kernels)
+            fused = need and LCE_FUSED_CE
+            if fused:
+                rc = lib.apertis_cross_entropy_fwd_bwd(ptr(logits), ptr(lab), ptr(lse), ptr(row_loss), ptr(gscale), ptr(logits), n,
+                                                       L, V, labels.shape[1], n_pos, ignore_index, code, stream_ptr())
+                if rc == -2:
+                    fused = False
+                else:
+                    check(rc, "apertis_cross_entropy_fwd_bwd")
+            if not fused:
+                check(lib.apertis_cross_entropy_fwd(ptr(logits), ptr(lab), ptr(lse), ptr(row_loss), n, L, V, labels.shape[1], n_pos,
+                                                    ignore_index, code, stream_ptr()), "apertis_cross_entropy_fwd")
             loss_sum += row_loss[:n * L].sum()
             if need:
-                check(lib.apertis_cross_entropy_bwd(ptr(logits), ptr(lab), ptr(lse), ptr(gscale), ptr(logits), n, L, V,
-                                                    labels.shape[1], n_pos, ignore_index, code, stream_ptr()),
-                      "apertis_cross_entropy_bwd")
+                if not fused:
+                    check(lib.apertis_cross_entropy_bwd(ptr(logits), ptr(lab), ptr(lse), ptr(gscale), ptr(logits), n, L, V,
+                                                        labels.shape[1], n_pos, ignore_index, code, stream_ptr()),
+                          "apertis_cross_entropy_bwd")
                 dl = logits.reshape(n * L, V)
                 torch.matmul(dl, w, out=dx[b0:b0 + n].reshape(n * L, H))
                 if own_wgrad:

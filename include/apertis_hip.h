@@ -49,10 +49,10 @@ extern "C" {
  * kernel; measured 15 % SLOWER at the bench shape (profiles/r6_probe_nt2i_vs_nt4r.log), so no caller sets it by default. */
 #define APERTIS_ACT_INTERLEAVED 0x400
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 6: 4.7 - apertis_cross_entropy_fwd_bwd; round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
-#define APERTIS_ABI_VERSION ((4 << 16) | 6)
+#define APERTIS_ABI_VERSION ((4 << 16) | 7)
 int apertis_abi_version(void);
 /* Name of the code-object architecture this library was compiled for ("gfx950"). */
 const char *apertis_arch(void);
@@ -661,6 +661,14 @@ int apertis_cross_entropy_bwd(const void *logits, const int64_t *labels, const f
                               const float *gscale, void *dlogits, int64_t B, int64_t L, int64_t V,
                               int64_t label_stride, int64_t n_pos, int64_t ignore_index, int dtype,
                               void *stream);
+/* Both passes in ONE launch, for a caller that knows gscale before the forward (the fused LM head + loss, core.py:1412-1450 as
+ * one op): lse / row_loss as apertis_cross_entropy_fwd leaves them and dlogits (may be `logits` itself) as
+ * apertis_cross_entropy_bwd does, bit for bit, with one read of the logits (a row is kept in its work-group's registers between
+ * the sweeps).  APERTIS_ERR_UNSUPPORTED when a row does not fit (V > 32768 bf16 / 16384 fp32) or the alignment rules of the
+ * two entry points fail: call those instead. */
+int apertis_cross_entropy_fwd_bwd(const void *logits, const int64_t *labels, float *lse, float *row_loss,
+                                  const float *gscale, void *dlogits, int64_t B, int64_t L, int64_t V,
+                                  int64_t label_stride, int64_t n_pos, int64_t ignore_index, int dtype, void *stream);
 
 /* ---- optimizer step of the trainer (reference src/training/pipeline.py:469-473 AdamW groups, :544-546
  * clip_grad_norm_ + optimizer.step).  A parameter group is described by a DEVICE table of apertis_opt_tensor records - fp32

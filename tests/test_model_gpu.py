@@ -263,6 +263,52 @@ def test_linear_cross_entropy_matches_lm_head_then_loss(dev, dt, B, L, H, V, Ll)
     assert float(hd.grad[:, n:].abs().max()) == 0.0     # positions without a target get an exact zero gradient
 
 
+@pytest.mark.parametrize("dt,B,L,V,Ll", [(torch.bfloat16, 3, 37, 32000, 37), (torch.float32, 2, 19, 16384, 24),
+                                         (torch.bfloat16, 2, 9, 512, 9), (torch.float32, 1, 5, 100, 5)])
+def test_cross_entropy_one_pass_equals_the_two_kernels(dev, dt, B, L, V, Ll):
+    """apertis_cross_entropy_fwd_bwd (round 6: log-sum-exp, loss and softmax - onehot of a row in one launch, the row kept in
+    registers between the sweeps) against apertis_cross_entropy_fwd + apertis_cross_entropy_bwd on the same logits: lse,
+    row losses and the gradient bit for bit - out of place and IN PLACE (dlogits = logits, as ops.linear_cross_entropy calls
+    it) -, ignored / out-of-range / beyond-n_pos rows zero; a vocabulary too wide for the registers is declined (-2)."""
+    from apertis_llm_amd import _lib
+    from apertis_llm_amd._lib import ptr, stream_ptr, dtype_code
+    lib = _lib.load()
+    torch.manual_seed(V + L)
+    logits = (torch.randn(B, L, V, device=dev) * 3).to(dt)
+    labels = torch.randint(0, V, (B, Ll), device=dev)
+    labels[0, 2] = -100
+    if Ll > 4:
+        labels[B - 1, 4] = V + 5            # out of range: skipped like an ignored one
+    n_pos = min(L, Ll) - 1
+    gscale = torch.tensor([0.37], device=dev)
+    code = dtype_code(logits)
+    lse_a, loss_a = torch.empty(B * L, device=dev), torch.empty(B * L, device=dev)
+    d_a = torch.empty_like(logits)
+    assert lib.apertis_cross_entropy_fwd(ptr(logits), ptr(labels), ptr(lse_a), ptr(loss_a), B, L, V, Ll, n_pos, -100, code, stream_ptr()) == 0
+    assert lib.apertis_cross_entropy_bwd(ptr(logits), ptr(labels), ptr(lse_a), ptr(gscale), ptr(d_a), B, L, V, Ll, n_pos, -100, code,
+                                         stream_ptr()) == 0
+    lse_b, loss_b = torch.full((B * L,), 7.0, device=dev), torch.full((B * L,), 7.0, device=dev)
+    d_b = torch.full_like(logits, 5.0)
+    assert lib.apertis_cross_entropy_fwd_bwd(ptr(logits), ptr(labels), ptr(lse_b), ptr(loss_b), ptr(gscale), ptr(d_b), B, L, V, Ll,
+                                             n_pos, -100, code, stream_ptr()) == 0
+    assert torch.equal(lse_a, lse_b) and torch.equal(loss_a, loss_b) and torch.equal(d_a, d_b)
+    inplace = logits.clone()
+    lse_c, loss_c = torch.empty(B * L, device=dev), torch.empty(B * L, device=dev)
+    assert lib.apertis_cross_entropy_fwd_bwd(ptr(inplace), ptr(labels), ptr(lse_c), ptr(loss_c), ptr(gscale), ptr(inplace), B, L, V, Ll,
+                                             n_pos, -100, code, stream_ptr()) == 0
+    assert torch.equal(inplace, d_a) and torch.equal(lse_c, lse_a) and torch.equal(loss_c, loss_a)
+    assert float(d_b[0, 1].abs().max()) == 0.0 and float(d_b[:, n_pos:].abs().max()) == 0.0   # (target labels[0, 2] ignored)
+    # against torch on the live rows
+    ref = F.cross_entropy(logits.float()[:, :n_pos].reshape(-1, V), torch.where(labels[:, 1:n_pos + 1] >= V, -100,
+                          labels[:, 1:n_pos + 1]).reshape(-1), ignore_index=-100, reduction="none").reshape(B, n_pos)
+    assert torch.allclose(loss_b.reshape(B, L)[:, :n_pos], ref, rtol=2e-6, atol=2e-6)
+    wide = 40000 if dt == torch.bfloat16 else 20000
+    big = torch.zeros(1, 2, wide, device=dev, dtype=dt)
+    lab2 = torch.zeros(1, 2, dtype=torch.int64, device=dev)
+    assert lib.apertis_cross_entropy_fwd_bwd(ptr(big), ptr(lab2), ptr(lse_b), ptr(loss_b), ptr(gscale), ptr(big), 1, 2, wide, 2, 1, -100,
+                                             dtype_code(big), stream_ptr()) == -2
+
+
 @pytest.mark.parametrize("B,L,chunk_rows", [(5, 48, 96), (2, 1100, 16384)])
 def test_linear_cross_entropy_weight_gradient_on_the_library_kernel(dev, monkeypatch, B, L, chunk_rows):
     """N4 at the bench's LM-head width (H = 704, V = 32000: apertis_grouped_gemm_tn_dense_variant accepts the shape), where the
