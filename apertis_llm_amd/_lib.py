@@ -100,6 +100,8 @@ SIGNATURES = {
     "apertis_moe_gather_ln_bwd_blocks": (_i64, [_i64]),
     "apertis_layernorm_fwd": (_i32, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "apertis_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "apertis_layernorm_combine_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _i64, _i64, _i64, _i32, _i32, _vp]),
     "apertis_dropout_add_layernorm_fwd": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i64, _f32,
                                                  _u64, _i32, _i32, _vp]),
     "apertis_dropout_add_layernorm_router_fwd": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp,

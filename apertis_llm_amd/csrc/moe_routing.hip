@@ -581,6 +581,27 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t *p, float4 v) 
   __builtin_nontemporal_store(__builtin_bit_cast(u2, o), reinterpret_cast<u2 *>(p));
 }
 
+// a row chunk kept in its storage form (the persistent row kernels hold the NEXT row this way: half the registers for bf16)
+template <typename TX> struct raw4;
+template <> struct raw4<float> { typedef float4 type; };
+template <> struct raw4<bf16_t> { typedef uint2 type; };
+// a row chunk in its storage form, streamed (non-temporal, see load4s)
+__device__ __forceinline__ float4 raw_load(const float *p) {
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ uint2 raw_load(const bf16_t *p) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p));
+  return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ float4 raw_to_f4(const float4 &v) { return v; }
+__device__ __forceinline__ float4 raw_to_f4(const uint2 &u) {
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+
 // Sum over the 64 lanes, the same value in every lane.  DPP adds inside the rows of 16 (quad swaps, half-row and row
 // mirrors), row broadcasts across them, one v_readlane of lane 63: seven VALU instructions.  As six __shfl_xor steps
 // (ds_bpermute_b32 + s_waitcnt lgkmcnt + add each, ~60 cycles of dependent latency per step) the ten reductions per row of
@@ -1037,12 +1058,28 @@ dropadd_ln_fwd_k(const TO *__restrict__ blk, const int32_t *__restrict__ slot_of
   if (lane == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
 }
 
-template <typename TX, typename TG, int IT>
-__global__ void __launch_bounds__(256)
+// COMB (round 6): the block output was the MoE combine of expert rows (dropadd_ln_fwd_k with slot_of): the masked gradient row
+// `dblk` is not stored - the row's combine backward (combine_bwd_k: dyr[slot] = w * dblk, dwk = <dblk, yr[slot]>, on dblk as
+// that kernel would have read it back, rounded to TG) runs here on the row in registers, for its K <= 2 slots.  Saves the
+// write and the read of [T, H] in the compute dtype (2 x 254 MB per layer at the bench shape) and a launch; same arithmetic
+// per output as the two kernels: dyr and dwk bit-identical.
+constexpr int LN_COMB_K = 2;
+// waves per SIMD the COMB form is compiled for at H = 513..768 (IT = 3): 3 = the plain form's occupancy (168 registers, a few
+// spilled: 482-500 us at the bench shape, alone), 1 = what the compiler takes by itself (two waves per SIMD, both rows' expert
+// rows in flight with the rows: 461-465 us)
+#ifndef APERTIS_LN_COMB_WAVES
+#define APERTIS_LN_COMB_WAVES 1
+#endif
+constexpr int LN_COMB_WAVES = APERTIS_LN_COMB_WAVES;
+template <typename TX, typename TG, int IT, bool COMB = false>
+__global__ void __launch_bounds__(256, COMB && IT == 3 ? LN_COMB_WAVES : 1)
 layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ mean_i,
                 const float *__restrict__ rstd_i, const TG *__restrict__ dy, const TX *__restrict__ dres,
                 TX *__restrict__ dx, TG *__restrict__ dblk, float drop_p, uint64_t seed, float *__restrict__ part,
-                int64_t T, int H) {
+                int64_t T, int H, const int32_t *__restrict__ slot_of = nullptr, const float *__restrict__ wk = nullptr,
+                int K = 0, const TG *__restrict__ yr = nullptr, TG *__restrict__ dyr = nullptr,
+                float *__restrict__ dwk = nullptr) {
+  typedef typename raw4<TG>::type rawg_t;
   // the dispatch picks IT = ceil(H / 256) for IT <= 4: every chunk below the last lies inside the row, no bounds test needed
   if constexpr (IT <= 4) __builtin_assume(H > 256 * (IT - 1));
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1058,7 +1095,13 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
   }
   for (int64_t r = r0; r < r1; r += 2) {
     const bool two = r + 1 < r1;
-    float4 xv[2][IT], dv[2][IT];
+    // (COMB: the incoming gradient rows wait in their storage form - half the registers for bf16 - to make room for the expert rows)
+    typedef typename std::conditional<COMB, rawg_t, float4>::type dv_t;
+    float4 xv[2][IT];
+    dv_t dv[2][IT];
+    [[maybe_unused]] int slot[2][LN_COMB_K];
+    [[maybe_unused]] float wsl[2][LN_COMB_K];
+    [[maybe_unused]] rawg_t yv[2][LN_COMB_K][IT];
     float mean[2], rstd[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -1067,19 +1110,34 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         int c = (lane + 64 * i) * 4;
-        if (c < H) { xv[q][i] = load4s<TX>(x + rr * H + c); dv[q][i] = load4s<TG>(dy + rr * H + c); }
-        else { xv[q][i] = make_float4(0, 0, 0, 0); dv[q][i] = make_float4(0, 0, 0, 0); }
+        if (c < H) {
+          xv[q][i] = load4s<TX>(x + rr * H + c);
+          if constexpr (COMB) dv[q][i] = raw_load(dy + rr * H + c); else dv[q][i] = load4s<TG>(dy + rr * H + c);
+        } else { xv[q][i] = make_float4(0, 0, 0, 0); dv[q][i] = dv_t{}; }
+      }
+      if constexpr (COMB) {   // the row's expert rows: in flight with the row itself
+#pragma unroll
+        for (int k = 0; k < LN_COMB_K; ++k) {
+          slot[q][k] = k < K ? __builtin_amdgcn_readfirstlane(slot_of[rr * K + k]) : -1;
+          wsl[q][k] = slot[q][k] >= 0 ? wk[rr * K + k] : 0.f;
+#pragma unroll
+          for (int i = 0; i < IT; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            yv[q][k][i] = (slot[q][k] >= 0 && c < H) ? raw_load(yr + (int64_t)slot[q][k] * H + c) : rawg_t{};
+          }
+        }
       }
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q == 1 && !two) break;
+      [[maybe_unused]] float dot[LN_COMB_K] = {0.f, 0.f};
       float s1 = 0.f, s2 = 0.f;
       float4 xh[IT], gd[IT];
 #pragma unroll
       for (int i = 0; i < IT; ++i) {
         int c = (lane + 64 * i) * 4;
-        const float4 xq = xv[q][i], dq = dv[q][i];
+        const float4 xq = xv[q][i], dq = raw_to_f4(dv[q][i]);
         xh[i] = make_float4((xq.x - mean[q]) * rstd[q], (xq.y - mean[q]) * rstd[q], (xq.z - mean[q]) * rstd[q],
                             (xq.w - mean[q]) * rstd[q]);
         gd[i] = make_float4(dq.x * g4[i].x, dq.y * g4[i].y, dq.z * g4[i].z, dq.w * g4[i].w);
@@ -1102,7 +1160,7 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
           const float4 dt = make_float4(rstd[q] * (gd[i].x - m1 - xh[i].x * m2) + rr.x, rstd[q] * (gd[i].y - m1 - xh[i].y * m2) + rr.y,
                                         rstd[q] * (gd[i].z - m1 - xh[i].z * m2) + rr.z, rstd[q] * (gd[i].w - m1 - xh[i].w * m2) + rr.w);
           store4<TX>(dst + c, dt);
-          if (dblk) {
+          if (COMB || dblk) {
             // block boundary, backward: x was res + dropout(blk), so the block output's gradient is the masked
             // copy of this row's total gradient (what apertis_dropout_bwd computes in a pass of its own)
             float e[4] = {dt.x, dt.y, dt.z, dt.w};
@@ -1115,7 +1173,31 @@ layernorm_bwd_k(const TX *__restrict__ x, const float *__restrict__ gamma, const
 #pragma unroll
               for (int j = 0; j < 4; ++j) e[j] = keep[j] ? e[j] * ks : 0.f;
             }
-            store4<TG>(dblk + (r + q) * H + c, make_float4(e[0], e[1], e[2], e[3]));
+            if constexpr (COMB) {
+              // d = dblk as combine_bwd_k reads it back (rounded to TG); its arithmetic, operation for operation
+              const float4 d = make_float4(to_f32(from_f32<TG>(e[0])), to_f32(from_f32<TG>(e[1])), to_f32(from_f32<TG>(e[2])),
+                                           to_f32(from_f32<TG>(e[3])));
+#pragma unroll
+              for (int k = 0; k < LN_COMB_K; ++k) {
+                if (slot[q][k] >= 0) {   // (wave-uniform)
+                  const float4 y = raw_to_f4(yv[q][k][i]);
+                  dot[k] += (d.x * y.x + d.y * y.y) + (d.z * y.z + d.w * y.w);
+                  store4<TG>(dyr + (int64_t)slot[q][k] * H + c,
+                             make_float4(d.x * wsl[q][k], d.y * wsl[q][k], d.z * wsl[q][k], d.w * wsl[q][k]));
+                }
+              }
+            } else {
+              store4<TG>(dblk + (r + q) * H + c, make_float4(e[0], e[1], e[2], e[3]));
+            }
+          }
+        }
+      }
+      if constexpr (COMB) {
+#pragma unroll
+        for (int k = 0; k < LN_COMB_K; ++k) {
+          if (slot[q][k] >= 0) {
+            const float dsum = wave_sum(dot[k]);
+            if (lane == 0) dwk[(r + q) * K + k] = dsum;
           }
         }
       }
@@ -1576,25 +1658,6 @@ gate_noise_fold_k(const float *__restrict__ npart, const float *__restrict__ w_n
 // expert path) once and writes dx once.  Forward: wave per row, lanes over H as in the LayerNorm kernels.
 // part: [gridDim.x][NN*H + NN + 2H] per-block sums of dW, db, dgamma, dbeta, folded in a fixed order.
 // ------------------------------------------------------------------------------------------
-template <typename TX> struct raw4;
-template <> struct raw4<float> { typedef float4 type; };
-template <> struct raw4<bf16_t> { typedef uint2 type; };
-// a row chunk in its storage form, streamed (non-temporal, see load4s)
-__device__ __forceinline__ float4 raw_load(const float *p) {
-  typedef __attribute__((ext_vector_type(4))) float f4;
-  const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
-  return make_float4(t.x, t.y, t.z, t.w);
-}
-__device__ __forceinline__ uint2 raw_load(const bf16_t *p) {
-  typedef __attribute__((ext_vector_type(2))) unsigned u2;
-  const u2 t = __builtin_nontemporal_load(reinterpret_cast<const u2 *>(p));
-  return make_uint2(t.x, t.y);
-}
-__device__ __forceinline__ float4 raw_to_f4(const float4 &v) { return v; }
-__device__ __forceinline__ float4 raw_to_f4(const uint2 &u) {
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xffff0000u));
-}
 
 template <typename TX, int IT, int NN>
 __global__ void __launch_bounds__(256)
@@ -3036,6 +3099,38 @@ extern "C" int apertis_layernorm_bwd(const void *x, const float *gamma, const fl
   const size_t lds = 3 * 2 * (size_t)H * sizeof(float);
   DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((layernorm_bwd_k<TA, TB, IT>), grid, block, lds, st,
       (const TA *)x, gamma, mean, rstd, (const TB *)dy, (const TA *)dres, (TA *)dx, (TB *)dblk, drop_p, seed, part, T, (int)H)));
+  const unsigned fx = (unsigned)ceil_div64(2 * H, 64);
+  if (ln_two_level(nblk)) {
+    float *fold = part + nblk * 2 * H;
+    const int64_t rpg = ceil_div64(nblk, LN_FOLD_GROUPS), ng = ceil_div64(nblk, rpg);
+    hipLaunchKernelGGL(ln_fold_k, dim3(fx, (unsigned)ng), dim3(1024), 0, st, part, nullptr, nullptr, nblk, (int)H, fold, rpg);
+    hipLaunchKernelGGL(ln_fold_k, dim3(fx), dim3(1024), 0, st, fold, dgamma, dbeta, ng, (int)H, nullptr, (int64_t)0);
+  } else {
+    hipLaunchKernelGGL(ln_fold_k, dim3(fx), dim3(1024), 0, st, part, dgamma, dbeta, nblk, (int)H, nullptr, (int64_t)0);
+  }
+  return apertis_check_launch();
+}
+
+// apertis_layernorm_bwd for a boundary whose block output was the MoE combine (apertis_dropout_add_layernorm_fwd with slot_of),
+// with apertis_moe_combine_bwd folded in: dx, dgamma, dbeta as apertis_layernorm_bwd leaves them, dyr [rows, H] and dwk [T, K]
+// (pre-zeroed by the caller: dropped slots are not written) as apertis_moe_combine_bwd would from the dblk that is never
+// stored.  K <= 2 (APERTIS_ERR_UNSUPPORTED otherwise: call the two entry points).
+extern "C" int apertis_layernorm_combine_bwd(const void *x, const float *gamma, const float *mean, const float *rstd,
+                                             const void *dy, const void *dres, void *dx, float drop_p, uint64_t seed,
+                                             float *part, float *dgamma, float *dbeta, const int32_t *slot_of, const float *wk,
+                                             const void *yr, void *dyr, float *dwk, int64_t T, int64_t H, int64_t K,
+                                             int dtype_x, int dtype_g, void *stream) {
+  if (!x || !gamma || !mean || !rstd || !dy || !dx || !part || !dgamma || !dbeta || !slot_of || !wk || !yr || !dyr || !dwk || T < 0)
+    return APERTIS_ERR_ARG;
+  if (drop_p < 0.f || drop_p >= 1.f || K < 1) return APERTIS_ERR_ARG;
+  if (check_H(H) || K > LN_COMB_K) return APERTIS_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nblk = ln_part_rows(T);
+  dim3 grid((unsigned)nblk), block(256);
+  const size_t lds = 3 * 2 * (size_t)H * sizeof(float);
+  DISPATCH_2T(dtype_x, dtype_g, DISPATCH_IT(H, hipLaunchKernelGGL((layernorm_bwd_k<TA, TB, IT, true>), grid, block, lds, st,
+      (const TA *)x, gamma, mean, rstd, (const TB *)dy, (const TA *)dres, (TA *)dx, (TB *)nullptr, drop_p, seed, part, T, (int)H,
+      slot_of, wk, (int)K, (const TB *)yr, (TB *)dyr, dwk)));
   const unsigned fx = (unsigned)ceil_div64(2 * H, 64);
   if (ln_two_level(nblk)) {
     float *fold = part + nblk * 2 * H;

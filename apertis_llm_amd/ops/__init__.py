@@ -30,7 +30,7 @@ _FORWARDED = {
     "SCAN_LOOKBACK_MIN_WGS": scan,
     "DWCONV_PAIR": ssm,
     "FUSE_ACT_BWD": moe, "SAVE_ACT_GRAD": moe, "ROWS_GRADIENT": moe, "NT2I": moe,
-    "FUSE_ROUTER_BOUNDARY_BWD": norm, "FUSED_ROUTER_BWD_CALLS": norm,
+    "FUSE_ROUTER_BOUNDARY_BWD": norm, "FUSED_ROUTER_BWD_CALLS": norm, "FUSE_COMBINE_BWD": norm,
     "GEMM_DYNAMIC_QUEUE": gemm, "TN_DYNAMIC_QUEUE": gemm, "DENSE_WGRAD_WIDE": gemm, "_splitk_depth": gemm,
     "TRAIN_PREP": prep, "WEIGHT_EPOCH": prep, "_ACTIVE_TRAIN_PREP": prep, "_prep_scope_depth": prep,
     "_TIMER": _base,

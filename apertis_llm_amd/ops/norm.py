@@ -204,11 +204,25 @@ class _DropoutAddLN(torch.autograd.Function):
         dxn2 = dxn.reshape(T, H).to(odt).contiguous()
         dres = None if dy is None else dy.reshape(T, H).to(y.dtype).contiguous()
         dx = torch.empty_like(y)
-        dblk = torch.empty(T, H, device=y.device, dtype=odt)
         nw = lib.apertis_layernorm_bwd_blocks(T, H)
         part = torch.empty(nw, 2, H, device=y.device, dtype=torch.float32)
         dg = torch.empty(H, device=y.device, dtype=torch.float32)
         db = torch.empty(H, device=y.device, dtype=torch.float32)
+        plan = ctx.plan
+        if plan is not None and FUSE_COMBINE_BWD and plan.K <= 2:
+            # the block output was the MoE combine: its backward inside the LayerNorm backward's pass over the row - the masked
+            # gradient rows [T, H] are neither written nor read back (round 6; bit-identical to the two launches below)
+            yr, wf = ctx.saved_tensors[4], ctx.saved_tensors[5]
+            dyr = torch.empty_like(yr)
+            dw = torch.zeros(plan.S, plan.K, device=yr.device, dtype=torch.float32)
+            rc = lib.apertis_layernorm_combine_bwd(ptr(y), ptr(g), ptr(mean), ptr(rstd), ptr(dxn2), ptr(dres), ptr(dx), p, seed,
+                                                   ptr(part), ptr(dg), ptr(db), ptr(plan.slot_of), ptr(wf), ptr(yr), ptr(dyr), ptr(dw),
+                                                   T, H, plan.K, dtype_code(y), dtype_code(dxn2), stream_ptr())
+            if rc != -2:
+                check(rc, "apertis_layernorm_combine_bwd")
+                blkdt, blkshape = ctx.cfg[5], ctx.cfg[7]
+                return dyr.reshape(blkshape).to(blkdt), dx.reshape(shape), dg.to(wdt), db.to(bdt), None, None, None, None, dw, None
+        dblk = torch.empty(T, H, device=y.device, dtype=odt)
         check(lib.apertis_layernorm_bwd(ptr(y), ptr(g), ptr(mean), ptr(rstd), ptr(dxn2), ptr(dres), ptr(dx), ptr(dblk), p, seed,
                                         ptr(part), ptr(dg), ptr(db), T, H, dtype_code(y), dtype_code(dxn2), stream_ptr()),
               "apertis_layernorm_bwd")
@@ -350,6 +364,8 @@ def layer_norm_pass(x, weight, bias, eps, out_dtype=None):
 
 # APERTIS_NO_FUSE_ROUTER_BWD=1: the router backward and the boundary's LayerNorm backward as two calls (xn's gradient through HBM)
 FUSE_ROUTER_BOUNDARY_BWD = not _os.environ.get("APERTIS_NO_FUSE_ROUTER_BWD")
+# the MoE combine's backward inside the LayerNorm backward of the boundary behind it (apertis_layernorm_combine_bwd, round 6)
+FUSE_COMBINE_BWD = _os.environ.get("APERTIS_FUSE_COMBINE_BWD", "1") == "1"
 
 
 FUSED_ROUTER_BWD_CALLS = 0        # (times the one-pass form ran: the tests look at it)

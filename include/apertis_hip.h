@@ -49,7 +49,7 @@ extern "C" {
  * kernel; measured 15 % SLOWER at the bench shape (profiles/r6_probe_nt2i_vs_nt4r.log), so no caller sets it by default. */
 #define APERTIS_ACT_INTERLEAVED 0x400
 
-/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 6: 4.7 - apertis_cross_entropy_fwd_bwd; round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
+/* Library/ABI version: (major<<16)|minor.  Bumped when a signature changes or an entry point is added (round 6: 4.7 - apertis_cross_entropy_fwd_bwd, apertis_layernorm_combine_bwd; round 5: 4.5 - apertis_scan_lookback_*, apertis_tiny_linear_bwd_pad; round 4: 4.4 - lean scan
  * entry points, apertis_scan_lean_fwd_dt, apertis_grouped_gemm_tn_dense_variant, apertis_weight_prep, apertis_ssm_decode_state_dt).  A host binding should
  * refuse a library whose version differs from the header it was written against (apertis_llm_amd/_lib.py does). */
 #define APERTIS_ABI_VERSION ((4 << 16) | 7)
@@ -491,6 +491,16 @@ int apertis_layernorm_bwd(const void *x, const float *gamma, const float *mean,
                           void *dblk, float drop_p, uint64_t seed, float *part,
                           float *dgamma, float *dbeta, int64_t T, int64_t H, int dtype_x,
                           int dtype_g, void *stream);
+/* apertis_layernorm_bwd for a boundary whose block output was the MoE combine (apertis_dropout_add_layernorm_fwd called with
+ * slot_of / wk: core.py:605 index_add_ of the weighted expert rows, then core.py:698 residual + dropout), with
+ * apertis_moe_combine_bwd folded in: the masked gradient row [T, H] in the compute dtype is neither written nor read back.
+ * dx, dgamma, dbeta as apertis_layernorm_bwd leaves them; dyr [rows, H] and dwk [T, K] (zeroed by the caller: dropped slots
+ * are not written) as apertis_moe_combine_bwd would have made them, bit for bit.  K <= 2, else APERTIS_ERR_UNSUPPORTED:
+ * call the two entry points.  `part` as for apertis_layernorm_bwd. */
+int apertis_layernorm_combine_bwd(const void *x, const float *gamma, const float *mean, const float *rstd, const void *dy,
+                                  const void *dres, void *dx, float drop_p, uint64_t seed, float *part, float *dgamma,
+                                  float *dbeta, const int32_t *slot_of, const float *wk, const void *yr, void *dyr, float *dwk,
+                                  int64_t T, int64_t H, int64_t K, int dtype_x, int dtype_g, void *stream);
 int64_t apertis_layernorm_bwd_blocks(int64_t T, int64_t H);
 /* Block boundary of the pre-norm stack in one pass: y = res + dropout(blk) (core.py:698,888; the mask of
  * apertis_dropout_add_fwd) and xn = LayerNorm(y) (the next sub-block's pre-norm).  res, y: dtype_x;

@@ -973,6 +973,53 @@ def test_boundary_with_moe_combine(dev, S, H, E, K, dt, p, cap):
         _close(u.float(), v.float(), n, **tol)
 
 
+@pytest.mark.parametrize("S,H,E,K,dt,p,cap", [(1000, 704, 8, 2, torch.bfloat16, 0.1, 200), (257, 64, 4, 1, torch.float32, 0.0, None),
+                                               (777, 1024, 8, 2, torch.bfloat16, 0.25, 150), (530, 704, 8, 2, torch.float32, 0.1, 90),
+                                               (300, 320, 4, 2, torch.bfloat16, 0.0, None)])
+def test_combine_backward_inside_the_layernorm_backward_is_bit_identical(dev, monkeypatch, S, H, E, K, dt, p, cap):
+    """apertis_layernorm_combine_bwd (round 6: the MoE combine's backward on the row that the boundary's LayerNorm backward
+    holds in registers - the masked gradient rows [T, H] never reach HBM) against apertis_layernorm_bwd followed by
+    apertis_moe_combine_bwd: all five gradients (expert rows, combine weights, residual, gamma, beta) bit for bit, with
+    capacity-dropped slots (their weight gradient stays zero), K = 1 and 2, every row-chunk count, fp32 and bf16 rows; and the
+    fused path is the one that ran (no [T, H] gradient row tensor is allocated: the two-launch entry point is not called)."""
+    from apertis_llm_amd import ops, _lib
+    torch.manual_seed(S + H + K)
+    logits = torch.randn(S, E, device=dev)
+    _, idx, w0 = ops.moe_gate_topk(logits, K)
+    plan = ops.moe_plan(idx, w0, E, cap, None)
+    rows = int(plan.max_rows)
+    yr0, res0 = torch.randn(rows, H).to(dt), torch.randn(S, H)
+    g0, b0 = torch.randn(H) * 0.2 + 1, torch.randn(H) * 0.1
+    gy, gn = torch.randn(S, H, device=dev), torch.randn(S, H, device=dev).to(dt)
+    lib = _lib.load()
+    calls = {"two": 0}
+    real = lib.apertis_moe_combine_bwd
+
+    def run(fused):
+        monkeypatch.setattr(ops.norm, "FUSE_COMBINE_BWD", fused)
+        L = [t.detach().clone().to(dev).requires_grad_(True) for t in (yr0, w0, res0, g0, b0)]
+        y, xn = ops._DropoutAddLN.apply(L[0], L[2], L[3], L[4], 1e-5, p, 424242, dt, L[1], plan)
+        ((y * gy).sum() + (xn.float() * gn.float()).sum()).backward()
+        return [t.grad for t in L]
+
+    class _Spy:
+        def __call__(self, *a):
+            calls["two"] += 1
+            return real(*a)
+    monkeypatch.setattr(lib, "apertis_moe_combine_bwd", _Spy(), raising=False)
+    a = run(True)
+    assert calls["two"] == 0, "the fused entry point must have been taken"
+    c = run(False)
+    assert calls["two"] == 1
+    n_rows = int(plan.offsets[-1])
+    for u, v, n in zip(a, c, ["dyr", "dw", "dres", "dgamma", "dbeta"]):
+        if n == "dyr":          # (rows past the last kept one are never written by either form)
+            u, v = u[:n_rows], v[:n_rows]
+        assert torch.equal(u, v), n
+    if cap is not None:
+        assert int((plan.slot_of < 0).sum()) > 0 and float(a[1][plan.slot_of < 0].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("sizes,N,K", [([4100, 0, 90, 513], 576, 96), ([2000, 2300], 512, 160), ([5000, 300, 0, 1], 1024, 704)])
 def test_grouped_gemm_nt_two_per_cu_kernel(dev, sizes, N, K):
     """The 256x128 two-work-groups-per-CU NT kernel (taken for an activation / second-output epilogue on a short K)
