@@ -121,6 +121,7 @@ struct PlanWs {
   int32_t *total, *keep, *mode, *quota, *seg_start, *bpart;   // bpart [PLAN_HIST_BLOCKS][P]: the histogram launch's rows
   uint32_t *thr, *smask;   // radix select: prefix found so far / bits already fixed
   int32_t *ghist;          // [P][256] digit histogram of the current radix pass
+  int32_t *done;           // [4] work-groups of plan_sel_hist_k that have added their bins, per digit (right behind ghist: one memset)
   int32_t *cnt_g, *cnt_t;  // [P][NCH]
   int P, NCH;
 };
@@ -138,6 +139,7 @@ PlanWs carve_ws(void *ws, int64_t S, int64_t E, int64_t K) {
   w.thr = (uint32_t *)p; p += w.P;
   w.smask = (uint32_t *)p; p += w.P;
   w.ghist = p; p += (int64_t)w.P * 256;
+  w.done = p; p += 4;
   w.cnt_g = p; p += (int64_t)w.P * w.NCH;
   w.cnt_t = p; p += (int64_t)w.P * w.NCH;
   w.bpart = p;   // [PLAN_HIST_BLOCKS][P]
@@ -281,13 +283,47 @@ plan_select_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict
   if (threadIdx.x == 0) { w.thr[p] = s_prefix; w.quota[p] = s_need; }
 }
 
+// one wave per slot: the bucket (from the top) where the running count reaches the slot's remaining need.  Runs in the LAST
+// work-group of plan_sel_hist_k to finish (round 6: a launch less per digit, four per plan): the bins were added by other
+// work-groups with device-scope atomics and are read here with device-scope loads (the XCDs' L2s are not coherent inside a kernel).
+__device__ __forceinline__ void plan_sel_pick(const PlanWs &w, int p, int lane, int shift) {
+  if (w.mode[p] != 2) return;
+  int32_t *h = w.ghist + p * 256;
+  // lane l owns bins 255-4l .. 252-4l (descending)
+  int c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) c[j] = __hip_atomic_load(h + 255 - 4 * lane - j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int mine = (c[0] + c[1]) + (c[2] + c[3]);
+  int incl = mine;   // inclusive prefix over lanes 0..l
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  const int need = w.quota[p];
+  const int before = incl - mine;
+  if (before < need && incl >= need) {   // exactly one lane
+    int cum = before, b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (cum < need && cum + c[j] >= need) { b = 255 - 4 * lane - j; break; }
+      cum += c[j];
+    }
+    w.quota[p] = need - cum;
+    w.thr[p] = w.thr[p] | ((uint32_t)b << shift);
+    w.smask[p] = w.smask[p] | (255u << shift);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[255 - 4 * lane - j] = 0;   // ready for the next digit
+}
+
 // The same radix select spread over the chip (one launch pair per 8-bit digit): every work-group histograms
 // its share of the tokens for ALL overflowing slots in LDS and adds the non-empty bins to the global
-// histogram (integer atomics: exact, order-free); plan_sel_pick_k then fixes the digit per slot.  The
+// histogram (integer atomics: exact, order-free); the last work-group to finish then fixes the digit per slot (plan_sel_pick).  The
 // one-block-per-slot kernel above walks all S tokens four times with at most E*K blocks busy (154 us at
 // S = 131k with 8 overflowing slots); kept for P > 32 slots (LDS).
 __global__ void __launch_bounds__(256)
-plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk, int64_t S, int E, int K, int shift) {
+plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restrict__ wk, int64_t S, int E, int K, int shift, int digit) {
   extern __shared__ int32_t lh[];   // [P][256]
   __shared__ int32_t s_mode[32];     // (P <= 32 on this path) the slots' state, once per work-group instead of three dependent
   __shared__ uint32_t s_mask[32], s_thr[32];   // global loads per element
@@ -317,40 +353,15 @@ plan_sel_hist_k(PlanWs w, const int32_t *__restrict__ idx, const float *__restri
   __syncthreads();
   for (int i = threadIdx.x; i < P * 256; i += 256)
     if (lh[i]) atomicAdd(&w.ghist[i], lh[i]);
-}
-
-// one wave per slot: the bucket (from the top) where the running count reaches the slot's remaining need
-__global__ void __launch_bounds__(64)
-plan_sel_pick_k(PlanWs w, int shift) {
-  const int p = blockIdx.x, lane = threadIdx.x;
-  if (w.mode[p] != 2) return;
-  int32_t *h = w.ghist + p * 256;
-  // lane l owns bins 255-4l .. 252-4l (descending)
-  int c[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c[j] = h[255 - 4 * lane - j];
-  const int mine = (c[0] + c[1]) + (c[2] + c[3]);
-  int incl = mine;   // inclusive prefix over lanes 0..l
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_up(incl, off);
-    if (lane >= off) incl += v;
-  }
-  const int need = w.quota[p];
-  const int before = incl - mine;
-  if (before < need && incl >= need) {   // exactly one lane
-    int cum = before, b = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (cum < need && cum + c[j] >= need) { b = 255 - 4 * lane - j; break; }
-      cum += c[j];
-    }
-    w.quota[p] = need - cum;
-    w.thr[p] = w.thr[p] | ((uint32_t)b << shift);
-    w.smask[p] = w.smask[p] | (255u << shift);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) h[255 - 4 * lane - j] = 0;   // ready for the next digit
+  // the last work-group to get here fixes the digit of every slot (round 5: a launch of its own per digit)
+  __threadfence();
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = atomicAdd(&w.done[digit], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  for (int p = threadIdx.x >> 6; p < P; p += 4) plan_sel_pick(w, p, threadIdx.x & 63, shift);
 }
 
 __device__ __forceinline__ void plan_flags(const PlanWs &w, const int32_t *idx, const float *wk, int64_t s,
@@ -2941,7 +2952,7 @@ extern "C" int apertis_moe_gate_topk_bwd(const float *gates, const int32_t *idx,
 
 extern "C" int64_t apertis_moe_plan_workspace_bytes(int64_t S, int64_t E, int64_t K) {
   int64_t P = E * K, NCH = ceil_div64(S > 0 ? S : 1, 64);
-  return (7 * P + 256 * P + 2 * P * NCH + PLAN_HIST_BLOCKS * P) * 4 + 64;
+  return (7 * P + 256 * P + 4 + 2 * P * NCH + PLAN_HIST_BLOCKS * P) * 4 + 64;
 }
 
 extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_t *active,
@@ -2967,13 +2978,11 @@ extern "C" int apertis_moe_plan(const int32_t *idx, const float *w, const uint8_
   if (S > 0) {
     if (capacity > 0) {
       if (pw.P <= 32) {
-        hipMemsetAsync(pw.ghist, 0, sizeof(int32_t) * pw.P * 256, st);
+        hipMemsetAsync(pw.ghist, 0, sizeof(int32_t) * (pw.P * 256 + 4), st);   // (the bins and the four arrival counters)
         const unsigned nbh = (unsigned)std::min<int64_t>(ceil_div64(S * K, 1024), 512);
-        for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int shift = 24; shift >= 0; shift -= 8)
           hipLaunchKernelGGL(plan_sel_hist_k, dim3(nbh), dim3(256), (size_t)pw.P * 256 * sizeof(int32_t), st, pw, idx, w, S,
-                             (int)E, (int)K, shift);
-          hipLaunchKernelGGL(plan_sel_pick_k, dim3(pw.P), dim3(64), 0, st, pw, shift);
-        }
+                             (int)E, (int)K, shift, 3 - shift / 8);
       } else {
         hipLaunchKernelGGL(plan_select_k, dim3(pw.P), dim3(1024), 0, st, pw, idx, w, S, (int)K);
       }
